@@ -1,0 +1,208 @@
+"""ctypes binding of libcurdle_g1.so (C ABI: include/curdle_g1.h).
+
+No torch, no fallbacks: if the shared library is missing this module raises at import, and every
+device entry point raises `NativeError` when no GPU / HIP error -- there is no CPU path for the MSM.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcurdle_g1.so")
+
+POINT_BYTES = 144
+NPHASE = 7
+PHASE_NAMES = ("prepare", "hist", "scan", "scatter", "accumulate", "seg_reduce", "bit_tree")
+
+OK, ERR_ARG, ERR_HIP, ERR_ENCODING, ERR_NOT_ON_CURVE, ERR_NOT_IN_SUBGROUP = range(6)
+
+
+class NativeError(RuntimeError):
+    """HIP / argument failure inside libcurdle_g1.so (never silently replaced by a CPU path)."""
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -m curdleproofs_pie_amd.build` "
+        "(hipcc --offload-arch=gfx950).  There is no pure-Python fallback."
+    )
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_u8p = c_char_p  # immutable byte buffers in
+_buf = c_void_p  # mutable buffers out (ctypes.create_string_buffer / addresses)
+
+
+def _proto(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+# host single-element ops
+cg1_identity = _proto("cg1_identity", None, _buf)
+cg1_generator = _proto("cg1_generator", None, _buf)
+cg1_add = _proto("cg1_add", None, _buf, _u8p, _u8p)
+cg1_sub = _proto("cg1_sub", None, _buf, _u8p, _u8p)
+cg1_neg = _proto("cg1_neg", None, _buf, _u8p)
+cg1_double = _proto("cg1_double", None, _buf, _u8p)
+cg1_mul = _proto("cg1_mul", None, _buf, _u8p, _u8p)
+cg1_eq = _proto("cg1_eq", c_int, _u8p, _u8p)
+cg1_is_identity = _proto("cg1_is_identity", c_int, _u8p)
+cg1_compress = _proto("cg1_compress", None, _buf, _u8p)
+cg1_decompress = _proto("cg1_decompress", c_int, _buf, _u8p, c_int)
+cg1_to_affine96 = _proto("cg1_to_affine96", None, _buf, _u8p)
+cg1_from_affine96 = _proto("cg1_from_affine96", c_int, _buf, _u8p, c_int)
+cg1_batch_to_affine96 = _proto("cg1_batch_to_affine96", None, _buf, _u8p, c_size_t)
+cg1_batch_decompress = _proto("cg1_batch_decompress", c_int, _buf, _u8p, c_size_t, c_int, POINTER(c_size_t))
+cg1_batch_compress = _proto("cg1_batch_compress", None, _buf, _u8p, c_size_t)
+# device
+cg1_device_count = _proto("cg1_device_count", c_int)
+cg1_ctx_create = _proto("cg1_ctx_create", c_void_p, c_int)
+cg1_ctx_destroy = _proto("cg1_ctx_destroy", None, c_void_p)
+cg1_ctx_error = _proto("cg1_ctx_error", c_char_p, c_void_p)
+cg1_dev_malloc = _proto("cg1_dev_malloc", c_void_p, c_void_p, c_size_t)
+cg1_dev_free = _proto("cg1_dev_free", None, c_void_p, c_void_p)
+cg1_h2d = _proto("cg1_h2d", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+cg1_d2h = _proto("cg1_d2h", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+cg1_ctx_set_param = _proto("cg1_ctx_set_param", c_int, c_void_p, c_char_p, c_int)
+cg1_msm = _proto("cg1_msm", c_int, c_void_p, _u8p, _u8p, c_size_t, _buf)
+cg1_msm_device = _proto("cg1_msm_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, _buf)
+cg1_get_timings = _proto("cg1_get_timings", c_int, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_int))
+cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
+cg1_gen_scalars_device = _proto("cg1_gen_scalars_device", c_int, c_void_p, c_void_p, c_size_t, c_uint64)
+cg1_probe_madd = _proto("cg1_probe_madd", c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_int, POINTER(c_float))
+
+EXPORTED_SYMBOLS = [
+    "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",
+    "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
+    "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
+    "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_ctx_set_param",
+    "cg1_msm", "cg1_msm_device", "cg1_get_timings", "cg1_batch_mul_device", "cg1_gen_scalars_device", "cg1_probe_madd",
+]
+
+
+class DeviceBuffer:
+    """A hipMalloc'd region owned by a Context (plain device pointer + size)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        self.ptr = cg1_dev_malloc(ctx.handle, self.nbytes)
+        if not self.ptr:
+            raise NativeError(f"hipMalloc of {nbytes} bytes failed")
+
+    def upload(self, data: bytes, offset: int = 0) -> None:
+        assert offset + len(data) <= self.nbytes
+        self.ctx.check(cg1_h2d(self.ctx.handle, self.ptr + offset, data, len(data)))
+
+    def download(self, nbytes: int | None = None, offset: int = 0) -> bytes:
+        nbytes = self.nbytes - offset if nbytes is None else nbytes
+        out = ctypes.create_string_buffer(nbytes)
+        self.ctx.check(cg1_d2h(self.ctx.handle, out, self.ptr + offset, nbytes))
+        return out.raw
+
+    def free(self) -> None:
+        if self.ptr:
+            cg1_dev_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One per GPU: owns the HIP stream, the scratch buffers of the MSM pipeline and phase timers."""
+
+    def __init__(self, device: int = 0):
+        self.device = device
+        self.handle = cg1_ctx_create(device)
+        if not self.handle:
+            raise NativeError(
+                f"cg1_ctx_create({device}) failed: no MI355X/HIP device visible "
+                f"(cg1_device_count() = {cg1_device_count()}).  The MSM path has no CPU fallback."
+            )
+
+    def check(self, rc: int) -> None:
+        if rc != OK:
+            msg = cg1_ctx_error(self.handle)
+            raise NativeError(f"libcurdle_g1 error {rc}: {msg.decode() if msg else ''}")
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def set_param(self, name: str, value: int) -> None:
+        self.check(cg1_ctx_set_param(self.handle, name.encode(), value))
+
+    # ---- the hot path
+    def msm_host(self, points_affine96: bytes, scalars32: bytes, n: int) -> bytes:
+        assert len(points_affine96) >= 96 * n and len(scalars32) >= 32 * n
+        out = ctypes.create_string_buffer(POINT_BYTES)
+        self.check(cg1_msm(self.handle, points_affine96, scalars32, n, out))
+        return out.raw
+
+    def msm_device(self, d_points, d_scalars, n: int, window_c: int = 0, shard_rank: int = 0, shard_world: int = 1) -> bytes:
+        """d_points / d_scalars: DeviceBuffer or raw int device pointers (e.g. torch_tensor.data_ptr())."""
+        p = d_points.ptr if isinstance(d_points, DeviceBuffer) else int(d_points)
+        s = d_scalars.ptr if isinstance(d_scalars, DeviceBuffer) else int(d_scalars)
+        out = ctypes.create_string_buffer(POINT_BYTES)
+        self.check(cg1_msm_device(self.handle, p, s, n, window_c, shard_rank, shard_world, out))
+        return out.raw
+
+    def timings(self) -> dict:
+        ph = (c_float * NPHASE)()
+        tail = c_float()
+        c = c_int()
+        cg1_get_timings(self.handle, ph, ctypes.byref(tail), ctypes.byref(c))
+        d = {name: float(ph[i]) for i, name in enumerate(PHASE_NAMES)}
+        d["host_tail"] = float(tail.value)
+        d["window_c"] = int(c.value)
+        return d
+
+    def batch_mul_device(self, d_bases, nbase: int, d_scalars, d_out, n: int) -> None:
+        g = lambda b: b.ptr if isinstance(b, DeviceBuffer) else int(b)
+        self.check(cg1_batch_mul_device(self.handle, g(d_bases), nbase, g(d_scalars), g(d_out), n))
+
+    def gen_scalars_device(self, d_out, n: int, seed: int) -> None:
+        p = d_out.ptr if isinstance(d_out, DeviceBuffer) else int(d_out)
+        self.check(cg1_gen_scalars_device(self.handle, p, n, seed & 0xFFFFFFFFFFFFFFFF))
+
+    def probe_madd(self, d_points, npts: int, lanes: int, iters: int) -> float:
+        p = d_points.ptr if isinstance(d_points, DeviceBuffer) else int(d_points)
+        ms = c_float()
+        self.check(cg1_probe_madd(self.handle, p, npts, lanes, iters, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def close(self) -> None:
+        if self.handle:
+            cg1_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+_default_lock = threading.Lock()
+
+
+def default_context() -> Context:
+    """Process-wide context on the GPU named by CURDLE_G1_DEVICE / LOCAL_RANK (default 0)."""
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is None:
+            dev = int(os.environ.get("CURDLE_G1_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            if dev >= max(cg1_device_count(), 1):
+                dev = 0
+            _default_ctx = Context(dev)
+        return _default_ctx

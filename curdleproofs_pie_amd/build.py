@@ -1,0 +1,46 @@
+"""Build libcurdle_g1.so (HIP kernels for gfx950 + host C++ + C ABI) in-tree with hipcc.
+
+    python -m curdleproofs_pie_amd.build          # or: from curdleproofs_pie_amd.build import build; build()
+
+hipcc cross-compiles gfx950 without a GPU.  The .so is git-ignored but travels to the GPU box.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcurdle_g1.so")
+SOURCES = [os.path.join(CSRC, "msm_gpu.hip"), os.path.join(CSRC, "host_g1.cpp")]
+DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("fp28.h", "g1_xyzz.h", "host_g1.h", "bls_consts.h")] + [
+    os.path.join(HERE, "..", "include", "curdle_g1.h")
+]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libcurdle_g1.so (HIP toolchain required)")
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", *SOURCES, "-o", LIB + ".tmp"]
+    if verbose:
+        print("[curdleproofs_pie_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

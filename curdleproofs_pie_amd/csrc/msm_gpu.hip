@@ -1,0 +1,795 @@
+// MI355X (gfx950) Pippenger MSM over BLS12-381 G1 -- kernels and the per-device pipeline context.
+//
+// Replaces the hot loop of the reference's compute_MSM
+//   (/root/reference/curdleproofs/curdleproofs/msm_accumulator.py:6-12:  current += base * scalar)
+// with a signed-digit windowed-bucket method laid out for CDNA4:
+//
+//   k_prepare_points   96 B affine (std form)  -> 128 B records (x,y as 14x28-bit Montgomery limbs): one
+//                      aligned cache line per point, so the bucket gather below touches exactly one line.
+//   k_hist             per scalar: c-bit signed digits for this rank's windows -> per-bucket counts
+//   k_scan1/2/3        exclusive scan of (count, chunk count) per bucket  (chunk = <= Lb consecutive
+//                      entries of one bucket, Lb = max(L0, ceil(sqrt(count))) so a skewed bucket --
+//                      e.g. the reference's [beta]*ell all-equal scalars, same_perm.py:54-55 -- is split
+//                      into ~sqrt pieces instead of serialising one lane)
+//   k_scatter          counting-sort scatter: sorted[] = point index | sign<<31, grouped by bucket
+//   k_chunk_desc       (start,len) per chunk
+//   k_accumulate  ***  the dominant kernel: one lane per chunk, XYZZ mixed adds (8M+2S) over gathered points
+//   k_seg_reduce       per 4-bucket segment: run = sum B_k, tot = sum t*B_k   (running sums, depth 8)
+//   k_bit_tree         per (window, bit b of the segment index): tree-sum of the selected seg runs, in
+//                      registers -> wave shuffles -> LDS; emits canonical XYZZ words
+//   host tail          <= 256 doublings of Horner over <= nwin*(c-2) points (host_g1.cpp): a single lane's
+//                      EC op latency is ~20 us on the GPU vs ~0.5 us on a host core, so the strictly
+//                      serial tail belongs on the host.
+//
+// No MFMA: this is carry-propagating big-integer arithmetic.  The bound is the VALU integer-multiply
+// rate (v_mad_u64_u32), see fp28.h; HBM traffic is reported against the 8 TB/s roofline by bench.py.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include <chrono>
+#include "g1_xyzz.h"
+#include "host_g1.h"
+#include "../../include/curdle_g1.h"
+
+namespace cg1 {
+
+// ------------------------------------------------------------------ device records
+struct alignas(16) PreparedPoint {      // 128 B
+  uint32_t x[NL];
+  uint32_t y[NL];
+  uint32_t flags;                       // bit0: identity
+  uint32_t pad[3];
+};
+static_assert(sizeof(PreparedPoint) == 128, "one cache line per point");
+
+struct alignas(16) PointSum {           // 256 B: an XYZZ partial sum
+  uint32_t c[4][NL];
+  uint32_t inf;
+  uint32_t pad[7];
+};
+static_assert(sizeof(PointSum) == 256, "");
+
+struct alignas(16) PointWords {         // 208 B: canonical standard-form XYZZ (see xyzz_words)
+  uint32_t w[4][12];
+  uint32_t inf;
+  uint32_t pad[3];
+};
+static_assert(sizeof(PointWords) == 208, "");
+
+__device__ __forceinline__ void load_affine(const PreparedPoint* p, fp& x, fp& y, uint32_t& flags) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+  uint4 v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = q[i];
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(v);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { x.l[i] = w[i]; y.l[i] = w[NL + i]; }
+  flags = w[2 * NL];
+}
+
+__device__ __forceinline__ void store_sum(PointSum* dst, const xyzz& a) {
+  uint32_t w[64];
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { w[i] = a.X.l[i]; w[NL + i] = a.Y.l[i]; w[2 * NL + i] = a.ZZ.l[i]; w[3 * NL + i] = a.ZZZ.l[i]; }
+  w[4 * NL] = a.inf;
+#pragma unroll
+  for (int i = 4 * NL + 1; i < 64; ++i) w[i] = 0;
+  uint4* q = reinterpret_cast<uint4*>(dst);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+}
+
+__device__ __forceinline__ xyzz load_sum(const PointSum* src) {
+  const uint4* q = reinterpret_cast<const uint4*>(src);
+  uint32_t w[60];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) { uint4 v = q[i]; w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w; }
+  xyzz a;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) { a.X.l[i] = w[i]; a.Y.l[i] = w[NL + i]; a.ZZ.l[i] = w[2 * NL + i]; a.ZZZ.l[i] = w[3 * NL + i]; }
+  a.inf = w[4 * NL];
+  return a;
+}
+
+// ------------------------------------------------------------------ k_prepare_points
+__global__ void __launch_bounds__(256) k_prepare_points(const uint32_t* __restrict__ raw, PreparedPoint* __restrict__ out, uint32_t n) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(raw + 24ull * i);
+  uint32_t w[24];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { uint4 v = q[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+  uint32_t any = 0;
+#pragma unroll
+  for (int k = 0; k < 24; ++k) any |= w[k];
+  fp x = fp_to_mont(fp_from_words(w));
+  fp y = fp_to_mont(fp_from_words(w + 12));
+  uint32_t o[32];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) { o[k] = x.l[k]; o[NL + k] = y.l[k]; }
+  o[28] = any ? 0u : 1u;               // (0,0) is not on the curve: it encodes the identity
+  o[29] = o[30] = o[31] = 0;
+  uint4* d = reinterpret_cast<uint4*>(out + i);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+// ------------------------------------------------------------------ signed digit recoding
+// digit w of scalar s (LE words), window width c: value in [-(2^(c-1)-1), 2^(c-1)]
+struct DigitIter {
+  uint32_t s[8];
+  uint32_t carry;
+  int c;
+  __device__ __forceinline__ int next(int w) {         // must be called for w = 0,1,2,... in order
+    int bit = w * c;
+    uint32_t wi = bit >> 5, sh = bit & 31;
+    uint64_t v = (wi < 8) ? s[wi] : 0u;
+    if (wi + 1 < 8) v |= (uint64_t)s[wi + 1] << 32;
+    uint32_t raw = (uint32_t)(v >> sh) & ((1u << c) - 1u);
+    uint32_t d = raw + carry;
+    if (d > (1u << (c - 1))) { carry = 1; return (int)d - (1 << c); }
+    carry = 0;
+    return (int)d;
+  }
+};
+
+__device__ __forceinline__ void load_scalar(const uint32_t* scalars, uint32_t i, DigitIter& it) {
+  const uint4* q = reinterpret_cast<const uint4*>(scalars + 8ull * i);
+  uint4 a = q[0], b = q[1];
+  it.s[0] = a.x; it.s[1] = a.y; it.s[2] = a.z; it.s[3] = a.w;
+  it.s[4] = b.x; it.s[5] = b.y; it.s[6] = b.z; it.s[7] = b.w;
+  it.carry = 0;
+}
+
+// counts per (local window, bucket); skips zero digits and identity points
+__global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scalars, const PreparedPoint* __restrict__ pts,
+                                              uint32_t* __restrict__ hist, uint32_t n, int c, int nwin, int rank, int world) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (pts[i].flags & 1u) return;
+  DigitIter it; it.c = c;
+  load_scalar(scalars, i, it);
+  const uint32_t NB = 1u << (c - 1);
+  for (int w = 0; w < nwin; ++w) {
+    int d = it.next(w);
+    if (d == 0 || (w % world) != rank) continue;
+    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+    atomicAdd(&hist[(uint32_t)(w / world) * NB + b], 1u);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ scalars, const PreparedPoint* __restrict__ pts,
+                                                 uint32_t* __restrict__ cursor, const uint32_t* __restrict__ off,
+                                                 uint32_t* __restrict__ sorted, uint32_t n, int c, int nwin, int rank, int world) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (pts[i].flags & 1u) return;
+  DigitIter it; it.c = c;
+  load_scalar(scalars, i, it);
+  const uint32_t NB = 1u << (c - 1);
+  for (int w = 0; w < nwin; ++w) {
+    int d = it.next(w);
+    if (d == 0 || (w % world) != rank) continue;
+    uint32_t key = (uint32_t)(w / world) * NB + (uint32_t)(d < 0 ? -d : d) - 1u;
+    uint32_t slot = atomicSub(&cursor[key], 1u) - 1u;      // cursor starts at the bucket's count
+    sorted[off[key] + slot] = i | (d < 0 ? 0x80000000u : 0u);
+  }
+}
+
+// ------------------------------------------------------------------ scan of (count, chunks)
+__device__ __forceinline__ uint32_t isqrt_ceil(uint32_t v) {
+  uint32_t r = (uint32_t)sqrtf((float)v);
+  while ((uint64_t)r * r < v) ++r;
+  while (r > 0 && (uint64_t)(r - 1) * (r - 1) >= v) --r;
+  return r;
+}
+__device__ __forceinline__ uint32_t chunk_len(uint32_t cnt, uint32_t L0) {
+  uint32_t s = isqrt_ceil(cnt);
+  return s > L0 ? s : L0;
+}
+__device__ __forceinline__ uint32_t chunk_count(uint32_t cnt, uint32_t L0) {
+  if (cnt == 0) return 0;
+  uint32_t L = chunk_len(cnt, L0);
+  return (cnt + L - 1) / L;
+}
+
+constexpr int SCAN_ITEMS = 1024;        // per block of 256 threads
+// phase 1: per-block exclusive scan, block totals out
+__global__ void __launch_bounds__(256) k_scan1(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ choff,
+                                               uint2* __restrict__ block_tot, uint32_t nb_total, uint32_t L0) {
+  __shared__ uint2 sh[256];
+  uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  uint32_t cnt[4], ch[4];
+  uint2 local = make_uint2(0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cnt[k] = (base + k < nb_total) ? hist[base + k] : 0u;
+    ch[k] = chunk_count(cnt[k], L0);
+    local.x += cnt[k]; local.y += ch[k];
+  }
+  sh[threadIdx.x] = local;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {          // Hillis-Steele inclusive scan over 256 partials
+    uint2 v = make_uint2(0, 0);
+    if ((int)threadIdx.x >= d) v = sh[threadIdx.x - d];
+    __syncthreads();
+    sh[threadIdx.x].x += v.x; sh[threadIdx.x].y += v.y;
+    __syncthreads();
+  }
+  uint2 excl = make_uint2(sh[threadIdx.x].x - local.x, sh[threadIdx.x].y - local.y);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < nb_total) { off[base + k] = excl.x; choff[base + k] = excl.y; }
+    excl.x += cnt[k]; excl.y += ch[k];
+  }
+  if (threadIdx.x == 255) block_tot[blockIdx.x] = sh[255];
+}
+// phase 2: one block turns block totals into exclusive block prefixes (serial over tiles of 256)
+__global__ void __launch_bounds__(256) k_scan2(uint2* __restrict__ block_tot, uint32_t nblocks, uint32_t* __restrict__ off,
+                                               uint32_t* __restrict__ choff, uint32_t nb_total) {
+  __shared__ uint2 sh[256];
+  uint2 carry = make_uint2(0, 0);
+  for (uint32_t tile = 0; tile < nblocks; tile += 256) {
+    uint32_t i = tile + threadIdx.x;
+    uint2 v = (i < nblocks) ? block_tot[i] : make_uint2(0, 0);
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      uint2 u = make_uint2(0, 0);
+      if ((int)threadIdx.x >= d) u = sh[threadIdx.x - d];
+      __syncthreads();
+      sh[threadIdx.x].x += u.x; sh[threadIdx.x].y += u.y;
+      __syncthreads();
+    }
+    if (i < nblocks) block_tot[i] = make_uint2(carry.x + sh[threadIdx.x].x - v.x, carry.y + sh[threadIdx.x].y - v.y);
+    uint2 tot = sh[255];
+    __syncthreads();
+    carry.x += tot.x; carry.y += tot.y;
+  }
+  if (threadIdx.x == 0) { off[nb_total] = carry.x; choff[nb_total] = carry.y; }
+}
+__global__ void __launch_bounds__(256) k_scan3(const uint2* __restrict__ block_tot, uint32_t* __restrict__ off,
+                                               uint32_t* __restrict__ choff, uint32_t nb_total) {
+  uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  uint2 p = block_tot[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (base + k < nb_total) { off[base + k] += p.x; choff[base + k] += p.y; }
+}
+
+__global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__ off, const uint32_t* __restrict__ choff,
+                                                    uint2* __restrict__ desc, uint32_t nb_total, uint32_t L0) {
+  uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nb_total) return;
+  uint32_t start = off[b], cnt = off[b + 1] - start;
+  if (cnt == 0) return;
+  uint32_t L = chunk_len(cnt, L0), nch = (cnt + L - 1) / L, o = choff[b];
+  for (uint32_t k = 0; k < nch; ++k) {
+    uint32_t s = k * L;
+    desc[o + k] = make_uint2(start + s, (cnt - s < L) ? (cnt - s) : L);
+  }
+}
+
+// ------------------------------------------------------------------ k_accumulate (dominant kernel)
+__global__ void __launch_bounds__(256) k_accumulate(const uint2* __restrict__ desc, const uint32_t* __restrict__ total_chunks,
+                                                    const uint32_t* __restrict__ sorted, const PreparedPoint* __restrict__ pts,
+                                                    PointSum* __restrict__ sums) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= *total_chunks) return;
+  uint2 d = desc[t];
+  xyzz acc = xyzz_identity();
+  for (uint32_t j = 0; j < d.y; ++j) {
+    uint32_t e = sorted[d.x + j];
+    fp x, y; uint32_t flags;
+    load_affine(pts + (e & 0x7fffffffu), x, y, flags);
+    if (e >> 31) y = fp_neg<3>(y);
+    acc = xyzz_madd(acc, x, y);
+  }
+  store_sum(sums + t, acc);
+}
+
+// ------------------------------------------------------------------ k_seg_reduce
+// One lane per segment of `m` consecutive buckets of one window.  Bucket b of the window carries digit
+// value b+1.  Emits run_j = sum_t B_{jm+t}, tot_j = sum_t (t+1) B_{jm+t}  (t = 0..m-1).
+__global__ void __launch_bounds__(256) k_seg_reduce(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+                                                    PointSum* __restrict__ seg_run, PointSum* __restrict__ seg_tot,
+                                                    uint32_t nseg_total, uint32_t m) {
+  uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nseg_total) return;
+  xyzz run = xyzz_identity(), tot = xyzz_identity();
+  for (int t = (int)m - 1; t >= 0; --t) {
+    uint32_t b = s * m + (uint32_t)t;           // segments tile the flat (window, bucket) array
+    uint32_t c0 = choff[b], c1 = choff[b + 1];
+    for (uint32_t k = c0; k < c1; ++k) run = xyzz_add(run, load_sum(sums + k));
+    tot = xyzz_add(tot, run);
+  }
+  store_sum(seg_run + s, run);
+  store_sum(seg_tot + s, tot);
+}
+
+// ------------------------------------------------------------------ k_bit_tree
+__device__ __forceinline__ xyzz shfl_down_xyzz(const xyzz& a, int delta) {
+  xyzz r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    r.X.l[i] = __shfl_down(a.X.l[i], delta, 64);
+    r.Y.l[i] = __shfl_down(a.Y.l[i], delta, 64);
+    r.ZZ.l[i] = __shfl_down(a.ZZ.l[i], delta, 64);
+    r.ZZZ.l[i] = __shfl_down(a.ZZZ.l[i], delta, 64);
+  }
+  r.inf = __shfl_down(a.inf, delta, 64);
+  return r;
+}
+
+// grid = (nitems, nlw).  item 0: T = sum_j seg_tot[j];  item 1+b: Y_b = sum_{j: bit b of j} seg_run[j].
+__global__ void __launch_bounds__(256) k_bit_tree(const PointSum* __restrict__ seg_run, const PointSum* __restrict__ seg_tot,
+                                                  PointWords* __restrict__ out, uint32_t J) {
+  __shared__ PointSum sh[4];
+  const uint32_t item = blockIdx.x, lw = blockIdx.y;
+  const PointSum* src = (item == 0 ? seg_tot : seg_run) + (size_t)lw * J;
+  xyzz acc = xyzz_identity();
+  for (uint32_t j = threadIdx.x; j < J; j += 256) {
+    if (item == 0 || ((j >> (item - 1)) & 1u)) acc = xyzz_add(acc, load_sum(src + j));
+  }
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    xyzz o = shfl_down_xyzz(acc, delta);
+    if ((threadIdx.x & 63) < (uint32_t)delta) acc = xyzz_add(acc, o);
+  }
+  if ((threadIdx.x & 63) == 0) store_sum(&sh[threadIdx.x >> 6], acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) acc = xyzz_add(acc, load_sum(&sh[k]));
+    xyzz_words o;
+    xyzz_export(acc, o);
+    PointWords* dst = out + (size_t)lw * gridDim.x + item;
+    for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
+    dst->inf = o.inf;
+  }
+}
+
+// ------------------------------------------------------------------ fixed/variable-base batch scalar mul
+// out[i] = k_i * P_i (affine std words, identity -> zeros).  P_i = base[i % nbase].  Used to synthesise
+// benchmark/test points (k_i * G: the reference's get_random_point, util.py:67-68) and as the batched
+// counterpart of `G1Point * Scalar`.
+__global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ base_raw, uint32_t nbase,
+                                                   const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out_raw, uint32_t n) {
+  uint32_t i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[24];
+  const uint32_t* src = base_raw + 24ull * (i % nbase);
+  uint32_t any = 0;
+  for (int k = 0; k < 24; ++k) { w[k] = src[k]; any |= w[k]; }
+  uint32_t s[8];
+  for (int k = 0; k < 8; ++k) s[k] = scalars[8ull * i + k];
+  xyzz acc = xyzz_identity();
+  if (any) {
+    fp x = fp_to_mont(fp_from_words(w)), y = fp_to_mont(fp_from_words(w + 12));
+    for (int bit = 255; bit >= 0; --bit) {
+      acc = xyzz_dbl(acc);
+      if ((s[bit >> 5] >> (bit & 31)) & 1u) acc = xyzz_madd(acc, x, y);
+    }
+  }
+  uint32_t* dst = out_raw + 24ull * i;
+  if (acc.inf) { for (int k = 0; k < 24; ++k) dst[k] = 0; return; }
+  fp izz = fp_inv(acc.ZZ), izzz = fp_inv(acc.ZZZ);
+  uint32_t o[12];
+  fp_to_words(fp_mul(acc.X, izz), o);  for (int k = 0; k < 12; ++k) dst[k] = o[k];
+  fp_to_words(fp_mul(acc.Y, izzz), o); for (int k = 0; k < 12; ++k) dst[12 + k] = o[k];
+}
+
+// splitmix64-derived scalars in [1, 2^252): deterministic synthetic scalars (always < r)
+__global__ void __launch_bounds__(256) k_gen_scalars(uint32_t* __restrict__ out, uint32_t n, uint64_t seed) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t st = seed + 0x9E3779B97F4A7C15ull * (4ull * i + 1);
+  uint64_t v[4];
+  for (int k = 0; k < 4; ++k) {
+    st += 0x9E3779B97F4A7C15ull;
+    uint64_t z = st;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    v[k] = z ^ (z >> 31);
+  }
+  v[3] &= 0x0FFFFFFFFFFFFFFFull;       // < 2^252 < r
+  v[0] |= 1ull;                          // non-zero
+  for (int k = 0; k < 4; ++k) { out[8ull * i + 2 * k] = (uint32_t)v[k]; out[8ull * i + 2 * k + 1] = (uint32_t)(v[k] >> 32); }
+}
+
+// throughput probe: `iters` dependent mixed adds per lane on register-resident data (roofline of k_accumulate)
+__global__ void __launch_bounds__(256) k_probe_madd(const PreparedPoint* __restrict__ pts, uint32_t npts, PointSum* __restrict__ out, int iters) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  fp x, y; uint32_t flags;
+  load_affine(pts + (t % npts), x, y, flags);
+  fp x2, y2;
+  load_affine(pts + ((t + 1) % npts), x2, y2, flags);
+  xyzz acc = xyzz_from_affine(x, y);
+  for (int i = 0; i < iters; ++i) acc = xyzz_madd(acc, x2, y2);
+  store_sum(out + t, acc);
+}
+
+// ------------------------------------------------------------------ host-side context
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+  snprintf(ctx->err, sizeof ctx->err, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return CG1_ERR_HIP; } } while (0)
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  char err[256] = {0};
+  // capacity
+  size_t cap_n = 0, cap_nb = 0, cap_chunks = 0, cap_entries = 0, cap_out = 0;
+  PreparedPoint* d_pts = nullptr;
+  uint32_t *d_hist = nullptr, *d_off = nullptr, *d_choff = nullptr, *d_sorted = nullptr;
+  uint2 *d_blocktot = nullptr, *d_desc = nullptr;
+  PointSum *d_sums = nullptr, *d_segrun = nullptr, *d_segtot = nullptr;
+  PointWords* d_out = nullptr;
+  PointWords* h_out = nullptr;          // pinned
+  // staging for host-pointer entry points
+  void* d_stage_pts = nullptr; void* d_stage_sc = nullptr; size_t cap_stage = 0;
+  // timing
+  hipEvent_t ev[CG1_NPHASE + 1];
+  float phase_ms[CG1_NPHASE] = {0};
+  float host_tail_ms = 0;
+  uint32_t last_chunks = 0, last_entries = 0;
+  int last_c = 0;
+  uint32_t L0 = 64;
+  uint32_t seg_m = 4;
+};
+
+static void free_bufs(Ctx* c) {
+  auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+  F(c->d_pts); F(c->d_hist); F(c->d_off); F(c->d_choff); F(c->d_sorted); F(c->d_blocktot); F(c->d_desc);
+  F(c->d_sums); F(c->d_segrun); F(c->d_segtot); F(c->d_out);
+  if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
+  c->cap_n = c->cap_nb = c->cap_chunks = c->cap_entries = c->cap_out = 0;
+}
+
+static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems) {
+  size_t entries = n * nlw;
+  size_t chunks = nb_total + entries / ctx->L0 + 1;
+  if (n > ctx->cap_n) {
+    if (ctx->d_pts) (void)hipFree(ctx->d_pts);
+    HIPCHK(hipMalloc(&ctx->d_pts, n * sizeof(PreparedPoint)));
+    ctx->cap_n = n;
+  }
+  if (nb_total > ctx->cap_nb) {
+    auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+    F(ctx->d_hist); F(ctx->d_off); F(ctx->d_choff); F(ctx->d_blocktot); F(ctx->d_segrun); F(ctx->d_segtot);
+    HIPCHK(hipMalloc(&ctx->d_hist, nb_total * 4));
+    HIPCHK(hipMalloc(&ctx->d_off, (nb_total + 1) * 4));
+    HIPCHK(hipMalloc(&ctx->d_choff, (nb_total + 1) * 4));
+    HIPCHK(hipMalloc(&ctx->d_blocktot, (nb_total / SCAN_ITEMS + 2) * sizeof(uint2)));
+    HIPCHK(hipMalloc(&ctx->d_segrun, nb_total * sizeof(PointSum)));   // >= nb_total / m segments
+    HIPCHK(hipMalloc(&ctx->d_segtot, nb_total * sizeof(PointSum)));
+    ctx->cap_nb = nb_total;
+  }
+  if (entries > ctx->cap_entries) {
+    if (ctx->d_sorted) (void)hipFree(ctx->d_sorted);
+    HIPCHK(hipMalloc(&ctx->d_sorted, (entries + 1) * 4));
+    ctx->cap_entries = entries;
+  }
+  if (chunks > ctx->cap_chunks) {
+    if (ctx->d_desc) (void)hipFree(ctx->d_desc);
+    if (ctx->d_sums) (void)hipFree(ctx->d_sums);
+    HIPCHK(hipMalloc(&ctx->d_desc, chunks * sizeof(uint2)));
+    HIPCHK(hipMalloc(&ctx->d_sums, chunks * sizeof(PointSum)));
+    ctx->cap_chunks = chunks;
+  }
+  size_t nout = nlw * nitems;
+  if (nout > ctx->cap_out) {
+    if (ctx->d_out) (void)hipFree(ctx->d_out);
+    if (ctx->h_out) (void)hipHostFree(ctx->h_out);
+    HIPCHK(hipMalloc(&ctx->d_out, nout * sizeof(PointWords)));
+    HIPCHK(hipHostMalloc(&ctx->h_out, nout * sizeof(PointWords)));
+    ctx->cap_out = nout;
+  }
+  return CG1_OK;
+}
+
+static cg1h::fe fe_from_words12(const uint32_t w[12]) {
+  uint64_t v[6];
+  for (int i = 0; i < 6; ++i) v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+  return cg1h::fe_from_std(v);
+}
+static cg1h::jac jac_from_words(const PointWords& p) {
+  if (p.inf) return cg1h::jac_identity();
+  return cg1h::jac_from_xyzz(fe_from_words12(p.w[0]), fe_from_words12(p.w[1]), fe_from_words12(p.w[2]), fe_from_words12(p.w[3]));
+}
+
+int pick_window(size_t n) {
+  // c minimising  nwin*n (bucket adds)  +  nwin * 2^(c-1) * ~3 (reduction adds, weighted for their latency)
+  int best = 4; double best_cost = 1e300;
+  for (int c = 4; c <= 16; ++c) {
+    int nwin = 255 / c + 1;
+    double cost = (double)nwin * ((double)n + 3.0 * (double)(1u << (c - 1)));
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
+  result = cg1h::jac_identity();
+  if (n == 0) return CG1_OK;
+  if (n >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "n too large"); return CG1_ERR_ARG; }
+  if (world < 1 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
+  if (c <= 0) c = pick_window(n);
+  if (c < 4 || c > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const int nwin = 255 / c + 1;
+  const int nlw = (nwin - rank + world - 1) / world;           // windows w = rank, rank+world, ...
+  if (nlw <= 0) return CG1_OK;
+  const uint32_t NB = 1u << (c - 1);
+  const uint32_t m = std::min<uint32_t>(ctx->seg_m, NB);
+  const uint32_t J = NB / m;                                   // segments per window
+  int nbits = 0; while ((1u << nbits) < J) ++nbits;
+  const uint32_t nitems = 1 + nbits;
+  const size_t nb_total = (size_t)nlw * NB;
+  int rc = ensure(ctx, n, nb_total, nlw, nitems);
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  const uint32_t n32 = (uint32_t)n;
+  const uint32_t gn = (n32 + 255) / 256;
+
+  HIPCHK(hipEventRecord(ctx->ev[0], st));
+  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, n32);
+  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
+  hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_hist, n32, c, nwin, rank, world);
+  HIPCHK(hipEventRecord(ctx->ev[2], st));
+  const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
+  hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, ctx->L0);
+  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+  hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+  HIPCHK(hipEventRecord(ctx->ev[3], st));
+  hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, c, nwin, rank, world);
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, (uint32_t)nb_total, ctx->L0);
+  HIPCHK(hipEventRecord(ctx->ev[4], st));
+  const size_t max_chunks = nb_total + (n * (size_t)nlw) / ctx->L0 + 1;
+  hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((max_chunks + 255) / 256)), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
+  HIPCHK(hipEventRecord(ctx->ev[5], st));
+  const uint32_t nseg_total = (uint32_t)(nb_total / m);
+  hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
+  HIPCHK(hipEventRecord(ctx->ev[6], st));
+  hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_out, J);
+  HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)nlw * nitems * sizeof(PointWords), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(ctx->ev[7], st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  ctx->last_c = c;
+
+  // ---- host tail: Horner.  V_w = T_w + m * sum_b 2^b Y_{w,b};  result = sum_w 2^(c w) V_w.
+  auto t0 = std::chrono::steady_clock::now();
+  int lm = 0; while ((1u << lm) < m) ++lm;
+  cg1h::jac acc = cg1h::jac_identity();
+  int prev_w = -1;
+  for (int lw = nlw - 1; lw >= 0; --lw) {
+    const int w = rank + lw * world;
+    if (prev_w >= 0) for (int k = 0; k < c * (prev_w - w); ++k) acc = cg1h::jac_dbl(acc);
+    const PointWords* row = ctx->h_out + (size_t)lw * nitems;
+    cg1h::jac v = cg1h::jac_identity();
+    for (int b = nbits - 1; b >= 0; --b) { v = cg1h::jac_dbl(v); v = cg1h::jac_add(v, jac_from_words(row[1 + b])); }
+    for (int k = 0; k < lm; ++k) v = cg1h::jac_dbl(v);
+    v = cg1h::jac_add(v, jac_from_words(row[0]));
+    acc = cg1h::jac_add(acc, v);
+    prev_w = w;
+  }
+  for (int k = 0; k < c * prev_w; ++k) acc = cg1h::jac_dbl(acc);
+  result = acc;
+  ctx->host_tail_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return CG1_OK;
+}
+
+
+}  // namespace cg1
+
+// ================================================================== C ABI (include/curdle_g1.h)
+using cg1::Ctx;
+struct cg1_ctx : public cg1::Ctx {};
+
+static inline cg1h::jac blob_in(const uint8_t* b) { cg1h::jac j; memcpy(&j, b, sizeof j); return j; }
+static inline void blob_out(uint8_t* b, const cg1h::jac& j) { memcpy(b, &j, sizeof j); }
+static_assert(sizeof(cg1h::jac) == CG1_POINT_BYTES, "point blob size");
+
+extern "C" {
+
+void cg1_identity(uint8_t* out) { blob_out(out, cg1h::jac_identity()); }
+void cg1_generator(uint8_t* out) { blob_out(out, cg1h::jac_generator()); }
+void cg1_add(uint8_t* out, const uint8_t* a, const uint8_t* b) { blob_out(out, cg1h::jac_add(blob_in(a), blob_in(b))); }
+void cg1_sub(uint8_t* out, const uint8_t* a, const uint8_t* b) { blob_out(out, cg1h::jac_add(blob_in(a), cg1h::jac_neg(blob_in(b)))); }
+void cg1_neg(uint8_t* out, const uint8_t* a) { blob_out(out, cg1h::jac_neg(blob_in(a))); }
+void cg1_double(uint8_t* out, const uint8_t* a) { blob_out(out, cg1h::jac_dbl(blob_in(a))); }
+void cg1_mul(uint8_t* out, const uint8_t* a, const uint8_t* k) { blob_out(out, cg1h::jac_mul(blob_in(a), k)); }
+int cg1_eq(const uint8_t* a, const uint8_t* b) { return cg1h::jac_eq(blob_in(a), blob_in(b)) ? 1 : 0; }
+int cg1_is_identity(const uint8_t* a) { return cg1h::jac_is_identity(blob_in(a)) ? 1 : 0; }
+void cg1_compress(uint8_t* out48, const uint8_t* a) { cg1h::g1_compress(blob_in(a), out48); }
+static int map_dec(int rc) {
+  switch (rc) { case 0: return CG1_OK; case 1: case 2: return CG1_ERR_ENCODING; case 3: return CG1_ERR_NOT_ON_CURVE; default: return CG1_ERR_NOT_IN_SUBGROUP; }
+}
+int cg1_decompress(uint8_t* out, const uint8_t* in48, int check_subgroup) {
+  cg1h::jac j;
+  int rc = cg1h::g1_decompress(in48, check_subgroup != 0, j);
+  if (rc == 0) blob_out(out, j);
+  return map_dec(rc);
+}
+void cg1_to_affine96(uint8_t* out96, const uint8_t* a) {
+  cg1h::fe x, y; bool inf;
+  cg1h::jac_to_affine(blob_in(a), x, y, inf);
+  if (inf) { memset(out96, 0, 96); return; }
+  cg1h::fe_to_le48(x, out96); cg1h::fe_to_le48(y, out96 + 48);
+}
+int cg1_from_affine96(uint8_t* out, const uint8_t* in96, int check_on_curve) {
+  bool any = false;
+  for (int i = 0; i < 96; ++i) any = any || in96[i];
+  if (!any) { blob_out(out, cg1h::jac_identity()); return CG1_OK; }
+  cg1h::fe x, y;
+  if (!cg1h::fe_from_le48(in96, x) || !cg1h::fe_from_le48(in96 + 48, y)) return CG1_ERR_ENCODING;
+  cg1h::jac j = cg1h::jac_from_affine(x, y);
+  if (check_on_curve && !cg1h::jac_on_curve(j)) return CG1_ERR_NOT_ON_CURVE;
+  blob_out(out, j);
+  return CG1_OK;
+}
+void cg1_batch_to_affine96(uint8_t* out96, const uint8_t* blobs, size_t n) {
+  std::vector<cg1h::jac> pts(n);
+  std::vector<cg1h::fe> xs(n), ys(n);
+  std::vector<uint8_t> inf(n);
+  for (size_t i = 0; i < n; ++i) pts[i] = blob_in(blobs + CG1_POINT_BYTES * i);
+  cg1h::jac_batch_to_affine(pts.data(), n, xs.data(), ys.data(), inf.data());
+  for (size_t i = 0; i < n; ++i) {
+    uint8_t* o = out96 + 96 * i;
+    if (inf[i]) { memset(o, 0, 96); continue; }
+    cg1h::fe_to_le48(xs[i], o); cg1h::fe_to_le48(ys[i], o + 48);
+  }
+}
+int cg1_batch_decompress(uint8_t* out_blobs, const uint8_t* in48, size_t n, int check_subgroup, size_t* bad_index) {
+  for (size_t i = 0; i < n; ++i) {
+    int rc = cg1_decompress(out_blobs + CG1_POINT_BYTES * i, in48 + 48 * i, check_subgroup);
+    if (rc) { if (bad_index) *bad_index = i; return rc; }
+  }
+  return CG1_OK;
+}
+void cg1_batch_compress(uint8_t* out48, const uint8_t* blobs, size_t n) {
+  std::vector<cg1h::jac> pts(n);
+  std::vector<cg1h::fe> xs(n), ys(n);
+  std::vector<uint8_t> inf(n);
+  for (size_t i = 0; i < n; ++i) pts[i] = blob_in(blobs + CG1_POINT_BYTES * i);
+  cg1h::jac_batch_to_affine(pts.data(), n, xs.data(), ys.data(), inf.data());
+  for (size_t i = 0; i < n; ++i) {
+    uint8_t* o = out48 + 48 * i;
+    if (inf[i]) { memset(o, 0, 48); o[0] = 0xC0; continue; }
+    cg1h::fe_to_be48(xs[i], o);
+    o[0] |= 0x80;
+    if (cg1h::fe_lex_largest(ys[i])) o[0] |= 0x20;
+  }
+}
+
+// ---------------------------------------------------------------- device
+int cg1_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+cg1_ctx* cg1_ctx_create(int device) {
+  int n = cg1_device_count();
+  if (device < 0 || device >= n) return nullptr;
+  if (hipSetDevice(device) != hipSuccess) return nullptr;
+  cg1_ctx* ctx = new cg1_ctx();
+  ctx->device = device;
+  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+  for (int i = 0; i <= CG1_NPHASE; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return nullptr; }
+  return ctx;
+}
+void cg1_ctx_destroy(cg1_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  cg1::free_bufs(ctx);
+  if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
+  if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
+  for (int i = 0; i <= CG1_NPHASE; ++i) (void)hipEventDestroy(ctx->ev[i]);
+  (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+const char* cg1_ctx_error(const cg1_ctx* ctx) { return ctx ? ctx->err : "null context (no GPU visible?)"; }
+
+void* cg1_dev_malloc(cg1_ctx* ctx, size_t bytes) {
+  if (!ctx) return nullptr;
+  void* p = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+  return p;
+}
+void cg1_dev_free(cg1_ctx* ctx, void* p) { if (ctx && p) { (void)hipSetDevice(ctx->device); (void)hipFree(p); } }
+int cg1_h2d(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return CG1_ERR_HIP;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+  return CG1_OK;
+}
+int cg1_d2h(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return CG1_ERR_HIP;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return CG1_OK;
+}
+int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return CG1_ERR_ARG;
+  if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
+  if (!strcmp(name, "seg_m")) { if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return CG1_ERR_ARG; ctx->seg_m = (uint32_t)value; return CG1_OK; }
+  return CG1_ERR_ARG;
+}
+
+int cg1_msm_device(cg1_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, int window_c, int shard_rank,
+                   int shard_world, uint8_t* out) {
+  if (!ctx) return CG1_ERR_HIP;
+  cg1h::jac r;
+  int rc = cg1::msm_device(ctx, d_points, d_scalars, n, window_c, shard_rank, shard_world, r);
+  if (rc == CG1_OK) blob_out(out, r);
+  return rc;
+}
+
+int cg1_msm(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars, size_t n, uint8_t* out) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) { blob_out(out, cg1h::jac_identity()); return CG1_OK; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n > ctx->cap_stage) {
+    if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
+    if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
+    ctx->d_stage_pts = ctx->d_stage_sc = nullptr; ctx->cap_stage = 0;
+    HIPCHK(hipMalloc(&ctx->d_stage_pts, n * 96));
+    HIPCHK(hipMalloc(&ctx->d_stage_sc, n * 32));
+    ctx->cap_stage = n;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return cg1_msm_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, n, 0, 0, 1, out);
+}
+
+int cg1_get_timings(const cg1_ctx* ctx, float* phase_ms, float* host_tail_ms, int* window_c) {
+  if (!ctx) return CG1_ERR_ARG;
+  if (phase_ms) for (int i = 0; i < CG1_NPHASE; ++i) phase_ms[i] = ctx->phase_ms[i];
+  if (host_tail_ms) *host_tail_ms = ctx->host_tail_ms;
+  if (window_c) *window_c = ctx->last_c;
+  return CG1_OK;
+}
+
+int cg1_batch_mul_device(cg1_ctx* ctx, const void* d_bases, size_t nbase, const void* d_scalars, void* d_out, size_t n) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (nbase == 0 && n) return CG1_ERR_ARG;
+  if (n == 0) return CG1_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(cg1::k_batch_mul, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                     (const uint32_t*)d_bases, (uint32_t)nbase, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
+int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) return CG1_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(cg1::k_gen_scalars, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (uint32_t*)d_out, (uint32_t)n, seed);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
+int cg1_probe_madd(cg1_ctx* ctx, const void* d_points, size_t npts, size_t lanes, int iters, float* ms) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (npts == 0 || lanes == 0 || lanes % 256) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  cg1::PreparedPoint* prep = nullptr; cg1::PointSum* out = nullptr;
+  HIPCHK(hipMalloc(&prep, npts * sizeof(cg1::PreparedPoint)));
+  HIPCHK(hipMalloc(&out, lanes * sizeof(cg1::PointSum)));
+  hipLaunchKernelGGL(cg1::k_prepare_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_points, prep, (uint32_t)npts);
+  hipLaunchKernelGGL(cg1::k_probe_madd, dim3((unsigned)(lanes / 256)), dim3(256), 0, ctx->stream, prep, (uint32_t)npts, out, 2);
+  HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+  hipLaunchKernelGGL(cg1::k_probe_madd, dim3((unsigned)(lanes / 256)), dim3(256), 0, ctx->stream, prep, (uint32_t)npts, out, iters);
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
+  (void)hipFree(prep); (void)hipFree(out);
+  return CG1_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+"""GPU-backed `compute_MSM` / `MSMAccumulator` -- same names, arguments and error behaviour as
+/root/reference/curdleproofs/curdleproofs/msm_accumulator.py:6-68, with the hot loop on the MI355X.
+
+    from curdleproofs_pie_amd.msm_accumulator import MSMAccumulator, compute_MSM
+
+There is no CPU fallback: without a GPU (or without libcurdle_g1.so) these raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, List, Tuple
+
+from . import _native as N
+from .py_arkworks_bls12381 import CURVE_ORDER, G1Point, Scalar, points_to_affine96, points_to_compressed
+from .util import random_scalar
+
+_ZERO96 = bytes(96)
+
+
+def compute_MSM(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> G1Point:
+    """sum_i scalars[i] * bases[i]  (msm_accumulator.py:6-12).
+
+    `zip` semantics like the reference: any iterables, truncated to the shorter (the reference's tests pass a
+    `map` object, test_curdleproofs.py:432).  Neither argument is retained or mutated.
+    """
+    pairs = list(zip(bases, scalars))
+    n = len(pairs)
+    if n == 0:
+        return G1Point.identity()  # msm_accumulator.py:9
+    pts = points_to_affine96([p for p, _ in pairs])
+    sc = b"".join(s._v.to_bytes(32, "little") for _, s in pairs)
+    out = N.default_context().msm_host(pts, sc, n)
+    return G1Point._from_blob(out)
+
+
+class MSMAccumulator:
+    """Random-linear-combination batching of `C == MSM(bases, scalars)` checks (msm_accumulator.py:32-68).
+
+    Same observable behaviour: one `random_scalar()` draw per `accumulate_check` (so seeded runs draw in the
+    same order, :43), identity bases skipped (:49-50), equal bases merged by their 48-byte compression (:54-58),
+    `verify()` raises AssertionError on mismatch (:68) and ValueError when nothing was accumulated (:63).
+    Internals differ where the reference wastes work (its own TODO at :52-53): keys come from ONE batched
+    normalisation per call, the affine form is kept next to the key so nothing is decompressed again (:65),
+    and the left-hand sides `rho_i * C_i` join the final GPU MSM instead of costing a scalar-mul each (:45):
+        sum_j s_j B_j - sum_i rho_i C_i == 0.
+    """
+
+    def __init__(self) -> None:
+        self._lhs: List[Tuple[bytes, int]] = []           # (affine96 of C_i, rho_i)
+        self.base_scalar_map: Dict[bytes, List] = {}       # compressed48 -> [scalar int, affine96]
+
+    @property
+    def A_c(self) -> G1Point:  # the reference's running left-hand side (:45); computed on demand
+        n = len(self._lhs)
+        if n == 0:
+            return G1Point.identity()
+        out = N.default_context().msm_host(b"".join(a for a, _ in self._lhs),
+                                           b"".join(r.to_bytes(32, "little") for _, r in self._lhs), n)
+        return G1Point._from_blob(out)
+
+    def accumulate_check(self, C: G1Point, bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> None:
+        random_factor = random_scalar()  # :43  (exactly one draw per call)
+        rho = random_factor._v
+        pairs = list(zip(bases, scalars))  # :47
+        pts = [C] + [b for b, _ in pairs]
+        aff = points_to_affine96(pts)
+        keys = points_to_compressed(pts)
+        self._lhs.append((aff[:96], rho))
+        m = self.base_scalar_map
+        for i, (_, scalar) in enumerate(pairs, start=1):
+            a = aff[96 * i: 96 * i + 96]
+            if a == _ZERO96:  # :49-50 zero bases contribute nothing
+                continue
+            k = keys[i]
+            ent = m.get(k)
+            if ent is None:
+                m[k] = [rho * scalar._v % CURVE_ORDER, a]
+            else:
+                ent[0] = (ent[0] + rho * scalar._v) % CURVE_ORDER  # :58
+
+    def verify(self) -> None:
+        if not self.base_scalar_map:
+            # the reference unpacks `zip(*{}.items())` into two names (:63)
+            raise ValueError("not enough values to unpack (expected 2, got 0)")
+        ents = list(self.base_scalar_map.values())
+        pts = b"".join(e[1] for e in ents) + b"".join(a for a, _ in self._lhs)
+        sc = b"".join(e[0].to_bytes(32, "little") for e in ents) + b"".join(
+            ((-r) % CURVE_ORDER).to_bytes(32, "little") for _, r in self._lhs)
+        n = len(ents) + len(self._lhs)
+        out = N.default_context().msm_host(pts, sc, n)
+        assert N.cg1_is_identity(out) == 1  # computed == self.A_c  (:68)

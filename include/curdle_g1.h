@@ -1,0 +1,104 @@
+/* curdle_g1.h -- C ABI of libcurdle_g1.so: the MI355X-native BLS12-381 G1 / MSM engine that drops in
+ * behind curdleproofs.pie's compute_MSM / MSMAccumulator and the G1Point surface of py_arkworks_bls12381.
+ *
+ * The reference has no FFI of its own: its boundary is the Python import
+ *     from py_arkworks_bls12381 import G1Point, Scalar
+ * (curdleproofs/curdleproofs/util.py:4, msm_accumulator.py:3, ...) plus
+ *     from curdleproofs.msm_accumulator import MSMAccumulator, compute_MSM
+ * (curdleproofs.py:17, ipa.py:23, grand_prod.py:17, same_msm.py:19, same_perm.py:14).
+ * Each entry point below names the reference interface it stands behind.  The ctypes binding a
+ * maintainer adds is shown in INTEGRATION.md (and lives in curdleproofs_pie_amd/_native.py).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns an int status (CG1_OK == 0) unless it
+ *     cannot fail; no exceptions cross the boundary; no global mutable state outside a cg1_ctx.
+ *   - "point blob": 144 opaque bytes (host Jacobian X,Y,Z; 6x64-bit Montgomery limbs each).
+ *   - "affine96": x || y, each a 48-byte little-endian integer < p in standard (non-Montgomery) form;
+ *     the all-zero record encodes the identity ((0,0) is not on the curve).
+ *   - "scalar32": 32-byte little-endian canonical Fr element (< r), as Scalar.to_le_bytes() returns.
+ *   - "compressed48": the 48-byte ZCash-format compression G1Point.to_compressed_bytes() returns.
+ *   - device entry points fail with CG1_ERR_HIP when no GPU / HIP error; there is NO CPU fallback.
+ */
+#ifndef CURDLE_G1_H
+#define CURDLE_G1_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CG1_OK            0
+#define CG1_ERR_ARG       1   /* bad argument (size, window width, shard spec) */
+#define CG1_ERR_HIP       2   /* HIP runtime error or no device; message via cg1_ctx_error */
+#define CG1_ERR_ENCODING  3   /* malformed compressed48 / affine96 / scalar32 -> Python ValueError */
+#define CG1_ERR_NOT_ON_CURVE 4
+#define CG1_ERR_NOT_IN_SUBGROUP 5
+
+#define CG1_POINT_BYTES 144
+#define CG1_NPHASE 7          /* prepare, hist, scan, scatter, accumulate, seg_reduce, bit_tree(+D2H) */
+
+typedef struct cg1_ctx cg1_ctx;
+
+/* ---------------- host-side single-element G1 ops (G1Point operators; stub __init__.pyi:5-30) ---- */
+void cg1_identity(uint8_t out[CG1_POINT_BYTES]);                      /* G1Point.identity()        util.py:11 */
+void cg1_generator(uint8_t out[CG1_POINT_BYTES]);                     /* G1Point()                 util.py:9  */
+void cg1_add(uint8_t out[CG1_POINT_BYTES], const uint8_t* a, const uint8_t* b);      /* __add__ */
+void cg1_sub(uint8_t out[CG1_POINT_BYTES], const uint8_t* a, const uint8_t* b);      /* __sub__ */
+void cg1_neg(uint8_t out[CG1_POINT_BYTES], const uint8_t* a);                        /* __neg__ */
+void cg1_double(uint8_t out[CG1_POINT_BYTES], const uint8_t* a);
+void cg1_mul(uint8_t out[CG1_POINT_BYTES], const uint8_t* a, const uint8_t scalar32[32]);  /* __mul__(Scalar) */
+int  cg1_eq(const uint8_t* a, const uint8_t* b);                      /* __eq__; 1 equal, 0 not    util.py:17-18 */
+int  cg1_is_identity(const uint8_t* a);
+void cg1_compress(uint8_t out48[48], const uint8_t* a);               /* to_compressed_bytes       util.py:27-28 */
+/* from_compressed_bytes (check_subgroup=1) / from_compressed_bytes_unchecked (0)   util.py:35-36,
+ * msm_accumulator.py:65.  Returns CG1_OK or CG1_ERR_ENCODING / _NOT_ON_CURVE / _NOT_IN_SUBGROUP. */
+int  cg1_decompress(uint8_t out[CG1_POINT_BYTES], const uint8_t in48[48], int check_subgroup);
+void cg1_to_affine96(uint8_t out96[96], const uint8_t* a);
+int  cg1_from_affine96(uint8_t out[CG1_POINT_BYTES], const uint8_t in96[96], int check_on_curve);
+/* n point blobs -> n affine96 records with ONE field inversion (input marshalling for the MSM) */
+void cg1_batch_to_affine96(uint8_t* out96, const uint8_t* blobs, size_t n);
+/* n compressed48 -> n point blobs; stops at the first bad encoding and returns its status, *bad_index set */
+int  cg1_batch_decompress(uint8_t* out_blobs, const uint8_t* in48, size_t n, int check_subgroup, size_t* bad_index);
+void cg1_batch_compress(uint8_t* out48, const uint8_t* blobs, size_t n);
+
+/* ---------------- device context --------------------------------------------------------------- */
+int  cg1_device_count(void);                                         /* 0 when no GPU is visible */
+cg1_ctx* cg1_ctx_create(int device);                                 /* NULL on failure (no GPU) */
+void cg1_ctx_destroy(cg1_ctx* ctx);
+const char* cg1_ctx_error(const cg1_ctx* ctx);                       /* message of the last failure */
+void* cg1_dev_malloc(cg1_ctx* ctx, size_t bytes);                    /* NULL on failure */
+void cg1_dev_free(cg1_ctx* ctx, void* p);
+int  cg1_h2d(cg1_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int  cg1_d2h(cg1_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int  cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value);   /* "chunk_len" (L0), "seg_m" */
+
+/* ---------------- the hot path: compute_MSM  (msm_accumulator.py:6-12) ------------------------- */
+/* sum_i scalars[i] * points[i], inputs in host memory (copied to the device by the call). */
+int cg1_msm(cg1_ctx* ctx, const uint8_t* points_affine96, const uint8_t* scalars32, size_t n,
+            uint8_t out[CG1_POINT_BYTES]);
+/* Same with inputs already resident in device memory (hipMalloc / cg1_dev_malloc / a torch tensor's
+ * data_ptr).  window_c: bucket window width 4..16, 0 = choose from n.
+ * (shard_rank, shard_world): this call sums only windows w = shard_rank (mod shard_world) and returns
+ * sum_w 2^(c w) S_w for those -- the per-GPU partial of a window-sharded MSM; (0,1) = the whole MSM.
+ * window_c must then be the same on every rank. */
+int cg1_msm_device(cg1_ctx* ctx, const void* d_points_affine96, const void* d_scalars32, size_t n,
+                   int window_c, int shard_rank, int shard_world, uint8_t out[CG1_POINT_BYTES]);
+/* per-phase GPU times (hipEvents on the context's stream) and host Horner tail of the last MSM call */
+int cg1_get_timings(const cg1_ctx* ctx, float phase_ms[CG1_NPHASE], float* host_tail_ms, int* window_c);
+
+/* ---------------- batched scalar multiplication (`G1Point * Scalar`, vectorised) --------------- */
+/* out[i] = scalars[i] * bases[i % nbase]; all device pointers; affine96 in and out.
+ * nbase = 1 is the fixed-base case (get_random_point: G * random_scalar(), util.py:67-68). */
+int cg1_batch_mul_device(cg1_ctx* ctx, const void* d_bases_affine96, size_t nbase, const void* d_scalars32,
+                         void* d_out_affine96, size_t n);
+/* deterministic synthetic scalars in [1, 2^252) from a 64-bit seed (splitmix64), device memory */
+int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out_scalars32, size_t n, uint64_t seed);
+/* roofline probe for the dominant kernel: `iters` dependent mixed adds per lane on `lanes` lanes;
+ * returns elapsed ms in *ms */
+int cg1_probe_madd(cg1_ctx* ctx, const void* d_points_affine96, size_t npts, size_t lanes, int iters, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURDLE_G1_H */

@@ -1,0 +1,93 @@
+// TEST-ONLY harness: compiles the *device* field/group headers (fp28.h, g1_xyzz.h) for the host with
+// CG1_CHECK_BOUNDS so every 64-bit column accumulator, lazy add and lazy subtract is range-checked
+// (abort on violation).  Driven from tests/test_fp28_host.py through ctypes and compared against the
+// big-int oracle.  Never linked into the product library.
+#include <cstring>
+#include "../../curdleproofs_pie_amd/csrc/g1_xyzz.h"
+
+using namespace cg1;
+
+static fp load_mont(const uint8_t* le48) {
+  uint32_t w[12];
+  memcpy(w, le48, 48);
+  return fp_to_mont(fp_from_words(w));
+}
+static void store_std(const fp& a, uint8_t* le48) {
+  uint32_t w[12];
+  fp_to_words(a, w);
+  memcpy(le48, w, 48);
+}
+
+extern "C" {
+
+void t_fp_mul(const uint8_t* a, const uint8_t* b, uint8_t* out) { store_std(fp_mul(load_mont(a), load_mont(b)), out); }
+void t_fp_sqr(const uint8_t* a, uint8_t* out) { store_std(fp_sqr(load_mont(a)), out); }
+void t_fp_inv(const uint8_t* a, uint8_t* out) { store_std(fp_inv(load_mont(a)), out); }
+// (a - b) * c and (a + b) * c : exercises the lazy forms feeding a product
+void t_fp_submul(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* out) {
+  store_std(fp_mul(fp_sub<3>(load_mont(a), load_mont(b)), load_mont(c)), out);
+}
+void t_fp_addmul(const uint8_t* a, const uint8_t* b, const uint8_t* c, uint8_t* out) {
+  store_std(fp_mul(fp_add(load_mont(a), load_mont(b)), load_mont(c)), out);
+}
+int t_fp_is_zero_diff(const uint8_t* a, const uint8_t* b) {   // a - b + 12p == 0 mod p ?
+  return fp_is_zero_mod_p(fp_sub<12>(load_mont(a), load_mont(b)), 14) ? 1 : 0;
+}
+
+static void export_xyzz(const xyzz& a, uint8_t* out /* 4*48 + 4 */) {
+  xyzz_words o;
+  xyzz_export(a, o);
+  memcpy(out, o.w, 4 * 48);
+  memcpy(out + 4 * 48, &o.inf, 4);
+}
+
+// acc = sum_i (+/-) P_i using the mixed add, points given as affine 96-byte records (x||y LE, std form).
+// neg[i] != 0 negates y lazily exactly as the bucket kernel does.
+void t_madd_seq(const uint8_t* pts96, const uint8_t* neg, int n, uint8_t* out) {
+  xyzz acc = xyzz_identity();
+  for (int i = 0; i < n; ++i) {
+    fp x = load_mont(pts96 + 96 * i), y = load_mont(pts96 + 96 * i + 48);
+    if (neg[i]) y = fp_neg<3>(y);
+    acc = xyzz_madd(acc, x, y);
+  }
+  export_xyzz(acc, out);
+}
+
+// Sum the same sequence as a balanced tree of full adds (exercises xyzz_add, incl. P+P and P-P).
+void t_add_tree(const uint8_t* pts96, const uint8_t* neg, int n, uint8_t* out) {
+  if (n == 0) { export_xyzz(xyzz_identity(), out); return; }
+  xyzz* v = new xyzz[n];
+  for (int i = 0; i < n; ++i) {
+    fp x = load_mont(pts96 + 96 * i), y = load_mont(pts96 + 96 * i + 48);
+    if (neg[i]) y = fp_neg<3>(y);
+    v[i] = xyzz_from_affine(x, y);
+  }
+  for (int m = n; m > 1; m = (m + 1) / 2)
+    for (int i = 0; i < m / 2; ++i) v[i] = xyzz_add(v[i], v[m - 1 - i]);
+  export_xyzz(v[0], out);
+  delete[] v;
+}
+
+// k * P by double-and-add over XYZZ (dbl + madd), k given as 32 LE bytes.
+void t_scalar_mul(const uint8_t* pt96, const uint8_t* k32, uint8_t* out) {
+  fp x = load_mont(pt96), y = load_mont(pt96 + 48);
+  xyzz acc = xyzz_identity();
+  for (int bit = 255; bit >= 0; --bit) {
+    acc = xyzz_dbl(acc);
+    if ((k32[bit >> 3] >> (bit & 7)) & 1) acc = xyzz_madd(acc, x, y);
+  }
+  export_xyzz(acc, out);
+}
+
+// running-sum pattern of the bucket reduction: run += B_k; tot += run  (k from high to low)
+void t_running_sum(const uint8_t* pts96, int n, uint8_t* out) {
+  xyzz run = xyzz_identity(), tot = xyzz_identity();
+  for (int i = n - 1; i >= 0; --i) {
+    fp x = load_mont(pts96 + 96 * i), y = load_mont(pts96 + 96 * i + 48);
+    run = xyzz_add(run, xyzz_from_affine(x, y));
+    tot = xyzz_add(tot, run);
+  }
+  export_xyzz(tot, out);
+}
+
+}  // extern "C"
