@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py -- BLS12-381 G1 MSM throughput on MI355X (BASELINE.json metric: G1 scalar-muls/sec at MSM size 2^20).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete compute_MSM-equivalent call (msm_accumulator.py:6-12 of the reference) over one
+batch of synthetic input that is already resident in HBM: point preparation, signed-digit recode, counting
+sort, bucket accumulation, bucket reduction, D2H of the window sums and the host Horner tail are all inside
+the timed region.  Workload at N=1: BASELINE.json configs[1]'s shape at the metric's size -- one MSM of 2^20
+random G1 points (k_i*G) with scalars uniform in [1, r-1] (the reference's random_scalar, util.py:21-24).
+At N>1 (weak scaling): ONE MSM of N*2^20 terms whose signed-digit windows are sharded across the ranks
+(--shard windows, the north_star's decomposition) or whose points are (--shard points); the partial G1 sums
+are all-gathered over RCCL and added on every rank.  value = total terms processed / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def raw96_gen():
+    gx = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
+    gy = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
+    return gx.to_bytes(48, "little") + gy.to_bytes(48, "little")
+
+
+def cpu_baseline(ctx, d_points, d_scalars, sample_n):
+    """The reference algorithm (naive per-term double-and-add loop) as restated by oracle/msm_oracle.c,
+    1 thread (the reference is single-threaded), on the first `sample_n` terms of the same workload."""
+    from oracle import c_oracle as C  # the only use of the oracle in bench.py: the reported CPU baseline
+
+    p = d_points.download(96 * sample_n)
+    s = d_scalars.download(32 * sample_n)
+    t0 = time.perf_counter()
+    C.compute_msm(p, s, sample_n)
+    dt = time.perf_counter() - t0
+    return {"value": sample_n / dt, "unit": "G1 scalar-muls/s", "cores": 1, "kind": "port",
+            "sample": f"naive reference loop (msm_accumulator.py:6-12 restated in C, 255-bit double-and-add + add per term) "
+                      f"over the first {sample_n} terms of the same workload, {dt:.1f} s on one host core; "
+                      f"cost is linear in n so the 2^20 figure is this rate"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--logn", type=int, default=20, help="log2 of terms per GPU")
+    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--shard", choices=["windows", "points"], default="windows")
+    ap.add_argument("--cpu-sample-logn", type=int, default=15)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    from curdleproofs_pie_amd import _native as N
+    from curdleproofs_pie_amd import build as B
+    B.build(verbose=False)
+
+    dist = None
+    torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    ctx = N.Context(local_rank)
+
+    n_per_gpu = 1 << args.logn
+    n_total = n_per_gpu * world
+    c = args.window
+    # ---- synthetic inputs, generated on the GPU and left resident in HBM
+    if args.shard == "windows":
+        n_local, seed_off = n_total, 0            # every rank holds the whole MSM
+    else:
+        n_local, seed_off = n_per_gpu, 1000 * rank  # this rank's shard of the points
+    d_k = ctx.alloc(32 * n_local)
+    d_pts = ctx.alloc(96 * n_local)
+    d_sc = ctx.alloc(32 * n_local)
+    d_g = ctx.alloc(96)
+    d_g.upload(raw96_gen())
+    ctx.gen_scalars_device(d_k, n_local, 0xC0FFEE + seed_off)
+    ctx.batch_mul_device(d_g, 1, d_k, d_pts, n_local)       # P_i = k_i * G  (get_random_point, util.py:67-68)
+    ctx.gen_scalars_device(d_sc, n_local, 0xBEEF + seed_off)
+    d_k.free()
+
+    from curdleproofs_pie_amd.distributed import all_reduce_g1
+
+    def step():
+        if args.shard == "windows":
+            part = ctx.msm_device(d_pts, d_sc, n_local, window_c=c, shard_rank=rank, shard_world=world)
+        else:
+            part = ctx.msm_device(d_pts, d_sc, n_local, window_c=c)
+        return all_reduce_g1(part) if world > 1 else part
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        ctx.sync()
+
+    results = []
+    for _ in range(args.warmup):
+        results.append(step())
+    phase_acc = {}
+    barrier_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        results.append(step())
+        for k, v in ctx.timings().items():
+            phase_acc[k] = phase_acc.get(k, 0.0) + v
+    barrier_sync()
+    elapsed = time.perf_counter() - t0
+    same = all(N.cg1_eq(r, results[0]) for r in results[1:])
+    if not same:
+        sys.exit("bench.py: MSM results differ between steps")
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_total * args.steps / elapsed
+        acc_ms = phase_acc["accumulate"] / args.steps
+        # roofline of the dominant kernel (k_accumulate): ALGORITHMIC bytes = 128 B per (point, scalar) term
+        # (96 B affine point + 32 B scalar) x the terms one launch processes
+        terms_per_launch = n_local
+        achieved = 128.0 * terms_per_launch / (acc_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath) and world == 1 and args.logn == 20:
+            try:
+                traffic = json.load(open(tpath)).get("k_accumulate_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "BLS12-381 G1 scalar-muls/sec at MSM size 2^20",
+            "value": value,
+            "unit": "G1 scalar-muls/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (14x28-bit-limb Montgomery Fp, 64-bit column accumulators)",
+            "data": "synthetic: points k_i*G and scalars uniform in [1,r-1], splitmix64-seeded, generated on the GPU",
+            "config": {"workload": f"single MSM of 2^{args.logn} x {world} BLS12-381 G1 terms, resident in HBM, "
+                                   f"{'window' if args.shard == 'windows' else 'point'}-sharded over {world} GPU(s)",
+                       "terms_total": n_total, "terms_per_gpu": n_per_gpu, "window_c": c, "shard": args.shard,
+                       "bit_exact_vs_oracle": "tests/test_msm_gpu.py"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "kernel": "k_accumulate", "kernel_ms": acc_ms,
+                         "note": "path is integer-multiply (v_mad_u64_u32) bound, not HBM-bound: see DESIGN.md"},
+            "phases_ms": {k: v / args.steps for k, v in phase_acc.items() if k != "window_c"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(ctx, d_pts, d_sc, 1 << args.cpu_sample_logn)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

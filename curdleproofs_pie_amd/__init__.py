@@ -3,8 +3,20 @@ compute_MSM / MSMAccumulator and the G1Point / Scalar surface of py_arkworks_bls
 
 Host code is plain Python + ctypes over libcurdle_g1.so (hand-written HIP for gfx950 + host C++);
 no torch, no Triton, no CPU fallback for the batched paths.
-"""
-from .py_arkworks_bls12381 import G1Point, Scalar, CURVE_ORDER  # noqa: F401
-from .msm_accumulator import MSMAccumulator, compute_MSM  # noqa: F401
 
+Attributes resolve lazily so that `python -m curdleproofs_pie_amd.build` can run before the shared
+library exists; touching any of them without the library raises ImportError (never a fallback).
+"""
 __all__ = ["G1Point", "Scalar", "CURVE_ORDER", "MSMAccumulator", "compute_MSM"]
+
+
+def __getattr__(name):
+    if name in ("G1Point", "Scalar", "CURVE_ORDER"):
+        from . import py_arkworks_bls12381 as m
+
+        return getattr(m, name)
+    if name in ("MSMAccumulator", "compute_MSM"):
+        from . import msm_accumulator as m
+
+        return getattr(m, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

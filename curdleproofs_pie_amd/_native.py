@@ -69,6 +69,7 @@ cg1_dev_malloc = _proto("cg1_dev_malloc", c_void_p, c_void_p, c_size_t)
 cg1_dev_free = _proto("cg1_dev_free", None, c_void_p, c_void_p)
 cg1_h2d = _proto("cg1_h2d", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
 cg1_d2h = _proto("cg1_d2h", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+cg1_ctx_sync = _proto("cg1_ctx_sync", c_int, c_void_p)
 cg1_ctx_set_param = _proto("cg1_ctx_set_param", c_int, c_void_p, c_char_p, c_int)
 cg1_msm = _proto("cg1_msm", c_int, c_void_p, _u8p, _u8p, c_size_t, _buf)
 cg1_msm_device = _proto("cg1_msm_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, _buf)
@@ -81,7 +82,7 @@ EXPORTED_SYMBOLS = [
     "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
-    "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_ctx_set_param",
+    "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_ctx_sync", "cg1_ctx_set_param",
     "cg1_msm", "cg1_msm_device", "cg1_get_timings", "cg1_batch_mul_device", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 
@@ -137,6 +138,9 @@ class Context:
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
+
+    def sync(self) -> None:
+        self.check(cg1_ctx_sync(self.handle))
 
     def set_param(self, name: str, value: int) -> None:
         self.check(cg1_ctx_set_param(self.handle, name.encode(), value))

@@ -379,21 +379,30 @@ __global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ 
   fp_to_words(fp_mul(acc.Y, izzz), o); for (int k = 0; k < 12; ++k) dst[12 + k] = o[k];
 }
 
-// splitmix64-derived scalars in [1, 2^252): deterministic synthetic scalars (always < r)
+// splitmix64-derived scalars, uniform in [1, r-1] (the reference's random_scalar distribution,
+// util.py:21-24) by rejection from 255-bit draws; deterministic in (seed, i)
 __global__ void __launch_bounds__(256) k_gen_scalars(uint32_t* __restrict__ out, uint32_t n, uint64_t seed) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  uint64_t st = seed + 0x9E3779B97F4A7C15ull * (4ull * i + 1);
+  uint64_t st = seed + 0x9E3779B97F4A7C15ull * (64ull * i + 1);
   uint64_t v[4];
-  for (int k = 0; k < 4; ++k) {
-    st += 0x9E3779B97F4A7C15ull;
-    uint64_t z = st;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    v[k] = z ^ (z >> 31);
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    for (int k = 0; k < 4; ++k) {
+      st += 0x9E3779B97F4A7C15ull;
+      uint64_t z = st;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      v[k] = z ^ (z >> 31);
+    }
+    v[3] &= 0x7FFFFFFFFFFFFFFFull;       // 255 bits
+    bool lt = false, decided = false;     // v < r ?
+    for (int k = 3; k >= 0 && !decided; --k) {
+      if (v[k] != H_FR[k]) { lt = v[k] < H_FR[k]; decided = true; }
+    }
+    bool nz = (v[0] | v[1] | v[2] | v[3]) != 0;
+    if (lt && nz) break;
+    if (attempt == 63) { v[3] = 0; v[0] |= 1; }   // unreachable in practice (p ~ 2^-64)
   }
-  v[3] &= 0x0FFFFFFFFFFFFFFFull;       // < 2^252 < r
-  v[0] |= 1ull;                          // non-zero
   for (int k = 0; k < 4; ++k) { out[8ull * i + 2 * k] = (uint32_t)v[k]; out[8ull * i + 2 * k + 1] = (uint32_t)(v[k] >> 32); }
 }
 
@@ -710,6 +719,12 @@ int cg1_d2h(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return CG1_ERR_HIP;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return CG1_OK;
+}
+int cg1_ctx_sync(cg1_ctx* ctx) {
+  if (!ctx) return CG1_ERR_HIP;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipDeviceSynchronize());
   return CG1_OK;
 }
 int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {

@@ -71,6 +71,7 @@ void* cg1_dev_malloc(cg1_ctx* ctx, size_t bytes);                    /* NULL on 
 void cg1_dev_free(cg1_ctx* ctx, void* p);
 int  cg1_h2d(cg1_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  cg1_d2h(cg1_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int  cg1_ctx_sync(cg1_ctx* ctx);                                     /* hipDeviceSynchronize on the context's GPU */
 int  cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value);   /* "chunk_len" (L0), "seg_m" */
 
 /* ---------------- the hot path: compute_MSM  (msm_accumulator.py:6-12) ------------------------- */

@@ -1,0 +1,79 @@
+"""The N>1 combine step on CPU: world_size-2 `gloo` ranks each hold one partial G1 sum (a share of the
+terms of one MSM, computed here with the host operators), all-gather the 144-byte blobs and add them --
+exactly what curdleproofs_pie_amd.distributed does over RCCL on the GPU box.  Every rank must end with the
+same group element as the single-process oracle."""
+import os
+import socket
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, mode, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import ctypes
+    import random
+
+    import torch.distributed as dist
+
+    from curdleproofs_pie_amd import _native as N
+    from curdleproofs_pie_amd.distributed import all_reduce_g1
+    from curdleproofs_pie_amd.py_arkworks_bls12381 import G1Point, Scalar
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = random.Random(2024)          # same inputs on every rank
+    n = 24
+    bases = [G1Point() * Scalar(rng.randint(1, 2 ** 200)) for _ in range(n)]
+    scalars = [rng.randint(0, 2 ** 255 - 20) for _ in range(n)]
+    part = G1Point.identity()
+    if mode == "points":               # rank owns a contiguous slice of the terms
+        lo, hi = rank * n // world, (rank + 1) * n // world
+        for b, s in zip(bases[lo:hi], scalars[lo:hi]):
+            part = part + b * Scalar(s)
+    else:                              # rank owns the 16-bit windows w = rank (mod world) of every scalar
+        for b, s in zip(bases, scalars):
+            mine = sum(((s >> (16 * w)) & 0xFFFF) << (16 * w) for w in range(16) if w % world == rank)
+            part = part + b * Scalar(mine)
+    total = all_reduce_g1(part._b)
+    out = ctypes.create_string_buffer(48)
+    N.cg1_compress(out, total)
+    q.put((rank, out.raw.hex()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["windows", "points"])
+def test_two_rank_g1_all_reduce(native_lib, mode):
+    import random
+
+    import torch.multiprocessing as mp
+
+    from oracle import bls12_381 as O
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = random.Random(2024)
+    n = 24
+    ks = [rng.randint(1, 2 ** 200) for _ in range(n)]
+    scalars = [rng.randint(0, 2 ** 255 - 20) for _ in range(n)]
+    want = O.g1_compress(O.g1_mul(O.G1_GEN, sum(k * (s % O.R) for k, s in zip(ks, scalars)) % O.R)).hex()
+    assert got[0] == got[1] == want

@@ -1,0 +1,78 @@
+"""The gfx950 field / group code (csrc/fp28.h, csrc/g1_xyzz.h) compiled for the host with CG1_CHECK_BOUNDS:
+every 64-bit column accumulator, lazy add and lazy subtract is range-checked (abort on violation) and the
+results are compared with the big-int oracle.  This is how the device arithmetic is validated without a GPU."""
+import ctypes
+import random
+
+from conftest import raw96
+from oracle import bls12_381 as O
+
+P = O.P
+
+
+def b48(v):
+    return v.to_bytes(48, "little")
+
+
+def parse_xyzz(buf):
+    b = buf.raw
+    if int.from_bytes(b[192:196], "little"):
+        return None
+    X, Y, ZZ, ZZZ = (int.from_bytes(b[48 * i: 48 * i + 48], "little") for i in range(4))
+    assert (pow(ZZ, 3, P) - pow(ZZZ, 2, P)) % P == 0
+    return (X * pow(ZZ, -1, P) % P, Y * pow(ZZZ, -1, P) % P)
+
+
+def test_field_ops(fp28_harness):
+    L = fp28_harness
+    rng = random.Random(1)
+    o = ctypes.create_string_buffer(48)
+    edge = [0, 1, 2, P - 1, P - 2, (1 << 380), (1 << 381) - 1 - ((1 << 381) - 1 >= P) * 0 if ((1 << 381) - 1) < P else P - 3]
+    vals = edge + [rng.randrange(P) for _ in range(300)]
+    for i, a in enumerate(vals):
+        b = vals[(7 * i + 3) % len(vals)]
+        c = vals[(11 * i + 5) % len(vals)]
+        L.t_fp_mul(b48(a), b48(b), o); assert int.from_bytes(o.raw, "little") == a * b % P
+        L.t_fp_sqr(b48(a), o); assert int.from_bytes(o.raw, "little") == a * a % P
+        L.t_fp_submul(b48(a), b48(b), b48(c), o); assert int.from_bytes(o.raw, "little") == (a - b) * c % P
+        L.t_fp_addmul(b48(a), b48(b), b48(c), o); assert int.from_bytes(o.raw, "little") == (a + b) * c % P
+        assert L.t_fp_is_zero_diff(b48(a), b48(b)) == (1 if a == b else 0)
+        assert L.t_fp_is_zero_diff(b48(a), b48(a)) == 1
+    for a in [1, 2, P - 1] + [rng.randrange(1, P) for _ in range(10)]:
+        L.t_fp_inv(b48(a), o); assert int.from_bytes(o.raw, "little") == pow(a, -1, P)
+
+
+def test_group_law_with_exceptional_cases(fp28_harness):
+    L = fp28_harness
+    rng = random.Random(2)
+    pts = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(24)]
+    o = ctypes.create_string_buffer(196)
+
+    def check(seq, negs):
+        buf = b"".join(raw96(p) for p in seq)
+        want = None
+        for p, s in zip(seq, negs):
+            want = O.g1_add(want, O.g1_neg(p) if s else p)
+        L.t_madd_seq(buf, bytes(negs), len(seq), o); assert parse_xyzz(o) == want
+        L.t_add_tree(buf, bytes(negs), len(seq), o); assert parse_xyzz(o) == want
+
+    check(pts, [rng.randrange(2) for _ in pts])
+    check([], [])
+    check([pts[0]], [1])
+    check([pts[0], pts[0]], [0, 0])                       # P + P through the mixed add
+    check([pts[0], pts[0]], [0, 1])                       # P + (-P)
+    check([pts[0]] * 9, [0] * 9)
+    check([pts[0], pts[0], pts[0], pts[1], pts[0]], [0, 1, 0, 0, 0])
+    s01 = O.g1_add(pts[0], pts[1])
+    check([pts[0], pts[1], s01], [0, 0, 0])               # accumulator == next point -> doubling branch
+    check([pts[0], pts[1], s01], [0, 0, 1])               # accumulator == -next point -> identity
+    check([pts[0], pts[1], s01, pts[5]], [0, 0, 1, 0])    # continue after hitting the identity
+    for k in [0, 1, 2, 99, O.R - 1, rng.randrange(O.R)]:
+        L.t_scalar_mul(raw96(O.G1_GEN), k.to_bytes(32, "little"), o)
+        assert parse_xyzz(o) == O.g1_mul(O.G1_GEN, k)
+    seq = pts[:13]
+    L.t_running_sum(b"".join(raw96(p) for p in seq), len(seq), o)
+    want = None
+    for i, p in enumerate(seq):
+        want = O.g1_add(want, O.g1_mul(p, i + 1))
+    assert parse_xyzz(o) == want

@@ -1,0 +1,38 @@
+"""Drop-in proof for the G1Point / Scalar surface: the REFERENCE'S OWN test-suite
+(/root/reference/curdleproofs/curdleproofs/test_curdleproofs.py -- API snapshot, known answers, IPA, grand
+product, same-permutation, same-MSM, same-scalar, the N=64 shuffle argument, the N=128 negative tests, serde,
+Whisk byte interface) runs UNMODIFIED with `curdleproofs_pie_amd.py_arkworks_bls12381` injected where the
+Rust wheel `py_arkworks_bls12381` would be imported.
+
+This is BASELINE.json configs[0] (ell=64 prove+verify on the CPU path).  It needs /root/reference, so it runs
+only in the build container (not on the GPU box) and is skipped elsewhere; nothing is copied from the reference
+and no bytecode is written next to it.  The reference's compute_MSM here is its own Python loop over our host
+operators; the GPU compute_MSM / MSMAccumulator are covered by tests/test_python_face_gpu.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_PKG = "/root/reference/curdleproofs"
+REF_TEST = os.path.join(REF_PKG, "curdleproofs", "test_curdleproofs.py")
+
+RUNNER = r"""
+import sys
+sys.dont_write_bytecode = True
+sys.path.insert(0, {root!r}); sys.path.insert(0, {ref!r}); sys.path.insert(0, "/root/reference/merlin_transcripts")
+import curdleproofs_pie_amd.py_arkworks_bls12381 as backend
+sys.modules["py_arkworks_bls12381"] = backend
+import pytest
+sys.exit(int(pytest.main(["-x", "-q", "-p", "no:cacheprovider", {test!r}])))
+"""
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TEST), reason="reference tree not present (GPU box)")
+def test_reference_test_suite_passes_on_our_backend(native_lib):
+    code = RUNNER.format(root=ROOT, ref=REF_PKG, test=REF_TEST)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, cwd="/tmp")
+    tail = (r.stdout + r.stderr)[-2000:]
+    assert r.returncode == 0, tail
+    assert "18 passed" in r.stdout, tail
