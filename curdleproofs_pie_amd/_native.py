@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libcurdle_g1.so")
 
 POINT_BYTES = 144
 NPHASE = 7
-PHASE_NAMES = ("prepare", "hist", "scan", "scatter", "accumulate", "seg_reduce", "bit_tree")
+PHASE_NAMES = ("prepare", "sort_count", "sort_scatter", "chunks", "accumulate", "seg_reduce", "bit_tree")
 
 OK, ERR_ARG, ERR_HIP, ERR_ENCODING, ERR_NOT_ON_CURVE, ERR_NOT_IN_SUBGROUP = range(6)
 
@@ -74,6 +74,7 @@ cg1_ctx_set_param = _proto("cg1_ctx_set_param", c_int, c_void_p, c_char_p, c_int
 cg1_msm = _proto("cg1_msm", c_int, c_void_p, _u8p, _u8p, c_size_t, _buf)
 cg1_msm_device = _proto("cg1_msm_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, _buf)
 cg1_get_timings = _proto("cg1_get_timings", c_int, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_int))
+cg1_get_host_timings = _proto("cg1_get_host_timings", c_int, c_void_p, POINTER(c_float))
 cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
 cg1_gen_scalars_device = _proto("cg1_gen_scalars_device", c_int, c_void_p, c_void_p, c_size_t, c_uint64)
 cg1_probe_madd = _proto("cg1_probe_madd", c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_int, POINTER(c_float))
@@ -83,7 +84,7 @@ EXPORTED_SYMBOLS = [
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_ctx_sync", "cg1_ctx_set_param",
-    "cg1_msm", "cg1_msm_device", "cg1_get_timings", "cg1_batch_mul_device", "cg1_gen_scalars_device", "cg1_probe_madd",
+    "cg1_msm", "cg1_msm_device", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 
 
@@ -168,6 +169,10 @@ class Context:
         d = {name: float(ph[i]) for i, name in enumerate(PHASE_NAMES)}
         d["host_tail"] = float(tail.value)
         d["window_c"] = int(c.value)
+        hm = (c_float * 4)()
+        cg1_get_host_timings(self.handle, hm)
+        for i, name in enumerate(("host_enqueue", "host_wait", "host_events", "host_horner")):
+            d[name] = float(hm[i])
         return d
 
     def batch_mul_device(self, d_bases, nbase: int, d_scalars, d_out, n: int) -> None:

@@ -101,8 +101,6 @@ CG1_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
   return r;
 }
 
-CG1_HD xyzz xyzz_neg(const xyzz& a) { xyzz r = a; if (!a.inf) r.Y = fp_norm(fp_neg<6>(a.Y)); return r; }
-
 // ---- canonical export: XYZZ with standard-form (non-Montgomery) canonical coordinates, 4 x 12 words
 // (+ a flag word).  The host maps it to Jacobian (X*ZZ, Y*ZZZ, ZZ) without an inversion.
 struct xyzz_words { uint32_t w[4][12]; uint32_t inf; };

@@ -179,6 +179,162 @@ __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ sc
   }
 }
 
+constexpr int SCAN_ITEMS = 1024;        // items per block of 256 threads in the scans
+
+// ------------------------------------------------------------------ two-level partition sort (no global atomics)
+// Replaces k_hist/k_scatter (16.7 M global atomics each at n = 2^20: 0.63 + 0.87 ms) when n <= 2^23.
+//   k_digits        scalar -> one u16 signed digit per owned window, window-major  [nlw][n]
+//   k_part_count    block = (window, tile of PART_TILE points): LDS histogram over the HIGH bits of the bucket
+//                   ("bin"), written as block_counts[window][bin][tile]
+//   k_uscan1/2/3    exclusive scan of block_counts: lexicographic (window, bin, tile) order = final layout
+//   k_part_scatter  same blocks: LDS cursors seeded from the scan, entries (sub | sign | idx) land bin-grouped
+//   k_bin_sort      block = (window, bin): LDS histogram/scan over the LOW bits ("sub"), emits the per-bucket
+//                   counts + offsets and the final sorted[] array; all traffic of a block stays inside its bin
+constexpr uint32_t PART_TILE = 4096;
+constexpr uint32_t PART_MAX_N = 1u << 23;      // idx 23 bits | sign 1 bit | sub 8 bits
+
+__device__ __forceinline__ uint32_t digit_mag(uint32_t e, uint32_t& neg) {   // e != 0: u16 two's complement digit
+  if (e == 0x8000u) { neg = 0; return 0x8000u; }                             // +2^15 (only for c = 16)
+  int d = (int)(int16_t)(uint16_t)e;
+  neg = d < 0;
+  return (uint32_t)(d < 0 ? -d : d);
+}
+
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const PreparedPoint* __restrict__ pts,
+                                                uint16_t* __restrict__ digits, uint32_t n, int c, int nwin, int rank, int world) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const bool inf = pts[i].flags & 1u;
+  DigitIter it; it.c = c;
+  load_scalar(scalars, i, it);
+  for (int w = 0; w < nwin; ++w) {
+    int d = it.next(w);
+    if ((w % world) != rank) continue;
+    digits[(size_t)(w / world) * n + i] = inf ? (uint16_t)0 : (uint16_t)(d & 0xFFFF);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_part_count(const uint16_t* __restrict__ digits, uint32_t* __restrict__ block_counts,
+                                                    uint32_t n, uint32_t nslices, uint32_t nbins, uint32_t sub_bits) {
+  __shared__ uint32_t cnt[128];
+  if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t slice = blockIdx.x, lw = blockIdx.y;
+  const uint16_t* dg = digits + (size_t)lw * n;
+  for (uint32_t k = 0; k < PART_TILE / 256; ++k) {
+    uint32_t i = slice * PART_TILE + k * 256 + threadIdx.x;
+    if (i < n) {
+      uint32_t e = dg[i];
+      if (e) { uint32_t neg; uint32_t mag = digit_mag(e, neg); atomicAdd(&cnt[(mag - 1u) >> sub_bits], 1u); }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < nbins) block_counts[((size_t)lw * nbins + threadIdx.x) * nslices + slice] = cnt[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ block_base,
+                                                      uint32_t* __restrict__ part, uint32_t n, uint32_t nslices, uint32_t nbins,
+                                                      uint32_t sub_bits) {
+  __shared__ uint32_t cur[128];
+  const uint32_t slice = blockIdx.x, lw = blockIdx.y;
+  if (threadIdx.x < nbins) cur[threadIdx.x] = block_base[((size_t)lw * nbins + threadIdx.x) * nslices + slice];
+  __syncthreads();
+  const uint16_t* dg = digits + (size_t)lw * n;
+  const uint32_t sub_mask = (1u << sub_bits) - 1u;
+  for (uint32_t k = 0; k < PART_TILE / 256; ++k) {
+    uint32_t i = slice * PART_TILE + k * 256 + threadIdx.x;
+    if (i < n) {
+      uint32_t e = dg[i];
+      if (e) {
+        uint32_t neg; uint32_t b = digit_mag(e, neg) - 1u;
+        uint32_t pos = atomicAdd(&cur[b >> sub_bits], 1u);
+        part[pos] = i | (neg << 23) | ((b & sub_mask) << 24);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
+                                                  uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted,
+                                                  uint32_t nbins_total, uint32_t nslices, uint32_t sub_bits) {
+  __shared__ uint32_t cnt[256];
+  __shared__ uint32_t cur[256];
+  const uint32_t g = blockIdx.x;
+  const uint32_t start = block_base[(size_t)g * nslices];
+  const uint32_t end = block_base[(size_t)(g + 1) * nslices];     // element [nbins_total*nslices] holds the grand total
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t e = start + threadIdx.x; e < end; e += 256) atomicAdd(&cnt[part[e] >> 24], 1u);
+  __syncthreads();
+  const uint32_t mine = cnt[threadIdx.x];
+  cur[threadIdx.x] = mine;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? cur[threadIdx.x - d] : 0u;
+    __syncthreads();
+    cur[threadIdx.x] += u;
+    __syncthreads();
+  }
+  const uint32_t excl = cur[threadIdx.x] - mine;
+  __syncthreads();
+  cur[threadIdx.x] = start + excl;
+  if (threadIdx.x < (1u << sub_bits)) hist[((size_t)g << sub_bits) + threadIdx.x] = mine;
+  __syncthreads();
+  for (uint32_t e = start + threadIdx.x; e < end; e += 256) {
+    uint32_t v = part[e];
+    uint32_t pos = atomicAdd(&cur[v >> 24], 1u);
+    sorted[pos] = (v & 0x7fffffu) | ((v >> 23 & 1u) << 31);
+  }
+}
+
+// generic in-place exclusive scan of u32 (total written to a[n])
+__global__ void __launch_bounds__(256) k_uscan1(uint32_t* __restrict__ a, uint32_t* __restrict__ block_tot, uint32_t n) {
+  __shared__ uint32_t sh[256];
+  uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  uint32_t v[4], local = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v[k] = (base + k < n) ? a[base + k] : 0u; local += v[k]; }
+  sh[threadIdx.x] = local;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += u;
+    __syncthreads();
+  }
+  uint32_t excl = sh[threadIdx.x] - local;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (base + k < n) a[base + k] = excl; excl += v[k]; }
+  if (threadIdx.x == 255) block_tot[blockIdx.x] = sh[255];
+}
+__global__ void __launch_bounds__(256) k_uscan2(uint32_t* __restrict__ block_tot, uint32_t nblocks, uint32_t* __restrict__ a, uint32_t n) {
+  __shared__ uint32_t sh[256];
+  uint32_t carry = 0;
+  for (uint32_t tile = 0; tile < nblocks; tile += 256) {
+    uint32_t i = tile + threadIdx.x;
+    uint32_t v = (i < nblocks) ? block_tot[i] : 0u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      uint32_t u = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += u;
+      __syncthreads();
+    }
+    if (i < nblocks) block_tot[i] = carry + sh[threadIdx.x] - v;
+    uint32_t tot = sh[255];
+    __syncthreads();
+    carry += tot;
+  }
+  if (threadIdx.x == 0) a[n] = carry;
+}
+__global__ void __launch_bounds__(256) k_uscan3(const uint32_t* __restrict__ block_tot, uint32_t* __restrict__ a, uint32_t n) {
+  uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  uint32_t p = block_tot[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (base + k < n) a[base + k] += p;
+}
+
 // ------------------------------------------------------------------ scan of (count, chunks)
 __device__ __forceinline__ uint32_t isqrt_ceil(uint32_t v) {
   uint32_t r = (uint32_t)sqrtf((float)v);
@@ -196,7 +352,6 @@ __device__ __forceinline__ uint32_t chunk_count(uint32_t cnt, uint32_t L0) {
   return (cnt + L - 1) / L;
 }
 
-constexpr int SCAN_ITEMS = 1024;        // per block of 256 threads
 // phase 1: per-block exclusive scan, block totals out
 __global__ void __launch_bounds__(256) k_scan1(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ choff,
                                                uint2* __restrict__ block_tot, uint32_t nb_total, uint32_t L0) {
@@ -259,33 +414,87 @@ __global__ void __launch_bounds__(256) k_scan3(const uint2* __restrict__ block_t
   for (int k = 0; k < 4; ++k) if (base + k < nb_total) { off[base + k] += p.x; choff[base + k] += p.y; }
 }
 
+constexpr uint32_t LEN_BINS = 256;      // chunk-length keys: min(len, 255)
+__device__ __forceinline__ uint32_t len_key(uint32_t len) { return len < LEN_BINS - 1 ? len : LEN_BINS - 1; }
+
 __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__ off, const uint32_t* __restrict__ choff,
-                                                    uint2* __restrict__ desc, uint32_t nb_total, uint32_t L0) {
+                                                    uint2* __restrict__ desc, uint32_t* __restrict__ len_hist,
+                                                    uint32_t nb_total, uint32_t L0) {
+  __shared__ uint32_t sh[LEN_BINS];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
   uint32_t b = blockIdx.x * 256 + threadIdx.x;
-  if (b >= nb_total) return;
-  uint32_t start = off[b], cnt = off[b + 1] - start;
-  if (cnt == 0) return;
-  uint32_t L = chunk_len(cnt, L0), nch = (cnt + L - 1) / L, o = choff[b];
-  for (uint32_t k = 0; k < nch; ++k) {
-    uint32_t s = k * L;
-    desc[o + k] = make_uint2(start + s, (cnt - s < L) ? (cnt - s) : L);
+  if (b < nb_total) {
+    uint32_t start = off[b], cnt = off[b + 1] - start;
+    if (cnt) {
+      uint32_t L = chunk_len(cnt, L0), nch = (cnt + L - 1) / L, o = choff[b];
+      for (uint32_t k = 0; k < nch; ++k) {
+        uint32_t s = k * L, len = (cnt - s < L) ? (cnt - s) : L;
+        desc[o + k] = make_uint2(start + s, len);
+        atomicAdd(&sh[len_key(len)], 1u);
+      }
+    }
   }
+  __syncthreads();
+  uint32_t v = sh[threadIdx.x];
+  if (v) atomicAdd(&len_hist[threadIdx.x], v);
+}
+
+// one block: len_cursor[k] = number of chunks with a LONGER key (descending order => longest chunks first)
+__global__ void __launch_bounds__(256) k_len_scan(const uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor) {
+  __shared__ uint32_t sh[LEN_BINS];
+  uint32_t rev = LEN_BINS - 1 - threadIdx.x;          // thread i handles key 255-i
+  uint32_t v = len_hist[rev];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += u;
+    __syncthreads();
+  }
+  len_cursor[rev] = sh[threadIdx.x] - v;
+}
+
+// order[] = chunk ids sorted by descending length key (stable enough: order inside a key is arbitrary)
+__global__ void __launch_bounds__(256) k_order(const uint2* __restrict__ desc, const uint32_t* __restrict__ total_chunks,
+                                               uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
+  __shared__ uint32_t cnt[LEN_BINS];
+  __shared__ uint32_t base[LEN_BINS];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  bool live = t < *total_chunks;
+  uint32_t key = 0, local = 0;
+  if (live) { key = len_key(desc[t].y); local = atomicAdd(&cnt[key], 1u); }
+  __syncthreads();
+  uint32_t c = cnt[threadIdx.x];
+  if (c) base[threadIdx.x] = atomicAdd(&len_cursor[threadIdx.x], c);
+  __syncthreads();
+  if (live) order[base[key] + local] = t;
 }
 
 // ------------------------------------------------------------------ k_accumulate (dominant kernel)
 __global__ void __launch_bounds__(256) k_accumulate(const uint2* __restrict__ desc, const uint32_t* __restrict__ total_chunks,
-                                                    const uint32_t* __restrict__ sorted, const PreparedPoint* __restrict__ pts,
-                                                    PointSum* __restrict__ sums) {
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= *total_chunks) return;
-  uint2 d = desc[t];
+                                                    const uint32_t* __restrict__ order, const uint32_t* __restrict__ sorted,
+                                                    const PreparedPoint* __restrict__ pts, PointSum* __restrict__ sums) {
+  uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= *total_chunks) return;
+  const uint32_t t = order[g];              // chunks in descending length: lanes of a wave finish together
+  const uint2 d = desc[t];
+  const uint32_t* ent = sorted + d.x;
   xyzz acc = xyzz_identity();
+  uint32_t e = ent[0];
+  fp x, y; uint32_t flags;
+  load_affine(pts + (e & 0x7fffffffu), x, y, flags);
   for (uint32_t j = 0; j < d.y; ++j) {
-    uint32_t e = sorted[d.x + j];
-    fp x, y; uint32_t flags;
-    load_affine(pts + (e & 0x7fffffffu), x, y, flags);
+    // prefetch the next entry's point while this one is being added
+    uint32_t en = ent[(j + 1 < d.y) ? j + 1 : j];
+    fp xn, yn;
+    load_affine(pts + (en & 0x7fffffffu), xn, yn, flags);
     if (e >> 31) y = fp_neg<3>(y);
     acc = xyzz_madd(acc, x, y);
+    e = en; x = xn; y = yn;
   }
   store_sum(sums + t, acc);
 }
@@ -323,15 +532,25 @@ __device__ __forceinline__ xyzz shfl_down_xyzz(const xyzz& a, int delta) {
   return r;
 }
 
-// grid = (nitems, nlw).  item 0: T = sum_j seg_tot[j];  item 1+b: Y_b = sum_{j: bit b of j} seg_run[j].
+// stage 1: grid = (nitems, nlw, S).  item 0: T = sum_j seg_tot[j];  item 1+b: Y_b = sum_{j: bit b of j} seg_run[j].
+// Only the SELECTED j are enumerated (all J for item 0, the J/2 with bit b set otherwise) so no lane idles in
+// the serial part; block z takes BT_ELEMS consecutive selected elements (8 per lane).  The cost model that
+// shaped this: one wave-level EC add step is ~25 us and the chip runs 2048 of them at once, so total
+// wave-steps = waves x (elements per lane + 6 shuffle levels + 2) must be kept small, not just the depth.
+constexpr uint32_t BT_ELEMS = 2048;
 __global__ void __launch_bounds__(256) k_bit_tree(const PointSum* __restrict__ seg_run, const PointSum* __restrict__ seg_tot,
-                                                  PointWords* __restrict__ out, uint32_t J) {
+                                                  PointSum* __restrict__ partial, uint32_t J) {
   __shared__ PointSum sh[4];
-  const uint32_t item = blockIdx.x, lw = blockIdx.y;
+  const uint32_t item = blockIdx.x, lw = blockIdx.y, S = gridDim.z, z = blockIdx.z;
   const PointSum* src = (item == 0 ? seg_tot : seg_run) + (size_t)lw * J;
+  const uint32_t count = (item == 0) ? J : (J >> 1);
+  const uint32_t e0 = z * BT_ELEMS, e1 = (e0 + BT_ELEMS < count) ? e0 + BT_ELEMS : count;
   xyzz acc = xyzz_identity();
-  for (uint32_t j = threadIdx.x; j < J; j += 256) {
-    if (item == 0 || ((j >> (item - 1)) & 1u)) acc = xyzz_add(acc, load_sum(src + j));
+  const uint32_t b = item - 1;                   // bit index for item >= 1
+  for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
+    // e-th index with bit b set: insert a 1 at bit position b
+    uint32_t j = (item == 0) ? e : ((((e >> b) << 1) | 1u) << b) | (e & ((1u << b) - 1u));
+    acc = xyzz_add(acc, load_sum(src + j));
   }
   for (int delta = 32; delta >= 1; delta >>= 1) {
     xyzz o = shfl_down_xyzz(acc, delta);
@@ -339,11 +558,29 @@ __global__ void __launch_bounds__(256) k_bit_tree(const PointSum* __restrict__ s
   }
   if ((threadIdx.x & 63) == 0) store_sum(&sh[threadIdx.x >> 6], acc);
   __syncthreads();
+  if (threadIdx.x < 64) {
+    acc = (threadIdx.x < 4) ? load_sum(&sh[threadIdx.x]) : xyzz_identity();
+    for (int delta = 2; delta >= 1; delta >>= 1) {
+      xyzz o = shfl_down_xyzz(acc, delta);
+      if (threadIdx.x < (uint32_t)delta) acc = xyzz_add(acc, o);
+    }
+    if (threadIdx.x == 0) store_sum(partial + ((size_t)lw * gridDim.x + item) * S + z, acc);
+  }
+}
+
+// stage 2: one wave per (window, item): shuffle-tree over the S <= 64 slice partials, export canonical words
+__global__ void __launch_bounds__(64) k_bit_tree_final(const PointSum* __restrict__ partial, PointWords* __restrict__ out, uint32_t S) {
+  const size_t idx = blockIdx.x;
+  xyzz acc = (threadIdx.x < S) ? load_sum(partial + idx * S + threadIdx.x) : xyzz_identity();
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    if ((uint32_t)delta >= S) continue;      // wave-uniform
+    xyzz o = shfl_down_xyzz(acc, delta);
+    if (threadIdx.x < (uint32_t)delta) acc = xyzz_add(acc, o);
+  }
   if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; ++k) acc = xyzz_add(acc, load_sum(&sh[k]));
     xyzz_words o;
     xyzz_export(acc, o);
-    PointWords* dst = out + (size_t)lw * gridDim.x + item;
+    PointWords* dst = out + idx;
     for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
     dst->inf = o.inf;
   }
@@ -431,6 +668,11 @@ struct Ctx {
   PreparedPoint* d_pts = nullptr;
   uint32_t *d_hist = nullptr, *d_off = nullptr, *d_choff = nullptr, *d_sorted = nullptr;
   uint2 *d_blocktot = nullptr, *d_desc = nullptr;
+  uint32_t *d_order = nullptr, *d_lenhist = nullptr;      // [2*LEN_BINS]: histogram, cursor
+  PointSum* d_partial = nullptr; size_t cap_partial = 0;
+  uint16_t* d_digits = nullptr; uint32_t* d_part = nullptr; uint32_t* d_blockcnt = nullptr; uint32_t* d_ublocktot = nullptr;
+  size_t cap_digits = 0, cap_part = 0, cap_blockcnt = 0;
+  int use_partition_sort = 1;
   PointSum *d_sums = nullptr, *d_segrun = nullptr, *d_segtot = nullptr;
   PointWords* d_out = nullptr;
   PointWords* h_out = nullptr;          // pinned
@@ -440,6 +682,8 @@ struct Ctx {
   hipEvent_t ev[CG1_NPHASE + 1];
   float phase_ms[CG1_NPHASE] = {0};
   float host_tail_ms = 0;
+  float host_ms[4] = {0, 0, 0, 0};      // enqueue, wait-for-GPU, event readout, Horner tail
+  int profile = 1;                      // read the per-phase hipEvents after each call
   uint32_t last_chunks = 0, last_entries = 0;
   int last_c = 0;
   uint32_t L0 = 64;
@@ -449,7 +693,10 @@ struct Ctx {
 static void free_bufs(Ctx* c) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(c->d_pts); F(c->d_hist); F(c->d_off); F(c->d_choff); F(c->d_sorted); F(c->d_blocktot); F(c->d_desc);
-  F(c->d_sums); F(c->d_segrun); F(c->d_segtot); F(c->d_out);
+  F(c->d_sums); F(c->d_segrun); F(c->d_segtot); F(c->d_out); F(c->d_order); F(c->d_lenhist); F(c->d_partial);
+  c->cap_partial = 0;
+  F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot);
+  c->cap_digits = c->cap_part = c->cap_blockcnt = 0;
   if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
   c->cap_n = c->cap_nb = c->cap_chunks = c->cap_entries = c->cap_out = 0;
 }
@@ -481,11 +728,40 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
   if (chunks > ctx->cap_chunks) {
     if (ctx->d_desc) (void)hipFree(ctx->d_desc);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
+    if (ctx->d_order) (void)hipFree(ctx->d_order);
+    HIPCHK(hipMalloc(&ctx->d_order, chunks * 4));
     HIPCHK(hipMalloc(&ctx->d_desc, chunks * sizeof(uint2)));
     HIPCHK(hipMalloc(&ctx->d_sums, chunks * sizeof(PointSum)));
     ctx->cap_chunks = chunks;
   }
+  if (!ctx->d_lenhist) HIPCHK(hipMalloc(&ctx->d_lenhist, 2 * LEN_BINS * 4));
+  if (ctx->use_partition_sort && n <= PART_MAX_N) {
+    const size_t nslices = (n + PART_TILE - 1) / PART_TILE;
+    const size_t nbc = nlw * 128 * nslices + 1;            // nbins <= 128
+    if (entries > ctx->cap_digits) {
+      if (ctx->d_digits) (void)hipFree(ctx->d_digits);
+      HIPCHK(hipMalloc(&ctx->d_digits, entries * 2 + 16));
+      ctx->cap_digits = entries;
+    }
+    if (entries > ctx->cap_part) {
+      if (ctx->d_part) (void)hipFree(ctx->d_part);
+      HIPCHK(hipMalloc(&ctx->d_part, (entries + 1) * 4));
+      ctx->cap_part = entries;
+    }
+    if (nbc > ctx->cap_blockcnt) {
+      if (ctx->d_blockcnt) (void)hipFree(ctx->d_blockcnt);
+      if (ctx->d_ublocktot) (void)hipFree(ctx->d_ublocktot);
+      HIPCHK(hipMalloc(&ctx->d_blockcnt, nbc * 4));
+      HIPCHK(hipMalloc(&ctx->d_ublocktot, (nbc / SCAN_ITEMS + 2) * 4));
+      ctx->cap_blockcnt = nbc;
+    }
+  }
   size_t nout = nlw * nitems;
+  if (nout * 64 > ctx->cap_partial) {
+    if (ctx->d_partial) (void)hipFree(ctx->d_partial);
+    HIPCHK(hipMalloc(&ctx->d_partial, nout * 64 * sizeof(PointSum)));
+    ctx->cap_partial = nout * 64;
+  }
   if (nout > ctx->cap_out) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
@@ -540,36 +816,71 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   const uint32_t n32 = (uint32_t)n;
   const uint32_t gn = (n32 + 255) / 256;
 
+  auto h0 = std::chrono::steady_clock::now();
   HIPCHK(hipEventRecord(ctx->ev[0], st));
   hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, n32);
   HIPCHK(hipEventRecord(ctx->ev[1], st));
-  HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
-  hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_hist, n32, c, nwin, rank, world);
-  HIPCHK(hipEventRecord(ctx->ev[2], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
-  hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, ctx->L0);
-  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
-  hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
-  HIPCHK(hipEventRecord(ctx->ev[3], st));
-  hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, c, nwin, rank, world);
-  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, (uint32_t)nb_total, ctx->L0);
-  HIPCHK(hipEventRecord(ctx->ev[4], st));
+  if (ctx->use_partition_sort && n <= PART_MAX_N) {
+    // ---- two-level partition sort: no global atomics
+    const uint32_t bb = (uint32_t)c - 1u;                       // bucket bits
+    const uint32_t sub_bits = bb < 8u ? bb : 8u, nbins = 1u << (bb - sub_bits);
+    const uint32_t nslices = (n32 + PART_TILE - 1) / PART_TILE;
+    const uint32_t nbc = (uint32_t)nlw * nbins * nslices;
+    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_digits, n32, c, nwin, rank, world);
+    hipLaunchKernelGGL(k_part_count, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, n32, nslices, nbins, sub_bits);
+    const uint32_t ublk = (nbc + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    hipLaunchKernelGGL(k_uscan1, dim3(ublk), dim3(256), 0, st, ctx->d_blockcnt, ctx->d_ublocktot, nbc);
+    hipLaunchKernelGGL(k_uscan2, dim3(1), dim3(256), 0, st, ctx->d_ublocktot, ublk, ctx->d_blockcnt, nbc);
+    hipLaunchKernelGGL(k_uscan3, dim3(ublk), dim3(256), 0, st, ctx->d_ublocktot, ctx->d_blockcnt, nbc);
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    hipLaunchKernelGGL(k_part_scatter, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, ctx->d_part, n32, nslices, nbins, sub_bits);
+    hipLaunchKernelGGL(k_bin_sort, dim3((uint32_t)nlw * nbins), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, ctx->d_hist, ctx->d_sorted, (uint32_t)nlw * nbins, nslices, sub_bits);
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, ctx->L0);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+    hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+  } else {
+    // ---- global-atomic counting sort (any n < 2^31)
+    HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
+    hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_hist, n32, c, nwin, rank, world);
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, ctx->L0);
+    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+    hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, c, nwin, rank, world);
+  }
+  HIPCHK(hipMemsetAsync(ctx->d_lenhist, 0, LEN_BINS * 4, st));
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, (uint32_t)nb_total, ctx->L0);
   const size_t max_chunks = nb_total + (n * (size_t)nlw) / ctx->L0 + 1;
-  hipLaunchKernelGGL(k_accumulate, dim3((uint32_t)((max_chunks + 255) / 256)), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
+  const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
+  hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS);
+  hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
+  HIPCHK(hipEventRecord(ctx->ev[4], st));
+  hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   const uint32_t nseg_total = (uint32_t)(nb_total / m);
   hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
   HIPCHK(hipEventRecord(ctx->ev[6], st));
-  hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_out, J);
+  uint32_t S = (J + BT_ELEMS - 1) / BT_ELEMS; if (S < 1) S = 1; if (S > 64) S = 64;   // J <= 2^15 / seg_m
+  hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw, S), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_partial, J);
+  hipLaunchKernelGGL(k_bit_tree_final, dim3((uint32_t)(nitems * nlw)), dim3(64), 0, st, ctx->d_partial, ctx->d_out, S);
   HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)nlw * nitems * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[7], st));
+  auto h1 = std::chrono::steady_clock::now();
   HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
-  for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  auto h2 = std::chrono::steady_clock::now();
+  if (ctx->profile)
+    for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
   ctx->last_c = c;
 
   // ---- host tail: Horner.  V_w = T_w + m * sum_b 2^b Y_{w,b};  result = sum_w 2^(c w) V_w.
   auto t0 = std::chrono::steady_clock::now();
+  ctx->host_ms[0] = std::chrono::duration<float, std::milli>(h1 - h0).count();
+  ctx->host_ms[1] = std::chrono::duration<float, std::milli>(h2 - h1).count();
+  ctx->host_ms[2] = std::chrono::duration<float, std::milli>(t0 - h2).count();
   int lm = 0; while ((1u << lm) < m) ++lm;
   cg1h::jac acc = cg1h::jac_identity();
   int prev_w = -1;
@@ -587,6 +898,7 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   for (int k = 0; k < c * prev_w; ++k) acc = cg1h::jac_dbl(acc);
   result = acc;
   ctx->host_tail_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->host_ms[3] = ctx->host_tail_ms;
   return CG1_OK;
 }
 
@@ -730,6 +1042,8 @@ int cg1_ctx_sync(cg1_ctx* ctx) {
 int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return CG1_ERR_ARG;
   if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
+  if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
+  if (!strcmp(name, "profile")) { ctx->profile = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "seg_m")) { if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return CG1_ERR_ARG; ctx->seg_m = (uint32_t)value; return CG1_OK; }
   return CG1_ERR_ARG;
 }
@@ -765,6 +1079,12 @@ int cg1_get_timings(const cg1_ctx* ctx, float* phase_ms, float* host_tail_ms, in
   if (phase_ms) for (int i = 0; i < CG1_NPHASE; ++i) phase_ms[i] = ctx->phase_ms[i];
   if (host_tail_ms) *host_tail_ms = ctx->host_tail_ms;
   if (window_c) *window_c = ctx->last_c;
+  return CG1_OK;
+}
+
+int cg1_get_host_timings(const cg1_ctx* ctx, float host_ms[4]) {
+  if (!ctx || !host_ms) return CG1_ERR_ARG;
+  for (int i = 0; i < 4; ++i) host_ms[i] = ctx->host_ms[i];
   return CG1_OK;
 }
 

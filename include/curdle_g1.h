@@ -36,7 +36,7 @@ extern "C" {
 #define CG1_ERR_NOT_IN_SUBGROUP 5
 
 #define CG1_POINT_BYTES 144
-#define CG1_NPHASE 7          /* prepare, hist, scan, scatter, accumulate, seg_reduce, bit_tree(+D2H) */
+#define CG1_NPHASE 7          /* prepare, sort_count, sort_scatter, chunks, accumulate, seg_reduce, bit_tree(+D2H) */
 
 typedef struct cg1_ctx cg1_ctx;
 
@@ -72,7 +72,7 @@ void cg1_dev_free(cg1_ctx* ctx, void* p);
 int  cg1_h2d(cg1_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  cg1_d2h(cg1_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int  cg1_ctx_sync(cg1_ctx* ctx);                                     /* hipDeviceSynchronize on the context's GPU */
-int  cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value);   /* "chunk_len" (L0), "seg_m" */
+int  cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value);   /* "chunk_len" (L0), "seg_m", "profile" */
 
 /* ---------------- the hot path: compute_MSM  (msm_accumulator.py:6-12) ------------------------- */
 /* sum_i scalars[i] * points[i], inputs in host memory (copied to the device by the call). */
@@ -87,6 +87,9 @@ int cg1_msm_device(cg1_ctx* ctx, const void* d_points_affine96, const void* d_sc
                    int window_c, int shard_rank, int shard_world, uint8_t out[CG1_POINT_BYTES]);
 /* per-phase GPU times (hipEvents on the context's stream) and host Horner tail of the last MSM call */
 int cg1_get_timings(const cg1_ctx* ctx, float phase_ms[CG1_NPHASE], float* host_tail_ms, int* window_c);
+
+/* host-side wall times of the last MSM call: enqueue, wait-for-GPU, event readout, Horner tail (ms) */
+int cg1_get_host_timings(const cg1_ctx* ctx, float host_ms[4]);
 
 /* ---------------- batched scalar multiplication (`G1Point * Scalar`, vectorised) --------------- */
 /* out[i] = scalars[i] * bases[i % nbase]; all device pointers; affine96 in and out.
