@@ -34,10 +34,8 @@ CG1_HD xyzz xyzz_dbl(const xyzz& a) {
   fp M = fp_add(fp_dbl(XX), XX);            // limbs < 3*2^28
   fp MM = fp_sqr(M);
   fp X3 = fp_norm(fp_add(MM, fp_dbl(fp_neg<3>(S))));          // value < 7.1p
-  fp T1 = fp_mul(M, fp_sub<12>(S, X3));
-  fp T2 = fp_mul(W, a.Y);
   r.X = X3;
-  r.Y = fp_norm(fp_sub<3>(T1, T2));         // value < 4.1p
+  r.Y = fp_mul2(M, fp_sub<12>(S, X3), W, fp_neg<6>(a.Y));     // M(S-X3) - W*Y1 in one reduction; N-form, < 1.1p
   r.ZZ = fp_mul(V, a.ZZ);
   r.ZZZ = fp_mul(W, a.ZZZ);
   r.inf = 0;
@@ -61,10 +59,8 @@ CG1_HD xyzz xyzz_madd(const xyzz& a, const fp& x2, const fp& y2) {
   fp Q = fp_mul(a.X, PP);
   fp RR = fp_sqr(R);
   fp X3 = fp_norm(fp_add(fp_add(RR, fp_neg<3>(PPP)), fp_dbl(fp_neg<3>(Q))));   // value < 10.1p
-  fp T1 = fp_mul(R, fp_sub<12>(Q, X3));
-  fp T2 = fp_mul(a.Y, PPP);
   r.X = X3;
-  r.Y = fp_norm(fp_sub<3>(T1, T2));         // value < 4.1p
+  r.Y = fp_mul2(R, fp_sub<12>(Q, X3), PPP, fp_neg<6>(a.Y));   // R(Q-X3) - Y1*PPP in one reduction; N-form, < 1.1p
   r.ZZ = fp_mul(a.ZZ, PP);
   r.ZZZ = fp_mul(a.ZZZ, PPP);
   r.inf = 0;
@@ -91,10 +87,8 @@ CG1_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
   fp Q = fp_mul(U1, PP);
   fp RR = fp_sqr(R);
   fp X3 = fp_norm(fp_add(fp_add(RR, fp_neg<3>(PPP)), fp_dbl(fp_neg<3>(Q))));
-  fp T1 = fp_mul(R, fp_sub<12>(Q, X3));
-  fp T2 = fp_mul(S1, PPP);
   r.X = X3;
-  r.Y = fp_norm(fp_sub<3>(T1, T2));
+  r.Y = fp_mul2(R, fp_sub<12>(Q, X3), PPP, fp_neg<3>(S1));    // R(Q-X3) - S1*PPP in one reduction
   r.ZZ = fp_mul(fp_mul(a.ZZ, b.ZZ), PP);
   r.ZZZ = fp_mul(fp_mul(a.ZZZ, b.ZZZ), PPP);
   r.inf = 0;

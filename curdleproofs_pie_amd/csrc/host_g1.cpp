@@ -40,19 +40,27 @@ fe fe_sub(const fe& a, const fe& b) {
 }
 fe fe_neg(const fe& a) { return fe_is_zero(a) ? a : fe_sub(fe_zero(), a); }
 
+// CIOS with the "no-carry" shortcut: p < 2^381 leaves the top word of every partial sum below 2^63, so the
+// running value never needs a 7th word beyond one carry word (the method used by gnark/arkworks for moduli with
+// a free top bit).  Fully unrolled by the compiler (fixed trip counts).
 fe fe_mul(const fe& a, const fe& b) {
-  uint64_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+#pragma GCC unroll 6
   for (int i = 0; i < 6; ++i) {
-    u128 c = 0;
-    for (int j = 0; j < 6; ++j) { c += (u128)a.l[j] * b.l[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
-    c += t[6]; t[6] = (uint64_t)c; t[7] = (uint64_t)(c >> 64);
-    uint64_t m = t[0] * H_PINV;
-    c = ((u128)m * H_P[0] + t[0]) >> 64;
-    for (int j = 1; j < 6; ++j) { c += (u128)m * H_P[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
-    c += t[6]; t[5] = (uint64_t)c; t[6] = t[7] + (uint64_t)(c >> 64);
+    const uint64_t bi = b.l[i];
+    u128 c = (u128)a.l[0] * bi + t0;
+    const uint64_t m = (uint64_t)c * H_PINV;
+    u128 d = (u128)m * H_P[0] + (uint64_t)c;          // low word becomes 0
+    c >>= 64; d >>= 64;
+    c += (u128)a.l[1] * bi + t1; d += (u128)m * H_P[1] + (uint64_t)c; t0 = (uint64_t)d; c >>= 64; d >>= 64;
+    c += (u128)a.l[2] * bi + t2; d += (u128)m * H_P[2] + (uint64_t)c; t1 = (uint64_t)d; c >>= 64; d >>= 64;
+    c += (u128)a.l[3] * bi + t3; d += (u128)m * H_P[3] + (uint64_t)c; t2 = (uint64_t)d; c >>= 64; d >>= 64;
+    c += (u128)a.l[4] * bi + t4; d += (u128)m * H_P[4] + (uint64_t)c; t3 = (uint64_t)d; c >>= 64; d >>= 64;
+    c += (u128)a.l[5] * bi + t5; d += (u128)m * H_P[5] + (uint64_t)c; t4 = (uint64_t)d; c >>= 64; d >>= 64;
+    t5 = (uint64_t)c + (uint64_t)d;                   // fits: p < 2^381
   }
-  fe r = mk(t);
-  if (t[6] || geq_p(r.l)) sub_p(r.l);
+  fe r; r.l[0] = t0; r.l[1] = t1; r.l[2] = t2; r.l[3] = t3; r.l[4] = t4; r.l[5] = t5;
+  if (geq_p(r.l)) sub_p(r.l);
   return r;
 }
 fe fe_sqr(const fe& a) { return fe_mul(a, a); }

@@ -34,6 +34,19 @@ int t_fp_is_zero_diff(const uint8_t* a, const uint8_t* b) {   // a - b + 12p == 
   return fp_is_zero_mod_p(fp_sub<12>(load_mont(a), load_mont(b)), 14) ? 1 : 0;
 }
 
+// Worst-case limb magnitudes admitted by the static bound analysis of g1_xyzz.h: every 64-bit column
+// accumulator must still fit (mad64 asserts).  Values are meaningless; only magnitudes matter.
+int t_worst_case_bounds() {
+  fp lazy, neg, norm;
+  for (int i = 0; i < NL; ++i) { lazy.l[i] = 0x2FFFFFFFu; neg.l[i] = 0x1FFFFFFFu; norm.l[i] = 0x0FFFFFFFu; }
+  lazy.l[NL - 1] = 0x00FFFFFFu; neg.l[NL - 1] = 0x00FFFFFFu; norm.l[NL - 1] = 0x000FFFFFu;   // top limbs are small
+  fp r1 = fp_mul(lazy, lazy);            // (sub result) x (sub result): R*(Q-X3), M*(S-X3)
+  fp r2 = fp_sqr(lazy);                  // P^2, R^2, M^2
+  fp r3 = fp_mul2(lazy, lazy, norm, neg);  // fused Y3
+  fp r4 = fp_mul(neg, norm);             // lazily negated y times ZZZ
+  return (int)((r1.l[0] ^ r2.l[0] ^ r3.l[0] ^ r4.l[0]) & 1u) | 2;
+}
+
 static void export_xyzz(const xyzz& a, uint8_t* out /* 4*48 + 4 */) {
   xyzz_words o;
   xyzz_export(a, o);

@@ -42,6 +42,11 @@ def test_field_ops(fp28_harness):
         L.t_fp_inv(b48(a), o); assert int.from_bytes(o.raw, "little") == pow(a, -1, P)
 
 
+def test_worst_case_limb_magnitudes_do_not_overflow(fp28_harness):
+    # aborts the process (CG1_ASSERT) if any column accumulator would exceed 64 bits at the admitted maxima
+    assert fp28_harness.t_worst_case_bounds() & 2
+
+
 def test_group_law_with_exceptional_cases(fp28_harness):
     L = fp28_harness
     rng = random.Random(2)
