@@ -7,7 +7,7 @@ no torch, no Triton, no CPU fallback for the batched paths.
 Attributes resolve lazily so that `python -m curdleproofs_pie_amd.build` can run before the shared
 library exists; touching any of them without the library raises ImportError (never a fallback).
 """
-__all__ = ["G1Point", "Scalar", "CURVE_ORDER", "MSMAccumulator", "compute_MSM"]
+__all__ = ["G1Point", "Scalar", "CURVE_ORDER", "MSMAccumulator", "compute_MSM", "compute_MSM_batch"]
 
 
 def __getattr__(name):
@@ -15,7 +15,7 @@ def __getattr__(name):
         from . import py_arkworks_bls12381 as m
 
         return getattr(m, name)
-    if name in ("MSMAccumulator", "compute_MSM"):
+    if name in ("MSMAccumulator", "compute_MSM", "compute_MSM_batch"):
         from . import msm_accumulator as m
 
         return getattr(m, name)

@@ -73,6 +73,8 @@ cg1_ctx_sync = _proto("cg1_ctx_sync", c_int, c_void_p)
 cg1_ctx_set_param = _proto("cg1_ctx_set_param", c_int, c_void_p, c_char_p, c_int)
 cg1_msm = _proto("cg1_msm", c_int, c_void_p, _u8p, _u8p, c_size_t, _buf)
 cg1_msm_device = _proto("cg1_msm_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, _buf)
+cg1_msm_batched_device = _proto("cg1_msm_batched_device", c_int, c_void_p, c_void_p, c_void_p, POINTER(ctypes.c_uint32), c_size_t, c_int, _buf)
+cg1_msm_batched = _proto("cg1_msm_batched", c_int, c_void_p, _u8p, _u8p, POINTER(ctypes.c_uint32), c_size_t, _buf)
 cg1_get_timings = _proto("cg1_get_timings", c_int, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_int))
 cg1_get_host_timings = _proto("cg1_get_host_timings", c_int, c_void_p, POINTER(c_float))
 cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
@@ -84,7 +86,7 @@ EXPORTED_SYMBOLS = [
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_ctx_sync", "cg1_ctx_set_param",
-    "cg1_msm", "cg1_msm_device", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_gen_scalars_device", "cg1_probe_madd",
+    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 
 
@@ -160,6 +162,25 @@ class Context:
         out = ctypes.create_string_buffer(POINT_BYTES)
         self.check(cg1_msm_device(self.handle, p, s, n, window_c, shard_rank, shard_world, out))
         return out.raw
+
+    def msm_batched_device(self, d_points, d_scalars, offsets, window_c: int = 0) -> list:
+        """Regime B: offsets = [0, n_0, n_0+n_1, ...] (host ints); returns one 144-byte blob per MSM."""
+        m = len(offsets) - 1
+        p = d_points.ptr if isinstance(d_points, DeviceBuffer) else int(d_points)
+        s = d_scalars.ptr if isinstance(d_scalars, DeviceBuffer) else int(d_scalars)
+        arr = (ctypes.c_uint32 * (m + 1))(*offsets)
+        out = ctypes.create_string_buffer(POINT_BYTES * max(m, 1))
+        self.check(cg1_msm_batched_device(self.handle, p, s, arr, m, window_c, out))
+        raw = out.raw
+        return [raw[POINT_BYTES * j: POINT_BYTES * (j + 1)] for j in range(m)]
+
+    def msm_batched_host(self, points_affine96: bytes, scalars32: bytes, offsets) -> list:
+        m = len(offsets) - 1
+        arr = (ctypes.c_uint32 * (m + 1))(*offsets)
+        out = ctypes.create_string_buffer(POINT_BYTES * max(m, 1))
+        self.check(cg1_msm_batched(self.handle, points_affine96, scalars32, arr, m, out))
+        raw = out.raw
+        return [raw[POINT_BYTES * j: POINT_BYTES * (j + 1)] for j in range(m)]
 
     def timings(self) -> dict:
         ph = (c_float * NPHASE)()

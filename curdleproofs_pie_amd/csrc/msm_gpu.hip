@@ -335,6 +335,78 @@ __global__ void __launch_bounds__(256) k_uscan3(const uint32_t* __restrict__ blo
   for (int k = 0; k < 4; ++k) if (base + k < n) a[base + k] += p;
 }
 
+// ------------------------------------------------------------------ regime B: many independent small MSMs
+// A batch of M MSMs (MSM j = terms [offs[j], offs[j+1]) of one concatenated input) -- e.g. the 5*ell+7-term
+// final MSMs of 1024 MSMAccumulator.verify() calls (msm_accumulator.py:60-68).  Bucket space is indexed by
+// group g = j*nwin + w; with NB <= 256 buckets per group the counting sort of a group lives in one block's
+// LDS.  Everything between the sort and the bucket sums (chunking, length ordering, k_accumulate, k_seg_reduce)
+// is the same code as regime A, so lanes of one wave work on chunks of equal length from ANY msm/window.
+__global__ void __launch_bounds__(256) k_group_count(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ offs,
+                                                     uint32_t* __restrict__ hist, uint32_t N, uint32_t NB, uint32_t nwin) {
+  __shared__ uint32_t cnt[256];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t j = blockIdx.x, w = blockIdx.y;
+  const uint32_t o0 = offs[j], o1 = offs[j + 1];
+  const uint16_t* dg = digits + (size_t)w * N;
+  for (uint32_t i = o0 + threadIdx.x; i < o1; i += 256) {
+    uint32_t e = dg[i];
+    if (e) { uint32_t neg; atomicAdd(&cnt[digit_mag(e, neg) - 1u], 1u); }
+  }
+  __syncthreads();
+  if (threadIdx.x < NB) hist[((size_t)j * nwin + w) * NB + threadIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_group_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ offs,
+                                                       const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted,
+                                                       uint32_t N, uint32_t NB, uint32_t nwin) {
+  __shared__ uint32_t cur[256];
+  const uint32_t j = blockIdx.x, w = blockIdx.y;
+  if (threadIdx.x < NB) cur[threadIdx.x] = off[((size_t)j * nwin + w) * NB + threadIdx.x];
+  __syncthreads();
+  const uint32_t o0 = offs[j], o1 = offs[j + 1];
+  const uint16_t* dg = digits + (size_t)w * N;
+  for (uint32_t i = o0 + threadIdx.x; i < o1; i += 256) {
+    uint32_t e = dg[i];
+    if (e) {
+      uint32_t neg; uint32_t b = digit_mag(e, neg) - 1u;
+      uint32_t pos = atomicAdd(&cur[b], 1u);
+      sorted[pos] = i | (neg << 31);
+    }
+  }
+}
+
+// one lane per group: S_g = sum_s tot_s + m * sum_s s*run_s over the group's J = NB/m segments
+__global__ void __launch_bounds__(256) k_group_reduce(const PointSum* __restrict__ seg_run, const PointSum* __restrict__ seg_tot,
+                                                      PointSum* __restrict__ group_sum, uint32_t ngroups, uint32_t J, uint32_t log2m) {
+  uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const PointSum* run = seg_run + (size_t)g * J;
+  const PointSum* tot = seg_tot + (size_t)g * J;
+  xyzz r = xyzz_identity(), t = xyzz_identity();
+  for (uint32_t s = J - 1; s >= 1; --s) { r = xyzz_add(r, load_sum(run + s)); t = xyzz_add(t, r); }   // t = sum s*run_s
+  for (uint32_t k = 0; k < log2m; ++k) t = xyzz_dbl(t);
+  for (uint32_t s = 0; s < J; ++s) t = xyzz_add(t, load_sum(tot + s));
+  store_sum(group_sum + g, t);
+}
+
+// one lane per MSM: Horner over its nwin window sums, result as canonical words
+__global__ void __launch_bounds__(64) k_msm_horner(const PointSum* __restrict__ group_sum, PointWords* __restrict__ out,
+                                                   uint32_t M, uint32_t nwin, uint32_t c) {
+  uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= M) return;
+  xyzz acc = xyzz_identity();
+  for (int w = (int)nwin - 1; w >= 0; --w) {
+    for (uint32_t k = 0; k < c; ++k) acc = xyzz_dbl(acc);
+    acc = xyzz_add(acc, load_sum(group_sum + (size_t)j * nwin + w));
+  }
+  xyzz_words o;
+  xyzz_export(acc, o);
+  PointWords* dst = out + j;
+  for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
+  dst->inf = o.inf;
+}
+
 // ------------------------------------------------------------------ scan of (count, chunks)
 __device__ __forceinline__ uint32_t isqrt_ceil(uint32_t v) {
   uint32_t r = (uint32_t)sqrtf((float)v);
@@ -673,6 +745,9 @@ struct Ctx {
   uint16_t* d_digits = nullptr; uint32_t* d_part = nullptr; uint32_t* d_blockcnt = nullptr; uint32_t* d_ublocktot = nullptr;
   size_t cap_digits = 0, cap_part = 0, cap_blockcnt = 0;
   int use_partition_sort = 1;
+  uint32_t* d_boffs = nullptr; size_t cap_boffs = 0;          // regime B: MSM offsets, group sums, per-MSM results
+  PointSum* d_gsum = nullptr; size_t cap_gsum = 0;
+  PointWords* d_bout = nullptr; PointWords* h_bout = nullptr; size_t cap_bout = 0;
   PointSum *d_sums = nullptr, *d_segrun = nullptr, *d_segtot = nullptr;
   PointWords* d_out = nullptr;
   PointWords* h_out = nullptr;          // pinned
@@ -695,7 +770,9 @@ static void free_bufs(Ctx* c) {
   F(c->d_pts); F(c->d_hist); F(c->d_off); F(c->d_choff); F(c->d_sorted); F(c->d_blocktot); F(c->d_desc);
   F(c->d_sums); F(c->d_segrun); F(c->d_segtot); F(c->d_out); F(c->d_order); F(c->d_lenhist); F(c->d_partial);
   c->cap_partial = 0;
-  F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot);
+  F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot); F(c->d_boffs); F(c->d_gsum); F(c->d_bout);
+  if (c->h_bout) { (void)hipHostFree(c->h_bout); c->h_bout = nullptr; }
+  c->cap_boffs = c->cap_gsum = c->cap_bout = 0;
   c->cap_digits = c->cap_part = c->cap_blockcnt = 0;
   if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
   c->cap_n = c->cap_nb = c->cap_chunks = c->cap_entries = c->cap_out = 0;
@@ -786,6 +863,7 @@ int pick_window(size_t n) {
   // c minimising  nwin*n (bucket adds)  +  nwin * 2^(c-1) * ~3 (reduction adds, weighted for their latency)
   int best = 4; double best_cost = 1e300;
   for (int c = 4; c <= 16; ++c) {
+    if (255 % c == 0) continue;          // top window would hold only the recoding carry: one hot bucket
     int nwin = 255 / c + 1;
     double cost = (double)nwin * ((double)n + 3.0 * (double)(1u << (c - 1)));
     if (cost < best_cost) { best_cost = cost; best = c; }
@@ -902,6 +980,110 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   return CG1_OK;
 }
 
+
+int pick_window_batched(size_t n_avg) {
+  int best = 4; double best_cost = 1e300;
+  for (int c = 4; c <= 9; ++c) {                       // NB <= 256: a group's counting sort fits one block's LDS
+    if (255 % c == 0) continue;                        // top window would hold only the recoding carry: one hot bucket
+    int nwin = 255 / c + 1;
+    double NB = (double)(1u << (c - 1));
+    double cost = (double)nwin * ((double)n_avg + 1.4 * (2.0 * NB + 3.0 * NB / 8.0)) + 1.4 * 255.0;
+    if (cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
+// M independent MSMs over one concatenated (points, scalars) input resident on the device.
+int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, const uint32_t* h_offsets, size_t M,
+                       int c, std::vector<cg1h::jac>& results) {
+  results.assign(M, cg1h::jac_identity());
+  if (M == 0) return CG1_OK;
+  const size_t N = h_offsets[M];
+  for (size_t j = 0; j < M; ++j) if (h_offsets[j] > h_offsets[j + 1]) { snprintf(ctx->err, sizeof ctx->err, "offsets not monotone"); return CG1_ERR_ARG; }
+  if (h_offsets[0] != 0) { snprintf(ctx->err, sizeof ctx->err, "offsets[0] must be 0"); return CG1_ERR_ARG; }
+  if (N == 0) return CG1_OK;
+  if (N >= (1ull << 31) || M > 65535) { snprintf(ctx->err, sizeof ctx->err, "batch too large"); return CG1_ERR_ARG; }
+  if (c <= 0) c = pick_window_batched((N + M - 1) / M);
+  if (c < 4 || c > 9) { snprintf(ctx->err, sizeof ctx->err, "batched window width %d out of range [4,9]", c); return CG1_ERR_ARG; }
+  HIPCHK(hipSetDevice(ctx->device));
+  const uint32_t nwin = 255 / c + 1, NB = 1u << (c - 1);
+  const size_t G = M * nwin, nb_total = G * NB;
+  if (nb_total >= (1ull << 31) || N * nwin >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "batch too large"); return CG1_ERR_ARG; }
+  const uint32_t m = 8 < NB ? 8 : NB;                 // segment length of k_seg_reduce
+  uint32_t log2m = 0; while ((1u << log2m) < m) ++log2m;
+  const uint32_t J = NB / m;
+  int rc = ensure(ctx, N, nb_total, nwin, 1);
+  if (rc) return rc;
+  // batch-only buffers
+  if ((M + 1) > ctx->cap_boffs) {
+    if (ctx->d_boffs) (void)hipFree(ctx->d_boffs);
+    HIPCHK(hipMalloc(&ctx->d_boffs, (M + 1) * 4));
+    ctx->cap_boffs = M + 1;
+  }
+  if (G > ctx->cap_gsum) {
+    if (ctx->d_gsum) (void)hipFree(ctx->d_gsum);
+    HIPCHK(hipMalloc(&ctx->d_gsum, G * sizeof(PointSum)));
+    ctx->cap_gsum = G;
+  }
+  if (M > ctx->cap_bout) {
+    if (ctx->d_bout) (void)hipFree(ctx->d_bout);
+    if (ctx->h_bout) (void)hipHostFree(ctx->h_bout);
+    HIPCHK(hipMalloc(&ctx->d_bout, M * sizeof(PointWords)));
+    HIPCHK(hipHostMalloc(&ctx->h_bout, M * sizeof(PointWords)));
+    ctx->cap_bout = M;
+  }
+  if (N * nwin > ctx->cap_digits) {
+    if (ctx->d_digits) (void)hipFree(ctx->d_digits);
+    HIPCHK(hipMalloc(&ctx->d_digits, N * nwin * 2 + 16));
+    ctx->cap_digits = N * nwin;
+  }
+  hipStream_t st = ctx->stream;
+  const uint32_t N32 = (uint32_t)N, gn = (N32 + 255) / 256;
+  auto h0 = std::chrono::steady_clock::now();
+  HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, st));
+  HIPCHK(hipEventRecord(ctx->ev[0], st));
+  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, N32);
+  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_digits, N32, c, (int)nwin, 0, 1);
+  hipLaunchKernelGGL(k_group_count, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_hist, N32, NB, nwin);
+  HIPCHK(hipEventRecord(ctx->ev[2], st));
+  const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
+  hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, ctx->L0);
+  hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+  hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+  hipLaunchKernelGGL(k_group_scatter, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_off, ctx->d_sorted, N32, NB, nwin);
+  HIPCHK(hipEventRecord(ctx->ev[3], st));
+  HIPCHK(hipMemsetAsync(ctx->d_lenhist, 0, LEN_BINS * 4, st));
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, (uint32_t)nb_total, ctx->L0);
+  const size_t max_chunks = nb_total + (N * (size_t)nwin) / ctx->L0 + 1;
+  const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
+  hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS);
+  hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
+  HIPCHK(hipEventRecord(ctx->ev[4], st));
+  hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
+  HIPCHK(hipEventRecord(ctx->ev[5], st));
+  const uint32_t nseg_total = (uint32_t)(nb_total / m);
+  hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
+  hipLaunchKernelGGL(k_group_reduce, dim3((uint32_t)((G + 255) / 256)), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_gsum, (uint32_t)G, J, log2m);
+  HIPCHK(hipEventRecord(ctx->ev[6], st));
+  hipLaunchKernelGGL(k_msm_horner, dim3((uint32_t)((M + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
+  HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, M * sizeof(PointWords), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipEventRecord(ctx->ev[7], st));
+  auto h1 = std::chrono::steady_clock::now();
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipGetLastError());
+  auto h2 = std::chrono::steady_clock::now();
+  if (ctx->profile)
+    for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  ctx->last_c = c;
+  for (size_t j = 0; j < M; ++j) results[j] = jac_from_words(ctx->h_bout[j]);
+  auto h3 = std::chrono::steady_clock::now();
+  ctx->host_ms[0] = std::chrono::duration<float, std::milli>(h1 - h0).count();
+  ctx->host_ms[1] = std::chrono::duration<float, std::milli>(h2 - h1).count();
+  ctx->host_ms[2] = 0;
+  ctx->host_ms[3] = ctx->host_tail_ms = std::chrono::duration<float, std::milli>(h3 - h2).count();
+  return CG1_OK;
+}
 
 }  // namespace cg1
 
@@ -1072,6 +1254,37 @@ int cg1_msm(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars, size_t 
   HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
   return cg1_msm_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, n, 0, 0, 1, out);
+}
+
+int cg1_msm_batched_device(cg1_ctx* ctx, const void* d_points, const void* d_scalars, const uint32_t* offsets, size_t n_msm,
+                           int window_c, uint8_t* out_blobs) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (!offsets && n_msm) return CG1_ERR_ARG;
+  std::vector<cg1h::jac> res;
+  int rc = cg1::msm_batched_device(ctx, d_points, d_scalars, offsets, n_msm, window_c, res);
+  if (rc == CG1_OK) for (size_t j = 0; j < n_msm; ++j) blob_out(out_blobs + CG1_POINT_BYTES * j, res[j]);
+  return rc;
+}
+
+int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars, const uint32_t* offsets, size_t n_msm,
+                    uint8_t* out_blobs) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n_msm == 0) return CG1_OK;
+  if (!offsets) return CG1_ERR_ARG;
+  const size_t n = offsets[n_msm];
+  if (n == 0) { for (size_t j = 0; j < n_msm; ++j) blob_out(out_blobs + CG1_POINT_BYTES * j, cg1h::jac_identity()); return CG1_OK; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n > ctx->cap_stage) {
+    if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
+    if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
+    ctx->d_stage_pts = ctx->d_stage_sc = nullptr; ctx->cap_stage = 0;
+    HIPCHK(hipMalloc(&ctx->d_stage_pts, n * 96));
+    HIPCHK(hipMalloc(&ctx->d_stage_sc, n * 32));
+    ctx->cap_stage = n;
+  }
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  return cg1_msm_batched_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, offsets, n_msm, 0, out_blobs);
 }
 
 int cg1_get_timings(const cg1_ctx* ctx, float* phase_ms, float* host_tail_ms, int* window_c) {

@@ -32,6 +32,27 @@ def compute_MSM(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> G1Point:
     return G1Point._from_blob(out)
 
 
+def compute_MSM_batch(jobs: Iterable[Tuple[Iterable[G1Point], Iterable[Scalar]]]) -> List[G1Point]:
+    """[compute_MSM(bases, scalars) for (bases, scalars) in jobs] as ONE GPU launch chain (regime B).
+
+    For many independent small MSMs -- e.g. the final MSMs of a batch of proofs' MSMAccumulator.verify()
+    (msm_accumulator.py:60-68): BASELINE config 3 is 1024 of them at 627 terms each."""
+    all_pts: List[G1Point] = []
+    sc_parts: List[bytes] = []
+    offsets = [0]
+    for bases, scalars in jobs:
+        pairs = list(zip(bases, scalars))
+        all_pts.extend(p for p, _ in pairs)
+        sc_parts.extend(s._v.to_bytes(32, "little") for _, s in pairs)
+        offsets.append(len(all_pts))
+    if len(offsets) == 1:
+        return []
+    if not all_pts:
+        return [G1Point.identity() for _ in offsets[1:]]
+    blobs = N.default_context().msm_batched_host(points_to_affine96(all_pts), b"".join(sc_parts), offsets)
+    return [G1Point._from_blob(b) for b in blobs]
+
+
 class MSMAccumulator:
     """Random-linear-combination batching of `C == MSM(bases, scalars)` checks (msm_accumulator.py:32-68).
 
@@ -76,6 +97,29 @@ class MSMAccumulator:
                 m[k] = [rho * scalar._v % CURVE_ORDER, a]
             else:
                 ent[0] = (ent[0] + rho * scalar._v) % CURVE_ORDER  # :58
+
+    def _final_msm_terms(self) -> Tuple[bytes, bytes, int]:
+        ents = list(self.base_scalar_map.values())
+        pts = b"".join(e[1] for e in ents) + b"".join(a for a, _ in self._lhs)
+        sc = b"".join(e[0].to_bytes(32, "little") for e in ents) + b"".join(
+            ((-r) % CURVE_ORDER).to_bytes(32, "little") for _, r in self._lhs)
+        return pts, sc, len(ents) + len(self._lhs)
+
+    @staticmethod
+    def verify_many(accumulators: List["MSMAccumulator"]) -> List[bool]:
+        """`verify()` of many independent accumulators (one per proof) in ONE batched GPU call.
+        Returns one bool per accumulator instead of raising, so a bad proof does not hide the others."""
+        for a in accumulators:
+            if not a.base_scalar_map:
+                raise ValueError("not enough values to unpack (expected 2, got 0)")
+        if not accumulators:
+            return []
+        pts, sc, offsets = [], [], [0]
+        for a in accumulators:
+            p, s, n = a._final_msm_terms()
+            pts.append(p); sc.append(s); offsets.append(offsets[-1] + n)
+        blobs = N.default_context().msm_batched_host(b"".join(pts), b"".join(sc), offsets)
+        return [N.cg1_is_identity(b) == 1 for b in blobs]
 
     def verify(self) -> None:
         if not self.base_scalar_map:

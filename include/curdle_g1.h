@@ -85,6 +85,14 @@ int cg1_msm(cg1_ctx* ctx, const uint8_t* points_affine96, const uint8_t* scalars
  * window_c must then be the same on every rank. */
 int cg1_msm_device(cg1_ctx* ctx, const void* d_points_affine96, const void* d_scalars32, size_t n,
                    int window_c, int shard_rank, int shard_world, uint8_t out[CG1_POINT_BYTES]);
+/* Regime B -- a batch of n_msm INDEPENDENT small MSMs in one launch chain (e.g. the 5*ell+7-term final MSMs of
+ * many MSMAccumulator.verify() calls, msm_accumulator.py:60-68; BASELINE config 3: 1024 x 627 terms).
+ * MSM j sums terms [offsets[j], offsets[j+1]) of the concatenated inputs; offsets is a HOST array of
+ * n_msm+1 entries with offsets[0] == 0; out_blobs receives n_msm point blobs.  window_c 4..9, 0 = auto. */
+int cg1_msm_batched_device(cg1_ctx* ctx, const void* d_points_affine96, const void* d_scalars32,
+                           const uint32_t* offsets, size_t n_msm, int window_c, uint8_t* out_blobs);
+int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points_affine96, const uint8_t* scalars32,
+                    const uint32_t* offsets, size_t n_msm, uint8_t* out_blobs);
 /* per-phase GPU times (hipEvents on the context's stream) and host Horner tail of the last MSM call */
 int cg1_get_timings(const cg1_ctx* ctx, float phase_ms[CG1_NPHASE], float* host_tail_ms, int* window_c);
 

@@ -152,3 +152,53 @@ def test_batch_mul_variable_base(native_lib, ctx):
     out = do.download()
     for i in range(n):
         assert out[96 * i: 96 * i + 96] == raw96(O.g1_mul(bases[i % 6], sc[i])), i
+
+
+def test_batched_small_msms_ragged(native_lib, ctx):
+    """Regime B: independent MSMs of ragged sizes (incl. empty) in one launch chain, each vs the naive oracle."""
+    N = native_lib
+    rng = random.Random(31)
+    base = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(40)] + [None]
+    sizes = [0, 1, 2, 5, 0, 64, 131, 307, 627, 3, 33]
+    pts, sc, offsets = [], [], [0]
+    for n in sizes:
+        for _ in range(n):
+            pts.append(base[rng.randrange(len(base))])
+            sc.append(rng.choice([0, 1, O.R - 1, rng.randint(0, O.R - 1), rng.randint(0, O.R - 1)]))
+        offsets.append(len(pts))
+    p96 = b"".join(raw96(p) for p in pts)
+    s32 = b"".join(s.to_bytes(32, "little") for s in sc)
+    for c in (0, 4, 6, 9):
+        dp, ds = ctx.alloc(len(p96)), ctx.alloc(len(s32))
+        dp.upload(p96); ds.upload(s32)
+        blobs = ctx.msm_batched_device(dp, ds, offsets, window_c=c)
+        assert len(blobs) == len(sizes)
+        for j, n in enumerate(sizes):
+            lo, hi = offsets[j], offsets[j + 1]
+            want = C.compress(C.compute_msm(p96[96 * lo: 96 * hi], s32[32 * lo: 32 * hi], n))
+            assert compress_blob(N, blobs[j]) == want, (c, j, n)
+    assert [compress_blob(N, b) for b in ctx.msm_batched_host(p96, s32, offsets)] == [compress_blob(N, b) for b in blobs]
+
+
+def test_batched_1024_x_627_closed_form(native_lib, ctx):
+    """BASELINE config 3's MSM content: 1024 independent 627-term MSMs (5*ell+7 at ell=124).  Points k_i*G,
+    so MSM_j == (sum_{i in j} k_i s_i mod r) * G exactly."""
+    N = native_lib
+    M, n = 1024, 627
+    tot = M * n
+    dk, dg, dp, ds = ctx.alloc(32 * tot), ctx.alloc(96), ctx.alloc(96 * tot), ctx.alloc(32 * tot)
+    ctx.gen_scalars_device(dk, tot, 11); ctx.gen_scalars_device(ds, tot, 12)
+    dg.upload(raw96(O.G1_GEN))
+    ctx.batch_mul_device(dg, 1, dk, dp, tot)
+    kb, sb = dk.download(), ds.download()
+    blobs = ctx.msm_batched_device(dp, ds, [n * j for j in range(M + 1)])
+    assert len(blobs) == M
+    for j in list(range(0, M, 97)) + [M - 1]:
+        acc = 0
+        for i in range(n * j, n * (j + 1)):
+            acc += int.from_bytes(kb[32 * i: 32 * i + 32], "little") * int.from_bytes(sb[32 * i: 32 * i + 32], "little")
+        assert compress_blob(N, blobs[j]) == O.g1_compress(O.g1_mul(O.G1_GEN, acc % O.R)), j
+    # and every MSM of the batch agrees with the single-MSM path (regime A kernels)
+    for j in (0, 511, 1023):
+        single = ctx.msm_device(dp.ptr + 96 * n * j, ds.ptr + 32 * n * j, n)
+        assert N.cg1_eq(single, blobs[j]) == 1

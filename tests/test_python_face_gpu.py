@@ -68,3 +68,30 @@ def test_msm_accumulator(api):
     random.seed(123); acc2 = A.MSMAccumulator(); acc2.accumulate_check(naive(G, a, A), G, a); after = random.random()
     random.seed(123); U.random_scalar(); assert random.random() == after
     assert acc2.A_c == naive(G, a, A) * A.Scalar(acc2._lhs[0][1])
+
+
+def test_compute_msm_batch_and_verify_many(api):
+    A, U = api
+    from curdleproofs_pie_amd.msm_accumulator import compute_MSM_batch
+
+    random.seed(6)
+    jobs = []
+    for n in (3, 0, 17, 64):
+        jobs.append(([U.get_random_point() for _ in range(n)], [U.random_scalar() for _ in range(n)]))
+    got = compute_MSM_batch(jobs)
+    assert len(got) == 4
+    for (b, s), g in zip(jobs, got):
+        assert g == naive(b, s, A)
+    assert compute_MSM_batch([]) == []
+    # many accumulators (one per "proof"), one bad
+    G = [U.get_random_point() for _ in range(12)]
+    accs = []
+    for k in range(5):
+        a = [U.random_scalar() for _ in range(12)]
+        acc = A.MSMAccumulator()
+        C = naive(G, a, A)
+        if k == 3:
+            C = C + U.G1
+        acc.accumulate_check(C, G, a)
+        accs.append(acc)
+    assert A.MSMAccumulator.verify_many(accs) == [True, True, True, False, True]
