@@ -78,6 +78,8 @@ cg1_msm_batched = _proto("cg1_msm_batched", c_int, c_void_p, _u8p, _u8p, POINTER
 cg1_get_timings = _proto("cg1_get_timings", c_int, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_int))
 cg1_get_host_timings = _proto("cg1_get_host_timings", c_int, c_void_p, POINTER(c_float))
 cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
+cg1_batch_mul_add_device = _proto("cg1_batch_mul_add_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
+cg1_batch_mul_add = _proto("cg1_batch_mul_add", c_int, c_void_p, _u8p, c_size_t, _u8p, c_size_t, _u8p, _buf, c_size_t)
 cg1_gen_scalars_device = _proto("cg1_gen_scalars_device", c_int, c_void_p, c_void_p, c_size_t, c_uint64)
 cg1_probe_madd = _proto("cg1_probe_madd", c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_int, POINTER(c_float))
 
@@ -86,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_ctx_sync", "cg1_ctx_set_param",
-    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_gen_scalars_device", "cg1_probe_madd",
+    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 
 
@@ -199,6 +201,12 @@ class Context:
     def batch_mul_device(self, d_bases, nbase: int, d_scalars, d_out, n: int) -> None:
         g = lambda b: b.ptr if isinstance(b, DeviceBuffer) else int(b)
         self.check(cg1_batch_mul_device(self.handle, g(d_bases), nbase, g(d_scalars), g(d_out), n))
+
+    def batch_mul_add_host(self, bases96: bytes, nbase: int, scalars32: bytes, nscalars: int, addend96, n: int) -> bytes:
+        """out[i] = addend[i] + scalars[i % nscalars] * bases[i % nbase] (host buffers; affine96 in/out)."""
+        out = ctypes.create_string_buffer(96 * max(n, 1))
+        self.check(cg1_batch_mul_add(self.handle, bases96, nbase, scalars32, nscalars, addend96, out, n))
+        return out.raw[: 96 * n]
 
     def gen_scalars_device(self, d_out, n: int, seed: int) -> None:
         p = d_out.ptr if isinstance(d_out, DeviceBuffer) else int(d_out)

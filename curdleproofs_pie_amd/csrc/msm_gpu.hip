@@ -658,12 +658,17 @@ __global__ void __launch_bounds__(64) k_bit_tree_final(const PointSum* __restric
   }
 }
 
-// ------------------------------------------------------------------ fixed/variable-base batch scalar mul
-// out[i] = k_i * P_i (affine std words, identity -> zeros).  P_i = base[i % nbase].  Used to synthesise
-// benchmark/test points (k_i * G: the reference's get_random_point, util.py:67-68) and as the batched
-// counterpart of `G1Point * Scalar`.
+// ------------------------------------------------------------------ batched scalar mul / fold
+// out[i] = addend[i] + k_i * P_i   with P_i = base[i % nbase], k_i = scalars[i % nscalars], addend optional.
+// Covers the vectorised `G1Point * Scalar` patterns of the callers:
+//   nbase = 1                  fixed base:        get_random_point = G * random_scalar()   (util.py:67-68)
+//   nscalars = 1               same-scalar map:   [R * k for R in vec_R]                   (curdleproofs.py:310-311)
+//   nscalars = 1, addend = L   fold:              G_L[i] + G_R[i] * gamma                  (ipa.py:142-146, same_msm.py:122-126)
+//   per-index scalars          G_i * beta^-i                                               (grand_prod.py:64-71)
+// Affine std words in and out (identity = zeros); one lane per output, double-and-add MSB first.
 __global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ base_raw, uint32_t nbase,
-                                                   const uint32_t* __restrict__ scalars, uint32_t* __restrict__ out_raw, uint32_t n) {
+                                                   const uint32_t* __restrict__ scalars, uint32_t nscalars,
+                                                   const uint32_t* __restrict__ addend_raw, uint32_t* __restrict__ out_raw, uint32_t n) {
   uint32_t i = blockIdx.x * 128 + threadIdx.x;
   if (i >= n) return;
   uint32_t w[24];
@@ -671,18 +676,28 @@ __global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ 
   uint32_t any = 0;
   for (int k = 0; k < 24; ++k) { w[k] = src[k]; any |= w[k]; }
   uint32_t s[8];
-  for (int k = 0; k < 8; ++k) s[k] = scalars[8ull * i + k];
+  for (int k = 0; k < 8; ++k) s[k] = scalars[8ull * (i % nscalars) + k];
   xyzz acc = xyzz_identity();
   if (any) {
     fp x = fp_to_mont(fp_from_words(w)), y = fp_to_mont(fp_from_words(w + 12));
-    for (int bit = 255; bit >= 0; --bit) {
+    int top = 255;
+    while (top >= 0 && !((s[top >> 5] >> (top & 31)) & 1u)) --top;     // skip leading zero bits (per lane)
+    for (int bit = top; bit >= 0; --bit) {
       acc = xyzz_dbl(acc);
       if ((s[bit >> 5] >> (bit & 31)) & 1u) acc = xyzz_madd(acc, x, y);
     }
   }
+  if (addend_raw) {
+    const uint32_t* a = addend_raw + 24ull * i;
+    uint32_t aw[24], aany = 0;
+    for (int k = 0; k < 24; ++k) { aw[k] = a[k]; aany |= aw[k]; }
+    if (aany) acc = xyzz_madd(acc, fp_to_mont(fp_from_words(aw)), fp_to_mont(fp_from_words(aw + 12)));
+  }
   uint32_t* dst = out_raw + 24ull * i;
   if (acc.inf) { for (int k = 0; k < 24; ++k) dst[k] = 0; return; }
-  fp izz = fp_inv(acc.ZZ), izzz = fp_inv(acc.ZZZ);
+  // x = X/ZZ, y = Y/ZZZ with ONE inversion: 1/(ZZ*ZZZ)
+  fp t = fp_inv(fp_mul(acc.ZZ, acc.ZZZ));
+  fp izz = fp_mul(t, acc.ZZZ), izzz = fp_mul(t, acc.ZZ);
   uint32_t o[12];
   fp_to_words(fp_mul(acc.X, izz), o);  for (int k = 0; k < 12; ++k) dst[k] = o[k];
   fp_to_words(fp_mul(acc.Y, izzz), o); for (int k = 0; k < 12; ++k) dst[12 + k] = o[k];
@@ -1301,16 +1316,39 @@ int cg1_get_host_timings(const cg1_ctx* ctx, float host_ms[4]) {
   return CG1_OK;
 }
 
-int cg1_batch_mul_device(cg1_ctx* ctx, const void* d_bases, size_t nbase, const void* d_scalars, void* d_out, size_t n) {
+int cg1_batch_mul_add_device(cg1_ctx* ctx, const void* d_bases, size_t nbase, const void* d_scalars, size_t nscalars,
+                             const void* d_addend, void* d_out, size_t n) {
   if (!ctx) return CG1_ERR_HIP;
-  if (nbase == 0 && n) return CG1_ERR_ARG;
+  if ((nbase == 0 || nscalars == 0) && n) return CG1_ERR_ARG;
   if (n == 0) return CG1_OK;
+  if (n >= (1ull << 31)) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   hipLaunchKernelGGL(cg1::k_batch_mul, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                     (const uint32_t*)d_bases, (uint32_t)nbase, (const uint32_t*)d_scalars, (uint32_t*)d_out, (uint32_t)n);
+                     (const uint32_t*)d_bases, (uint32_t)nbase, (const uint32_t*)d_scalars, (uint32_t)nscalars,
+                     (const uint32_t*)d_addend, (uint32_t*)d_out, (uint32_t)n);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   return CG1_OK;
+}
+int cg1_batch_mul_device(cg1_ctx* ctx, const void* d_bases, size_t nbase, const void* d_scalars, void* d_out, size_t n) {
+  return cg1_batch_mul_add_device(ctx, d_bases, nbase, d_scalars, n ? n : 1, nullptr, d_out, n);
+}
+// host-pointer convenience: H2D, kernel, D2H
+int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases, size_t nbase, const uint8_t* scalars, size_t nscalars,
+                      const uint8_t* addend, uint8_t* out, size_t n) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) return CG1_OK;
+  if (nbase == 0 || nscalars == 0) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  void *db = nullptr, *ds = nullptr, *da = nullptr, *dout = nullptr;
+  HIPCHK(hipMalloc(&db, nbase * 96)); HIPCHK(hipMalloc(&ds, nscalars * 32)); HIPCHK(hipMalloc(&dout, n * 96));
+  HIPCHK(hipMemcpy(db, bases, nbase * 96, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ds, scalars, nscalars * 32, hipMemcpyHostToDevice));
+  if (addend) { HIPCHK(hipMalloc(&da, n * 96)); HIPCHK(hipMemcpy(da, addend, n * 96, hipMemcpyHostToDevice)); }
+  int rc = cg1_batch_mul_add_device(ctx, db, nbase, ds, nscalars, da, dout, n);
+  if (rc == CG1_OK) { hipError_t e = hipMemcpy(out, dout, n * 96, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = CG1_ERR_HIP; }
+  (void)hipFree(db); (void)hipFree(ds); (void)hipFree(dout); if (da) (void)hipFree(da);
+  return rc;
 }
 int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
   if (!ctx) return CG1_ERR_HIP;

@@ -53,6 +53,51 @@ def compute_MSM_batch(jobs: Iterable[Tuple[Iterable[G1Point], Iterable[Scalar]]]
     return [G1Point._from_blob(b) for b in blobs]
 
 
+def _blobs_from_affine96(raw: bytes, n: int) -> List[G1Point]:
+    import ctypes
+
+    out = []
+    for i in range(n):
+        b = ctypes.create_string_buffer(N.POINT_BYTES)
+        rc = N.cg1_from_affine96(b, raw[96 * i: 96 * i + 96], 0)
+        assert rc == N.OK
+        out.append(G1Point._from_blob(b.raw))
+    return out
+
+
+def batch_mul(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> List[G1Point]:
+    """[b * s for b, s in zip(bases, scalars)] on the GPU (e.g. G_i * beta^-i, grand_prod.py:64-71)."""
+    pairs = list(zip(bases, scalars))
+    n = len(pairs)
+    if n == 0:
+        return []
+    raw = N.default_context().batch_mul_add_host(points_to_affine96([p for p, _ in pairs]), n,
+                                                 b"".join(s._v.to_bytes(32, "little") for _, s in pairs), n, None, n)
+    return _blobs_from_affine96(raw, n)
+
+
+def batch_mul_same_scalar(bases: Iterable[G1Point], scalar: Scalar) -> List[G1Point]:
+    """[b * scalar for b in bases] on the GPU (e.g. vec_T = [R * k ...], curdleproofs.py:310-311)."""
+    bases = list(bases)
+    n = len(bases)
+    if n == 0:
+        return []
+    raw = N.default_context().batch_mul_add_host(points_to_affine96(bases), n, scalar._v.to_bytes(32, "little"), 1, None, n)
+    return _blobs_from_affine96(raw, n)
+
+
+def batch_fold(left: Iterable[G1Point], right: Iterable[G1Point], scalar: Scalar) -> List[G1Point]:
+    """[l + r * scalar for l, r in zip(left, right)] on the GPU (the IPA / same-MSM folding step,
+    ipa.py:142-146, same_msm.py:122-126)."""
+    pairs = list(zip(left, right))
+    n = len(pairs)
+    if n == 0:
+        return []
+    raw = N.default_context().batch_mul_add_host(points_to_affine96([r for _, r in pairs]), n, scalar._v.to_bytes(32, "little"), 1,
+                                                 points_to_affine96([l for l, _ in pairs]), n)
+    return _blobs_from_affine96(raw, n)
+
+
 class MSMAccumulator:
     """Random-linear-combination batching of `C == MSM(bases, scalars)` checks (msm_accumulator.py:32-68).
 

@@ -104,7 +104,17 @@ int cg1_get_host_timings(const cg1_ctx* ctx, float host_ms[4]);
  * nbase = 1 is the fixed-base case (get_random_point: G * random_scalar(), util.py:67-68). */
 int cg1_batch_mul_device(cg1_ctx* ctx, const void* d_bases_affine96, size_t nbase, const void* d_scalars32,
                          void* d_out_affine96, size_t n);
-/* deterministic synthetic scalars in [1, 2^252) from a 64-bit seed (splitmix64), device memory */
+/* General form: out[i] = addend[i] + scalars[i % nscalars] * bases[i % nbase]   (addend may be NULL).
+ * nscalars = 1: same-scalar map  [R*k for R in vec_R]  (curdleproofs.py:310-311);
+ * nscalars = 1 with addend = L:  fold  G_L[i] + G_R[i]*gamma  (ipa.py:142-146, same_msm.py:122-126);
+ * per-index scalars:             G_i * beta^-i  (grand_prod.py:64-71). */
+int cg1_batch_mul_add_device(cg1_ctx* ctx, const void* d_bases_affine96, size_t nbase, const void* d_scalars32,
+                             size_t nscalars, const void* d_addend_affine96, void* d_out_affine96, size_t n);
+/* same, all buffers in host memory (copied in and out by the call) */
+int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t nbase, const uint8_t* scalars32, size_t nscalars,
+                      const uint8_t* addend_affine96, uint8_t* out_affine96, size_t n);
+/* deterministic synthetic scalars, uniform in [1, r-1] (util.py:21-24 distribution), from a 64-bit seed
+ * (splitmix64 + rejection), device memory */
 int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out_scalars32, size_t n, uint64_t seed);
 /* roofline probe for the dominant kernel: `iters` dependent mixed adds per lane on `lanes` lanes;
  * returns elapsed ms in *ms */

@@ -95,3 +95,25 @@ def test_compute_msm_batch_and_verify_many(api):
         acc.accumulate_check(C, G, a)
         accs.append(acc)
     assert A.MSMAccumulator.verify_many(accs) == [True, True, True, False, True]
+
+
+def test_batch_mul_patterns(api):
+    """Vectorised `G1Point * Scalar` patterns of the callers against the host operators."""
+    A, U = api
+    from curdleproofs_pie_amd.msm_accumulator import batch_fold, batch_mul, batch_mul_same_scalar
+
+    random.seed(8)
+    n = 37
+    L = [U.get_random_point() for _ in range(n)]
+    Rr = [U.get_random_point() for _ in range(n)]
+    L[5] = U.Z1
+    Rr[7] = U.Z1
+    sc = [U.random_scalar() for _ in range(n)]
+    sc[3] = A.Scalar(0)
+    gamma = U.random_scalar()
+    assert batch_mul(Rr, sc) == [r * s for r, s in zip(Rr, sc)]                       # grand_prod.py:64-71
+    assert batch_mul_same_scalar(Rr, gamma) == [r * gamma for r in Rr]                # curdleproofs.py:310-311
+    assert batch_fold(L, Rr, gamma) == [l + r * gamma for l, r in zip(L, Rr)]         # ipa.py:142-146
+    assert batch_fold(L, L, A.Scalar(A.CURVE_ORDER - 1)) == [U.Z1] * n                # l + (-1) l == identity
+    assert batch_fold(L, L, A.Scalar(1)) == [l + l for l in L]                        # doubling through the add
+    assert batch_mul([], []) == []
