@@ -59,3 +59,42 @@ def sharded_msm(ctx: "N.Context", d_points, d_scalars, n: int, rank: int, world:
     else:
         raise ValueError(f"unknown shard mode {mode!r}")
     return all_reduce_g1(part, group=group)
+
+
+def sharded_msm_batch(jobs_affine, rank: int, world: int, group=None, compute=None) -> List[bytes]:
+    """Many INDEPENDENT MSMs (e.g. one final accumulator MSM per proof; BASELINE config 5: 16384 proofs over
+    8 GPUs) sharded job-per-GPU: rank g computes jobs g, g+world, ... with the regime-B batched kernels, then the
+    per-job result blobs are all-gathered so every rank holds all results.  Embarrassingly parallel: the only
+    collective is that final gather of 144 bytes per job (no data-path exchange).
+
+    jobs_affine: list of (points_affine96: bytes, scalars32: bytes, n: int).
+    compute: callable(list_of_jobs) -> list of blobs for this rank's share; defaults to the GPU batched path
+             (curdleproofs_pie_amd has no CPU path; the parameter exists so the gloo tests can exercise the
+             sharding/gather logic on a CPU-only box with the host operators).
+    """
+    mine = list(range(rank, len(jobs_affine), world))
+    my_jobs = [jobs_affine[i] for i in mine]
+    if compute is None:
+        def compute(js):
+            if not js:
+                return []
+            offs = [0]
+            for _, _, n in js:
+                offs.append(offs[-1] + n)
+            return N.default_context().msm_batched_host(b"".join(p for p, _, _ in js), b"".join(s for _, s, _ in js), offs)
+    my_blobs = compute(my_jobs)
+    assert len(my_blobs) == len(my_jobs)
+    import torch.distributed as dist
+
+    if world == 1 or not dist.is_initialized():
+        out = [None] * len(jobs_affine)
+        for i, b in zip(mine, my_blobs):
+            out[i] = bytes(b)
+        return out
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (mine, [bytes(b) for b in my_blobs]), group=group)
+    out = [None] * len(jobs_affine)
+    for idxs, blobs in gathered:
+        for i, b in zip(idxs, blobs):
+            out[i] = b
+    return out

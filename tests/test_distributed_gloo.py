@@ -77,3 +77,67 @@ def test_two_rank_g1_all_reduce(native_lib, mode):
     scalars = [rng.randint(0, 2 ** 255 - 20) for _ in range(n)]
     want = O.g1_compress(O.g1_mul(O.G1_GEN, sum(k * (s % O.R) for k, s in zip(ks, scalars)) % O.R)).hex()
     assert got[0] == got[1] == want
+
+
+def _worker_batch(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import ctypes
+    import random
+
+    import torch.distributed as dist
+
+    from curdleproofs_pie_amd import _native as N
+    from curdleproofs_pie_amd.distributed import sharded_msm_batch
+    from curdleproofs_pie_amd.py_arkworks_bls12381 import G1Point, Scalar, points_to_affine96
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = random.Random(77)
+    jobs, truth = [], []
+    for n in (3, 1, 0, 5, 2):          # 5 independent "proofs"
+        ks = [rng.randint(1, 2 ** 100) for _ in range(n)]
+        ss = [rng.randint(0, 2 ** 250) for _ in range(n)]
+        pts = [G1Point() * Scalar(k) for k in ks]
+        jobs.append((points_to_affine96(pts), b"".join(s.to_bytes(32, "little") for s in ss), n))
+        truth.append(sum(k * s for k, s in zip(ks, ss)))
+
+    def host_compute(js):              # CPU stand-in for the GPU batched kernels (test only)
+        out = []
+        for p96, s32, n in js:
+            acc = G1Point.identity()
+            for i in range(n):
+                b = ctypes.create_string_buffer(N.POINT_BYTES)
+                assert N.cg1_from_affine96(b, p96[96 * i: 96 * i + 96], 1) == 0
+                acc = acc + G1Point._from_blob(b.raw) * Scalar(int.from_bytes(s32[32 * i: 32 * i + 32], "little"))
+            out.append(acc._b)
+        return out
+
+    blobs = sharded_msm_batch(jobs, rank, world, compute=host_compute)
+    res = []
+    for b in blobs:
+        o = ctypes.create_string_buffer(48)
+        N.cg1_compress(o, b)
+        res.append(o.raw.hex())
+    q.put((rank, res, truth))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_job_sharding(native_lib):
+    import torch.multiprocessing as mp
+
+    from oracle import bls12_381 as O
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_batch, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, r0, truth), (_, r1, _) = got
+    assert r0 == r1
+    assert r0 == [O.g1_compress(O.g1_mul(O.G1_GEN, t % O.R)).hex() for t in truth]
