@@ -8,9 +8,9 @@
 //                      aligned cache line per point, so the bucket gather below touches exactly one line.
 //   k_hist             per scalar: c-bit signed digits for this rank's windows -> per-bucket counts
 //   k_scan1/2/3        exclusive scan of (count, chunk count) per bucket  (chunk = <= Lb consecutive
-//                      entries of one bucket, Lb = max(L0, ceil(sqrt(count))) so a skewed bucket --
-//                      e.g. the reference's [beta]*ell all-equal scalars, same_perm.py:54-55 -- is split
-//                      into ~sqrt pieces instead of serialising one lane)
+//                      entries of one bucket, Lb = max(L0, count/4096) so a skewed bucket -- e.g. the
+//                      reference's [beta]*ell all-equal scalars, same_perm.py:54-55 -- is split into many
+//                      pieces whose sums k_heavy_combine adds with a block-wide tree)
 //   k_scatter          counting-sort scatter: sorted[] = point index | sign<<31, grouped by bucket
 //   k_chunk_desc       (start,len) per chunk
 //   k_accumulate  ***  the dominant kernel: one lane per chunk, XYZZ mixed adds (8M+2S) over gathered points
@@ -200,6 +200,26 @@ __device__ __forceinline__ uint32_t digit_mag(uint32_t e, uint32_t& neg) {   // 
   return (uint32_t)(d < 0 ? -d : d);
 }
 
+// LDS counter increment that returns this lane's slot.  When every active lane of the wave carries the SAME
+// key (skewed scalars: all-equal, tiny range, recoding-carry window) the wave issues ONE atomic for all of them
+// instead of 64 serialised same-address atomics.  Must be called convergently by the whole wave.
+__device__ int g_wave_agg = 1;         // A/B switch (cg1_ctx_set_param "wave_agg")
+__device__ __forceinline__ uint32_t lds_ranked_inc(uint32_t* ctr, uint32_t key, bool active) {
+  if (!g_wave_agg) return active ? atomicAdd(&ctr[key], 1u) : 0u;
+  const unsigned long long amask = __ballot(active);
+  if (amask == 0ull) return 0u;
+  const int leader = __ffsll((long long)amask) - 1;
+  const uint32_t k0 = __shfl(key, leader, 64);
+  if (__ballot(active && key != k0) == 0ull) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&ctr[k0], (uint32_t)__popcll(amask));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
+  }
+  return active ? atomicAdd(&ctr[key], 1u) : 0u;
+}
+
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const PreparedPoint* __restrict__ pts,
                                                 uint16_t* __restrict__ digits, uint32_t n, int c, int nwin, int rank, int world) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
@@ -223,10 +243,9 @@ __global__ void __launch_bounds__(256) k_part_count(const uint16_t* __restrict__
   const uint16_t* dg = digits + (size_t)lw * n;
   for (uint32_t k = 0; k < PART_TILE / 256; ++k) {
     uint32_t i = slice * PART_TILE + k * 256 + threadIdx.x;
-    if (i < n) {
-      uint32_t e = dg[i];
-      if (e) { uint32_t neg; uint32_t mag = digit_mag(e, neg); atomicAdd(&cnt[(mag - 1u) >> sub_bits], 1u); }
-    }
+    uint32_t e = (i < n) ? (uint32_t)dg[i] : 0u;
+    uint32_t neg, key = e ? ((digit_mag(e, neg) - 1u) >> sub_bits) : 0u;
+    lds_ranked_inc(cnt, key, e != 0u);
   }
   __syncthreads();
   if (threadIdx.x < nbins) block_counts[((size_t)lw * nbins + threadIdx.x) * nslices + slice] = cnt[threadIdx.x];
@@ -243,14 +262,10 @@ __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t* __restrict
   const uint32_t sub_mask = (1u << sub_bits) - 1u;
   for (uint32_t k = 0; k < PART_TILE / 256; ++k) {
     uint32_t i = slice * PART_TILE + k * 256 + threadIdx.x;
-    if (i < n) {
-      uint32_t e = dg[i];
-      if (e) {
-        uint32_t neg; uint32_t b = digit_mag(e, neg) - 1u;
-        uint32_t pos = atomicAdd(&cur[b >> sub_bits], 1u);
-        part[pos] = i | (neg << 23) | ((b & sub_mask) << 24);
-      }
-    }
+    uint32_t e = (i < n) ? (uint32_t)dg[i] : 0u;
+    uint32_t neg = 0, b = e ? (digit_mag(e, neg) - 1u) : 0u;
+    uint32_t pos = lds_ranked_inc(cur, b >> sub_bits, e != 0u);
+    if (e) part[pos] = i | (neg << 23) | ((b & sub_mask) << 24);
   }
 }
 
@@ -264,7 +279,11 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ p
   const uint32_t end = block_base[(size_t)(g + 1) * nslices];     // element [nbins_total*nslices] holds the grand total
   cnt[threadIdx.x] = 0;
   __syncthreads();
-  for (uint32_t e = start + threadIdx.x; e < end; e += 256) atomicAdd(&cnt[part[e] >> 24], 1u);
+  const uint32_t span = ((end - start + 255u) / 256u) * 256u;       // whole waves iterate together
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const bool live = start + o < end;
+    lds_ranked_inc(cnt, live ? (part[start + o] >> 24) : 0u, live);
+  }
   __syncthreads();
   const uint32_t mine = cnt[threadIdx.x];
   cur[threadIdx.x] = mine;
@@ -280,10 +299,11 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ p
   cur[threadIdx.x] = start + excl;
   if (threadIdx.x < (1u << sub_bits)) hist[((size_t)g << sub_bits) + threadIdx.x] = mine;
   __syncthreads();
-  for (uint32_t e = start + threadIdx.x; e < end; e += 256) {
-    uint32_t v = part[e];
-    uint32_t pos = atomicAdd(&cur[v >> 24], 1u);
-    sorted[pos] = (v & 0x7fffffu) | ((v >> 23 & 1u) << 31);
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const bool live = start + o < end;
+    const uint32_t v = live ? part[start + o] : 0u;
+    const uint32_t pos = lds_ranked_inc(cur, v >> 24, live);
+    if (live) sorted[pos] = (v & 0x7fffffu) | ((v >> 23 & 1u) << 31);
   }
 }
 
@@ -349,9 +369,11 @@ __global__ void __launch_bounds__(256) k_group_count(const uint16_t* __restrict_
   const uint32_t j = blockIdx.x, w = blockIdx.y;
   const uint32_t o0 = offs[j], o1 = offs[j + 1];
   const uint16_t* dg = digits + (size_t)w * N;
-  for (uint32_t i = o0 + threadIdx.x; i < o1; i += 256) {
-    uint32_t e = dg[i];
-    if (e) { uint32_t neg; atomicAdd(&cnt[digit_mag(e, neg) - 1u], 1u); }
+  const uint32_t span = ((o1 - o0 + 255u) / 256u) * 256u;
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const uint32_t e = (o0 + o < o1) ? (uint32_t)dg[o0 + o] : 0u;
+    uint32_t neg;
+    lds_ranked_inc(cnt, e ? digit_mag(e, neg) - 1u : 0u, e != 0u);
   }
   __syncthreads();
   if (threadIdx.x < NB) hist[((size_t)j * nwin + w) * NB + threadIdx.x] = cnt[threadIdx.x];
@@ -366,13 +388,14 @@ __global__ void __launch_bounds__(256) k_group_scatter(const uint16_t* __restric
   __syncthreads();
   const uint32_t o0 = offs[j], o1 = offs[j + 1];
   const uint16_t* dg = digits + (size_t)w * N;
-  for (uint32_t i = o0 + threadIdx.x; i < o1; i += 256) {
-    uint32_t e = dg[i];
-    if (e) {
-      uint32_t neg; uint32_t b = digit_mag(e, neg) - 1u;
-      uint32_t pos = atomicAdd(&cur[b], 1u);
-      sorted[pos] = i | (neg << 31);
-    }
+  const uint32_t span = ((o1 - o0 + 255u) / 256u) * 256u;
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const uint32_t i = o0 + o;
+    const uint32_t e = (i < o1) ? (uint32_t)dg[i] : 0u;
+    uint32_t neg = 0;
+    const uint32_t b = e ? digit_mag(e, neg) - 1u : 0u;
+    const uint32_t pos = lds_ranked_inc(cur, b, e != 0u);
+    if (e) sorted[pos] = i | (neg << 31);
   }
 }
 
@@ -408,14 +431,14 @@ __global__ void __launch_bounds__(64) k_msm_horner(const PointSum* __restrict__ 
 }
 
 // ------------------------------------------------------------------ scan of (count, chunks)
-__device__ __forceinline__ uint32_t isqrt_ceil(uint32_t v) {
-  uint32_t r = (uint32_t)sqrtf((float)v);
-  while ((uint64_t)r * r < v) ++r;
-  while (r > 0 && (uint64_t)(r - 1) * (r - 1) >= v) --r;
-  return r;
-}
+// Chunk length of a bucket with `cnt` entries: L0 normally; a skewed bucket (e.g. the reference's [beta]*ell
+// all-equal scalars, same_perm.py:54-55, or the recoding carry of a top window) is cut into at most
+// MAX_CHUNKS_PER_BUCKET pieces whose partial sums are then combined by a block-wide tree (k_heavy_combine)
+// instead of serialising one lane.
+constexpr uint32_t MAX_CHUNKS_PER_BUCKET = 4096;
+constexpr uint32_t HEAVY_MIN_CHUNKS = 5;        // buckets with >= this many chunks go through k_heavy_combine
 __device__ __forceinline__ uint32_t chunk_len(uint32_t cnt, uint32_t L0) {
-  uint32_t s = isqrt_ceil(cnt);
+  uint32_t s = (cnt + MAX_CHUNKS_PER_BUCKET - 1) / MAX_CHUNKS_PER_BUCKET;
   return s > L0 ? s : L0;
 }
 __device__ __forceinline__ uint32_t chunk_count(uint32_t cnt, uint32_t L0) {
@@ -491,7 +514,8 @@ __device__ __forceinline__ uint32_t len_key(uint32_t len) { return len < LEN_BIN
 
 __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__ off, const uint32_t* __restrict__ choff,
                                                     uint2* __restrict__ desc, uint32_t* __restrict__ len_hist,
-                                                    uint32_t nb_total, uint32_t L0) {
+                                                    uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
+                                                    uint32_t heavy_cap, uint32_t nb_total, uint32_t L0) {
   __shared__ uint32_t sh[LEN_BINS];
   sh[threadIdx.x] = 0;
   __syncthreads();
@@ -504,6 +528,10 @@ __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__
         uint32_t s = k * L, len = (cnt - s < L) ? (cnt - s) : L;
         desc[o + k] = make_uint2(start + s, len);
         atomicAdd(&sh[len_key(len)], 1u);
+      }
+      if (nch >= HEAVY_MIN_CHUNKS) {
+        uint32_t slot = atomicAdd(&heavy[0], 1u);
+        if (slot < heavy_cap) heavy[1 + slot] = b;
       }
     }
   }
@@ -571,10 +599,43 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint2* __restrict__ de
   store_sum(sums + t, acc);
 }
 
+// ------------------------------------------------------------------ k_heavy_combine
+// Blocks stride over the heavy-bucket list; one block adds ALL chunk sums of its bucket (<= 4096):
+// <= 16 serial adds per lane, then wave shuffles, then LDS.  The total replaces the bucket's first chunk sum and
+// the bucket is flagged so k_seg_reduce reads only that slot.
+__device__ __forceinline__ xyzz shfl_down_xyzz(const xyzz& a, int delta);
+__global__ void __launch_bounds__(256) k_heavy_combine(const uint32_t* __restrict__ heavy, uint32_t heavy_cap,
+                                                       const uint32_t* __restrict__ choff, PointSum* __restrict__ sums,
+                                                       uint8_t* __restrict__ combined) {
+  __shared__ PointSum sh[4];
+  uint32_t nheavy = heavy[0];
+  if (nheavy > heavy_cap) nheavy = heavy_cap;
+  for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+    const uint32_t b = heavy[1 + h];
+    const uint32_t c0 = choff[b], c1 = choff[b + 1];
+    xyzz acc = xyzz_identity();
+    for (uint32_t k = c0 + threadIdx.x; k < c1; k += 256) acc = xyzz_add(acc, load_sum(sums + k));
+    __syncthreads();                     // every chunk sum has been read before slot c0 is overwritten
+    for (int delta = 32; delta >= 1; delta >>= 1) {
+      xyzz o = shfl_down_xyzz(acc, delta);
+      if ((threadIdx.x & 63) < (uint32_t)delta) acc = xyzz_add(acc, o);
+    }
+    if ((threadIdx.x & 63) == 0) store_sum(&sh[threadIdx.x >> 6], acc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int k = 1; k < 4; ++k) acc = xyzz_add(acc, load_sum(&sh[k]));
+      store_sum(sums + c0, acc);
+      combined[b] = 1;
+    }
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ k_seg_reduce
 // One lane per segment of `m` consecutive buckets of one window.  Bucket b of the window carries digit
 // value b+1.  Emits run_j = sum_t B_{jm+t}, tot_j = sum_t (t+1) B_{jm+t}  (t = 0..m-1).
 __global__ void __launch_bounds__(256) k_seg_reduce(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+                                                    const uint8_t* __restrict__ combined,
                                                     PointSum* __restrict__ seg_run, PointSum* __restrict__ seg_tot,
                                                     uint32_t nseg_total, uint32_t m) {
   uint32_t s = blockIdx.x * 256 + threadIdx.x;
@@ -583,6 +644,7 @@ __global__ void __launch_bounds__(256) k_seg_reduce(const uint32_t* __restrict__
   for (int t = (int)m - 1; t >= 0; --t) {
     uint32_t b = s * m + (uint32_t)t;           // segments tile the flat (window, bucket) array
     uint32_t c0 = choff[b], c1 = choff[b + 1];
+    if (combined[b]) c1 = c0 + 1;        // k_heavy_combine already folded all chunks into the first slot
     for (uint32_t k = c0; k < c1; ++k) run = xyzz_add(run, load_sum(sums + k));
     tot = xyzz_add(tot, run);
   }
@@ -760,6 +822,8 @@ struct Ctx {
   uint16_t* d_digits = nullptr; uint32_t* d_part = nullptr; uint32_t* d_blockcnt = nullptr; uint32_t* d_ublocktot = nullptr;
   size_t cap_digits = 0, cap_part = 0, cap_blockcnt = 0;
   int use_partition_sort = 1;
+  uint32_t* d_heavy = nullptr; size_t cap_heavy = 0;         // [0] count, then heavy bucket ids
+  uint8_t* d_combined = nullptr; size_t cap_combined = 0;
   uint32_t* d_boffs = nullptr; size_t cap_boffs = 0;          // regime B: MSM offsets, group sums, per-MSM results
   PointSum* d_gsum = nullptr; size_t cap_gsum = 0;
   PointWords* d_bout = nullptr; PointWords* h_bout = nullptr; size_t cap_bout = 0;
@@ -827,6 +891,19 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
     ctx->cap_chunks = chunks;
   }
   if (!ctx->d_lenhist) HIPCHK(hipMalloc(&ctx->d_lenhist, 2 * LEN_BINS * 4));
+  {
+    const size_t hcap = entries / (ctx->L0 * (HEAVY_MIN_CHUNKS - 1)) + 2;     // a heavy bucket holds > (MIN-1)*L0 entries
+    if (hcap > ctx->cap_heavy) {
+      if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
+      HIPCHK(hipMalloc(&ctx->d_heavy, (hcap + 1) * 4));
+      ctx->cap_heavy = hcap;
+    }
+    if (nb_total > ctx->cap_combined) {
+      if (ctx->d_combined) (void)hipFree(ctx->d_combined);
+      HIPCHK(hipMalloc(&ctx->d_combined, nb_total));
+      ctx->cap_combined = nb_total;
+    }
+  }
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
     const size_t nslices = (n + PART_TILE - 1) / PART_TILE;
     const size_t nbc = nlw * 128 * nslices + 1;            // nbins <= 128
@@ -945,7 +1022,9 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, c, nwin, rank, world);
   }
   HIPCHK(hipMemsetAsync(ctx->d_lenhist, 0, LEN_BINS * 4, st));
-  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, (uint32_t)nb_total, ctx->L0);
+  HIPCHK(hipMemsetAsync(ctx->d_heavy, 0, 4, st));
+  HIPCHK(hipMemsetAsync(ctx->d_combined, 0, nb_total, st));
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, ctx->L0);
   const size_t max_chunks = nb_total + (n * (size_t)nlw) / ctx->L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS);
@@ -954,7 +1033,8 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   const uint32_t nseg_total = (uint32_t)(nb_total / m);
-  hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
+  hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
+  hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
   HIPCHK(hipEventRecord(ctx->ev[6], st));
   uint32_t S = (J + BT_ELEMS - 1) / BT_ELEMS; if (S < 1) S = 1; if (S > 64) S = 64;   // J <= 2^15 / seg_m
   hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw, S), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_partial, J);
@@ -969,26 +1049,24 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
   ctx->last_c = c;
 
-  // ---- host tail: Horner.  V_w = T_w + m * sum_b 2^b Y_{w,b};  result = sum_w 2^(c w) V_w.
+  // ---- host tail: ONE Horner over global bit positions.
+  //   result = sum_w 2^(c w) [ T_w + m * sum_b 2^b Y_{w,b} ] = sum over points P with weight 2^e(P),
+  //   e(T_w) = c w,  e(Y_{w,b}) = c w + log2(m) + b  (< c (w+1) since log2(m) + nbits = c - 1).
   auto t0 = std::chrono::steady_clock::now();
   ctx->host_ms[0] = std::chrono::duration<float, std::milli>(h1 - h0).count();
   ctx->host_ms[1] = std::chrono::duration<float, std::milli>(h2 - h1).count();
   ctx->host_ms[2] = std::chrono::duration<float, std::milli>(t0 - h2).count();
   int lm = 0; while ((1u << lm) < m) ++lm;
   cg1h::jac acc = cg1h::jac_identity();
-  int prev_w = -1;
-  for (int lw = nlw - 1; lw >= 0; --lw) {
-    const int w = rank + lw * world;
-    if (prev_w >= 0) for (int k = 0; k < c * (prev_w - w); ++k) acc = cg1h::jac_dbl(acc);
-    const PointWords* row = ctx->h_out + (size_t)lw * nitems;
-    cg1h::jac v = cg1h::jac_identity();
-    for (int b = nbits - 1; b >= 0; --b) { v = cg1h::jac_dbl(v); v = cg1h::jac_add(v, jac_from_words(row[1 + b])); }
-    for (int k = 0; k < lm; ++k) v = cg1h::jac_dbl(v);
-    v = cg1h::jac_add(v, jac_from_words(row[0]));
-    acc = cg1h::jac_add(acc, v);
-    prev_w = w;
+  const int top_w = rank + (nlw - 1) * world;
+  for (int e = c * top_w + lm + nbits - 1; e >= 0; --e) {
+    acc = cg1h::jac_dbl(acc);
+    const int w = e / c, r = e % c;
+    if (w % world != rank) continue;
+    const PointWords* row = ctx->h_out + (size_t)(w / world) * nitems;
+    if (r == 0) acc = cg1h::jac_add(acc, jac_from_words(row[0]));
+    if (r >= lm && r - lm < nbits) acc = cg1h::jac_add(acc, jac_from_words(row[1 + (r - lm)]));
   }
-  for (int k = 0; k < c * prev_w; ++k) acc = cg1h::jac_dbl(acc);
   result = acc;
   ctx->host_tail_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
   ctx->host_ms[3] = ctx->host_tail_ms;
@@ -1069,7 +1147,9 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_group_scatter, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_off, ctx->d_sorted, N32, NB, nwin);
   HIPCHK(hipEventRecord(ctx->ev[3], st));
   HIPCHK(hipMemsetAsync(ctx->d_lenhist, 0, LEN_BINS * 4, st));
-  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, (uint32_t)nb_total, ctx->L0);
+  HIPCHK(hipMemsetAsync(ctx->d_heavy, 0, 4, st));
+  HIPCHK(hipMemsetAsync(ctx->d_combined, 0, nb_total, st));
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, ctx->L0);
   const size_t max_chunks = nb_total + (N * (size_t)nwin) / ctx->L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS);
@@ -1078,7 +1158,8 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   const uint32_t nseg_total = (uint32_t)(nb_total / m);
-  hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
+  hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
+  hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
   hipLaunchKernelGGL(k_group_reduce, dim3((uint32_t)((G + 255) / 256)), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_gsum, (uint32_t)G, J, log2m);
   HIPCHK(hipEventRecord(ctx->ev[6], st));
   hipLaunchKernelGGL(k_msm_horner, dim3((uint32_t)((M + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
@@ -1240,6 +1321,12 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return CG1_ERR_ARG;
   if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
+  if (!strcmp(name, "wave_agg")) {
+    int v = value ? 1 : 0;
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(cg1::g_wave_agg), &v, sizeof v));
+    return CG1_OK;
+  }
   if (!strcmp(name, "profile")) { ctx->profile = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "seg_m")) { if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return CG1_ERR_ARG; ctx->seg_m = (uint32_t)value; return CG1_OK; }
   return CG1_ERR_ARG;
