@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--shard", choices=["windows", "points"], default="windows")
     ap.add_argument("--cpu-sample-logn", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="transport of the N>1 partial-sum exchange (nccl == RCCL; gloo only to rehearse on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -72,12 +75,16 @@ def main():
 
     dist = None
     torch = None
+    dev_index = 0 if args.same_device else local_rank
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    ctx = N.Context(local_rank)
+        if args.backend == "nccl":
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
+    ctx = N.Context(dev_index)
 
     n_per_gpu = 1 << args.logn
     n_total = n_per_gpu * world
@@ -109,7 +116,8 @@ def main():
     def barrier_sync():
         if world > 1:
             dist.barrier()
-            torch.cuda.synchronize()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
         ctx.sync()
 
     results = []
@@ -129,7 +137,7 @@ def main():
         sys.exit("bench.py: MSM results differ between steps")
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -11,7 +11,7 @@ import threading
 from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcurdle_g1.so")
+LIB_PATH = os.environ.get("CURDLE_G1_LIB") or os.path.join(HERE, "libcurdle_g1.so")
 
 POINT_BYTES = 144
 NPHASE = 7

@@ -27,6 +27,16 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
 
 
+def build_variant(out_path: str, extra_flags, verbose: bool = True) -> str:
+    """A/B builds for experiments (e.g. -DCG1_NO_ASM_MAD); select at run time with CURDLE_G1_LIB=<path>."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", *extra_flags, *SOURCES, "-o", out_path]
+    if verbose:
+        print("[curdleproofs_pie_amd.build]", " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out_path
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not needs_build():
         return LIB

@@ -50,6 +50,22 @@ CG1_KP_TAB(12)
 CG1_KP_TAB(32)
 #undef CG1_KP_TAB
 
+// acc + a*b.  hipcc re-associates every column into a fresh accumulator plus a 64-bit add of the shifted carry
+// (one extra half-rate v_lshl_add_u64 per column, ~6 % of a Montgomery product).  Pinning the dependent chain
+// with inline asm (-DCG1_ASM_MAD) was measured and is a LOSS on ROCm 7.2: the compiler pads every asm statement
+// with an s_nop, k_accumulate stays at 2.43 ms and the latency-bound kernels get 20-35 % slower
+// (same-box A/B, round 1).  Kept only as an experiment switch.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(CG1_ASM_MAD)
+__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc");
+  return c;
+}
+// b is a compile-time constant (a limb of p): keep it in an SGPR
+__device__ __forceinline__ uint64_t mad64c(uint32_t a, uint32_t b, uint64_t c) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "s"(b) : "vcc");
+  return c;
+}
+#else
 CG1_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
 #if defined(CG1_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
   unsigned __int128 w = (unsigned __int128)a * b + c;
@@ -57,6 +73,8 @@ CG1_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
 #endif
   return (uint64_t)a * b + c;        // -> v_mad_u64_u32
 }
+CG1_HD uint64_t mad64c(uint32_t a, uint32_t b, uint64_t c) { return mad64(a, b, c); }
+#endif
 
 CG1_HD fp fp_zero() { fp r; for (int i = 0; i < NL; ++i) r.l[i] = 0; return r; }
 CG1_HD fp fp_one()  {                // Montgomery form of 1 (N-form)
@@ -79,9 +97,9 @@ CG1_HD fp fp_mul(const fp& a, const fp& b) {
 #pragma unroll
     for (int i = 0; i <= k; ++i) acc = mad64(a.l[i], b.l[k - i], acc);
 #pragma unroll
-    for (int i = 0; i < k; ++i) acc = mad64(q[i], c_p(k - i), acc);
+    for (int i = 0; i < k; ++i) acc = mad64c(q[i], c_p(k - i), acc);
     q[k] = ((uint32_t)acc * D_PINV) & LMASK;
-    acc = mad64(q[k], c_p(0), acc);
+    acc = mad64c(q[k], c_p(0), acc);
     acc >>= 28;
   }
 #pragma unroll
@@ -89,7 +107,7 @@ CG1_HD fp fp_mul(const fp& a, const fp& b) {
 #pragma unroll
     for (int i = k - NL + 1; i < NL; ++i) acc = mad64(a.l[i], b.l[k - i], acc);
 #pragma unroll
-    for (int i = k - NL + 1; i < NL; ++i) acc = mad64(q[i], c_p(k - i), acc);
+    for (int i = k - NL + 1; i < NL; ++i) acc = mad64c(q[i], c_p(k - i), acc);
     r.l[k - NL] = (uint32_t)acc & LMASK;
     acc >>= 28;
   }
@@ -110,9 +128,9 @@ CG1_HD fp fp_mul2(const fp& a, const fp& b, const fp& c, const fp& d) {
 #pragma unroll
     for (int i = 0; i <= k; ++i) { acc = mad64(a.l[i], b.l[k - i], acc); acc = mad64(c.l[i], d.l[k - i], acc); }
 #pragma unroll
-    for (int i = 0; i < k; ++i) acc = mad64(q[i], c_p(k - i), acc);
+    for (int i = 0; i < k; ++i) acc = mad64c(q[i], c_p(k - i), acc);
     q[k] = ((uint32_t)acc * D_PINV) & LMASK;
-    acc = mad64(q[k], c_p(0), acc);
+    acc = mad64c(q[k], c_p(0), acc);
     acc >>= 28;
   }
 #pragma unroll
@@ -120,7 +138,7 @@ CG1_HD fp fp_mul2(const fp& a, const fp& b, const fp& c, const fp& d) {
 #pragma unroll
     for (int i = k - NL + 1; i < NL; ++i) { acc = mad64(a.l[i], b.l[k - i], acc); acc = mad64(c.l[i], d.l[k - i], acc); }
 #pragma unroll
-    for (int i = k - NL + 1; i < NL; ++i) acc = mad64(q[i], c_p(k - i), acc);
+    for (int i = k - NL + 1; i < NL; ++i) acc = mad64c(q[i], c_p(k - i), acc);
     r.l[k - NL] = (uint32_t)acc & LMASK;
     acc >>= 28;
   }
@@ -143,9 +161,9 @@ CG1_HD fp fp_sqr(const fp& a) {
     for (int i = 0; 2 * i < k; ++i) acc = mad64(a.l[i], a2[k - i], acc);
     if ((k & 1) == 0) acc = mad64(a.l[k / 2], a.l[k / 2], acc);
 #pragma unroll
-    for (int i = 0; i < k; ++i) acc = mad64(q[i], c_p(k - i), acc);
+    for (int i = 0; i < k; ++i) acc = mad64c(q[i], c_p(k - i), acc);
     q[k] = ((uint32_t)acc * D_PINV) & LMASK;
-    acc = mad64(q[k], c_p(0), acc);
+    acc = mad64c(q[k], c_p(0), acc);
     acc >>= 28;
   }
 #pragma unroll
@@ -154,7 +172,7 @@ CG1_HD fp fp_sqr(const fp& a) {
     for (int i = k - NL + 1; 2 * i < k; ++i) acc = mad64(a.l[i], a2[k - i], acc);
     if ((k & 1) == 0) acc = mad64(a.l[k / 2], a.l[k / 2], acc);
 #pragma unroll
-    for (int i = k - NL + 1; i < NL; ++i) acc = mad64(q[i], c_p(k - i), acc);
+    for (int i = k - NL + 1; i < NL; ++i) acc = mad64c(q[i], c_p(k - i), acc);
     r.l[k - NL] = (uint32_t)acc & LMASK;
     acc >>= 28;
   }

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/TAG_* (from tools/collect_profiles.sh) into committed summaries under profiles/.
+usage: python tools/summarize_profiles.py TAG OUTPREFIX   e.g.  r01v4 profiles/r01_v4"""
+import collections
+import csv
+import glob
+import json
+import shutil
+import sys
+
+tag, out = sys.argv[1], sys.argv[2]
+
+
+def agg(pattern):
+    files = glob.glob(pattern)
+    a = collections.defaultdict(list)
+    if not files:
+        return a
+    for r in csv.DictReader(open(files[0])):
+        a[(r["Kernel_Name"].split("(")[0], r["Counter_Name"])].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in a.items()}
+
+
+shutil.copy(glob.glob(f"gpurun_out/{tag}_kt/*/*_kernel_stats.csv")[0], out + "_kernel_stats.csv")
+shutil.copy(f"gpurun_out/{tag}_bench.json", out + "_bench.json")
+f, w, q = agg(f"gpurun_out/{tag}_fetch/*/*_counter_collection.csv"), agg(f"gpurun_out/{tag}_write/*/*_counter_collection.csv"), agg(f"gpurun_out/{tag}_sq/*/*_counter_collection.csv")
+lines = ["# rocprofv3 --pmc summaries of `python3 bench.py` (one 2^20-term MSM per step, c=16), MI355X",
+         "# separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE.  FETCH/WRITE in KiB per launch (average over launches).",
+         "# gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-B read requests at 64 B -> doubled in hbm_bytes.",
+         "kernel,FETCH_SIZE_KiB,WRITE_SIZE_KiB,hbm_bytes=(2*F+W)*1024,launches"]
+for k in sorted({k[0] for k in f}):
+    F = f.get((k, "FETCH_SIZE"), (0, 0))[0]
+    W = w.get((k, "WRITE_SIZE"), (0, 0))[0]
+    lines.append(f"{k},{F:.1f},{W:.1f},{(2 * F + W) * 1024:.0f},{f[(k, 'FETCH_SIZE')][1]}")
+lines += ["", "kernel,counter,avg_per_launch"]
+for (k, c), (v, n) in sorted(q.items()):
+    if k.startswith("cg1::k_accumulate") or k.startswith("cg1::k_seg") or k.startswith("cg1::k_bit"):
+        lines.append(f"{k},{c},{v:.0f}")
+open(out + "_pmc_summary.csv", "w").write("\n".join(lines) + "\n")
+F, W = f[("cg1::k_accumulate", "FETCH_SIZE")][0], w[("cg1::k_accumulate", "WRITE_SIZE")][0]
+json.dump({"source": out + "_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over python3 bench.py --steps 4 --warmup 1)",
+           "workload": "single MSM of 2^20 terms, c=16, 1 GPU",
+           "k_accumulate_FETCH_SIZE_KiB": F, "k_accumulate_WRITE_SIZE_KiB": W,
+           "k_accumulate_hbm_bytes_per_launch": (2 * F + W) * 1024,
+           "note": "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; these fabric-side counters include "
+                   "Infinity-Cache hits (the 128 MiB prepared-point array fits the 256 MiB cache), so true HBM traffic is lower. "
+                   "Expected from the access pattern: 16 windows x 2^20 gathers x 128 B = 2.15 GB."},
+          open("profiles/pmc_traffic.json", "w"), indent=1)
+print(open(out + "_kernel_stats.csv").read()[:1500])
+print(json.load(open("profiles/pmc_traffic.json"))["k_accumulate_hbm_bytes_per_launch"])
