@@ -202,3 +202,60 @@ def test_batched_1024_x_627_closed_form(native_lib, ctx):
     for j in (0, 511, 1023):
         single = ctx.msm_device(dp.ptr + 96 * n * j, ds.ptr + 32 * n * j, n)
         assert N.cg1_eq(single, blobs[j]) == 1
+
+
+def test_pipeline_variants_agree(native_lib, golden):
+    """Same results through the alternative code paths: global-atomic counting sort (used for n > 2^23),
+    other chunk lengths / segment sizes, wave-aggregation off."""
+    N = native_lib
+    c2 = N.Context(0)
+    try:
+        rng = random.Random(55)
+        n = 3000
+        base = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(24)]
+        p96 = b"".join(raw96(base[rng.randrange(24)]) for _ in range(n))
+        s32 = b"".join(rng.choice([rng.randint(0, O.R - 1), 7, O.R - 1]).to_bytes(32, "little") for _ in range(n))
+        want = C.compress(C.compute_msm(p96, s32, n))
+        for params in ({"partition_sort": 0}, {"chunk_len": 1}, {"chunk_len": 7}, {"chunk_len": 4096}, {"seg_m": 1},
+                       {"seg_m": 2}, {"seg_m": 16}, {"wave_agg": 0}, {"partition_sort": 0, "chunk_len": 3, "seg_m": 8}):
+            for k, v in params.items():
+                c2.set_param(k, v)
+            for c in (0, 6, 16):
+                assert gpu_msm(N, c2, p96, s32, n, window_c=c) == want, (params, c)
+            for k in params:   # back to defaults
+                c2.set_param(k, {"partition_sort": 1, "chunk_len": 64, "seg_m": 4, "wave_agg": 1}[k])
+    finally:
+        c2.close()
+
+
+def test_two_contexts_concurrently(native_lib):
+    """One context per stream: independent MSMs issued from two host threads on the same GPU."""
+    import threading
+
+    N = native_lib
+    rng = random.Random(66)
+    n = 2000
+    base = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(16)]
+    jobs = []
+    for _ in range(2):
+        p96 = b"".join(raw96(base[rng.randrange(16)]) for _ in range(n))
+        s32 = b"".join(rng.randint(0, O.R - 1).to_bytes(32, "little") for _ in range(n))
+        jobs.append((p96, s32, C.compress(C.compute_msm(p96, s32, n))))
+    ctxs = [N.Context(0), N.Context(0)]
+    out = [None, None]
+
+    def work(i):
+        res = []
+        for _ in range(5):
+            res.append(compress_blob(N, ctxs[i].msm_host(jobs[i][0], jobs[i][1], n)))
+        out[i] = res
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(2):
+        assert out[i] == [jobs[i][2]] * 5
+    for c in ctxs:
+        c.close()
