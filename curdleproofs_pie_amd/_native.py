@@ -83,7 +83,22 @@ cg1_batch_mul_add = _proto("cg1_batch_mul_add", c_int, c_void_p, _u8p, c_size_t,
 cg1_gen_scalars_device = _proto("cg1_gen_scalars_device", c_int, c_void_p, c_void_p, c_size_t, c_uint64)
 cg1_probe_madd = _proto("cg1_probe_madd", c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_int, POINTER(c_float))
 
+# native Merlin transcript (host)
+MERLIN_STATE_BYTES = 208
+cg1_strobe_new = _proto("cg1_strobe_new", None, _buf, _u8p, c_size_t)
+cg1_strobe_meta_ad = _proto("cg1_strobe_meta_ad", c_int, _buf, _u8p, c_size_t, c_int)
+cg1_strobe_ad = _proto("cg1_strobe_ad", c_int, _buf, _u8p, c_size_t, c_int)
+cg1_strobe_prf = _proto("cg1_strobe_prf", c_int, _buf, _buf, c_size_t, c_int)
+cg1_strobe_key = _proto("cg1_strobe_key", c_int, _buf, _u8p, c_size_t, c_int)
+cg1_merlin_init = _proto("cg1_merlin_init", None, _buf, _u8p, c_size_t)
+cg1_merlin_append = _proto("cg1_merlin_append", None, _buf, _u8p, c_size_t, _u8p, c_size_t)
+cg1_merlin_append_list = _proto("cg1_merlin_append_list", None, _buf, _u8p, c_size_t, _u8p, c_size_t, c_size_t)
+cg1_merlin_challenge = _proto("cg1_merlin_challenge", None, _buf, _u8p, c_size_t, _buf, c_size_t)
+cg1_merlin_challenge_scalar = _proto("cg1_merlin_challenge_scalar", None, _buf, _u8p, c_size_t, _buf)
+
 EXPORTED_SYMBOLS = [
+    "cg1_strobe_new", "cg1_strobe_meta_ad", "cg1_strobe_ad", "cg1_strobe_prf", "cg1_strobe_key", "cg1_merlin_init",
+    "cg1_merlin_append", "cg1_merlin_append_list", "cg1_merlin_challenge", "cg1_merlin_challenge_scalar",
     "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",

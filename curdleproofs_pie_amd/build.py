@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcurdle_g1.so")
-SOURCES = [os.path.join(CSRC, "msm_gpu.hip"), os.path.join(CSRC, "host_g1.cpp")]
+SOURCES = [os.path.join(CSRC, "msm_gpu.hip"), os.path.join(CSRC, "host_g1.cpp"), os.path.join(CSRC, "merlin.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("fp28.h", "g1_xyzz.h", "host_g1.h", "bls_consts.h")] + [
     os.path.join(HERE, "..", "include", "curdle_g1.h")
 ]

@@ -1,0 +1,162 @@
+// Native Merlin v1.0 transcript (STROBE-128 over Keccak-f[1600]) -- SURVEY.md 8(f) row 1.
+//
+// Stands behind /root/reference/merlin_transcripts/merlin_transcripts/{merlin_transcript.py:6-24,
+// strobe.py:16-107, keccak.py:16-66} and the Fiat-Shamir adaptor curdleproofs/curdleproofs/
+// curdleproofs_transcript.py:7-28.  The reference's pure-Python Keccak costs ~0.8 ms per permutation and a
+// N=128 shuffle verification makes ~727 of them (~0.57 s of hashing per proof); this is the same
+// construction in C++ (~1 us per permutation).  Host code by design: one transcript is a strictly serial
+// sponge; the batched (one transcript per lane) HIP version is a later row.
+//
+// State is a caller-owned 208-byte blob (200-byte sponge, pos, pos_begin, cur_flags): no handles, no globals.
+#include <cstdint>
+#include <cstring>
+#include "../../include/curdle_g1.h"
+
+namespace {
+
+constexpr int STROBE_R = 166;                       // strobe.py:4
+constexpr uint8_t FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_T = 8, FLAG_M = 16, FLAG_K = 32;   // strobe.py:6-11
+
+struct Strobe {
+  uint8_t st[200];
+  uint8_t pos, pos_begin, cur_flags, pad[5];
+};
+static_assert(sizeof(Strobe) == CG1_MERLIN_STATE_BYTES, "merlin state blob size");
+
+inline uint64_t rotl(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
+
+void keccak_f1600(uint8_t* bytes) {
+  static const uint64_t RC[24] = {
+      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+      0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+      0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+      0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
+  static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
+  uint64_t a[25];
+  for (int i = 0; i < 25; ++i) {            // lanes are little-endian 64-bit words, lane index x + 5y
+    uint64_t v = 0;
+    for (int j = 7; j >= 0; --j) v = (v << 8) | bytes[8 * i + j];
+    a[i] = v;
+  }
+  for (int round = 0; round < 24; ++round) {
+    uint64_t c[5];
+    for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];        // theta
+    for (int x = 0; x < 5; ++x) {
+      uint64_t d = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1);
+      for (int y = 0; y < 25; y += 5) a[y + x] ^= d;
+    }
+    uint64_t cur = a[1];                                                                        // rho + pi
+    for (int t = 0; t < 24; ++t) {
+      int j = PIL[t];
+      uint64_t tmp = a[j];
+      a[j] = rotl(cur, ROT[t]);
+      cur = tmp;
+    }
+    for (int y = 0; y < 25; y += 5) {                                                           // chi
+      uint64_t r0 = a[y], r1 = a[y + 1], r2 = a[y + 2], r3 = a[y + 3], r4 = a[y + 4];
+      a[y] = r0 ^ (~r1 & r2); a[y + 1] = r1 ^ (~r2 & r3); a[y + 2] = r2 ^ (~r3 & r4);
+      a[y + 3] = r3 ^ (~r4 & r0); a[y + 4] = r4 ^ (~r0 & r1);
+    }
+    a[0] ^= RC[round];                                                                          // iota
+  }
+  for (int i = 0; i < 25; ++i) for (int j = 0; j < 8; ++j) bytes[8 * i + j] = (uint8_t)(a[i] >> (8 * j));
+}
+
+void run_f(Strobe& s) {                              // strobe.py:55-61
+  s.st[s.pos] ^= s.pos_begin;
+  s.st[s.pos + 1] ^= 0x04;
+  s.st[STROBE_R + 1] ^= 0x80;
+  keccak_f1600(s.st);
+  s.pos = 0; s.pos_begin = 0;
+}
+void absorb(Strobe& s, const uint8_t* d, size_t n) {  // strobe.py:63-68
+  for (size_t i = 0; i < n; ++i) { s.st[s.pos++] ^= d[i]; if (s.pos == STROBE_R) run_f(s); }
+}
+void overwrite(Strobe& s, const uint8_t* d, size_t n) {   // strobe.py:70-75
+  for (size_t i = 0; i < n; ++i) { s.st[s.pos++] = d[i]; if (s.pos == STROBE_R) run_f(s); }
+}
+void squeeze(Strobe& s, uint8_t* out, size_t n) {     // strobe.py:77-87
+  for (size_t i = 0; i < n; ++i) { out[i] = s.st[s.pos]; s.st[s.pos++] = 0; if (s.pos == STROBE_R) run_f(s); }
+}
+int begin_op(Strobe& s, uint8_t flags, bool more) {   // strobe.py:89-107
+  if (more) return s.cur_flags == flags ? 0 : CG1_ERR_ARG;
+  if (flags & FLAG_T) return CG1_ERR_ARG;
+  uint8_t hdr[2] = {s.pos_begin, flags};
+  s.pos_begin = (uint8_t)(s.pos + 1);
+  s.cur_flags = flags;
+  absorb(s, hdr, 2);
+  if ((flags & (FLAG_C | FLAG_K)) && s.pos != 0) run_f(s);
+  return 0;
+}
+int meta_ad(Strobe& s, const uint8_t* d, size_t n, bool more) { int rc = begin_op(s, FLAG_M | FLAG_A, more); if (!rc) absorb(s, d, n); return rc; }
+int ad(Strobe& s, const uint8_t* d, size_t n, bool more) { int rc = begin_op(s, FLAG_A, more); if (!rc) absorb(s, d, n); return rc; }
+int prf(Strobe& s, uint8_t* out, size_t n, bool more) { int rc = begin_op(s, FLAG_I | FLAG_A | FLAG_C, more); if (!rc) squeeze(s, out, n); return rc; }
+int key(Strobe& s, const uint8_t* d, size_t n, bool more) { int rc = begin_op(s, FLAG_A | FLAG_C, more); if (!rc) overwrite(s, d, n); return rc; }
+
+inline void le32(uint8_t out[4], size_t v) { for (int i = 0; i < 4; ++i) out[i] = (uint8_t)(v >> (8 * i)); }
+
+const uint64_t FR[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+bool fr_canonical_nonzero(const uint8_t b[32]) {
+  uint64_t w[4]; uint64_t any = 0;
+  for (int i = 0; i < 4; ++i) { uint64_t v = 0; for (int j = 7; j >= 0; --j) v = (v << 8) | b[8 * i + j]; w[i] = v; any |= v; }
+  if (!any) return false;
+  for (int i = 3; i >= 0; --i) { if (w[i] != FR[i]) return w[i] < FR[i]; }
+  return false;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Strobe128.new(protocol_label)   strobe.py:23-36
+void cg1_strobe_new(uint8_t* state, const uint8_t* label, size_t len) {
+  Strobe& s = *reinterpret_cast<Strobe*>(state);
+  memset(&s, 0, sizeof s);
+  const uint8_t hdr[6] = {1, STROBE_R + 2, 1, 0, 1, 96};
+  memcpy(s.st, hdr, 6);
+  memcpy(s.st + 6, "STROBEv1.0.2", 12);
+  keccak_f1600(s.st);
+  meta_ad(s, label, len, false);
+}
+int cg1_strobe_meta_ad(uint8_t* state, const uint8_t* d, size_t n, int more) { return meta_ad(*reinterpret_cast<Strobe*>(state), d, n, more != 0); }
+int cg1_strobe_ad(uint8_t* state, const uint8_t* d, size_t n, int more) { return ad(*reinterpret_cast<Strobe*>(state), d, n, more != 0); }
+int cg1_strobe_prf(uint8_t* state, uint8_t* out, size_t n, int more) { return prf(*reinterpret_cast<Strobe*>(state), out, n, more != 0); }
+int cg1_strobe_key(uint8_t* state, const uint8_t* d, size_t n, int more) { return key(*reinterpret_cast<Strobe*>(state), d, n, more != 0); }
+
+// MerlinTranscript(label)   merlin_transcript.py:6-9
+void cg1_merlin_init(uint8_t* state, const uint8_t* label, size_t len) {
+  cg1_strobe_new(state, reinterpret_cast<const uint8_t*>("Merlin v1.0"), 11);
+  cg1_merlin_append(state, reinterpret_cast<const uint8_t*>("dom-sep"), 7, label, len);
+}
+// append_message(label, message)   merlin_transcript.py:11-15
+void cg1_merlin_append(uint8_t* state, const uint8_t* label, size_t llen, const uint8_t* msg, size_t mlen) {
+  Strobe& s = *reinterpret_cast<Strobe*>(state);
+  uint8_t dl[4]; le32(dl, mlen);
+  meta_ad(s, label, llen, false);
+  meta_ad(s, dl, 4, true);
+  ad(s, msg, mlen, false);
+}
+// append_list(label, items) of equal-size items   curdleproofs_transcript.py:11-13
+void cg1_merlin_append_list(uint8_t* state, const uint8_t* label, size_t llen, const uint8_t* items, size_t item_len, size_t count) {
+  for (size_t i = 0; i < count; ++i) cg1_merlin_append(state, label, llen, items + i * item_len, item_len);
+}
+// challenge_bytes(label, length)   merlin_transcript.py:20-24
+void cg1_merlin_challenge(uint8_t* state, const uint8_t* label, size_t llen, uint8_t* out, size_t n) {
+  Strobe& s = *reinterpret_cast<Strobe*>(state);
+  uint8_t dl[4]; le32(dl, n);
+  meta_ad(s, label, llen, false);
+  meta_ad(s, dl, 4, true);
+  prf(s, out, n, false);
+}
+// get_and_append_challenge(label): rejection-sample 32 PRF bytes < r and non-zero, re-append the accepted bytes
+// curdleproofs_transcript.py:15-25
+void cg1_merlin_challenge_scalar(uint8_t* state, const uint8_t* label, size_t llen, uint8_t out32[32]) {
+  for (;;) {
+    cg1_merlin_challenge(state, label, llen, out32, 32);
+    if (fr_canonical_nonzero(out32)) { cg1_merlin_append(state, label, llen, out32, 32); return; }
+  }
+}
+
+}  // extern "C"

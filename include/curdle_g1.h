@@ -120,6 +120,24 @@ int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out_scalars32, size_t n, uint64
  * returns elapsed ms in *ms */
 int cg1_probe_madd(cg1_ctx* ctx, const void* d_points_affine96, size_t npts, size_t lanes, int iters, float* ms);
 
+/* ---------------- native Merlin transcript (host C++) ------------------------
+ * Stands behind merlin_transcripts/merlin_transcripts/{merlin_transcript.py:6-24, strobe.py:16-107,
+ * keccak.py:16-66} and curdleproofs/curdleproofs/curdleproofs_transcript.py:7-28.
+ * `state` is a caller-owned CG1_MERLIN_STATE_BYTES blob; copying the blob forks the transcript. */
+#define CG1_MERLIN_STATE_BYTES 208
+void cg1_strobe_new(uint8_t* state, const uint8_t* protocol_label, size_t len);                 /* Strobe128.new */
+int  cg1_strobe_meta_ad(uint8_t* state, const uint8_t* data, size_t len, int more);
+int  cg1_strobe_ad(uint8_t* state, const uint8_t* data, size_t len, int more);
+int  cg1_strobe_prf(uint8_t* state, uint8_t* out, size_t len, int more);
+int  cg1_strobe_key(uint8_t* state, const uint8_t* data, size_t len, int more);
+void cg1_merlin_init(uint8_t* state, const uint8_t* label, size_t len);                          /* MerlinTranscript(label) */
+void cg1_merlin_append(uint8_t* state, const uint8_t* label, size_t label_len, const uint8_t* msg, size_t msg_len);
+void cg1_merlin_append_list(uint8_t* state, const uint8_t* label, size_t label_len, const uint8_t* items,
+                            size_t item_len, size_t count);                                       /* append_list */
+void cg1_merlin_challenge(uint8_t* state, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len);
+/* get_and_append_challenge: 32 LE bytes of a canonical non-zero Fr element, already re-appended */
+void cg1_merlin_challenge_scalar(uint8_t* state, const uint8_t* label, size_t label_len, uint8_t out32[32]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,14 +24,18 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, {root!r}); sys.path.insert(0, {ref!r}); sys.path.insert(0, "/root/reference/merlin_transcripts")
 import curdleproofs_pie_amd.py_arkworks_bls12381 as backend
 sys.modules["py_arkworks_bls12381"] = backend
+if {native_merlin!r}:
+    import curdleproofs_pie_amd.merlin as native_merlin      # SURVEY 8(f) row 1: native transcript in place of
+    sys.modules["merlin_transcripts"] = native_merlin        # the pure-Python merlin_transcripts package
 import pytest
 sys.exit(int(pytest.main(["-x", "-q", "-p", "no:cacheprovider", {test!r}])))
 """
 
 
 @pytest.mark.skipif(not os.path.exists(REF_TEST), reason="reference tree not present (GPU box)")
-def test_reference_test_suite_passes_on_our_backend(native_lib):
-    code = RUNNER.format(root=ROOT, ref=REF_PKG, test=REF_TEST)
+@pytest.mark.parametrize("native_merlin", [False, True], ids=["reference_transcript", "native_transcript"])
+def test_reference_test_suite_passes_on_our_backend(native_lib, native_merlin):
+    code = RUNNER.format(root=ROOT, ref=REF_PKG, test=REF_TEST, native_merlin=native_merlin)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=1500, cwd="/tmp")
     tail = (r.stdout + r.stderr)[-2000:]
     assert r.returncode == 0, tail
