@@ -80,6 +80,8 @@ cg1_get_host_timings = _proto("cg1_get_host_timings", c_int, c_void_p, POINTER(c
 cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
 cg1_batch_mul_add_device = _proto("cg1_batch_mul_add_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
 cg1_batch_mul_add = _proto("cg1_batch_mul_add", c_int, c_void_p, _u8p, c_size_t, _u8p, c_size_t, _u8p, _buf, c_size_t)
+cg1_batch_decompress_device = _proto("cg1_batch_decompress_device", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int)
+cg1_batch_decompress_gpu = _proto("cg1_batch_decompress_gpu", c_int, c_void_p, _u8p, _buf, c_size_t, c_int, POINTER(c_size_t))
 cg1_gen_scalars_device = _proto("cg1_gen_scalars_device", c_int, c_void_p, c_void_p, c_size_t, c_uint64)
 cg1_probe_madd = _proto("cg1_probe_madd", c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_int, POINTER(c_float))
 
@@ -103,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_ctx_sync", "cg1_ctx_set_param",
-    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_gen_scalars_device", "cg1_probe_madd",
+    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 
 
@@ -221,6 +223,16 @@ class Context:
         """out[i] = addend[i] + scalars[i % nscalars] * bases[i % nbase] (host buffers; affine96 in/out)."""
         out = ctypes.create_string_buffer(96 * max(n, 1))
         self.check(cg1_batch_mul_add(self.handle, bases96, nbase, scalars32, nscalars, addend96, out, n))
+        return out.raw[: 96 * n]
+
+    def batch_decompress_host(self, data48: bytes, n: int, check_subgroup: bool = False) -> bytes:
+        """n compressed48 -> n affine96 on the GPU; raises ValueError (like the wheel) on the first bad encoding."""
+        out = ctypes.create_string_buffer(96 * max(n, 1))
+        bad = c_size_t(0)
+        rc = cg1_batch_decompress_gpu(self.handle, data48, out, n, 1 if check_subgroup else 0, ctypes.byref(bad))
+        if rc in (ERR_ENCODING, ERR_NOT_ON_CURVE, ERR_NOT_IN_SUBGROUP):
+            raise ValueError(f"Err From Rust: serialised data seems to be invalid (point {bad.value}, code {rc})")
+        self.check(rc)
         return out.raw[: 96 * n]
 
     def gen_scalars_device(self, d_out, n: int, seed: int) -> None:

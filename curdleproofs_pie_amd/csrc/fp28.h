@@ -281,10 +281,8 @@ CG1_HD void fp_to_words(const fp& a, uint32_t w[12]) {
   }
 }
 
-// a^(p-2): inversion by Fermat (used off the hot path: affine outputs of generated points, compression).
-CG1_HD fp fp_inv(const fp& a) {
-  // p-2 as 6 x 64 words, MSB first scan
-  constexpr uint64_t e[6] = {H_INV_EXP[0], H_INV_EXP[1], H_INV_EXP[2], H_INV_EXP[3], H_INV_EXP[4], H_INV_EXP[5]};
+// a^e for a 384-bit exponent given as 6 x 64-bit words (square-and-multiply, MSB first).  Off the hot path.
+CG1_HD fp fp_pow6(const fp& a, const uint64_t e[6]) {
   fp r = fp_one();
   for (int wi = 5; wi >= 0; --wi) {
     uint64_t word = e[wi];
@@ -294,6 +292,16 @@ CG1_HD fp fp_inv(const fp& a) {
     }
   }
   return r;
+}
+// a^(p-2): inversion by Fermat (affine outputs of generated points).
+CG1_HD fp fp_inv(const fp& a) {
+  constexpr uint64_t e[6] = {H_INV_EXP[0], H_INV_EXP[1], H_INV_EXP[2], H_INV_EXP[3], H_INV_EXP[4], H_INV_EXP[5]};
+  return fp_pow6(a, e);
+}
+// a^((p+1)/4): the square root candidate (p = 3 mod 4); the caller checks r^2 == a.
+CG1_HD fp fp_sqrt_candidate(const fp& a) {
+  constexpr uint64_t e[6] = {H_SQRT_EXP[0], H_SQRT_EXP[1], H_SQRT_EXP[2], H_SQRT_EXP[3], H_SQRT_EXP[4], H_SQRT_EXP[5]};
+  return fp_pow6(a, e);
 }
 
 }  // namespace cg1

@@ -765,6 +765,69 @@ __global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ 
   fp_to_words(fp_mul(acc.Y, izzz), o); for (int k = 0; k < 12; ++k) dst[12 + k] = o[k];
 }
 
+// ------------------------------------------------------------------ batched 48-byte G1 decompression
+// One lane per point: parse the ZCash-format encoding (util.py:35-36 -> G1Point.from_compressed_bytes[_unchecked]),
+// y = sqrt(x^3 + 4) by exponentiation, sign select, optional subgroup test  [z^2]P == phi(P) + P.
+// out: affine96 (zeros = identity), status: 0 ok, CG1_ERR_ENCODING / _NOT_ON_CURVE / _NOT_IN_SUBGROUP.
+__global__ void __launch_bounds__(128) k_batch_decompress(const uint8_t* __restrict__ in48, uint32_t* __restrict__ out_raw,
+                                                          uint8_t* __restrict__ status, uint32_t n, int check_subgroup) {
+  uint32_t i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* b = in48 + 48ull * i;
+  uint32_t* dst = out_raw + 24ull * i;
+  for (int k = 0; k < 24; ++k) dst[k] = 0;
+  const uint8_t flags = b[0];
+  const bool compressed = flags & 0x80, infinity = flags & 0x40, largest = flags & 0x20;
+  uint32_t w[12];
+  for (int j = 0; j < 12; ++j) {                // big-endian bytes -> little-endian words
+    const uint8_t* q = b + 44 - 4 * j;
+    uint32_t b0 = (j == 11) ? (uint32_t)(q[0] & 0x1F) : (uint32_t)q[0];
+    w[j] = (b0 << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+  }
+  if (!compressed || (infinity && largest)) { status[i] = CG1_ERR_ENCODING; return; }
+  if (infinity) {
+    uint32_t any = 0;
+    for (int j = 0; j < 12; ++j) any |= w[j];
+    status[i] = any ? CG1_ERR_ENCODING : CG1_OK;
+    return;
+  }
+  bool lt = false, decided = false;             // x < p ?
+  for (int j = 11; j >= 0 && !decided; --j) if (w[j] != W_P[j]) { lt = w[j] < W_P[j]; decided = true; }
+  if (!lt) { status[i] = CG1_ERR_ENCODING; return; }
+  const fp x = fp_to_mont(fp_from_words(w));
+  fp four = fp_one(); four = fp_dbl(fp_dbl(four));
+  const fp rhs = fp_norm(fp_add(fp_mul(fp_sqr(x), x), four));
+  fp y = fp_sqrt_candidate(rhs);
+  if (!fp_is_zero_mod_p(fp_sub<3>(fp_sqr(y), fp_mul(rhs, fp_one())), 8)) { status[i] = CG1_ERR_NOT_ON_CURVE; return; }
+  uint32_t yw[12];
+  fp_to_words(y, yw);
+  bool is_large = false; decided = false;       // y > (p-1)/2 ?
+  for (int j = 11; j >= 0 && !decided; --j) if (yw[j] != W_P_MINUS_1_HALF[j]) { is_large = yw[j] > W_P_MINUS_1_HALF[j]; decided = true; }
+  if (is_large != largest) {                     // y := p - y  (y != 0: the curve has no point with y = 0)
+    uint64_t borrow = 0;
+    for (int j = 0; j < 12; ++j) {
+      uint64_t d = (uint64_t)W_P[j] - yw[j] - borrow;
+      yw[j] = (uint32_t)d; borrow = (d >> 32) & 1;
+    }
+    y = fp_to_mont(fp_from_words(yw));
+  }
+  if (check_subgroup) {
+    constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
+    fp beta; for (int k = 0; k < NL; ++k) beta.l[k] = bt[k];
+    xyzz acc = xyzz_identity();
+    for (int bit = 127; bit >= 0; --bit) {       // [z^2] P
+      acc = xyzz_dbl(acc);
+      if ((H_ZSQ[bit >> 6] >> (bit & 63)) & 1ull) acc = xyzz_madd(acc, x, y);
+    }
+    const fp yneg = fp_neg<3>(y);
+    acc = xyzz_madd(acc, x, yneg);               // - P
+    acc = xyzz_madd(acc, fp_mul(x, beta), yneg); // - phi(P)
+    if (!acc.inf) { status[i] = CG1_ERR_NOT_IN_SUBGROUP; return; }
+  }
+  for (int k = 0; k < 12; ++k) { dst[k] = w[k]; dst[12 + k] = yw[k]; }
+  status[i] = CG1_OK;
+}
+
 // splitmix64-derived scalars, uniform in [1, r-1] (the reference's random_scalar distribution,
 // util.py:21-24) by rejection from 255-bit draws; deterministic in (seed, i)
 __global__ void __launch_bounds__(256) k_gen_scalars(uint32_t* __restrict__ out, uint32_t n, uint64_t seed) {
@@ -1437,6 +1500,37 @@ int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases, size_t nbase, const ui
   (void)hipFree(db); (void)hipFree(ds); (void)hipFree(dout); if (da) (void)hipFree(da);
   return rc;
 }
+// n compressed48 (device) -> n affine96 + n status bytes (device); returns CG1_OK when the kernel ran
+int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) return CG1_OK;
+  if (n >= (1ull << 31)) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(cg1::k_batch_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                     (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n, check_subgroup);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
+// host buffers: returns CG1_OK if every encoding is valid, else the first failing status with *bad_index set
+int cg1_batch_decompress_gpu(cg1_ctx* ctx, const uint8_t* in48, uint8_t* out_affine96, size_t n, int check_subgroup, size_t* bad_index) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) return CG1_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  void *din = nullptr, *dout = nullptr, *dst = nullptr;
+  HIPCHK(hipMalloc(&din, n * 48)); HIPCHK(hipMalloc(&dout, n * 96)); HIPCHK(hipMalloc(&dst, n));
+  HIPCHK(hipMemcpy(din, in48, n * 48, hipMemcpyHostToDevice));
+  int rc = cg1_batch_decompress_device(ctx, din, dout, dst, n, check_subgroup);
+  std::vector<uint8_t> st(n);
+  if (rc == CG1_OK) {
+    if (hipMemcpy(out_affine96, dout, n * 96, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(st.data(), dst, n, hipMemcpyDeviceToHost) != hipSuccess) rc = CG1_ERR_HIP;
+  }
+  (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dst);
+  if (rc != CG1_OK) return rc;
+  for (size_t i = 0; i < n; ++i) if (st[i]) { if (bad_index) *bad_index = i; return st[i]; }
+  return CG1_OK;
+}
+
 int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
   if (!ctx) return CG1_ERR_HIP;
   if (n == 0) return CG1_OK;

@@ -98,6 +98,19 @@ def batch_fold(left: Iterable[G1Point], right: Iterable[G1Point], scalar: Scalar
     return _blobs_from_affine96(raw, n)
 
 
+def batch_from_compressed(encodings: Iterable[bytes], checked: bool = False) -> List[G1Point]:
+    """[G1Point.from_compressed_bytes[_unchecked](e) for e in encodings] with the square roots (and subgroup
+    checks) on the GPU -- e.g. the 4*ell tracker points + every proof element of IsValidWhiskShuffleProof
+    (whisk_interface.py:96-106, util.py:143-147).  Raises ValueError on the first invalid encoding."""
+    enc = [bytes(e) for e in encodings]
+    if any(len(e) != 48 for e in enc):
+        raise ValueError("Err From Rust: serialised data seems to be invalid (need 48 bytes)")
+    if not enc:
+        return []
+    raw = N.default_context().batch_decompress_host(b"".join(enc), len(enc), checked)
+    return _blobs_from_affine96(raw, len(enc))
+
+
 class MSMAccumulator:
     """Random-linear-combination batching of `C == MSM(bases, scalars)` checks (msm_accumulator.py:32-68).
 

@@ -113,6 +113,12 @@ int cg1_batch_mul_add_device(cg1_ctx* ctx, const void* d_bases_affine96, size_t 
 /* same, all buffers in host memory (copied in and out by the call) */
 int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t nbase, const uint8_t* scalars32, size_t nscalars,
                       const uint8_t* addend_affine96, uint8_t* out_affine96, size_t n);
+/* Batched 48-byte decompression on the GPU: from_compressed_bytes_unchecked
+ * (check_subgroup = 0, util.py:35-36, BufReader.read_g1 util.py:143-147) / from_compressed_bytes (= 1).
+ * Device variant: per-point status byte (0 ok, CG1_ERR_ENCODING, _NOT_ON_CURVE, _NOT_IN_SUBGROUP), affine96 out.
+ * Host variant: CG1_OK iff all n encodings are valid, else the first failing status and *bad_index. */
+int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup);
+int cg1_batch_decompress_gpu(cg1_ctx* ctx, const uint8_t* in48, uint8_t* out_affine96, size_t n, int check_subgroup, size_t* bad_index);
 /* deterministic synthetic scalars, uniform in [1, r-1] (util.py:21-24 distribution), from a 64-bit seed
  * (splitmix64 + rejection), device memory */
 int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out_scalars32, size_t n, uint64_t seed);

@@ -117,3 +117,36 @@ def test_batch_mul_patterns(api):
     assert batch_fold(L, L, A.Scalar(A.CURVE_ORDER - 1)) == [U.Z1] * n                # l + (-1) l == identity
     assert batch_fold(L, L, A.Scalar(1)) == [l + l for l in L]                        # doubling through the add
     assert batch_mul([], []) == []
+
+
+def test_batch_from_compressed(api):
+    """GPU batched decompression == the host decoder, incl. identity, both sign branches and rejections."""
+    A, U = api
+    from curdleproofs_pie_amd.msm_accumulator import batch_from_compressed
+
+    random.seed(9)
+    pts = [U.get_random_point() for _ in range(70)] + [U.Z1, U.G1, -U.G1]
+    enc = [bytes(p.to_compressed_bytes()) for p in pts]
+    assert sum(1 for e in enc if e[0] & 0x20) > 10 and sum(1 for e in enc if not e[0] & 0x20) > 10
+    assert batch_from_compressed(enc) == pts
+    assert batch_from_compressed(enc, checked=True) == pts
+    assert batch_from_compressed([]) == []
+    for bad in (bytes(48), bytes([0xE0]) + bytes(47), bytes([0xC0]) + bytes(46) + b"\\x01", bytes([0x9F]) + b"\\xff" * 47):
+        with pytest.raises(ValueError):
+            batch_from_compressed(enc[:3] + [bad] + enc[3:6])
+    x = 1
+    while O.fp_sqrt((x ** 3 + 4) % O.P) is not None:
+        x += 1
+    e = bytearray(x.to_bytes(48, "big")); e[0] |= 0x80
+    with pytest.raises(ValueError):
+        batch_from_compressed([bytes(e)])
+    x = 1
+    while True:   # on the curve, outside the subgroup: only the checked decoder rejects it
+        y = O.fp_sqrt((x ** 3 + 4) % O.P)
+        if y is not None and not O.g1_in_subgroup((x, y)):
+            break
+        x += 1
+    e = bytearray(x.to_bytes(48, "big")); e[0] |= 0x80
+    assert batch_from_compressed([bytes(e)]) == [A.G1Point.from_compressed_bytes_unchecked(bytes(e))]
+    with pytest.raises(ValueError):
+        batch_from_compressed(enc[:2] + [bytes(e)], checked=True)
