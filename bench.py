@@ -40,10 +40,55 @@ def cpu_baseline(ctx, d_points, d_scalars, sample_n):
     t0 = time.perf_counter()
     C.compute_msm(p, s, sample_n)
     dt = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    C.msm_bucket(p, s, sample_n)
+    dt_b = time.perf_counter() - t1
     return {"value": sample_n / dt, "unit": "G1 scalar-muls/s", "cores": 1, "kind": "port",
+            "stronger_non_reference_baseline": {"what": "textbook bucket-method MSM in C (oracle/msm_oracle.c orc_msm_bucket), 1 core, "
+                                                        f"same {sample_n}-term sample (rate grows with n)", "value": sample_n / dt_b},
             "sample": f"naive reference loop (msm_accumulator.py:6-12 restated in C, 255-bit double-and-add + add per term) "
                       f"over the first {sample_n} terms of the same workload, {dt:.1f} s on one host core; "
                       f"cost is linear in n so the 2^20 figure is this rate"}
+
+
+def side_mode(args):
+    """Secondary measurements (single GPU, not the driver's contract line)."""
+    from curdleproofs_pie_amd import _native as N
+
+    ctx = N.Context(0)
+    d_g = ctx.alloc(96)
+    d_g.upload(raw96_gen())
+    if args.mode == "batched":
+        M, n = 1024, 627                       # 5*ell + 7 at ell = 124 (Whisk N = 128), SURVEY 3.2
+        tot = M * n
+        d_k, d_pts, d_sc = ctx.alloc(32 * tot), ctx.alloc(96 * tot), ctx.alloc(32 * tot)
+        ctx.gen_scalars_device(d_k, tot, 1); ctx.batch_mul_device(d_g, 1, d_k, d_pts, tot); ctx.gen_scalars_device(d_sc, tot, 2)
+        offs = [n * j for j in range(M + 1)]
+        for _ in range(args.warmup):
+            ctx.msm_batched_device(d_pts, d_sc, offs)
+        ctx.sync(); t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.msm_batched_device(d_pts, d_sc, offs)
+        ctx.sync(); el = time.perf_counter() - t0
+        print(json.dumps({"metric": "final-accumulator MSMs/sec (1024 independent 627-term MSMs per step; the MSM content of "
+                                    "BASELINE config 3, not whole-proof verification)", "value": M * args.steps / el,
+                          "unit": "MSMs/s", "scalar_muls_per_s": tot * args.steps / el, "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+                          "phases_ms": ctx.timings()}))
+    else:
+        n = 1 << args.logn
+        d_k, d_pts, d_sc = ctx.alloc(32 * n), ctx.alloc(96 * n), ctx.alloc(32 * n)
+        ctx.gen_scalars_device(d_k, n, 1); ctx.batch_mul_device(d_g, 1, d_k, d_pts, n); ctx.gen_scalars_device(d_sc, n, 2)
+        hp, hs = d_pts.download(), d_sc.download()
+        for _ in range(args.warmup):
+            ctx.msm_host(hp, hs, n)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.msm_host(hp, hs, n)
+        el = time.perf_counter() - t0
+        print(json.dumps({"metric": "BLS12-381 G1 scalar-muls/sec at MSM size 2^%d, inputs in pageable HOST memory (PCIe-inclusive; "
+                                    "never the headline value)" % args.logn, "value": n * args.steps / el, "unit": "G1 scalar-muls/s",
+                          "ms_per_step": el / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup}))
 
 
 def main():
@@ -56,6 +101,9 @@ def main():
     ap.add_argument("--shard", choices=["windows", "points"], default="windows")
     ap.add_argument("--cpu-sample-logn", type=int, default=15)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["msm", "batched", "pcie"], default="msm",
+                    help="msm: the headline metric (default). batched: BASELINE config 3's MSM content (1024 independent "
+                         "627-term accumulator MSMs per step, regime B). pcie: the headline MSM with inputs in HOST memory")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="transport of the N>1 partial-sum exchange (nccl == RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
@@ -75,6 +123,8 @@ def main():
 
     dist = None
     torch = None
+    if args.mode != "msm":
+        return side_mode(args)
     dev_index = 0 if args.same_device else local_rank
     if world > 1:
         import torch

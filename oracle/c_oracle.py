@@ -26,6 +26,7 @@ def lib():
         build()
         _lib = ctypes.CDLL(LIB)
         _lib.orc_compute_msm.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+        _lib.orc_msm_bucket.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         _lib.orc_scalar_mul.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
         _lib.orc_add.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
         _lib.orc_compress.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
@@ -36,6 +37,15 @@ def compute_msm(points96: bytes, scalars32: bytes, n: int) -> bytes:
     """msm_accumulator.py:6-12 on affine96 / scalar32 buffers; returns affine96 (zeros = identity)."""
     out = ctypes.create_string_buffer(96)
     lib().orc_compute_msm(points96, scalars32, n, out)
+    return out.raw
+
+
+def msm_bucket(points96: bytes, scalars32: bytes, n: int, c: int = 0) -> bytes:
+    """Bucket-method MSM (same result as compute_msm, NOT the reference's algorithm; for large parity sizes)."""
+    if c <= 0:
+        c = max(4, min(16, n.bit_length() - 3))
+    out = ctypes.create_string_buffer(96)
+    lib().orc_msm_bucket(points96, scalars32, n, c, out)
     return out.raw
 
 

@@ -161,6 +161,39 @@ void orc_compute_msm(const uint8_t* points96, const uint8_t* scalars32, size_t n
     current = pt_add(current, pt_scalar_mul(pt_from_affine96(points96 + 96 * i), scalars32 + 32 * i));   /* :11 */
   pt_to_affine96(current, out96);                                       /* :12 */
 }
+/* Same group element as orc_compute_msm by the textbook bucket method (unsigned c-bit windows, running-sum
+ * bucket reduction, Horner over windows).  NOT the reference's algorithm: it exists so that parity tests can
+ * compare the GPU at 2^16..2^18 terms in seconds, and as a clearly-labelled stronger CPU baseline in bench.py.
+ * Cross-checked against the naive loop in tests/test_oracle_kat.py. */
+#include <stdlib.h>
+void orc_msm_bucket(const uint8_t* points96, const uint8_t* scalars32, size_t n, int c, uint8_t out96[96]) {
+  if (c < 2) c = 2;
+  if (c > 20) c = 20;
+  const int nwin = (256 + c - 1) / c;
+  const size_t nb = (size_t)1 << c;
+  pt* pts = (pt*)malloc((n ? n : 1) * sizeof(pt));
+  pt* buckets = (pt*)malloc(nb * sizeof(pt));
+  for (size_t i = 0; i < n; ++i) pts[i] = pt_from_affine96(points96 + 96 * i);
+  pt total = pt_identity();
+  for (int w = nwin - 1; w >= 0; --w) {
+    for (int k = 0; k < c; ++k) total = pt_double(total);
+    for (size_t b = 0; b < nb; ++b) buckets[b] = pt_identity();
+    for (size_t i = 0; i < n; ++i) {
+      const uint8_t* k = scalars32 + 32 * i;
+      uint32_t d = 0;
+      for (int t = 0; t < c; ++t) {
+        int bit = w * c + t;
+        if (bit < 256 && ((k[bit >> 3] >> (bit & 7)) & 1)) d |= 1u << t;
+      }
+      if (d) buckets[d] = pt_add(buckets[d], pts[i]);
+    }
+    pt run = pt_identity(), acc = pt_identity();
+    for (size_t b = nb - 1; b >= 1; --b) { run = pt_add(run, buckets[b]); acc = pt_add(acc, run); }
+    total = pt_add(total, acc);
+  }
+  pt_to_affine96(total, out96);
+  free(pts); free(buckets);
+}
 void orc_scalar_mul(const uint8_t* point96, const uint8_t* scalar32, uint8_t out96[96]) {
   pt_to_affine96(pt_scalar_mul(pt_from_affine96(point96), scalar32), out96);
 }

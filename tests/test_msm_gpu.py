@@ -259,3 +259,18 @@ def test_two_contexts_concurrently(native_lib):
         assert out[i] == [jobs[i][2]] * 5
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("logn", [16, 18])
+def test_config2_full_size_vs_cpu_oracle(native_lib, ctx, logn):
+    """BASELINE config 2: one MSM of 2^16 random G1 points, bit-exact vs the CPU (and 2^18 for good measure).
+    CPU side: the C oracle's bucket method (cross-checked against its naive reference loop on CPU)."""
+    n = 1 << logn
+    dk, dg, dp, ds = ctx.alloc(32 * n), ctx.alloc(96), ctx.alloc(96 * n), ctx.alloc(32 * n)
+    ctx.gen_scalars_device(dk, n, 100 + logn); ctx.gen_scalars_device(ds, n, 200 + logn)
+    dg.upload(raw96(O.G1_GEN))
+    ctx.batch_mul_device(dg, 1, dk, dp, n)
+    p96, s32 = dp.download(), ds.download()
+    want = C.compress(C.msm_bucket(p96, s32, n))
+    for c in (0, 16):
+        assert compress_blob(native_lib, ctx.msm_device(dp, ds, n, window_c=c)) == want

@@ -72,6 +72,17 @@ def test_c_oracle_matches_python_oracle():
     assert C.add(raw96(a), raw96(O.g1_neg(a))) == bytes(96)
 
 
+def test_c_bucket_oracle_matches_c_naive_oracle():
+    rng = random.Random(14)
+    pts = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(16)] + [None]
+    for n in (0, 1, 17, 1024):
+        p96 = b"".join(raw96(pts[rng.randrange(17)]) for _ in range(n))
+        s32 = b"".join(rng.choice([0, 1, O.R - 1, rng.randint(0, O.R - 1), rng.randint(0, O.R - 1)]).to_bytes(32, "little") for _ in range(n))
+        want = C.compute_msm(p96, s32, n)
+        for c in (0, 2, 7, 13):
+            assert C.msm_bucket(p96, s32, n, c) == want, (n, c)
+
+
 def test_naive_and_bucket_oracles_agree():
     rng = random.Random(12)
     pts = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(40)]
