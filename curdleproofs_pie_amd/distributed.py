@@ -29,8 +29,14 @@ def sum_blobs(blobs: List[bytes]) -> bytes:
     return acc.raw
 
 
+_bufs = {}
+
+
 def all_reduce_g1(partial_blob: bytes, group=None, device: Optional[str] = None) -> bytes:
-    """All-gather every rank's partial G1 point and add them; returns the same blob on all ranks."""
+    """All-gather every rank's partial G1 point and add them; returns the same blob on all ranks.
+
+    One collective per call: a single all-gather of 144 bytes per rank into a cached device buffer, one D2H copy,
+    world-1 host additions."""
     import torch
     import torch.distributed as dist
 
@@ -39,10 +45,20 @@ def all_reduce_g1(partial_blob: bytes, group=None, device: Optional[str] = None)
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     dev = device or ("cuda" if backend == "nccl" else "cpu")
-    mine = torch.frombuffer(bytearray(partial_blob), dtype=torch.uint8).to(dev)
-    gathered = [torch.empty(N.POINT_BYTES, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    return sum_blobs([bytes(t.cpu().numpy().tobytes()) for t in gathered])
+    key = (dev, world)
+    if key not in _bufs:
+        _bufs[key] = (torch.empty(N.POINT_BYTES, dtype=torch.uint8, device=dev),
+                      torch.empty(world * N.POINT_BYTES, dtype=torch.uint8, device=dev))
+    mine, gathered = _bufs[key]
+    mine.copy_(torch.frombuffer(bytearray(partial_blob), dtype=torch.uint8))
+    try:
+        dist.all_gather_into_tensor(gathered, mine, group=group)
+        raw = gathered.cpu().numpy().tobytes()
+    except (RuntimeError, NotImplementedError):      # transports without the flat form
+        lst = [torch.empty(N.POINT_BYTES, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(lst, mine, group=group)
+        raw = b"".join(t.cpu().numpy().tobytes() for t in lst)
+    return sum_blobs([raw[i * N.POINT_BYTES:(i + 1) * N.POINT_BYTES] for i in range(world)])
 
 
 def sharded_msm(ctx: "N.Context", d_points, d_scalars, n: int, rank: int, world: int, window_c: int = 16,
