@@ -720,6 +720,93 @@ __global__ void __launch_bounds__(64) k_bit_tree_final(const PointSum* __restric
   }
 }
 
+// ------------------------------------------------------------------ 2-D bucket reduction (regime A default)
+// S_w = sum_b (b+1) B_b over the window's 2^(c-1) buckets, b = h * 2^lb + l:
+//     S_w = T0 + 2^lb * sum_h h A_h + sum_l l C_l,   A_h = sum_l B_{h,l} (row sums),  C_l = sum_h B_{h,l} (column sums),
+//     T0 = sum_h A_h.
+// k_rowcol forms all row and column sums in ONE launch (2 EC adds per bucket; blocks [0, nrow_blocks) take rows,
+// the rest columns; <= 8 serial adds per lane, then a shuffle tree inside 32 / 16 lanes).  k_small_tree then
+// turns the 2^hb row sums and 2^lb column sums of a window into 1 + hb + lb points (plain sum + one masked sum per
+// index bit) whose power-of-two weights the host Horner applies.  Versus k_seg_reduce + k_bit_tree this halves
+// the wave-level EC-add steps (47 K -> ~20 K at c = 16) and shortens the dependent chain (~27 -> ~22 steps).
+__device__ __forceinline__ xyzz bucket_sum(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+                                           const uint8_t* __restrict__ combined, uint32_t b) {
+  uint32_t c0 = choff[b], c1 = choff[b + 1];
+  if (combined[b]) c1 = c0 + 1;
+  xyzz acc = xyzz_identity();
+  for (uint32_t k = c0; k < c1; ++k) acc = xyzz_add(acc, load_sum(sums + k));
+  return acc;
+}
+
+__global__ void __launch_bounds__(256) k_rowcol(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+                                                const uint8_t* __restrict__ combined, PointSum* __restrict__ rowsum,
+                                                PointSum* __restrict__ colsum, uint32_t nlw, uint32_t hb, uint32_t lb,
+                                                uint32_t nrow_blocks) {
+  const uint32_t R = 1u << hb, Cn = 1u << lb;
+  if (blockIdx.x < nrow_blocks) {
+    const uint32_t lpr = Cn < 32u ? Cn : 32u, serial = Cn / lpr;
+    const uint32_t gr = blockIdx.x * (256u / lpr) + threadIdx.x / lpr;     // global row = lw * R + h
+    const uint32_t part = threadIdx.x % lpr;
+    const bool live = gr < nlw * R;
+    xyzz acc = xyzz_identity();
+    if (live)
+      for (uint32_t t = 0; t < serial; ++t) acc = xyzz_add(acc, bucket_sum(choff, sums, combined, gr * Cn + part * serial + t));
+    for (uint32_t delta = lpr >> 1; delta >= 1; delta >>= 1) {
+      xyzz o = shfl_down_xyzz(acc, (int)delta);
+      if (part < delta) acc = xyzz_add(acc, o);
+    }
+    if (live && part == 0) store_sum(rowsum + gr, acc);
+  } else {
+    const uint32_t lpc = R < 16u ? R : 16u, serial = R / lpc;
+    const uint32_t gc = (blockIdx.x - nrow_blocks) * (256u / lpc) + threadIdx.x / lpc;   // global column = lw * Cn + l
+    const uint32_t part = threadIdx.x % lpc;
+    const bool live = gc < nlw * Cn;
+    const uint32_t lw = gc / Cn, l = gc % Cn;
+    xyzz acc = xyzz_identity();
+    if (live)
+      for (uint32_t t = 0; t < serial; ++t) acc = xyzz_add(acc, bucket_sum(choff, sums, combined, (lw * R + part * serial + t) * Cn + l));
+    for (uint32_t delta = lpc >> 1; delta >= 1; delta >>= 1) {
+      xyzz o = shfl_down_xyzz(acc, (int)delta);
+      if (part < delta) acc = xyzz_add(acc, o);
+    }
+    if (live && part == 0) store_sum(colsum + gc, acc);
+  }
+}
+
+// grid = (1 + hb + lb, nlw), 256 threads.  item 0: T0 = sum_h A_h; item 1+k (k < hb): sum of A_h with bit k of h set;
+// item 1+hb+k (k < lb): sum of C_l with bit k of l set.  Requires 2^hb, 2^lb <= 256.  Emits canonical words.
+__global__ void __launch_bounds__(256) k_small_tree(const PointSum* __restrict__ rowsum, const PointSum* __restrict__ colsum,
+                                                    PointWords* __restrict__ out, uint32_t hb, uint32_t lb) {
+  __shared__ PointSum sh[4];
+  const uint32_t item = blockIdx.x, lw = blockIdx.y;
+  const bool on_rows = item <= hb;
+  const uint32_t J = on_rows ? (1u << hb) : (1u << lb);
+  const PointSum* src = on_rows ? rowsum + (size_t)lw * J : colsum + (size_t)lw * J;
+  const uint32_t bit = on_rows ? item - 1u : item - 1u - hb;           // unused for item 0
+  xyzz acc = xyzz_identity();
+  if (threadIdx.x < J && (item == 0 || ((threadIdx.x >> bit) & 1u))) acc = load_sum(src + threadIdx.x);
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    xyzz o = shfl_down_xyzz(acc, delta);
+    if ((threadIdx.x & 63) < (uint32_t)delta) acc = xyzz_add(acc, o);
+  }
+  if ((threadIdx.x & 63) == 0) store_sum(&sh[threadIdx.x >> 6], acc);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    acc = (threadIdx.x < 4) ? load_sum(&sh[threadIdx.x]) : xyzz_identity();
+    for (int delta = 2; delta >= 1; delta >>= 1) {
+      xyzz o = shfl_down_xyzz(acc, delta);
+      if (threadIdx.x < (uint32_t)delta) acc = xyzz_add(acc, o);
+    }
+    if (threadIdx.x == 0) {
+      xyzz_words o;
+      xyzz_export(acc, o);
+      PointWords* dst = out + (size_t)lw * gridDim.x + item;
+      for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
+      dst->inf = o.inf;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ batched scalar mul / fold
 // out[i] = addend[i] + k_i * P_i   with P_i = base[i % nbase], k_i = scalars[i % nscalars], addend optional.
 // Covers the vectorised `G1Point * Scalar` patterns of the callers:
@@ -885,6 +972,7 @@ struct Ctx {
   uint16_t* d_digits = nullptr; uint32_t* d_part = nullptr; uint32_t* d_blockcnt = nullptr; uint32_t* d_ublocktot = nullptr;
   size_t cap_digits = 0, cap_part = 0, cap_blockcnt = 0;
   int use_partition_sort = 1;
+  int reduce_2d = 1;                    // 1: k_rowcol + k_small_tree; 0: k_seg_reduce + k_bit_tree (A/B switch)
   uint32_t* d_heavy = nullptr; size_t cap_heavy = 0;         // [0] count, then heavy bucket ids
   uint8_t* d_combined = nullptr; size_t cap_combined = 0;
   uint32_t* d_boffs = nullptr; size_t cap_boffs = 0;          // regime B: MSM offsets, group sums, per-MSM results
@@ -1041,7 +1129,9 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   const uint32_t m = std::min<uint32_t>(ctx->seg_m, NB);
   const uint32_t J = NB / m;                                   // segments per window
   int nbits = 0; while ((1u << nbits) < J) ++nbits;
-  const uint32_t nitems = 1 + nbits;
+  const uint32_t bb = (uint32_t)c - 1u, lb2 = (bb + 1u) / 2u, hb2 = bb - lb2;       // 2-D split of the bucket index
+  const bool use2d = ctx->reduce_2d != 0;
+  const uint32_t nitems = use2d ? 1u + hb2 + lb2 : 1u + (uint32_t)nbits;
   const size_t nb_total = (size_t)nlw * NB;
   int rc = ensure(ctx, n, nb_total, nlw, nitems);
   if (rc) return rc;
@@ -1095,13 +1185,26 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   HIPCHK(hipEventRecord(ctx->ev[4], st));
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
   HIPCHK(hipEventRecord(ctx->ev[5], st));
-  const uint32_t nseg_total = (uint32_t)(nb_total / m);
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
-  hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
-  HIPCHK(hipEventRecord(ctx->ev[6], st));
-  uint32_t S = (J + BT_ELEMS - 1) / BT_ELEMS; if (S < 1) S = 1; if (S > 64) S = 64;   // J <= 2^15 / seg_m
-  hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw, S), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_partial, J);
-  hipLaunchKernelGGL(k_bit_tree_final, dim3((uint32_t)(nitems * nlw)), dim3(64), 0, st, ctx->d_partial, ctx->d_out, S);
+  if (use2d) {
+    const uint32_t R = 1u << hb2, Cn = 1u << lb2;
+    const uint32_t lpr = Cn < 32u ? Cn : 32u, lpc = R < 16u ? R : 16u;
+    const uint32_t nrow_blocks = ((uint32_t)nlw * R + (256u / lpr) - 1u) / (256u / lpr);
+    const uint32_t ncol_blocks = ((uint32_t)nlw * Cn + (256u / lpc) - 1u) / (256u / lpc);
+    PointSum* rowsum = ctx->d_segrun;                     // reuse the segment buffers (>= nb_total records each)
+    PointSum* colsum = ctx->d_segtot;
+    hipLaunchKernelGGL(k_rowcol, dim3(nrow_blocks + ncol_blocks), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
+                       rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks);
+    HIPCHK(hipEventRecord(ctx->ev[6], st));
+    hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
+  } else {
+    const uint32_t nseg_total = (uint32_t)(nb_total / m);
+    hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
+    HIPCHK(hipEventRecord(ctx->ev[6], st));
+    uint32_t S = (J + BT_ELEMS - 1) / BT_ELEMS; if (S < 1) S = 1; if (S > 64) S = 64;   // J <= 2^15 / seg_m
+    hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw, S), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_partial, J);
+    hipLaunchKernelGGL(k_bit_tree_final, dim3((uint32_t)(nitems * nlw)), dim3(64), 0, st, ctx->d_partial, ctx->d_out, S);
+  }
   HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)nlw * nitems * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
@@ -1122,13 +1225,20 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   int lm = 0; while ((1u << lm) < m) ++lm;
   cg1h::jac acc = cg1h::jac_identity();
   const int top_w = rank + (nlw - 1) * world;
-  for (int e = c * top_w + lm + nbits - 1; e >= 0; --e) {
+  for (int e = c * top_w + c - 2; e >= 0; --e) {
     acc = cg1h::jac_dbl(acc);
     const int w = e / c, r = e % c;
     if (w % world != rank) continue;
     const PointWords* row = ctx->h_out + (size_t)(w / world) * nitems;
     if (r == 0) acc = cg1h::jac_add(acc, jac_from_words(row[0]));
-    if (r >= lm && r - lm < nbits) acc = cg1h::jac_add(acc, jac_from_words(row[1 + (r - lm)]));
+    if (use2d) {
+      //   e(T0) = c w;  e(column bit k) = c w + k (k < lb);  e(row bit k) = c w + lb + k (k < hb)
+      if (r < (int)lb2) acc = cg1h::jac_add(acc, jac_from_words(row[1 + hb2 + r]));
+      else if (r - (int)lb2 < (int)hb2) acc = cg1h::jac_add(acc, jac_from_words(row[1 + (r - lb2)]));
+    } else {
+      //   e(T_w) = c w;  e(Y_{w,b}) = c w + log2(m) + b
+      if (r >= lm && r - lm < nbits) acc = cg1h::jac_add(acc, jac_from_words(row[1 + (r - lm)]));
+    }
   }
   result = acc;
   ctx->host_tail_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -1383,6 +1493,7 @@ int cg1_ctx_sync(cg1_ctx* ctx) {
 int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return CG1_ERR_ARG;
   if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
+  if (!strcmp(name, "reduce_2d")) { ctx->reduce_2d = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
     int v = value ? 1 : 0;

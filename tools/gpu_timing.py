@@ -22,19 +22,25 @@ def main():
     ctx.gen_scalars_device(dk, n, 1)
     ctx.batch_mul_device(dg, 1, dk, dp, n)
     ctx.gen_scalars_device(ds, n, 2)
-    for c in cs:
-        walls = []
-        acc = {}
-        for r in range(reps):
-            t = time.perf_counter()
-            ctx.msm_device(dp, ds, n, window_c=c)
-            walls.append((time.perf_counter() - t) * 1e3)
-            if r >= 2:
-                for k, v in ctx.timings().items():
-                    acc[k] = acc.get(k, 0) + v / (reps - 2)
-        w = sorted(walls[2:])
-        print(f"2^{logn} c={c}: wall min {w[0]:.3f} med {w[len(w)//2]:.3f} ms -> {n/w[len(w)//2]/1e3:.1f} M/s | " +
-              " ".join(f"{k}={v:.3f}" for k, v in acc.items() if k != "window_c"), flush=True)
+    variants = [("default", {})]
+    if os.environ.get("AB"):      # e.g. AB=reduce_2d=0,reduce_2d=1  -> interleaved A/B in one process
+        variants = [(kv, {kv.split("=")[0]: int(kv.split("=")[1])}) for kv in os.environ["AB"].split(",")] * 2
+    for name, params in variants:
+        for k, v in params.items():
+            ctx.set_param(k, v)
+        for c in cs:
+            walls = []
+            acc = {}
+            for r in range(reps):
+                t = time.perf_counter()
+                ctx.msm_device(dp, ds, n, window_c=c)
+                walls.append((time.perf_counter() - t) * 1e3)
+                if r >= 2:
+                    for k, v in ctx.timings().items():
+                        acc[k] = acc.get(k, 0) + v / (reps - 2)
+            w = sorted(walls[2:])
+            print(f"[{name}] 2^{logn} c={c}: wall min {w[0]:.3f} med {w[len(w)//2]:.3f} ms -> {n/w[len(w)//2]/1e3:.1f} M/s | " +
+                  " ".join(f"{k}={v:.3f}" for k, v in acc.items() if k != "window_c"), flush=True)
 
 
 if __name__ == "__main__":
