@@ -738,7 +738,7 @@ __device__ __forceinline__ xyzz bucket_sum(const uint32_t* __restrict__ choff, c
   return acc;
 }
 
-__global__ void __launch_bounds__(256) k_rowcol(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+__global__ void __launch_bounds__(256, 2) k_rowcol(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
                                                 const uint8_t* __restrict__ combined, PointSum* __restrict__ rowsum,
                                                 PointSum* __restrict__ colsum, uint32_t nlw, uint32_t hb, uint32_t lb,
                                                 uint32_t nrow_blocks) {
