@@ -95,7 +95,8 @@ __device__ __forceinline__ xyzz load_sum(const PointSum* src) {
 }
 
 // ------------------------------------------------------------------ k_prepare_points
-__global__ void __launch_bounds__(256) k_prepare_points(const uint32_t* __restrict__ raw, PreparedPoint* __restrict__ out, uint32_t n) {
+__global__ void __launch_bounds__(256) k_prepare_points(const uint32_t* __restrict__ raw, PreparedPoint* __restrict__ out,
+                                                        uint8_t* __restrict__ inf_flag, uint32_t n) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const uint4* q = reinterpret_cast<const uint4*>(raw + 24ull * i);
@@ -111,6 +112,7 @@ __global__ void __launch_bounds__(256) k_prepare_points(const uint32_t* __restri
 #pragma unroll
   for (int k = 0; k < NL; ++k) { o[k] = x.l[k]; o[NL + k] = y.l[k]; }
   o[28] = any ? 0u : 1u;               // (0,0) is not on the curve: it encodes the identity
+  inf_flag[i] = any ? 0 : 1;           // compact copy: the digit kernels must not touch the 128-B records
   o[29] = o[30] = o[31] = 0;
   uint4* d = reinterpret_cast<uint4*>(out + i);
 #pragma unroll
@@ -145,11 +147,11 @@ __device__ __forceinline__ void load_scalar(const uint32_t* scalars, uint32_t i,
 }
 
 // counts per (local window, bucket); skips zero digits and identity points
-__global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scalars, const PreparedPoint* __restrict__ pts,
+__global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
                                               uint32_t* __restrict__ hist, uint32_t n, int c, int nwin, int rank, int world) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  if (pts[i].flags & 1u) return;
+  if (inf_flag[i]) return;
   DigitIter it; it.c = c;
   load_scalar(scalars, i, it);
   const uint32_t NB = 1u << (c - 1);
@@ -161,12 +163,12 @@ __global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scala
   }
 }
 
-__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ scalars, const PreparedPoint* __restrict__ pts,
+__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
                                                  uint32_t* __restrict__ cursor, const uint32_t* __restrict__ off,
                                                  uint32_t* __restrict__ sorted, uint32_t n, int c, int nwin, int rank, int world) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  if (pts[i].flags & 1u) return;
+  if (inf_flag[i]) return;
   DigitIter it; it.c = c;
   load_scalar(scalars, i, it);
   const uint32_t NB = 1u << (c - 1);
@@ -220,11 +222,11 @@ __device__ __forceinline__ uint32_t lds_ranked_inc(uint32_t* ctr, uint32_t key, 
   return active ? atomicAdd(&ctr[key], 1u) : 0u;
 }
 
-__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const PreparedPoint* __restrict__ pts,
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
                                                 uint16_t* __restrict__ digits, uint32_t n, int c, int nwin, int rank, int world) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const bool inf = pts[i].flags & 1u;
+  const bool inf = inf_flag[i] != 0;
   DigitIter it; it.c = c;
   load_scalar(scalars, i, it);
   for (int w = 0; w < nwin; ++w) {
@@ -436,7 +438,8 @@ __global__ void __launch_bounds__(64) k_msm_horner(const PointSum* __restrict__ 
 // MAX_CHUNKS_PER_BUCKET pieces whose partial sums are then combined by a block-wide tree (k_heavy_combine)
 // instead of serialising one lane.
 constexpr uint32_t MAX_CHUNKS_PER_BUCKET = 4096;
-constexpr uint32_t HEAVY_MIN_CHUNKS = 5;        // buckets with >= this many chunks go through k_heavy_combine
+constexpr uint32_t HEAVY_MIN_CHUNKS = 17;       // buckets with >= this many chunks go through k_heavy_combine;
+                                                // 2..16 chunks are folded by one lane in k_bucket_fold
 __device__ __forceinline__ uint32_t chunk_len(uint32_t cnt, uint32_t L0) {
   uint32_t s = (cnt + MAX_CHUNKS_PER_BUCKET - 1) / MAX_CHUNKS_PER_BUCKET;
   return s > L0 ? s : L0;
@@ -629,6 +632,22 @@ __global__ void __launch_bounds__(256) k_heavy_combine(const uint32_t* __restric
     }
     __syncthreads();
   }
+}
+
+// ------------------------------------------------------------------ k_bucket_fold
+// One lane per bucket: buckets whose entries were cut into 2..16 chunks (a window-sharded rank owns few buckets,
+// so chunks are kept short for parallelism in k_accumulate) get their chunk sums added serially into the first
+// slot.  Buckets with more chunks were already handled by k_heavy_combine; single-chunk buckets are untouched.
+__global__ void __launch_bounds__(256) k_bucket_fold(const uint32_t* __restrict__ choff, PointSum* __restrict__ sums,
+                                                     uint8_t* __restrict__ combined, uint32_t nb_total) {
+  uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nb_total) return;
+  const uint32_t c0 = choff[b], c1 = choff[b + 1];
+  if (c1 - c0 < 2u || c1 - c0 >= HEAVY_MIN_CHUNKS) return;
+  xyzz acc = load_sum(sums + c0);
+  for (uint32_t k = c0 + 1; k < c1; ++k) acc = xyzz_add(acc, load_sum(sums + k));
+  store_sum(sums + c0, acc);
+  combined[b] = 1;
 }
 
 // ------------------------------------------------------------------ k_seg_reduce
@@ -965,6 +984,7 @@ struct Ctx {
   // capacity
   size_t cap_n = 0, cap_nb = 0, cap_chunks = 0, cap_entries = 0, cap_out = 0;
   PreparedPoint* d_pts = nullptr;
+  uint8_t* d_flags = nullptr;
   uint32_t *d_hist = nullptr, *d_off = nullptr, *d_choff = nullptr, *d_sorted = nullptr;
   uint2 *d_blocktot = nullptr, *d_desc = nullptr;
   uint32_t *d_order = nullptr, *d_lenhist = nullptr;      // [2*LEN_BINS]: histogram, cursor
@@ -997,7 +1017,7 @@ struct Ctx {
 
 static void free_bufs(Ctx* c) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
-  F(c->d_pts); F(c->d_hist); F(c->d_off); F(c->d_choff); F(c->d_sorted); F(c->d_blocktot); F(c->d_desc);
+  F(c->d_pts); F(c->d_flags); F(c->d_hist); F(c->d_off); F(c->d_choff); F(c->d_sorted); F(c->d_blocktot); F(c->d_desc);
   F(c->d_sums); F(c->d_segrun); F(c->d_segtot); F(c->d_out); F(c->d_order); F(c->d_lenhist); F(c->d_partial);
   c->cap_partial = 0;
   F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot); F(c->d_boffs); F(c->d_gsum); F(c->d_bout);
@@ -1013,7 +1033,9 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
   size_t chunks = nb_total + entries / ctx->L0 + 1;
   if (n > ctx->cap_n) {
     if (ctx->d_pts) (void)hipFree(ctx->d_pts);
+    if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     HIPCHK(hipMalloc(&ctx->d_pts, n * sizeof(PreparedPoint)));
+    HIPCHK(hipMalloc(&ctx->d_flags, n + 16));
     ctx->cap_n = n;
   }
   if (nb_total > ctx->cap_nb) {
@@ -1138,10 +1160,15 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   hipStream_t st = ctx->stream;
   const uint32_t n32 = (uint32_t)n;
   const uint32_t gn = (n32 + 255) / 256;
+  // chunk length: grows with the total entry count so that k_accumulate keeps >= 2^18 lanes busy without flooding the
+  // reduce phases with chunk sums: ~64 at 2^20 terms x 16 windows, 512 at 2^23.  A window-sharded rank (few buckets,
+  // long buckets) therefore gets several chunks per bucket; k_bucket_fold adds those (<= 16), k_heavy_combine the rest.
+  uint32_t L0 = ctx->L0;
+  while (L0 < 65536u && ((uint64_t)n * (uint64_t)nlw >> 18) > (uint64_t)L0) L0 <<= 1;
 
   auto h0 = std::chrono::steady_clock::now();
   HIPCHK(hipEventRecord(ctx->ev[0], st));
-  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, n32);
+  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32);
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
@@ -1150,7 +1177,7 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     const uint32_t sub_bits = bb < 8u ? bb : 8u, nbins = 1u << (bb - sub_bits);
     const uint32_t nslices = (n32 + PART_TILE - 1) / PART_TILE;
     const uint32_t nbc = (uint32_t)nlw * nbins * nslices;
-    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_digits, n32, c, nwin, rank, world);
+    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, n32, c, nwin, rank, world);
     hipLaunchKernelGGL(k_part_count, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, n32, nslices, nbins, sub_bits);
     const uint32_t ublk = (nbc + SCAN_ITEMS - 1) / SCAN_ITEMS;
     hipLaunchKernelGGL(k_uscan1, dim3(ublk), dim3(256), 0, st, ctx->d_blockcnt, ctx->d_ublocktot, nbc);
@@ -1160,25 +1187,25 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     hipLaunchKernelGGL(k_part_scatter, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, ctx->d_part, n32, nslices, nbins, sub_bits);
     hipLaunchKernelGGL(k_bin_sort, dim3((uint32_t)nlw * nbins), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, ctx->d_hist, ctx->d_sorted, (uint32_t)nlw * nbins, nslices, sub_bits);
     HIPCHK(hipEventRecord(ctx->ev[3], st));
-    hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, ctx->L0);
+    hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
   } else {
     // ---- global-atomic counting sort (any n < 2^31)
     HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
-    hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_hist, n32, c, nwin, rank, world);
+    hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_hist, n32, c, nwin, rank, world);
     HIPCHK(hipEventRecord(ctx->ev[2], st));
-    hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, ctx->L0);
+    hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     HIPCHK(hipEventRecord(ctx->ev[3], st));
-    hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, c, nwin, rank, world);
+    hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, c, nwin, rank, world);
   }
   HIPCHK(hipMemsetAsync(ctx->d_lenhist, 0, LEN_BINS * 4, st));
   HIPCHK(hipMemsetAsync(ctx->d_heavy, 0, 4, st));
   HIPCHK(hipMemsetAsync(ctx->d_combined, 0, nb_total, st));
-  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, ctx->L0);
-  const size_t max_chunks = nb_total + (n * (size_t)nlw) / ctx->L0 + 1;
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0);
+  const size_t max_chunks = nb_total + (n * (size_t)nlw) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS);
   hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
@@ -1186,6 +1213,7 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
+  hipLaunchKernelGGL(k_bucket_fold, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total);
   if (use2d) {
     const uint32_t R = 1u << hb2, Cn = 1u << lb2;
     const uint32_t lpr = Cn < 32u ? Cn : 32u, lpc = R < 16u ? R : 16u;
@@ -1308,9 +1336,9 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   auto h0 = std::chrono::steady_clock::now();
   HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(ctx->ev[0], st));
-  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, N32);
+  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, N32);
   HIPCHK(hipEventRecord(ctx->ev[1], st));
-  hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_pts, ctx->d_digits, N32, c, (int)nwin, 0, 1);
+  hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, N32, c, (int)nwin, 0, 1);
   hipLaunchKernelGGL(k_group_count, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_hist, N32, NB, nwin);
   HIPCHK(hipEventRecord(ctx->ev[2], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
@@ -1655,10 +1683,11 @@ int cg1_probe_madd(cg1_ctx* ctx, const void* d_points, size_t npts, size_t lanes
   if (!ctx) return CG1_ERR_HIP;
   if (npts == 0 || lanes == 0 || lanes % 256) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  cg1::PreparedPoint* prep = nullptr; cg1::PointSum* out = nullptr;
+  cg1::PreparedPoint* prep = nullptr; cg1::PointSum* out = nullptr; uint8_t* fl = nullptr;
   HIPCHK(hipMalloc(&prep, npts * sizeof(cg1::PreparedPoint)));
+  HIPCHK(hipMalloc(&fl, npts + 16));
   HIPCHK(hipMalloc(&out, lanes * sizeof(cg1::PointSum)));
-  hipLaunchKernelGGL(cg1::k_prepare_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_points, prep, (uint32_t)npts);
+  hipLaunchKernelGGL(cg1::k_prepare_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_points, prep, fl, (uint32_t)npts);
   hipLaunchKernelGGL(cg1::k_probe_madd, dim3((unsigned)(lanes / 256)), dim3(256), 0, ctx->stream, prep, (uint32_t)npts, out, 2);
   HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
   hipLaunchKernelGGL(cg1::k_probe_madd, dim3((unsigned)(lanes / 256)), dim3(256), 0, ctx->stream, prep, (uint32_t)npts, out, iters);
@@ -1666,7 +1695,7 @@ int cg1_probe_madd(cg1_ctx* ctx, const void* d_points, size_t npts, size_t lanes
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
-  (void)hipFree(prep); (void)hipFree(out);
+  (void)hipFree(prep); (void)hipFree(out); (void)hipFree(fl);
   return CG1_OK;
 }
 
