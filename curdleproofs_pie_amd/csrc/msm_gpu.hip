@@ -1011,7 +1011,7 @@ struct Ctx {
   int profile = 1;                      // read the per-phase hipEvents after each call
   uint32_t last_chunks = 0, last_entries = 0;
   int last_c = 0;
-  uint32_t L0 = 64;
+  uint32_t L0 = 8;                      // MINIMUM chunk length; the per-call length grows with the entry count
   uint32_t seg_m = 4;
 };
 
@@ -1028,9 +1028,9 @@ static void free_bufs(Ctx* c) {
   c->cap_n = c->cap_nb = c->cap_chunks = c->cap_entries = c->cap_out = 0;
 }
 
-static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems) {
+static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems, uint32_t L) {
   size_t entries = n * nlw;
-  size_t chunks = nb_total + entries / ctx->L0 + 1;
+  size_t chunks = nb_total + entries / L + 1;
   if (n > ctx->cap_n) {
     if (ctx->d_pts) (void)hipFree(ctx->d_pts);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
@@ -1065,7 +1065,7 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
   }
   if (!ctx->d_lenhist) HIPCHK(hipMalloc(&ctx->d_lenhist, 2 * LEN_BINS * 4));
   {
-    const size_t hcap = entries / (ctx->L0 * (HEAVY_MIN_CHUNKS - 1)) + 2;     // a heavy bucket holds > (MIN-1)*L0 entries
+    const size_t hcap = entries / ((size_t)L * (HEAVY_MIN_CHUNKS - 1)) + 2;     // a heavy bucket holds > (MIN-1)*L entries
     if (hcap > ctx->cap_heavy) {
       if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
       HIPCHK(hipMalloc(&ctx->d_heavy, (hcap + 1) * 4));
@@ -1125,15 +1125,11 @@ static cg1h::jac jac_from_words(const PointWords& p) {
 }
 
 int pick_window(size_t n) {
-  // c minimising  nwin*n (bucket adds)  +  nwin * 2^(c-1) * ~3 (reduction adds, weighted for their latency)
-  int best = 4; double best_cost = 1e300;
-  for (int c = 4; c <= 16; ++c) {
-    if (255 % c == 0) continue;          // top window would hold only the recoding carry: one hot bucket
-    int nwin = 255 / c + 1;
-    double cost = (double)nwin * ((double)n + 3.0 * (double)(1u << (c - 1)));
-    if (cost < best_cost) { best_cost = cost; best = c; }
-  }
-  return best;
+  // Only widths whose TOP window still holds >= min(c-1, 7) scalar bits (255 = (nwin-1)*c + t): with t = 2..3 all
+  // n terms of that window fall into <= 8 buckets.  Thresholds from tools/gpu_window_sweep.py on MI355X.
+  if (n <= 128) return 4;        // t = 3
+  if (n <= 8192) return 8;       // t = 7
+  return 16;                     // t = 15
 }
 
 int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
@@ -1155,17 +1151,17 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   const bool use2d = ctx->reduce_2d != 0;
   const uint32_t nitems = use2d ? 1u + hb2 + lb2 : 1u + (uint32_t)nbits;
   const size_t nb_total = (size_t)nlw * NB;
-  int rc = ensure(ctx, n, nb_total, nlw, nitems);
+  // chunk length: grows with the total entry count so that k_accumulate keeps >= 2^18 lanes busy without flooding the
+  // reduce phases with chunk sums (64 at 2^20 terms x 16 windows, 512 at 2^23) and shrinks to the minimum (8) for
+  // small inputs, where the dependent madd chain of one chunk IS the critical path.  Buckets cut into several chunks
+  // (window-sharded ranks, skew, thin top windows) are re-joined by k_bucket_fold (<= 16 chunks) / k_heavy_combine.
+  uint32_t L0 = ctx->L0;
+  while (L0 < 65536u && ((uint64_t)n * (uint64_t)nlw >> 18) > (uint64_t)L0) L0 <<= 1;
+  int rc = ensure(ctx, n, nb_total, nlw, nitems, L0);
   if (rc) return rc;
   hipStream_t st = ctx->stream;
   const uint32_t n32 = (uint32_t)n;
   const uint32_t gn = (n32 + 255) / 256;
-  // chunk length: grows with the total entry count so that k_accumulate keeps >= 2^18 lanes busy without flooding the
-  // reduce phases with chunk sums: ~64 at 2^20 terms x 16 windows, 512 at 2^23.  A window-sharded rank (few buckets,
-  // long buckets) therefore gets several chunks per bucket; k_bucket_fold adds those (<= 16), k_heavy_combine the rest.
-  uint32_t L0 = ctx->L0;
-  while (L0 < 65536u && ((uint64_t)n * (uint64_t)nlw >> 18) > (uint64_t)L0) L0 <<= 1;
-
   auto h0 = std::chrono::steady_clock::now();
   HIPCHK(hipEventRecord(ctx->ev[0], st));
   hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32);
@@ -1306,7 +1302,9 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   const uint32_t m = 8 < NB ? 8 : NB;                 // segment length of k_seg_reduce
   uint32_t log2m = 0; while ((1u << log2m) < m) ++log2m;
   const uint32_t J = NB / m;
-  int rc = ensure(ctx, N, nb_total, nwin, 1);
+  uint32_t L0 = ctx->L0;
+  while (L0 < 65536u && ((uint64_t)N * (uint64_t)nwin >> 18) > (uint64_t)L0) L0 <<= 1;
+  int rc = ensure(ctx, N, nb_total, nwin, 1, L0);
   if (rc) return rc;
   // batch-only buffers
   if ((M + 1) > ctx->cap_boffs) {
@@ -1342,7 +1340,7 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_group_count, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_hist, N32, NB, nwin);
   HIPCHK(hipEventRecord(ctx->ev[2], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
-  hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, ctx->L0);
+  hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
   hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
   hipLaunchKernelGGL(k_group_scatter, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_off, ctx->d_sorted, N32, NB, nwin);
@@ -1350,8 +1348,8 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   HIPCHK(hipMemsetAsync(ctx->d_lenhist, 0, LEN_BINS * 4, st));
   HIPCHK(hipMemsetAsync(ctx->d_heavy, 0, 4, st));
   HIPCHK(hipMemsetAsync(ctx->d_combined, 0, nb_total, st));
-  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, ctx->L0);
-  const size_t max_chunks = nb_total + (N * (size_t)nwin) / ctx->L0 + 1;
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0);
+  const size_t max_chunks = nb_total + (N * (size_t)nwin) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS);
   hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);

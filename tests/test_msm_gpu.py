@@ -224,7 +224,7 @@ def test_pipeline_variants_agree(native_lib, golden):
             for c in (0, 4, 5, 6, 9, 16):
                 assert gpu_msm(N, c2, p96, s32, n, window_c=c) == want, (params, c)
             for k in params:   # back to defaults
-                c2.set_param(k, {"partition_sort": 1, "chunk_len": 64, "seg_m": 4, "wave_agg": 1, "reduce_2d": 1}[k])
+                c2.set_param(k, {"partition_sort": 1, "chunk_len": 8, "seg_m": 4, "wave_agg": 1, "reduce_2d": 1}[k])
     finally:
         c2.close()
 

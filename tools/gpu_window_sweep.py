@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Which window width is fastest per MSM size (single call, latency included)?  Feeds pick_window()."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from curdleproofs_pie_amd import _native as N  # noqa: E402
+
+GX = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
+GY = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
+ctx = N.Context(0)
+nmax = 1 << 18
+dk, dp, ds, dg = ctx.alloc(32 * nmax), ctx.alloc(96 * nmax), ctx.alloc(32 * nmax), ctx.alloc(96)
+dg.upload(GX.to_bytes(48, "little") + GY.to_bytes(48, "little"))
+ctx.gen_scalars_device(dk, nmax, 1); ctx.batch_mul_device(dg, 1, dk, dp, nmax); ctx.gen_scalars_device(ds, nmax, 2)
+for n in (4, 64, 627, 1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18):
+    res = []
+    for c in (0, 4, 6, 7, 8, 9, 11, 12, 13, 14, 16):
+        w = []
+        for _ in range(6):
+            t = time.perf_counter(); ctx.msm_device(dp, ds, n, window_c=c); w.append((time.perf_counter() - t) * 1e3)
+        res.append((sorted(w[1:])[2], ctx.timings()["window_c"], c == 0))
+    print(f"n={n}: " + "  ".join(f"{'auto->' if a else ''}c{c}:{t:.3f}" for t, c, a in res), flush=True)
