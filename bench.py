@@ -199,6 +199,9 @@ def main():
         # (96 B affine point + 32 B scalar) x the terms one launch processes
         terms_per_launch = n_local
         achieved = 128.0 * terms_per_launch / (acc_ms * 1e-3) / 1e9
+        nwin = 255 // c + 1
+        local_windows = (nwin + world - 1) // world if args.shard == "windows" else nwin
+        mads = terms_per_launch * local_windows * 3542.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.logn == 20:
@@ -227,6 +230,12 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel": "k_accumulate", "kernel_ms": acc_ms,
                          "note": "path is integer-multiply (v_mad_u64_u32) bound, not HBM-bound: see DESIGN.md"},
+            # The bound that actually applies: 32x32+64 integer multiply-adds.  Algorithmic MADs of one
+            # k_accumulate launch = terms x windows x 3542 (XYZZ mixed add = 6 products x 392 + one fused double
+            # product x 588 + 2 squarings x 301 v_mad_u64_u32); peak = the chip-wide v_mad_u64_u32 rate measured by
+            # tools/ubench_valu.hip on MI355X (profiles/r01_ubench_valu_rates.txt, 2 waves/SIMD).
+            "roofline_int_mad": {"bound": "valu v_mad_u64_u32", "achieved": mads / (acc_ms * 1e-3) / 1e12, "peak": 30.3,
+                                 "unit": "T mad/s", "frac": mads / (acc_ms * 1e-3) / 30.3e12, "kernel": "k_accumulate"},
             "phases_ms": {k: v / args.steps for k, v in phase_acc.items() if k != "window_c"},
         }
         if world == 1 and not args.no_cpu_baseline:
