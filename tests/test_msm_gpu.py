@@ -93,9 +93,11 @@ def test_window_sharding_partials_sum_to_full(native_lib, ctx):
         assert compress_blob(N, acc.raw) == want, (world, cc)
 
 
-def test_structured_scalars(native_lib, ctx):
-    """Bucket skew: all-equal scalars (same_perm.py:54-55) and sigma = 0..n-1 (curdleproofs.py:315) at n = 2^12."""
-    n = 1 << 12
+@pytest.mark.parametrize("logn", [12, 17])
+def test_structured_scalars(native_lib, ctx, logn):
+    """Bucket skew: all-equal scalars (same_perm.py:54-55) and sigma = 0..n-1 (curdleproofs.py:315).
+    2^17 all-equal terms put 131072 entries into ONE bucket per window: 4096 chunks -> k_heavy_combine."""
+    n = 1 << logn
     rng = random.Random(5)
     ks = b"".join(rng.randint(1, O.R - 1).to_bytes(32, "little") for _ in range(n))
     dk, dg, dp = ctx.alloc(32 * n), ctx.alloc(96), ctx.alloc(96 * n)
