@@ -220,11 +220,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (14x28-bit-limb Montgomery Fp, 64-bit column accumulators)",
+            "dtype": "u32",
             "data": "synthetic: points k_i*G and scalars uniform in [1,r-1], splitmix64-seeded, generated on the GPU",
             "config": {"workload": f"single MSM of 2^{args.logn} x {world} BLS12-381 G1 terms, resident in HBM, "
                                    f"{'window' if args.shard == 'windows' else 'point'}-sharded over {world} GPU(s)",
                        "terms_total": n_total, "terms_per_gpu": n_per_gpu, "window_c": c, "shard": args.shard,
+                       "arithmetic": "381-bit Fp as 14 x 28-bit limbs in u32, Montgomery, 64-bit column accumulators (v_mad_u64_u32)",
                        "bit_exact_vs_oracle": "tests/test_msm_gpu.py"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
