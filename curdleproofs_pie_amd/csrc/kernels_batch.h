@@ -1,0 +1,151 @@
+// Batched scalar-mul / fold, batched G1 decompression, synthetic scalars, madd probe.
+// Part of the single translation unit csrc/msm_gpu.hip (included inside namespace cg1).
+#pragma once
+
+// ------------------------------------------------------------------ batched scalar mul / fold
+// out[i] = addend[i] + k_i * P_i   with P_i = base[i % nbase], k_i = scalars[i % nscalars], addend optional.
+// Covers the vectorised `G1Point * Scalar` patterns of the callers:
+//   nbase = 1                  fixed base:        get_random_point = G * random_scalar()   (util.py:67-68)
+//   nscalars = 1               same-scalar map:   [R * k for R in vec_R]                   (curdleproofs.py:310-311)
+//   nscalars = 1, addend = L   fold:              G_L[i] + G_R[i] * gamma                  (ipa.py:142-146, same_msm.py:122-126)
+//   per-index scalars          G_i * beta^-i                                               (grand_prod.py:64-71)
+// Affine std words in and out (identity = zeros); one lane per output, double-and-add MSB first.
+__global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ base_raw, uint32_t nbase,
+                                                   const uint32_t* __restrict__ scalars, uint32_t nscalars,
+                                                   const uint32_t* __restrict__ addend_raw, uint32_t* __restrict__ out_raw, uint32_t n) {
+  uint32_t i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[24];
+  const uint32_t* src = base_raw + 24ull * (i % nbase);
+  uint32_t any = 0;
+  for (int k = 0; k < 24; ++k) { w[k] = src[k]; any |= w[k]; }
+  uint32_t s[8];
+  for (int k = 0; k < 8; ++k) s[k] = scalars[8ull * (i % nscalars) + k];
+  xyzz acc = xyzz_identity();
+  if (any) {
+    fp x = fp_to_mont(fp_from_words(w)), y = fp_to_mont(fp_from_words(w + 12));
+    int top = 255;
+    while (top >= 0 && !((s[top >> 5] >> (top & 31)) & 1u)) --top;     // skip leading zero bits (per lane)
+    for (int bit = top; bit >= 0; --bit) {
+      acc = xyzz_dbl(acc);
+      if ((s[bit >> 5] >> (bit & 31)) & 1u) acc = xyzz_madd(acc, x, y);
+    }
+  }
+  if (addend_raw) {
+    const uint32_t* a = addend_raw + 24ull * i;
+    uint32_t aw[24], aany = 0;
+    for (int k = 0; k < 24; ++k) { aw[k] = a[k]; aany |= aw[k]; }
+    if (aany) acc = xyzz_madd(acc, fp_to_mont(fp_from_words(aw)), fp_to_mont(fp_from_words(aw + 12)));
+  }
+  uint32_t* dst = out_raw + 24ull * i;
+  if (acc.inf) { for (int k = 0; k < 24; ++k) dst[k] = 0; return; }
+  // x = X/ZZ, y = Y/ZZZ with ONE inversion: 1/(ZZ*ZZZ)
+  fp t = fp_inv(fp_mul(acc.ZZ, acc.ZZZ));
+  fp izz = fp_mul(t, acc.ZZZ), izzz = fp_mul(t, acc.ZZ);
+  uint32_t o[12];
+  fp_to_words(fp_mul(acc.X, izz), o);  for (int k = 0; k < 12; ++k) dst[k] = o[k];
+  fp_to_words(fp_mul(acc.Y, izzz), o); for (int k = 0; k < 12; ++k) dst[12 + k] = o[k];
+}
+
+// ------------------------------------------------------------------ batched 48-byte G1 decompression
+// One lane per point: parse the ZCash-format encoding (util.py:35-36 -> G1Point.from_compressed_bytes[_unchecked]),
+// y = sqrt(x^3 + 4) by exponentiation, sign select, optional subgroup test  [z^2]P == phi(P) + P.
+// out: affine96 (zeros = identity), status: 0 ok, CG1_ERR_ENCODING / _NOT_ON_CURVE / _NOT_IN_SUBGROUP.
+__global__ void __launch_bounds__(128) k_batch_decompress(const uint8_t* __restrict__ in48, uint32_t* __restrict__ out_raw,
+                                                          uint8_t* __restrict__ status, uint32_t n, int check_subgroup) {
+  uint32_t i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* b = in48 + 48ull * i;
+  uint32_t* dst = out_raw + 24ull * i;
+  for (int k = 0; k < 24; ++k) dst[k] = 0;
+  const uint8_t flags = b[0];
+  const bool compressed = flags & 0x80, infinity = flags & 0x40, largest = flags & 0x20;
+  uint32_t w[12];
+  for (int j = 0; j < 12; ++j) {                // big-endian bytes -> little-endian words
+    const uint8_t* q = b + 44 - 4 * j;
+    uint32_t b0 = (j == 11) ? (uint32_t)(q[0] & 0x1F) : (uint32_t)q[0];
+    w[j] = (b0 << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+  }
+  if (!compressed || (infinity && largest)) { status[i] = CG1_ERR_ENCODING; return; }
+  if (infinity) {
+    uint32_t any = 0;
+    for (int j = 0; j < 12; ++j) any |= w[j];
+    status[i] = any ? CG1_ERR_ENCODING : CG1_OK;
+    return;
+  }
+  bool lt = false, decided = false;             // x < p ?
+  for (int j = 11; j >= 0 && !decided; --j) if (w[j] != W_P[j]) { lt = w[j] < W_P[j]; decided = true; }
+  if (!lt) { status[i] = CG1_ERR_ENCODING; return; }
+  const fp x = fp_to_mont(fp_from_words(w));
+  fp four = fp_one(); four = fp_dbl(fp_dbl(four));
+  const fp rhs = fp_norm(fp_add(fp_mul(fp_sqr(x), x), four));
+  fp y = fp_sqrt_candidate(rhs);
+  if (!fp_is_zero_mod_p(fp_sub<3>(fp_sqr(y), fp_mul(rhs, fp_one())), 8)) { status[i] = CG1_ERR_NOT_ON_CURVE; return; }
+  uint32_t yw[12];
+  fp_to_words(y, yw);
+  bool is_large = false; decided = false;       // y > (p-1)/2 ?
+  for (int j = 11; j >= 0 && !decided; --j) if (yw[j] != W_P_MINUS_1_HALF[j]) { is_large = yw[j] > W_P_MINUS_1_HALF[j]; decided = true; }
+  if (is_large != largest) {                     // y := p - y  (y != 0: the curve has no point with y = 0)
+    uint64_t borrow = 0;
+    for (int j = 0; j < 12; ++j) {
+      uint64_t d = (uint64_t)W_P[j] - yw[j] - borrow;
+      yw[j] = (uint32_t)d; borrow = (d >> 32) & 1;
+    }
+    y = fp_to_mont(fp_from_words(yw));
+  }
+  if (check_subgroup) {
+    constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
+    fp beta; for (int k = 0; k < NL; ++k) beta.l[k] = bt[k];
+    xyzz acc = xyzz_identity();
+    for (int bit = 127; bit >= 0; --bit) {       // [z^2] P
+      acc = xyzz_dbl(acc);
+      if ((H_ZSQ[bit >> 6] >> (bit & 63)) & 1ull) acc = xyzz_madd(acc, x, y);
+    }
+    const fp yneg = fp_neg<3>(y);
+    acc = xyzz_madd(acc, x, yneg);               // - P
+    acc = xyzz_madd(acc, fp_mul(x, beta), yneg); // - phi(P)
+    if (!acc.inf) { status[i] = CG1_ERR_NOT_IN_SUBGROUP; return; }
+  }
+  for (int k = 0; k < 12; ++k) { dst[k] = w[k]; dst[12 + k] = yw[k]; }
+  status[i] = CG1_OK;
+}
+
+// splitmix64-derived scalars, uniform in [1, r-1] (the reference's random_scalar distribution,
+// util.py:21-24) by rejection from 255-bit draws; deterministic in (seed, i)
+__global__ void __launch_bounds__(256) k_gen_scalars(uint32_t* __restrict__ out, uint32_t n, uint64_t seed) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  uint64_t st = seed + 0x9E3779B97F4A7C15ull * (64ull * i + 1);
+  uint64_t v[4];
+  for (int attempt = 0; attempt < 64; ++attempt) {
+    for (int k = 0; k < 4; ++k) {
+      st += 0x9E3779B97F4A7C15ull;
+      uint64_t z = st;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+      z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+      v[k] = z ^ (z >> 31);
+    }
+    v[3] &= 0x7FFFFFFFFFFFFFFFull;       // 255 bits
+    bool lt = false, decided = false;     // v < r ?
+    for (int k = 3; k >= 0 && !decided; --k) {
+      if (v[k] != H_FR[k]) { lt = v[k] < H_FR[k]; decided = true; }
+    }
+    bool nz = (v[0] | v[1] | v[2] | v[3]) != 0;
+    if (lt && nz) break;
+    if (attempt == 63) { v[3] = 0; v[0] |= 1; }   // unreachable in practice (p ~ 2^-64)
+  }
+  for (int k = 0; k < 4; ++k) { out[8ull * i + 2 * k] = (uint32_t)v[k]; out[8ull * i + 2 * k + 1] = (uint32_t)(v[k] >> 32); }
+}
+
+// throughput probe: `iters` dependent mixed adds per lane on register-resident data (roofline of k_accumulate)
+__global__ void __launch_bounds__(256) k_probe_madd(const PreparedPoint* __restrict__ pts, uint32_t npts, PointSum* __restrict__ out, int iters) {
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  fp x, y; uint32_t flags;
+  load_affine(pts + (t % npts), x, y, flags);
+  fp x2, y2;
+  load_affine(pts + ((t + 1) % npts), x2, y2, flags);
+  xyzz acc = xyzz_from_affine(x, y);
+  for (int i = 0; i < iters; ++i) acc = xyzz_madd(acc, x2, y2);
+  store_sum(out + t, acc);
+}
+

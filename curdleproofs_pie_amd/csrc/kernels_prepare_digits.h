@@ -1,0 +1,93 @@
+// k_prepare_points, signed-digit recoding, the global-atomic counting sort (k_hist / k_scatter; n > 2^23) and k_digits.
+// Part of the single translation unit csrc/msm_gpu.hip (included inside namespace cg1).
+#pragma once
+
+// ------------------------------------------------------------------ k_prepare_points
+__global__ void __launch_bounds__(256) k_prepare_points(const uint32_t* __restrict__ raw, PreparedPoint* __restrict__ out,
+                                                        uint8_t* __restrict__ inf_flag, uint32_t n) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint4* q = reinterpret_cast<const uint4*>(raw + 24ull * i);
+  uint32_t w[24];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { uint4 v = q[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+  uint32_t any = 0;
+#pragma unroll
+  for (int k = 0; k < 24; ++k) any |= w[k];
+  fp x = fp_to_mont(fp_from_words(w));
+  fp y = fp_to_mont(fp_from_words(w + 12));
+  uint32_t o[32];
+#pragma unroll
+  for (int k = 0; k < NL; ++k) { o[k] = x.l[k]; o[NL + k] = y.l[k]; }
+  o[28] = any ? 0u : 1u;               // (0,0) is not on the curve: it encodes the identity
+  inf_flag[i] = any ? 0 : 1;           // compact copy: the digit kernels must not touch the 128-B records
+  o[29] = o[30] = o[31] = 0;
+  uint4* d = reinterpret_cast<uint4*>(out + i);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) d[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+}
+
+// ------------------------------------------------------------------ signed digit recoding
+// digit w of scalar s (LE words), window width c: value in [-(2^(c-1)-1), 2^(c-1)]
+struct DigitIter {
+  uint32_t s[8];
+  uint32_t carry;
+  int c;
+  __device__ __forceinline__ int next(int w) {         // must be called for w = 0,1,2,... in order
+    int bit = w * c;
+    uint32_t wi = bit >> 5, sh = bit & 31;
+    uint64_t v = (wi < 8) ? s[wi] : 0u;
+    if (wi + 1 < 8) v |= (uint64_t)s[wi + 1] << 32;
+    uint32_t raw = (uint32_t)(v >> sh) & ((1u << c) - 1u);
+    uint32_t d = raw + carry;
+    if (d > (1u << (c - 1))) { carry = 1; return (int)d - (1 << c); }
+    carry = 0;
+    return (int)d;
+  }
+};
+
+__device__ __forceinline__ void load_scalar(const uint32_t* scalars, uint32_t i, DigitIter& it) {
+  const uint4* q = reinterpret_cast<const uint4*>(scalars + 8ull * i);
+  uint4 a = q[0], b = q[1];
+  it.s[0] = a.x; it.s[1] = a.y; it.s[2] = a.z; it.s[3] = a.w;
+  it.s[4] = b.x; it.s[5] = b.y; it.s[6] = b.z; it.s[7] = b.w;
+  it.carry = 0;
+}
+
+// counts per (local window, bucket); skips zero digits and identity points
+__global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
+                                              uint32_t* __restrict__ hist, uint32_t n, int c, int nwin, int rank, int world) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (inf_flag[i]) return;
+  DigitIter it; it.c = c;
+  load_scalar(scalars, i, it);
+  const uint32_t NB = 1u << (c - 1);
+  for (int w = 0; w < nwin; ++w) {
+    int d = it.next(w);
+    if (d == 0 || (w % world) != rank) continue;
+    uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
+    atomicAdd(&hist[(uint32_t)(w / world) * NB + b], 1u);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
+                                                 uint32_t* __restrict__ cursor, const uint32_t* __restrict__ off,
+                                                 uint32_t* __restrict__ sorted, uint32_t n, int c, int nwin, int rank, int world) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (inf_flag[i]) return;
+  DigitIter it; it.c = c;
+  load_scalar(scalars, i, it);
+  const uint32_t NB = 1u << (c - 1);
+  for (int w = 0; w < nwin; ++w) {
+    int d = it.next(w);
+    if (d == 0 || (w % world) != rank) continue;
+    uint32_t key = (uint32_t)(w / world) * NB + (uint32_t)(d < 0 ? -d : d) - 1u;
+    uint32_t slot = atomicSub(&cursor[key], 1u) - 1u;      // cursor starts at the bucket's count
+    sorted[off[key] + slot] = i | (d < 0 ? 0x80000000u : 0u);
+  }
+}
+
+constexpr int SCAN_ITEMS = 1024;        // items per block of 256 threads in the scans
+

@@ -1,0 +1,168 @@
+// Bucket reductions: running-sum segments + bit tree (A/B fallback, regime B) and the 2-D row/column reduction.
+// Part of the single translation unit csrc/msm_gpu.hip (included inside namespace cg1).
+#pragma once
+
+// ------------------------------------------------------------------ k_seg_reduce
+// One lane per segment of `m` consecutive buckets of one window.  Bucket b of the window carries digit
+// value b+1.  Emits run_j = sum_t B_{jm+t}, tot_j = sum_t (t+1) B_{jm+t}  (t = 0..m-1).
+__global__ void __launch_bounds__(256) k_seg_reduce(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+                                                    const uint8_t* __restrict__ combined,
+                                                    PointSum* __restrict__ seg_run, PointSum* __restrict__ seg_tot,
+                                                    uint32_t nseg_total, uint32_t m) {
+  uint32_t s = blockIdx.x * 256 + threadIdx.x;
+  if (s >= nseg_total) return;
+  xyzz run = xyzz_identity(), tot = xyzz_identity();
+  for (int t = (int)m - 1; t >= 0; --t) {
+    uint32_t b = s * m + (uint32_t)t;           // segments tile the flat (window, bucket) array
+    uint32_t c0 = choff[b], c1 = choff[b + 1];
+    if (combined[b]) c1 = c0 + 1;        // k_heavy_combine already folded all chunks into the first slot
+    for (uint32_t k = c0; k < c1; ++k) run = xyzz_add(run, load_sum(sums + k));
+    tot = xyzz_add(tot, run);
+  }
+  store_sum(seg_run + s, run);
+  store_sum(seg_tot + s, tot);
+}
+
+// ------------------------------------------------------------------ k_bit_tree
+
+// stage 1: grid = (nitems, nlw, S).  item 0: T = sum_j seg_tot[j];  item 1+b: Y_b = sum_{j: bit b of j} seg_run[j].
+// Only the SELECTED j are enumerated (all J for item 0, the J/2 with bit b set otherwise) so no lane idles in
+// the serial part; block z takes BT_ELEMS consecutive selected elements (8 per lane).  The cost model that
+// shaped this: one wave-level EC add step is ~25 us and the chip runs 2048 of them at once, so total
+// wave-steps = waves x (elements per lane + 6 shuffle levels + 2) must be kept small, not just the depth.
+constexpr uint32_t BT_ELEMS = 2048;
+__global__ void __launch_bounds__(256) k_bit_tree(const PointSum* __restrict__ seg_run, const PointSum* __restrict__ seg_tot,
+                                                  PointSum* __restrict__ partial, uint32_t J) {
+  __shared__ PointSum sh[4];
+  const uint32_t item = blockIdx.x, lw = blockIdx.y, S = gridDim.z, z = blockIdx.z;
+  const PointSum* src = (item == 0 ? seg_tot : seg_run) + (size_t)lw * J;
+  const uint32_t count = (item == 0) ? J : (J >> 1);
+  const uint32_t e0 = z * BT_ELEMS, e1 = (e0 + BT_ELEMS < count) ? e0 + BT_ELEMS : count;
+  xyzz acc = xyzz_identity();
+  const uint32_t b = item - 1;                   // bit index for item >= 1
+  for (uint32_t e = e0 + threadIdx.x; e < e1; e += 256) {
+    // e-th index with bit b set: insert a 1 at bit position b
+    uint32_t j = (item == 0) ? e : ((((e >> b) << 1) | 1u) << b) | (e & ((1u << b) - 1u));
+    acc = xyzz_add(acc, load_sum(src + j));
+  }
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    xyzz o = shfl_down_xyzz(acc, delta);
+    if ((threadIdx.x & 63) < (uint32_t)delta) acc = xyzz_add(acc, o);
+  }
+  if ((threadIdx.x & 63) == 0) store_sum(&sh[threadIdx.x >> 6], acc);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    acc = (threadIdx.x < 4) ? load_sum(&sh[threadIdx.x]) : xyzz_identity();
+    for (int delta = 2; delta >= 1; delta >>= 1) {
+      xyzz o = shfl_down_xyzz(acc, delta);
+      if (threadIdx.x < (uint32_t)delta) acc = xyzz_add(acc, o);
+    }
+    if (threadIdx.x == 0) store_sum(partial + ((size_t)lw * gridDim.x + item) * S + z, acc);
+  }
+}
+
+// stage 2: one wave per (window, item): shuffle-tree over the S <= 64 slice partials, export canonical words
+__global__ void __launch_bounds__(64) k_bit_tree_final(const PointSum* __restrict__ partial, PointWords* __restrict__ out, uint32_t S) {
+  const size_t idx = blockIdx.x;
+  xyzz acc = (threadIdx.x < S) ? load_sum(partial + idx * S + threadIdx.x) : xyzz_identity();
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    if ((uint32_t)delta >= S) continue;      // wave-uniform
+    xyzz o = shfl_down_xyzz(acc, delta);
+    if (threadIdx.x < (uint32_t)delta) acc = xyzz_add(acc, o);
+  }
+  if (threadIdx.x == 0) {
+    xyzz_words o;
+    xyzz_export(acc, o);
+    PointWords* dst = out + idx;
+    for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
+    dst->inf = o.inf;
+  }
+}
+
+// ------------------------------------------------------------------ 2-D bucket reduction (regime A default)
+// S_w = sum_b (b+1) B_b over the window's 2^(c-1) buckets, b = h * 2^lb + l:
+//     S_w = T0 + 2^lb * sum_h h A_h + sum_l l C_l,   A_h = sum_l B_{h,l} (row sums),  C_l = sum_h B_{h,l} (column sums),
+//     T0 = sum_h A_h.
+// k_rowcol forms all row and column sums in ONE launch (2 EC adds per bucket; blocks [0, nrow_blocks) take rows,
+// the rest columns; <= 8 serial adds per lane, then a shuffle tree inside 32 / 16 lanes).  k_small_tree then
+// turns the 2^hb row sums and 2^lb column sums of a window into 1 + hb + lb points (plain sum + one masked sum per
+// index bit) whose power-of-two weights the host Horner applies.  Versus k_seg_reduce + k_bit_tree this halves
+// the wave-level EC-add steps (47 K -> ~20 K at c = 16) and shortens the dependent chain (~27 -> ~22 steps).
+__device__ __forceinline__ xyzz bucket_sum(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+                                           const uint8_t* __restrict__ combined, uint32_t b) {
+  uint32_t c0 = choff[b], c1 = choff[b + 1];
+  if (combined[b]) c1 = c0 + 1;
+  xyzz acc = xyzz_identity();
+  for (uint32_t k = c0; k < c1; ++k) acc = xyzz_add(acc, load_sum(sums + k));
+  return acc;
+}
+
+__global__ void __launch_bounds__(256, 2) k_rowcol(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+                                                const uint8_t* __restrict__ combined, PointSum* __restrict__ rowsum,
+                                                PointSum* __restrict__ colsum, uint32_t nlw, uint32_t hb, uint32_t lb,
+                                                uint32_t nrow_blocks) {
+  const uint32_t R = 1u << hb, Cn = 1u << lb;
+  if (blockIdx.x < nrow_blocks) {
+    const uint32_t lpr = Cn < 32u ? Cn : 32u, serial = Cn / lpr;
+    const uint32_t gr = blockIdx.x * (256u / lpr) + threadIdx.x / lpr;     // global row = lw * R + h
+    const uint32_t part = threadIdx.x % lpr;
+    const bool live = gr < nlw * R;
+    xyzz acc = xyzz_identity();
+    if (live)
+      for (uint32_t t = 0; t < serial; ++t) acc = xyzz_add(acc, bucket_sum(choff, sums, combined, gr * Cn + part * serial + t));
+    for (uint32_t delta = lpr >> 1; delta >= 1; delta >>= 1) {
+      xyzz o = shfl_down_xyzz(acc, (int)delta);
+      if (part < delta) acc = xyzz_add(acc, o);
+    }
+    if (live && part == 0) store_sum(rowsum + gr, acc);
+  } else {
+    const uint32_t lpc = R < 16u ? R : 16u, serial = R / lpc;
+    const uint32_t gc = (blockIdx.x - nrow_blocks) * (256u / lpc) + threadIdx.x / lpc;   // global column = lw * Cn + l
+    const uint32_t part = threadIdx.x % lpc;
+    const bool live = gc < nlw * Cn;
+    const uint32_t lw = gc / Cn, l = gc % Cn;
+    xyzz acc = xyzz_identity();
+    if (live)
+      for (uint32_t t = 0; t < serial; ++t) acc = xyzz_add(acc, bucket_sum(choff, sums, combined, (lw * R + part * serial + t) * Cn + l));
+    for (uint32_t delta = lpc >> 1; delta >= 1; delta >>= 1) {
+      xyzz o = shfl_down_xyzz(acc, (int)delta);
+      if (part < delta) acc = xyzz_add(acc, o);
+    }
+    if (live && part == 0) store_sum(colsum + gc, acc);
+  }
+}
+
+// grid = (1 + hb + lb, nlw), 256 threads.  item 0: T0 = sum_h A_h; item 1+k (k < hb): sum of A_h with bit k of h set;
+// item 1+hb+k (k < lb): sum of C_l with bit k of l set.  Requires 2^hb, 2^lb <= 256.  Emits canonical words.
+__global__ void __launch_bounds__(256) k_small_tree(const PointSum* __restrict__ rowsum, const PointSum* __restrict__ colsum,
+                                                    PointWords* __restrict__ out, uint32_t hb, uint32_t lb) {
+  __shared__ PointSum sh[4];
+  const uint32_t item = blockIdx.x, lw = blockIdx.y;
+  const bool on_rows = item <= hb;
+  const uint32_t J = on_rows ? (1u << hb) : (1u << lb);
+  const PointSum* src = on_rows ? rowsum + (size_t)lw * J : colsum + (size_t)lw * J;
+  const uint32_t bit = on_rows ? item - 1u : item - 1u - hb;           // unused for item 0
+  xyzz acc = xyzz_identity();
+  if (threadIdx.x < J && (item == 0 || ((threadIdx.x >> bit) & 1u))) acc = load_sum(src + threadIdx.x);
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    xyzz o = shfl_down_xyzz(acc, delta);
+    if ((threadIdx.x & 63) < (uint32_t)delta) acc = xyzz_add(acc, o);
+  }
+  if ((threadIdx.x & 63) == 0) store_sum(&sh[threadIdx.x >> 6], acc);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    acc = (threadIdx.x < 4) ? load_sum(&sh[threadIdx.x]) : xyzz_identity();
+    for (int delta = 2; delta >= 1; delta >>= 1) {
+      xyzz o = shfl_down_xyzz(acc, delta);
+      if (threadIdx.x < (uint32_t)delta) acc = xyzz_add(acc, o);
+    }
+    if (threadIdx.x == 0) {
+      xyzz_words o;
+      xyzz_export(acc, o);
+      PointWords* dst = out + (size_t)lw * gridDim.x + item;
+      for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
+      dst->inf = o.inf;
+    }
+  }
+}
+

@@ -1,0 +1,398 @@
+// Two-level LDS partition sort, regime-B group sort, scans, chunking and chunk-length ordering.
+// Part of the single translation unit csrc/msm_gpu.hip (included inside namespace cg1).
+#pragma once
+
+// ------------------------------------------------------------------ two-level partition sort (no global atomics)
+// Replaces k_hist/k_scatter (16.7 M global atomics each at n = 2^20: 0.63 + 0.87 ms) when n <= 2^23.
+//   k_digits        scalar -> one u16 signed digit per owned window, window-major  [nlw][n]
+//   k_part_count    block = (window, tile of PART_TILE points): LDS histogram over the HIGH bits of the bucket
+//                   ("bin"), written as block_counts[window][bin][tile]
+//   k_uscan1/2/3    exclusive scan of block_counts: lexicographic (window, bin, tile) order = final layout
+//   k_part_scatter  same blocks: LDS cursors seeded from the scan, entries (sub | sign | idx) land bin-grouped
+//   k_bin_sort      block = (window, bin): LDS histogram/scan over the LOW bits ("sub"), emits the per-bucket
+//                   counts + offsets and the final sorted[] array; all traffic of a block stays inside its bin
+constexpr uint32_t PART_TILE = 4096;
+constexpr uint32_t PART_MAX_N = 1u << 23;      // idx 23 bits | sign 1 bit | sub 8 bits
+
+__device__ __forceinline__ uint32_t digit_mag(uint32_t e, uint32_t& neg) {   // e != 0: u16 two's complement digit
+  if (e == 0x8000u) { neg = 0; return 0x8000u; }                             // +2^15 (only for c = 16)
+  int d = (int)(int16_t)(uint16_t)e;
+  neg = d < 0;
+  return (uint32_t)(d < 0 ? -d : d);
+}
+
+// LDS counter increment that returns this lane's slot.  When every active lane of the wave carries the SAME
+// key (skewed scalars: all-equal, tiny range, recoding-carry window) the wave issues ONE atomic for all of them
+// instead of 64 serialised same-address atomics.  Must be called convergently by the whole wave.
+__device__ int g_wave_agg = 1;         // A/B switch (cg1_ctx_set_param "wave_agg")
+__device__ __forceinline__ uint32_t lds_ranked_inc(uint32_t* ctr, uint32_t key, bool active) {
+  if (!g_wave_agg) return active ? atomicAdd(&ctr[key], 1u) : 0u;
+  const unsigned long long amask = __ballot(active);
+  if (amask == 0ull) return 0u;
+  const int leader = __ffsll((long long)amask) - 1;
+  const uint32_t k0 = __shfl(key, leader, 64);
+  if (__ballot(active && key != k0) == 0ull) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&ctr[k0], (uint32_t)__popcll(amask));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(amask & ((1ull << lane) - 1ull));
+  }
+  return active ? atomicAdd(&ctr[key], 1u) : 0u;
+}
+
+__global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
+                                                uint16_t* __restrict__ digits, uint32_t n, int c, int nwin, int rank, int world) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const bool inf = inf_flag[i] != 0;
+  DigitIter it; it.c = c;
+  load_scalar(scalars, i, it);
+  for (int w = 0; w < nwin; ++w) {
+    int d = it.next(w);
+    if ((w % world) != rank) continue;
+    digits[(size_t)(w / world) * n + i] = inf ? (uint16_t)0 : (uint16_t)(d & 0xFFFF);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_part_count(const uint16_t* __restrict__ digits, uint32_t* __restrict__ block_counts,
+                                                    uint32_t n, uint32_t nslices, uint32_t nbins, uint32_t sub_bits) {
+  __shared__ uint32_t cnt[128];
+  if (threadIdx.x < 128) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t slice = blockIdx.x, lw = blockIdx.y;
+  const uint16_t* dg = digits + (size_t)lw * n;
+  for (uint32_t k = 0; k < PART_TILE / 256; ++k) {
+    uint32_t i = slice * PART_TILE + k * 256 + threadIdx.x;
+    uint32_t e = (i < n) ? (uint32_t)dg[i] : 0u;
+    uint32_t neg, key = e ? ((digit_mag(e, neg) - 1u) >> sub_bits) : 0u;
+    lds_ranked_inc(cnt, key, e != 0u);
+  }
+  __syncthreads();
+  if (threadIdx.x < nbins) block_counts[((size_t)lw * nbins + threadIdx.x) * nslices + slice] = cnt[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ block_base,
+                                                      uint32_t* __restrict__ part, uint32_t n, uint32_t nslices, uint32_t nbins,
+                                                      uint32_t sub_bits) {
+  __shared__ uint32_t cur[128];
+  const uint32_t slice = blockIdx.x, lw = blockIdx.y;
+  if (threadIdx.x < nbins) cur[threadIdx.x] = block_base[((size_t)lw * nbins + threadIdx.x) * nslices + slice];
+  __syncthreads();
+  const uint16_t* dg = digits + (size_t)lw * n;
+  const uint32_t sub_mask = (1u << sub_bits) - 1u;
+  for (uint32_t k = 0; k < PART_TILE / 256; ++k) {
+    uint32_t i = slice * PART_TILE + k * 256 + threadIdx.x;
+    uint32_t e = (i < n) ? (uint32_t)dg[i] : 0u;
+    uint32_t neg = 0, b = e ? (digit_mag(e, neg) - 1u) : 0u;
+    uint32_t pos = lds_ranked_inc(cur, b >> sub_bits, e != 0u);
+    if (e) part[pos] = i | (neg << 23) | ((b & sub_mask) << 24);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
+                                                  uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted,
+                                                  uint32_t nbins_total, uint32_t nslices, uint32_t sub_bits) {
+  __shared__ uint32_t cnt[256];
+  __shared__ uint32_t cur[256];
+  const uint32_t g = blockIdx.x;
+  const uint32_t start = block_base[(size_t)g * nslices];
+  const uint32_t end = block_base[(size_t)(g + 1) * nslices];     // element [nbins_total*nslices] holds the grand total
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t span = ((end - start + 255u) / 256u) * 256u;       // whole waves iterate together
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const bool live = start + o < end;
+    lds_ranked_inc(cnt, live ? (part[start + o] >> 24) : 0u, live);
+  }
+  __syncthreads();
+  const uint32_t mine = cnt[threadIdx.x];
+  cur[threadIdx.x] = mine;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? cur[threadIdx.x - d] : 0u;
+    __syncthreads();
+    cur[threadIdx.x] += u;
+    __syncthreads();
+  }
+  const uint32_t excl = cur[threadIdx.x] - mine;
+  __syncthreads();
+  cur[threadIdx.x] = start + excl;
+  if (threadIdx.x < (1u << sub_bits)) hist[((size_t)g << sub_bits) + threadIdx.x] = mine;
+  __syncthreads();
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const bool live = start + o < end;
+    const uint32_t v = live ? part[start + o] : 0u;
+    const uint32_t pos = lds_ranked_inc(cur, v >> 24, live);
+    if (live) sorted[pos] = (v & 0x7fffffu) | ((v >> 23 & 1u) << 31);
+  }
+}
+
+// generic in-place exclusive scan of u32 (total written to a[n])
+__global__ void __launch_bounds__(256) k_uscan1(uint32_t* __restrict__ a, uint32_t* __restrict__ block_tot, uint32_t n) {
+  __shared__ uint32_t sh[256];
+  uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  uint32_t v[4], local = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { v[k] = (base + k < n) ? a[base + k] : 0u; local += v[k]; }
+  sh[threadIdx.x] = local;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += u;
+    __syncthreads();
+  }
+  uint32_t excl = sh[threadIdx.x] - local;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (base + k < n) a[base + k] = excl; excl += v[k]; }
+  if (threadIdx.x == 255) block_tot[blockIdx.x] = sh[255];
+}
+__global__ void __launch_bounds__(256) k_uscan2(uint32_t* __restrict__ block_tot, uint32_t nblocks, uint32_t* __restrict__ a, uint32_t n) {
+  __shared__ uint32_t sh[256];
+  uint32_t carry = 0;
+  for (uint32_t tile = 0; tile < nblocks; tile += 256) {
+    uint32_t i = tile + threadIdx.x;
+    uint32_t v = (i < nblocks) ? block_tot[i] : 0u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      uint32_t u = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += u;
+      __syncthreads();
+    }
+    if (i < nblocks) block_tot[i] = carry + sh[threadIdx.x] - v;
+    uint32_t tot = sh[255];
+    __syncthreads();
+    carry += tot;
+  }
+  if (threadIdx.x == 0) a[n] = carry;
+}
+__global__ void __launch_bounds__(256) k_uscan3(const uint32_t* __restrict__ block_tot, uint32_t* __restrict__ a, uint32_t n) {
+  uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  uint32_t p = block_tot[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (base + k < n) a[base + k] += p;
+}
+
+// ------------------------------------------------------------------ regime B: many independent small MSMs
+// A batch of M MSMs (MSM j = terms [offs[j], offs[j+1]) of one concatenated input) -- e.g. the 5*ell+7-term
+// final MSMs of 1024 MSMAccumulator.verify() calls (msm_accumulator.py:60-68).  Bucket space is indexed by
+// group g = j*nwin + w; with NB <= 256 buckets per group the counting sort of a group lives in one block's
+// LDS.  Everything between the sort and the bucket sums (chunking, length ordering, k_accumulate, k_seg_reduce)
+// is the same code as regime A, so lanes of one wave work on chunks of equal length from ANY msm/window.
+__global__ void __launch_bounds__(256) k_group_count(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ offs,
+                                                     uint32_t* __restrict__ hist, uint32_t N, uint32_t NB, uint32_t nwin) {
+  __shared__ uint32_t cnt[256];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t j = blockIdx.x, w = blockIdx.y;
+  const uint32_t o0 = offs[j], o1 = offs[j + 1];
+  const uint16_t* dg = digits + (size_t)w * N;
+  const uint32_t span = ((o1 - o0 + 255u) / 256u) * 256u;
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const uint32_t e = (o0 + o < o1) ? (uint32_t)dg[o0 + o] : 0u;
+    uint32_t neg;
+    lds_ranked_inc(cnt, e ? digit_mag(e, neg) - 1u : 0u, e != 0u);
+  }
+  __syncthreads();
+  if (threadIdx.x < NB) hist[((size_t)j * nwin + w) * NB + threadIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_group_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ offs,
+                                                       const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted,
+                                                       uint32_t N, uint32_t NB, uint32_t nwin) {
+  __shared__ uint32_t cur[256];
+  const uint32_t j = blockIdx.x, w = blockIdx.y;
+  if (threadIdx.x < NB) cur[threadIdx.x] = off[((size_t)j * nwin + w) * NB + threadIdx.x];
+  __syncthreads();
+  const uint32_t o0 = offs[j], o1 = offs[j + 1];
+  const uint16_t* dg = digits + (size_t)w * N;
+  const uint32_t span = ((o1 - o0 + 255u) / 256u) * 256u;
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const uint32_t i = o0 + o;
+    const uint32_t e = (i < o1) ? (uint32_t)dg[i] : 0u;
+    uint32_t neg = 0;
+    const uint32_t b = e ? digit_mag(e, neg) - 1u : 0u;
+    const uint32_t pos = lds_ranked_inc(cur, b, e != 0u);
+    if (e) sorted[pos] = i | (neg << 31);
+  }
+}
+
+// one lane per group: S_g = sum_s tot_s + m * sum_s s*run_s over the group's J = NB/m segments
+__global__ void __launch_bounds__(256) k_group_reduce(const PointSum* __restrict__ seg_run, const PointSum* __restrict__ seg_tot,
+                                                      PointSum* __restrict__ group_sum, uint32_t ngroups, uint32_t J, uint32_t log2m) {
+  uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  const PointSum* run = seg_run + (size_t)g * J;
+  const PointSum* tot = seg_tot + (size_t)g * J;
+  xyzz r = xyzz_identity(), t = xyzz_identity();
+  for (uint32_t s = J - 1; s >= 1; --s) { r = xyzz_add(r, load_sum(run + s)); t = xyzz_add(t, r); }   // t = sum s*run_s
+  for (uint32_t k = 0; k < log2m; ++k) t = xyzz_dbl(t);
+  for (uint32_t s = 0; s < J; ++s) t = xyzz_add(t, load_sum(tot + s));
+  store_sum(group_sum + g, t);
+}
+
+// one lane per MSM: Horner over its nwin window sums, result as canonical words
+__global__ void __launch_bounds__(64) k_msm_horner(const PointSum* __restrict__ group_sum, PointWords* __restrict__ out,
+                                                   uint32_t M, uint32_t nwin, uint32_t c) {
+  uint32_t j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= M) return;
+  xyzz acc = xyzz_identity();
+  for (int w = (int)nwin - 1; w >= 0; --w) {
+    for (uint32_t k = 0; k < c; ++k) acc = xyzz_dbl(acc);
+    acc = xyzz_add(acc, load_sum(group_sum + (size_t)j * nwin + w));
+  }
+  xyzz_words o;
+  xyzz_export(acc, o);
+  PointWords* dst = out + j;
+  for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
+  dst->inf = o.inf;
+}
+
+// ------------------------------------------------------------------ scan of (count, chunks)
+// Chunk length of a bucket with `cnt` entries: L0 normally; a skewed bucket (e.g. the reference's [beta]*ell
+// all-equal scalars, same_perm.py:54-55, or the recoding carry of a top window) is cut into at most
+// MAX_CHUNKS_PER_BUCKET pieces whose partial sums are then combined by a block-wide tree (k_heavy_combine)
+// instead of serialising one lane.
+constexpr uint32_t MAX_CHUNKS_PER_BUCKET = 4096;
+constexpr uint32_t HEAVY_MIN_CHUNKS = 17;       // buckets with >= this many chunks go through k_heavy_combine;
+                                                // 2..16 chunks are folded by one lane in k_bucket_fold
+__device__ __forceinline__ uint32_t chunk_len(uint32_t cnt, uint32_t L0) {
+  uint32_t s = (cnt + MAX_CHUNKS_PER_BUCKET - 1) / MAX_CHUNKS_PER_BUCKET;
+  return s > L0 ? s : L0;
+}
+__device__ __forceinline__ uint32_t chunk_count(uint32_t cnt, uint32_t L0) {
+  if (cnt == 0) return 0;
+  uint32_t L = chunk_len(cnt, L0);
+  return (cnt + L - 1) / L;
+}
+
+// phase 1: per-block exclusive scan, block totals out
+__global__ void __launch_bounds__(256) k_scan1(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ choff,
+                                               uint2* __restrict__ block_tot, uint32_t nb_total, uint32_t L0) {
+  __shared__ uint2 sh[256];
+  uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  uint32_t cnt[4], ch[4];
+  uint2 local = make_uint2(0, 0);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    cnt[k] = (base + k < nb_total) ? hist[base + k] : 0u;
+    ch[k] = chunk_count(cnt[k], L0);
+    local.x += cnt[k]; local.y += ch[k];
+  }
+  sh[threadIdx.x] = local;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {          // Hillis-Steele inclusive scan over 256 partials
+    uint2 v = make_uint2(0, 0);
+    if ((int)threadIdx.x >= d) v = sh[threadIdx.x - d];
+    __syncthreads();
+    sh[threadIdx.x].x += v.x; sh[threadIdx.x].y += v.y;
+    __syncthreads();
+  }
+  uint2 excl = make_uint2(sh[threadIdx.x].x - local.x, sh[threadIdx.x].y - local.y);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (base + k < nb_total) { off[base + k] = excl.x; choff[base + k] = excl.y; }
+    excl.x += cnt[k]; excl.y += ch[k];
+  }
+  if (threadIdx.x == 255) block_tot[blockIdx.x] = sh[255];
+}
+// phase 2: one block turns block totals into exclusive block prefixes (serial over tiles of 256)
+__global__ void __launch_bounds__(256) k_scan2(uint2* __restrict__ block_tot, uint32_t nblocks, uint32_t* __restrict__ off,
+                                               uint32_t* __restrict__ choff, uint32_t nb_total) {
+  __shared__ uint2 sh[256];
+  uint2 carry = make_uint2(0, 0);
+  for (uint32_t tile = 0; tile < nblocks; tile += 256) {
+    uint32_t i = tile + threadIdx.x;
+    uint2 v = (i < nblocks) ? block_tot[i] : make_uint2(0, 0);
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+      uint2 u = make_uint2(0, 0);
+      if ((int)threadIdx.x >= d) u = sh[threadIdx.x - d];
+      __syncthreads();
+      sh[threadIdx.x].x += u.x; sh[threadIdx.x].y += u.y;
+      __syncthreads();
+    }
+    if (i < nblocks) block_tot[i] = make_uint2(carry.x + sh[threadIdx.x].x - v.x, carry.y + sh[threadIdx.x].y - v.y);
+    uint2 tot = sh[255];
+    __syncthreads();
+    carry.x += tot.x; carry.y += tot.y;
+  }
+  if (threadIdx.x == 0) { off[nb_total] = carry.x; choff[nb_total] = carry.y; }
+}
+__global__ void __launch_bounds__(256) k_scan3(const uint2* __restrict__ block_tot, uint32_t* __restrict__ off,
+                                               uint32_t* __restrict__ choff, uint32_t nb_total) {
+  uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4;
+  uint2 p = block_tot[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) if (base + k < nb_total) { off[base + k] += p.x; choff[base + k] += p.y; }
+}
+
+constexpr uint32_t LEN_BINS = 256;      // chunk-length keys: min(len, 255)
+__device__ __forceinline__ uint32_t len_key(uint32_t len) { return len < LEN_BINS - 1 ? len : LEN_BINS - 1; }
+
+__global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__ off, const uint32_t* __restrict__ choff,
+                                                    uint2* __restrict__ desc, uint32_t* __restrict__ len_hist,
+                                                    uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
+                                                    uint32_t heavy_cap, uint32_t nb_total, uint32_t L0) {
+  __shared__ uint32_t sh[LEN_BINS];
+  sh[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  if (b < nb_total) {
+    uint32_t start = off[b], cnt = off[b + 1] - start;
+    if (cnt) {
+      uint32_t L = chunk_len(cnt, L0), nch = (cnt + L - 1) / L, o = choff[b];
+      for (uint32_t k = 0; k < nch; ++k) {
+        uint32_t s = k * L, len = (cnt - s < L) ? (cnt - s) : L;
+        desc[o + k] = make_uint2(start + s, len);
+        atomicAdd(&sh[len_key(len)], 1u);
+      }
+      if (nch >= HEAVY_MIN_CHUNKS) {
+        uint32_t slot = atomicAdd(&heavy[0], 1u);
+        if (slot < heavy_cap) heavy[1 + slot] = b;
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t v = sh[threadIdx.x];
+  if (v) atomicAdd(&len_hist[threadIdx.x], v);
+}
+
+// one block: len_cursor[k] = number of chunks with a LONGER key (descending order => longest chunks first)
+__global__ void __launch_bounds__(256) k_len_scan(const uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor) {
+  __shared__ uint32_t sh[LEN_BINS];
+  uint32_t rev = LEN_BINS - 1 - threadIdx.x;          // thread i handles key 255-i
+  uint32_t v = len_hist[rev];
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += u;
+    __syncthreads();
+  }
+  len_cursor[rev] = sh[threadIdx.x] - v;
+}
+
+// order[] = chunk ids sorted by descending length key (stable enough: order inside a key is arbitrary)
+__global__ void __launch_bounds__(256) k_order(const uint2* __restrict__ desc, const uint32_t* __restrict__ total_chunks,
+                                               uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
+  __shared__ uint32_t cnt[LEN_BINS];
+  __shared__ uint32_t base[LEN_BINS];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  bool live = t < *total_chunks;
+  uint32_t key = 0, local = 0;
+  if (live) { key = len_key(desc[t].y); local = atomicAdd(&cnt[key], 1u); }
+  __syncthreads();
+  uint32_t c = cnt[threadIdx.x];
+  if (c) base[threadIdx.x] = atomicAdd(&len_cursor[threadIdx.x], c);
+  __syncthreads();
+  if (live) order[base[key] + local] = t;
+}
+
