@@ -99,7 +99,7 @@ def main():
     ap.add_argument("--logn", type=int, default=20, help="log2 of terms per GPU")
     ap.add_argument("--window", type=int, default=16)
     ap.add_argument("--shard", choices=["windows", "points"], default="windows")
-    ap.add_argument("--cpu-sample-logn", type=int, default=15)
+    ap.add_argument("--cpu-sample-logn", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["msm", "batched", "pcie"], default="msm",
                     help="msm: the headline metric (default). batched: BASELINE config 3's MSM content (1024 independent "

@@ -277,3 +277,27 @@ def test_config2_full_size_vs_cpu_oracle(native_lib, ctx, logn):
     want = C.compress(C.msm_bucket(p96, s32, n))
     for c in (0, 16):
         assert compress_blob(native_lib, ctx.msm_device(dp, ds, n, window_c=c)) == want
+
+
+def test_argument_errors_are_reported(native_lib, ctx):
+    """Bad arguments come back as status codes -> NativeError with a message; nothing is silently 'fixed'."""
+    N = native_lib
+    dp, ds = ctx.alloc(96 * 4), ctx.alloc(32 * 4)
+    dp.upload(raw96(O.G1_GEN) * 4); ds.upload((5).to_bytes(32, "little") * 4)
+    for kw in ({"window_c": 3}, {"window_c": 17}, {"shard_rank": 2, "shard_world": 2}, {"shard_rank": -1, "shard_world": 1},
+               {"shard_world": 0}):
+        with pytest.raises(N.NativeError):
+            ctx.msm_device(dp, ds, 4, **kw)
+    with pytest.raises(N.NativeError):
+        ctx.msm_batched_device(dp, ds, [0, 3, 2, 4])           # offsets not monotone
+    with pytest.raises(N.NativeError):
+        ctx.msm_batched_device(dp, ds, [1, 4])                 # offsets[0] != 0
+    with pytest.raises(N.NativeError):
+        ctx.msm_batched_device(dp, ds, [0, 4], window_c=12)    # batched widths are 4..9
+    with pytest.raises(N.NativeError):
+        ctx.set_param("no_such_param", 1)
+    # the context stays usable after errors
+    want = O.g1_compress(O.g1_mul(O.G1_GEN, 20))
+    assert compress_blob(N, ctx.msm_device(dp, ds, 4)) == want
+    # ranks beyond the window count own nothing: identity partial
+    assert compress_blob(N, ctx.msm_device(dp, ds, 4, window_c=16, shard_rank=17, shard_world=20)) == bytes([0xC0]) + bytes(47)
