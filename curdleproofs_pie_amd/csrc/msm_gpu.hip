@@ -461,6 +461,14 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
 using cg1::Ctx;
 struct cg1_ctx : public cg1::Ctx {};
 
+namespace {
+struct DevBuf {                       // frees on every exit path of the host-pointer convenience entry points
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+};
+}  // namespace
+
 static inline cg1h::jac blob_in(const uint8_t* b) { cg1h::jac j; memcpy(&j, b, sizeof j); return j; }
 static inline void blob_out(uint8_t* b, const cg1h::jac& j) { memcpy(b, &j, sizeof j); }
 static_assert(sizeof(cg1h::jac) == CG1_POINT_BYTES, "point blob size");
@@ -702,15 +710,15 @@ int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases, size_t nbase, const ui
   if (n == 0) return CG1_OK;
   if (nbase == 0 || nscalars == 0) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  void *db = nullptr, *ds = nullptr, *da = nullptr, *dout = nullptr;
-  HIPCHK(hipMalloc(&db, nbase * 96)); HIPCHK(hipMalloc(&ds, nscalars * 32)); HIPCHK(hipMalloc(&dout, n * 96));
-  HIPCHK(hipMemcpy(db, bases, nbase * 96, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ds, scalars, nscalars * 32, hipMemcpyHostToDevice));
-  if (addend) { HIPCHK(hipMalloc(&da, n * 96)); HIPCHK(hipMemcpy(da, addend, n * 96, hipMemcpyHostToDevice)); }
-  int rc = cg1_batch_mul_add_device(ctx, db, nbase, ds, nscalars, da, dout, n);
-  if (rc == CG1_OK) { hipError_t e = hipMemcpy(out, dout, n * 96, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = CG1_ERR_HIP; }
-  (void)hipFree(db); (void)hipFree(ds); (void)hipFree(dout); if (da) (void)hipFree(da);
-  return rc;
+  DevBuf db, ds, da, dout;
+  HIPCHK(db.alloc(nbase * 96)); HIPCHK(ds.alloc(nscalars * 32)); HIPCHK(dout.alloc(n * 96));
+  HIPCHK(hipMemcpy(db.p, bases, nbase * 96, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ds.p, scalars, nscalars * 32, hipMemcpyHostToDevice));
+  if (addend) { HIPCHK(da.alloc(n * 96)); HIPCHK(hipMemcpy(da.p, addend, n * 96, hipMemcpyHostToDevice)); }
+  int rc = cg1_batch_mul_add_device(ctx, db.p, nbase, ds.p, nscalars, da.p, dout.p, n);
+  if (rc != CG1_OK) return rc;
+  HIPCHK(hipMemcpy(out, dout.p, n * 96, hipMemcpyDeviceToHost));
+  return CG1_OK;
 }
 // n compressed48 (device) -> n affine96 + n status bytes (device); returns CG1_OK when the kernel ran
 int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup) {
@@ -729,16 +737,14 @@ int cg1_batch_decompress_gpu(cg1_ctx* ctx, const uint8_t* in48, uint8_t* out_aff
   if (!ctx) return CG1_ERR_HIP;
   if (n == 0) return CG1_OK;
   HIPCHK(hipSetDevice(ctx->device));
-  void *din = nullptr, *dout = nullptr, *dst = nullptr;
-  HIPCHK(hipMalloc(&din, n * 48)); HIPCHK(hipMalloc(&dout, n * 96)); HIPCHK(hipMalloc(&dst, n));
-  HIPCHK(hipMemcpy(din, in48, n * 48, hipMemcpyHostToDevice));
-  int rc = cg1_batch_decompress_device(ctx, din, dout, dst, n, check_subgroup);
-  std::vector<uint8_t> st(n);
-  if (rc == CG1_OK) {
-    if (hipMemcpy(out_affine96, dout, n * 96, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(st.data(), dst, n, hipMemcpyDeviceToHost) != hipSuccess) rc = CG1_ERR_HIP;
-  }
-  (void)hipFree(din); (void)hipFree(dout); (void)hipFree(dst);
+  DevBuf din, dout, dst;
+  HIPCHK(din.alloc(n * 48)); HIPCHK(dout.alloc(n * 96)); HIPCHK(dst.alloc(n));
+  HIPCHK(hipMemcpy(din.p, in48, n * 48, hipMemcpyHostToDevice));
+  int rc = cg1_batch_decompress_device(ctx, din.p, dout.p, dst.p, n, check_subgroup);
   if (rc != CG1_OK) return rc;
+  std::vector<uint8_t> st(n);
+  HIPCHK(hipMemcpy(out_affine96, dout.p, n * 96, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(st.data(), dst.p, n, hipMemcpyDeviceToHost));
   for (size_t i = 0; i < n; ++i) if (st[i]) { if (bad_index) *bad_index = i; return st[i]; }
   return CG1_OK;
 }
@@ -756,19 +762,19 @@ int cg1_probe_madd(cg1_ctx* ctx, const void* d_points, size_t npts, size_t lanes
   if (!ctx) return CG1_ERR_HIP;
   if (npts == 0 || lanes == 0 || lanes % 256) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  cg1::PreparedPoint* prep = nullptr; cg1::PointSum* out = nullptr; uint8_t* fl = nullptr;
-  HIPCHK(hipMalloc(&prep, npts * sizeof(cg1::PreparedPoint)));
-  HIPCHK(hipMalloc(&fl, npts + 16));
-  HIPCHK(hipMalloc(&out, lanes * sizeof(cg1::PointSum)));
-  hipLaunchKernelGGL(cg1::k_prepare_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_points, prep, fl, (uint32_t)npts);
-  hipLaunchKernelGGL(cg1::k_probe_madd, dim3((unsigned)(lanes / 256)), dim3(256), 0, ctx->stream, prep, (uint32_t)npts, out, 2);
+  DevBuf prep, out, fl;
+  HIPCHK(prep.alloc(npts * sizeof(cg1::PreparedPoint)));
+  HIPCHK(fl.alloc(npts + 16));
+  HIPCHK(out.alloc(lanes * sizeof(cg1::PointSum)));
+  hipLaunchKernelGGL(cg1::k_prepare_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_points,
+                     (cg1::PreparedPoint*)prep.p, (uint8_t*)fl.p, (uint32_t)npts);
+  hipLaunchKernelGGL(cg1::k_probe_madd, dim3((unsigned)(lanes / 256)), dim3(256), 0, ctx->stream, (cg1::PreparedPoint*)prep.p, (uint32_t)npts, (cg1::PointSum*)out.p, 2);
   HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
-  hipLaunchKernelGGL(cg1::k_probe_madd, dim3((unsigned)(lanes / 256)), dim3(256), 0, ctx->stream, prep, (uint32_t)npts, out, iters);
+  hipLaunchKernelGGL(cg1::k_probe_madd, dim3((unsigned)(lanes / 256)), dim3(256), 0, ctx->stream, (cg1::PreparedPoint*)prep.p, (uint32_t)npts, (cg1::PointSum*)out.p, iters);
   HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
-  (void)hipFree(prep); (void)hipFree(out); (void)hipFree(fl);
   return CG1_OK;
 }
 
