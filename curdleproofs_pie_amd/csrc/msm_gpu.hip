@@ -36,6 +36,7 @@
 #include <algorithm>
 #include <chrono>
 #include "g1_xyzz.h"
+#include "g1_quad.h"
 #include "host_g1.h"
 #include "../../include/curdle_g1.h"
 
@@ -67,6 +68,7 @@ struct Ctx {
   uint16_t* d_digits = nullptr; uint32_t* d_part = nullptr; uint32_t* d_blockcnt = nullptr; uint32_t* d_ublocktot = nullptr;
   size_t cap_digits = 0, cap_part = 0, cap_blockcnt = 0;
   int use_partition_sort = 1;
+  int quad = 1;                         // quad-lane EC ops in the latency-bound kernels (A/B switch)
   int reduce_2d = 1;                    // 1: k_rowcol + k_small_tree; 0: k_seg_reduce + k_bit_tree (A/B switch)
   uint32_t* d_heavy = nullptr; size_t cap_heavy = 0;         // [0] count, then heavy bucket ids
   uint8_t* d_combined = nullptr; size_t cap_combined = 0;
@@ -295,7 +297,8 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     hipLaunchKernelGGL(k_rowcol, dim3(nrow_blocks + ncol_blocks), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
                        rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks);
     HIPCHK(hipEventRecord(ctx->ev[6], st));
-    hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
+    if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(512), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
+    else hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
   } else {
     const uint32_t nseg_total = (uint32_t)(nb_total / m);
     hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
@@ -436,7 +439,8 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
   hipLaunchKernelGGL(k_group_reduce, dim3((uint32_t)((G + 255) / 256)), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_gsum, (uint32_t)G, J, log2m);
   HIPCHK(hipEventRecord(ctx->ev[6], st));
-  hipLaunchKernelGGL(k_msm_horner, dim3((uint32_t)((M + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
+  if (ctx->quad) hipLaunchKernelGGL(k_msm_horner_quad, dim3((uint32_t)((M * 4 + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
+  else hipLaunchKernelGGL(k_msm_horner, dim3((uint32_t)((M + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
   HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, M * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
@@ -602,6 +606,7 @@ int cg1_ctx_sync(cg1_ctx* ctx) {
 int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return CG1_ERR_ARG;
   if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
+  if (!strcmp(name, "quad")) { ctx->quad = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "reduce_2d")) { ctx->reduce_2d = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
