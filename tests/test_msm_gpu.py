@@ -301,3 +301,76 @@ def test_argument_errors_are_reported(native_lib, ctx):
     assert compress_blob(N, ctx.msm_device(dp, ds, 4)) == want
     # ranks beyond the window count own nothing: identity partial
     assert compress_blob(N, ctx.msm_device(dp, ds, 4, window_c=16, shard_rank=17, shard_world=20)) == bytes([0xC0]) + bytes(47)
+
+
+def test_randomised_differential(native_lib, ctx):
+    """A few hundred random (n, window width, shard, input mix) cases against the C oracle's bucket MSM:
+    boundary sizes of the sort tiles (4096) and scan blocks (1024), identity bases, duplicates, negated pairs,
+    zero / one / r-1 / power-of-two / small scalars."""
+    N = native_lib
+    rng = random.Random(20241003)
+    base = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(48)]
+    base += [O.g1_neg(p) for p in base[:8]] + [None]
+    raws = [raw96(p) for p in base]
+    sizes = [1, 2, 3, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097, 8191, 8192, 8193, 12289]
+    checked = 0
+    for it in range(160):
+        n = rng.choice(sizes) if it % 3 else rng.randint(1, 3000)
+        kind = rng.randrange(5)
+        idx = [rng.randrange(len(raws)) if kind != 1 else rng.randrange(4) for _ in range(n)]
+        def scalar():
+            r = rng.random()
+            if kind == 2:
+                return rng.choice([0, 1, O.R - 1, 1 << rng.randrange(255), (1 << rng.randrange(1, 255)) - 1])
+            if kind == 3:
+                return rng.randrange(1 << 20)
+            return 0 if r < 0.02 else rng.randint(0, O.R - 1)
+        sc = [scalar() for _ in range(n)]
+        if kind == 4:
+            sc = [sc[0]] * n
+        p96 = b"".join(raws[i] for i in idx)
+        s32 = b"".join(s.to_bytes(32, "little") for s in sc)
+        want = C.compress(C.msm_bucket(p96, s32, n))
+        c = rng.choice([0, 0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+        dp, ds = ctx.alloc(96 * n), ctx.alloc(32 * n)
+        dp.upload(p96); ds.upload(s32)
+        if rng.random() < 0.3:
+            world = rng.choice([2, 3, 5, 8])
+            cc = c or 9
+            acc = ctypes.create_string_buffer(N.POINT_BYTES)
+            N.cg1_identity(acc)
+            for rk in range(world):
+                N.cg1_add(acc, acc.raw, ctx.msm_device(dp, ds, n, window_c=cc, shard_rank=rk, shard_world=world))
+            got = compress_blob(N, acc.raw)
+        else:
+            got = compress_blob(N, ctx.msm_device(dp, ds, n, window_c=c))
+        dp.free(); ds.free()
+        assert got == want, (it, n, kind, c)
+        checked += 1
+    assert checked == 160
+
+
+def test_randomised_batched_differential(native_lib, ctx):
+    N = native_lib
+    rng = random.Random(77001)
+    base = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(32)] + [None]
+    raws = [raw96(p) for p in base]
+    for it in range(12):
+        M = rng.randint(1, 40)
+        sizes = [rng.choice([0, 1, 2, 7, 64, 255, 256, 257, 700]) for _ in range(M)]
+        offs, p, s = [0], [], []
+        for n in sizes:
+            for _ in range(n):
+                p.append(raws[rng.randrange(len(raws))])
+                s.append(rng.choice([0, 1, O.R - 1, rng.randint(0, O.R - 1), rng.randint(0, O.R - 1)]).to_bytes(32, "little"))
+            offs.append(offs[-1] + n)
+        p96, s32 = b"".join(p), b"".join(s)
+        if not p96:
+            continue
+        dp, ds = ctx.alloc(len(p96)), ctx.alloc(len(s32))
+        dp.upload(p96); ds.upload(s32)
+        blobs = ctx.msm_batched_device(dp, ds, offs, window_c=rng.choice([0, 4, 5, 6, 7, 8, 9]))
+        dp.free(); ds.free()
+        for j, n in enumerate(sizes):
+            want = C.compress(C.msm_bucket(p96[96 * offs[j]: 96 * offs[j + 1]], s32[32 * offs[j]: 32 * offs[j + 1]], n, 6))
+            assert compress_blob(N, blobs[j]) == want, (it, j, n)
