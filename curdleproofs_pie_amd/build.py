@@ -21,11 +21,29 @@ DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("fp28.h", "g1_xyzz.h", "g1_qua
 ]
 
 
+def _source_hash() -> str:
+    """Content hash of every source the library is built from (mtimes do not survive copying the tree)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        if os.path.exists(d):
+            h.update(os.path.basename(d).encode())
+            with open(d, "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+HASH_FILE = LIB + ".srchash"
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(HASH_FILE):
         return True
-    t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS if os.path.exists(d))
+    try:
+        return open(HASH_FILE).read().strip() != _source_hash()
+    except OSError:
+        return True
 
 
 def build_variant(out_path: str, extra_flags, verbose: bool = True) -> str:
@@ -39,16 +57,31 @@ def build_variant(out_path: str, extra_flags, verbose: bool = True) -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
+    """Build if the sources changed.  Safe under concurrent callers (e.g. 8 bench ranks on a fresh box): an flock
+    serialises them, the staleness check is repeated under the lock and the .so is replaced atomically."""
     if not force and not needs_build():
         return LIB
+    import fcntl
+
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libcurdle_g1.so (HIP toolchain required)")
-    cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", *SOURCES, "-o", LIB + ".tmp"]
-    if verbose:
-        print("[curdleproofs_pie_amd.build]", " ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    os.replace(LIB + ".tmp", LIB)
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            tmp = f"{LIB}.tmp.{os.getpid()}"
+            cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", *SOURCES, "-o", tmp]
+            if verbose:
+                print("[curdleproofs_pie_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            os.replace(tmp, LIB)
+            with open(HASH_FILE + f".{os.getpid()}", "w") as f:
+                f.write(_source_hash())
+            os.replace(HASH_FILE + f".{os.getpid()}", HASH_FILE)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
