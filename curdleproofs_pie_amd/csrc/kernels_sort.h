@@ -74,10 +74,34 @@ __global__ void __launch_bounds__(256) k_part_count(const uint16_t* __restrict__
 
 __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ block_base,
                                                       uint32_t* __restrict__ part, uint32_t n, uint32_t nslices, uint32_t nbins,
-                                                      uint32_t sub_bits) {
-  __shared__ uint32_t cur[128];
+                                                      uint32_t sub_bits, int use_stage) {
+  __shared__ uint32_t cur[128];          // staged: local slot cursors; direct: global cursors
+  __shared__ uint32_t gbase[128];        // global base of this block's run in each bin
+  __shared__ uint32_t lbase[128];        // local exclusive offsets of the bins inside the tile
+  __shared__ uint32_t stage[PART_TILE];
+  __shared__ uint32_t gpos[PART_TILE];
   const uint32_t slice = blockIdx.x, lw = blockIdx.y;
-  if (threadIdx.x < nbins) cur[threadIdx.x] = block_base[((size_t)lw * nbins + threadIdx.x) * nslices + slice];
+  uint32_t mycnt = 0;
+  if (threadIdx.x < nbins) {
+    const size_t idx = ((size_t)lw * nbins + threadIdx.x) * nslices + slice;
+    gbase[threadIdx.x] = block_base[idx];
+    mycnt = block_base[idx + 1] - block_base[idx];      // exclusive scan in (window, bin, tile) order: next - this = count
+    lbase[threadIdx.x] = mycnt;
+  } else if (threadIdx.x < 128) {
+    lbase[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  if (use_stage) {                                      // exclusive scan of the <= 128 per-bin counts
+    for (int d = 1; d < 128; d <<= 1) {
+      uint32_t u = (threadIdx.x < 128 && (int)threadIdx.x >= d) ? lbase[threadIdx.x - d] : 0u;
+      __syncthreads();
+      if (threadIdx.x < 128) lbase[threadIdx.x] += u;
+      __syncthreads();
+    }
+    if (threadIdx.x < 128) { lbase[threadIdx.x] -= mycnt; cur[threadIdx.x] = lbase[threadIdx.x]; }
+  } else if (threadIdx.x < nbins) {
+    cur[threadIdx.x] = gbase[threadIdx.x];
+  }
   __syncthreads();
   const uint16_t* dg = digits + (size_t)lw * n;
   const uint32_t sub_mask = (1u << sub_bits) - 1u;
@@ -85,16 +109,27 @@ __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t* __restrict
     uint32_t i = slice * PART_TILE + k * 256 + threadIdx.x;
     uint32_t e = (i < n) ? (uint32_t)dg[i] : 0u;
     uint32_t neg = 0, b = e ? (digit_mag(e, neg) - 1u) : 0u;
-    uint32_t pos = lds_ranked_inc(cur, b >> sub_bits, e != 0u);
-    if (e) part[pos] = i | (neg << 23) | ((b & sub_mask) << 24);
+    const uint32_t bin = b >> sub_bits;
+    uint32_t pos = lds_ranked_inc(cur, bin, e != 0u);
+    const uint32_t val = i | (neg << 23) | ((b & sub_mask) << 24);
+    if (e) {
+      if (use_stage) { stage[pos] = val; gpos[pos] = gbase[bin] + (pos - lbase[bin]); }
+      else part[pos] = val;
+    }
+  }
+  if (use_stage) {
+    __syncthreads();
+    const uint32_t total = lbase[nbins - 1] + (block_base[((size_t)lw * nbins + nbins - 1) * nslices + slice + 1] - gbase[nbins - 1]);
+    for (uint32_t o = threadIdx.x; o < total; o += 256) part[gpos[o]] = stage[o];   // consecutive o of one bin -> consecutive addresses
   }
 }
-
+constexpr uint32_t BIN_STAGE = 12288;     // entries of a bin staged in LDS (48 KB) so sorted[] is written as full lines
 __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
                                                   uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted,
-                                                  uint32_t nbins_total, uint32_t nslices, uint32_t sub_bits) {
+                                                  uint32_t nbins_total, uint32_t nslices, uint32_t sub_bits, int use_stage) {
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t cur[256];
+  __shared__ uint32_t stage[BIN_STAGE];
   const uint32_t g = blockIdx.x;
   const uint32_t start = block_base[(size_t)g * nslices];
   const uint32_t end = block_base[(size_t)(g + 1) * nslices];     // element [nbins_total*nslices] holds the grand total
@@ -117,14 +152,20 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ p
   }
   const uint32_t excl = cur[threadIdx.x] - mine;
   __syncthreads();
-  cur[threadIdx.x] = start + excl;
+  const bool staged = use_stage && (end - start) <= BIN_STAGE;      // block-uniform
+  cur[threadIdx.x] = (staged ? 0u : start) + excl;
   if (threadIdx.x < (1u << sub_bits)) hist[((size_t)g << sub_bits) + threadIdx.x] = mine;
   __syncthreads();
   for (uint32_t o = threadIdx.x; o < span; o += 256) {
     const bool live = start + o < end;
     const uint32_t v = live ? part[start + o] : 0u;
     const uint32_t pos = lds_ranked_inc(cur, v >> 24, live);
-    if (live) sorted[pos] = (v & 0x7fffffu) | ((v >> 23 & 1u) << 31);
+    const uint32_t val = (v & 0x7fffffu) | ((v >> 23 & 1u) << 31);
+    if (live) { if (staged) stage[pos] = val; else sorted[pos] = val; }
+  }
+  if (staged) {                                                      // scattered inside LDS, streamed out in order
+    __syncthreads();
+    for (uint32_t o = threadIdx.x; start + o < end; o += 256) sorted[start + o] = stage[o];
   }
 }
 
