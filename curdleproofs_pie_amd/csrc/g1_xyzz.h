@@ -95,8 +95,9 @@ CG1_HD xyzz xyzz_add(const xyzz& a, const xyzz& b) {
   return r;
 }
 
-// ---- canonical export: XYZZ with standard-form (non-Montgomery) canonical coordinates, 4 x 12 words
-// (+ a flag word).  The host maps it to Jacobian (X*ZZ, Y*ZZZ, ZZ) without an inversion.
+// ---- canonical export: XYZZ with canonical coordinates in the HOST's Montgomery form (radix 2^384), 4 x 12 words
+// (+ a flag word).  The host reinterprets the words as its field elements and maps the point to Jacobian
+// (X*ZZ, Y*ZZZ, ZZ) without an inversion.
 struct xyzz_words { uint32_t w[4][12]; uint32_t inf; };
 CG1_HD void xyzz_export(const xyzz& a, xyzz_words& o) {
   o.inf = a.inf;
@@ -104,7 +105,7 @@ CG1_HD void xyzz_export(const xyzz& a, xyzz_words& o) {
     for (int c = 0; c < 4; ++c) for (int j = 0; j < 12; ++j) o.w[c][j] = 0;
     return;
   }
-  fp_to_words(a.X, o.w[0]); fp_to_words(a.Y, o.w[1]); fp_to_words(a.ZZ, o.w[2]); fp_to_words(a.ZZZ, o.w[3]);
+  fp_to_host_words(a.X, o.w[0]); fp_to_host_words(a.Y, o.w[1]); fp_to_host_words(a.ZZ, o.w[2]); fp_to_host_words(a.ZZZ, o.w[3]);
 }
 
 }  // namespace cg1

@@ -192,10 +192,10 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
   return CG1_OK;
 }
 
-static cg1h::fe fe_from_words12(const uint32_t w[12]) {
-  uint64_t v[6];
-  for (int i = 0; i < 6; ++i) v[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
-  return cg1h::fe_from_std(v);
+static cg1h::fe fe_from_words12(const uint32_t w[12]) {     // already canonical and in the host's Montgomery form
+  cg1h::fe r;
+  for (int i = 0; i < 6; ++i) r.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+  return r;
 }
 static cg1h::jac jac_from_words(const PointWords& p) {
   if (p.inf) return cg1h::jac_identity();

@@ -18,7 +18,11 @@ def parse_xyzz(buf):
     b = buf.raw
     if int.from_bytes(b[192:196], "little"):
         return None
+    # exported coordinates are canonical and in the host library's Montgomery form (x * 2^384 mod p)
     X, Y, ZZ, ZZZ = (int.from_bytes(b[48 * i: 48 * i + 48], "little") for i in range(4))
+    assert max(X, Y, ZZ, ZZZ) < P
+    rinv = pow(1 << 384, -1, P)
+    X, Y, ZZ, ZZZ = (v * rinv % P for v in (X, Y, ZZ, ZZZ))
     assert (pow(ZZ, 3, P) - pow(ZZZ, 2, P)) % P == 0
     return (X * pow(ZZ, -1, P) % P, Y * pow(ZZZ, -1, P) % P)
 
