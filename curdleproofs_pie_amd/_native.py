@@ -69,6 +69,7 @@ cg1_dev_malloc = _proto("cg1_dev_malloc", c_void_p, c_void_p, c_size_t)
 cg1_dev_free = _proto("cg1_dev_free", None, c_void_p, c_void_p)
 cg1_h2d = _proto("cg1_h2d", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
 cg1_d2h = _proto("cg1_d2h", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+cg1_d2h_2d = _proto("cg1_d2h_2d", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t)
 cg1_ctx_sync = _proto("cg1_ctx_sync", c_int, c_void_p)
 cg1_ctx_set_param = _proto("cg1_ctx_set_param", c_int, c_void_p, c_char_p, c_int)
 cg1_msm = _proto("cg1_msm", c_int, c_void_p, _u8p, _u8p, c_size_t, _buf)
@@ -98,13 +99,27 @@ cg1_merlin_append_list = _proto("cg1_merlin_append_list", None, _buf, _u8p, c_si
 cg1_merlin_challenge = _proto("cg1_merlin_challenge", None, _buf, _u8p, c_size_t, _buf, c_size_t)
 cg1_merlin_challenge_scalar = _proto("cg1_merlin_challenge_scalar", None, _buf, _u8p, c_size_t, _buf)
 
+# batch verifier front-end of the shuffle argument (host)
+cg1_shuffle_crs_create = _proto("cg1_shuffle_crs_create", c_void_p, _u8p, c_size_t, c_size_t)
+cg1_shuffle_crs_destroy = _proto("cg1_shuffle_crs_destroy", None, c_void_p)
+cg1_shuffle_proof_bytes = _proto("cg1_shuffle_proof_bytes", c_size_t, c_void_p)
+cg1_shuffle_points_per_proof = _proto("cg1_shuffle_points_per_proof", c_size_t, c_void_p)
+cg1_shuffle_crs_points = _proto("cg1_shuffle_crs_points", c_size_t, c_void_p)
+cg1_shuffle_challenges_per_proof = _proto("cg1_shuffle_challenges_per_proof", c_size_t, c_void_p)
+cg1_shuffle_prepare = _proto("cg1_shuffle_prepare", c_int, c_void_p, c_size_t, _u8p, _u8p, _u8p, _buf, c_size_t, _buf, _buf, _buf, _buf, _buf, c_int)
+cg1_shuffle_gather_points = _proto("cg1_shuffle_gather_points", c_int, c_void_p, c_size_t, _u8p, _u8p, _buf)
+cg1_shuffle_apply_point_status = _proto("cg1_shuffle_apply_point_status", c_int, _buf, _u8p, c_size_t, c_size_t, _buf, _buf, c_size_t)
+cg1_shuffle_sum_crs_scalars = _proto("cg1_shuffle_sum_crs_scalars", c_int, _buf, _buf, c_size_t, c_size_t, _buf)
+
 EXPORTED_SYMBOLS = [
+    "cg1_shuffle_crs_create", "cg1_shuffle_crs_destroy", "cg1_shuffle_proof_bytes", "cg1_shuffle_points_per_proof",
+    "cg1_shuffle_crs_points", "cg1_shuffle_challenges_per_proof", "cg1_shuffle_prepare", "cg1_shuffle_gather_points", "cg1_shuffle_apply_point_status", "cg1_shuffle_sum_crs_scalars",
     "cg1_strobe_new", "cg1_strobe_meta_ad", "cg1_strobe_ad", "cg1_strobe_prf", "cg1_strobe_key", "cg1_merlin_init",
     "cg1_merlin_append", "cg1_merlin_append_list", "cg1_merlin_challenge", "cg1_merlin_challenge_scalar",
     "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
-    "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_ctx_sync", "cg1_ctx_set_param",
+    "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_ctx_sync", "cg1_ctx_set_param",
     "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 

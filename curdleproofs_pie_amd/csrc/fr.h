@@ -1,0 +1,148 @@
+// Host-side BLS12-381 scalar field Fr (r = 0x73eda753...00000001, 255 bits): 4 x 64-bit limbs, Montgomery
+// radix 2^256, header-only.  Backs the verifier-side scalar work of the shuffle argument (csrc/shuffle_verify.cpp):
+// the reference does this with one Python `Scalar` object per operation over the Rust wheel
+// (py_arkworks_bls12381-stubs/__init__.pyi:32-54; ipa.py:164-186,216,227-229; same_msm.py:155-182,213;
+// grand_prod.py:139-170; same_perm.py:94-98), including one `inverse()` per vector element (util.py:51-54) --
+// here a vector is inverted with one field inversion (Montgomery's trick).
+#pragma once
+#include <cstdint>
+#include <cstddef>
+#include <cstring>
+#include <vector>
+#include "bls_consts.h"
+
+namespace cg1fr {
+
+typedef unsigned __int128 u128;
+
+struct fr { uint64_t l[4]; };       // Montgomery form, canonical (< r)
+
+static inline fr fr_zero() { return fr{{0, 0, 0, 0}}; }
+static inline fr fr_one() { return fr{{cg1::H_FR_R1[0], cg1::H_FR_R1[1], cg1::H_FR_R1[2], cg1::H_FR_R1[3]}}; }
+static inline bool fr_is_zero(const fr& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+static inline bool fr_eq(const fr& a, const fr& b) {
+  return ((a.l[0] ^ b.l[0]) | (a.l[1] ^ b.l[1]) | (a.l[2] ^ b.l[2]) | (a.l[3] ^ b.l[3])) == 0;
+}
+
+static inline bool geq_r(const uint64_t a[4]) {
+  for (int i = 3; i >= 0; --i) {
+    if (a[i] != cg1::H_FR[i]) return a[i] > cg1::H_FR[i];
+  }
+  return true;
+}
+static inline void sub_r(uint64_t a[4]) {
+  u128 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 d = (u128)a[i] - cg1::H_FR[i] - borrow;
+    a[i] = (uint64_t)d;
+    borrow = (d >> 64) & 1;
+  }
+}
+
+static inline fr fr_add(const fr& a, const fr& b) {
+  fr r;
+  u128 c = 0;
+  for (int i = 0; i < 4; ++i) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
+  if (geq_r(r.l)) sub_r(r.l);           // a + b < 2r < 2^256: no carry out
+  return r;
+}
+static inline fr fr_neg(const fr& a) {
+  if (fr_is_zero(a)) return a;
+  fr r;
+  u128 borrow = 0;
+  for (int i = 0; i < 4; ++i) {
+    u128 d = (u128)cg1::H_FR[i] - a.l[i] - borrow;
+    r.l[i] = (uint64_t)d;
+    borrow = (d >> 64) & 1;
+  }
+  return r;
+}
+static inline fr fr_sub(const fr& a, const fr& b) { return fr_add(a, fr_neg(b)); }
+
+// Montgomery product a * b / 2^256 mod r (CIOS)
+static inline fr fr_mul(const fr& a, const fr& b) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; ++i) {
+    u128 c = 0;
+    for (int j = 0; j < 4; ++j) {
+      c += (u128)a.l[j] * b.l[i] + t[j];
+      t[j] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[4] = (uint64_t)c;
+    t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * cg1::H_FR_INV;
+    c = (u128)m * cg1::H_FR[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; ++j) {
+      c += (u128)m * cg1::H_FR[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    c += t[4];
+    t[3] = (uint64_t)c;
+    t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  fr r{{t[0], t[1], t[2], t[3]}};
+  if (t[4] || geq_r(r.l)) sub_r(r.l);
+  return r;
+}
+static inline fr fr_sqr(const fr& a) { return fr_mul(a, a); }
+
+static inline fr fr_from_u64(uint64_t v) {
+  fr a{{v, 0, 0, 0}};
+  fr r2{{cg1::H_FR_R2[0], cg1::H_FR_R2[1], cg1::H_FR_R2[2], cg1::H_FR_R2[3]}};
+  return fr_mul(a, r2);
+}
+// 32 little-endian bytes, canonical (< r) required: false otherwise (Scalar.from_le_bytes raises ValueError,
+// test_curdleproofs.py:210-213)
+static inline bool fr_from_le32(const uint8_t* b, fr& out) {
+  fr a;
+  memcpy(a.l, b, 32);
+  if (geq_r(a.l)) return false;
+  fr r2{{cg1::H_FR_R2[0], cg1::H_FR_R2[1], cg1::H_FR_R2[2], cg1::H_FR_R2[3]}};
+  out = fr_mul(a, r2);
+  return true;
+}
+static inline void fr_to_le32(const fr& a, uint8_t* b) {
+  fr one{{1, 0, 0, 0}};
+  fr s = fr_mul(a, one);
+  memcpy(b, s.l, 32);
+}
+
+static inline fr fr_pow_u64(fr base, uint64_t e) {
+  fr acc = fr_one();
+  while (e) {
+    if (e & 1) acc = fr_mul(acc, base);
+    base = fr_sqr(base);
+    e >>= 1;
+  }
+  return acc;
+}
+
+// a^(r-2); 0 -> 0
+static inline fr fr_inv(const fr& a) {
+  fr acc = fr_one();
+  for (int i = 254; i >= 0; --i) {
+    acc = fr_sqr(acc);
+    if ((cg1::H_FR_MINUS_2[i >> 6] >> (i & 63)) & 1) acc = fr_mul(acc, a);
+  }
+  return acc;
+}
+
+// in-place inversion of n NON-ZERO elements with one field inversion
+static inline void fr_batch_inv(fr* v, size_t n) {
+  if (n == 0) return;
+  std::vector<fr> pre(n);
+  fr acc = fr_one();
+  for (size_t i = 0; i < n; ++i) { pre[i] = acc; acc = fr_mul(acc, v[i]); }
+  fr inv = fr_inv(acc);
+  for (size_t i = n; i-- > 0;) {
+    fr t = fr_mul(inv, pre[i]);
+    inv = fr_mul(inv, v[i]);
+    v[i] = t;
+  }
+}
+
+}  // namespace cg1fr

@@ -159,6 +159,24 @@ jac jac_add(const jac& p, const jac& q) {
   return r;
 }
 
+// p + (x2, y2) with the second operand affine and not the identity (7M + 4S instead of 11M + 5S)
+jac jac_madd(const jac& p, const fe& x2, const fe& y2) {
+  if (jac_is_identity(p)) return jac_from_affine(x2, y2);
+  fe Z1Z1 = fe_sqr(p.Z);
+  fe U2 = fe_mul(x2, Z1Z1), S2 = fe_mul(fe_mul(y2, p.Z), Z1Z1);
+  if (fe_eq(p.X, U2)) {
+    if (fe_eq(p.Y, S2)) return jac_dbl(p);
+    return jac_identity();
+  }
+  fe H = fe_sub(U2, p.X), Rr = fe_sub(S2, p.Y);
+  fe HH = fe_sqr(H), HHH = fe_mul(H, HH), V = fe_mul(p.X, HH);
+  jac r;
+  r.X = fe_sub(fe_sub(fe_sqr(Rr), HHH), fe_add(V, V));
+  r.Y = fe_sub(fe_mul(Rr, fe_sub(V, r.X)), fe_mul(p.Y, HHH));
+  r.Z = fe_mul(p.Z, H);
+  return r;
+}
+
 jac jac_neg(const jac& a) { jac r = a; r.Y = fe_neg(a.Y); return r; }
 
 bool jac_eq(const jac& a, const jac& b) {
@@ -226,6 +244,13 @@ void jac_batch_to_affine(const jac* pts, size_t n, fe* xs, fe* ys, uint8_t* inf)
     xs[i] = fe_mul(pts[i].X, zi2);
     ys[i] = fe_mul(pts[i].Y, fe_mul(zi2, zi));
   }
+}
+
+void g1_compress_affine(const fe& x, const fe& y, bool inf, uint8_t out[48]) {
+  if (inf) { memset(out, 0, 48); out[0] = 0xC0; return; }
+  fe_to_be48(x, out);
+  out[0] |= 0x80;
+  if (fe_lex_largest(y)) out[0] |= 0x20;
 }
 
 void g1_compress(const jac& a, uint8_t out[48]) {

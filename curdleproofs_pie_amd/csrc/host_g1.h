@@ -39,6 +39,7 @@ jac jac_generator();
 bool jac_is_identity(const jac& a);
 jac jac_dbl(const jac& a);
 jac jac_add(const jac& a, const jac& b);
+jac jac_madd(const jac& a, const fe& x2, const fe& y2);           // a + (x2, y2), affine operand not the identity
 jac jac_neg(const jac& a);
 bool jac_eq(const jac& a, const jac& b);
 jac jac_mul(const jac& a, const uint8_t scalar_le32[32]);        // any 256-bit scalar (not reduced)
@@ -51,6 +52,7 @@ void jac_batch_to_affine(const jac* pts, size_t n, fe* xs, fe* ys, uint8_t* inf)
 
 // ---- 48-byte compressed encoding (ZCash format)
 void g1_compress(const jac& a, uint8_t out[48]);
+void g1_compress_affine(const fe& x, const fe& y, bool inf, uint8_t out[48]);
 // 0 ok; 1 bad flags; 2 x >= p; 3 not on curve; 4 not in subgroup (only when check_subgroup)
 int g1_decompress(const uint8_t in[48], bool check_subgroup, jac& out);
 

@@ -25,6 +25,28 @@ static_assert(sizeof(Strobe) == CG1_MERLIN_STATE_BYTES, "merlin state blob size"
 
 inline uint64_t rotl(uint64_t v, int n) { return (v << n) | (v >> (64 - n)); }
 
+// Theta, rho+pi and chi with every lane index a compile-time constant (fully unrolled round; the 25 lanes live in
+// registers), two rounds per loop trip.  The host is little-endian, so lanes load/store with memcpy.
+#define CG1_KECCAK_ROUND(A, E, rc)                                                                  \
+  {                                                                                                 \
+    const uint64_t c0 = A[0] ^ A[5] ^ A[10] ^ A[15] ^ A[20], c1 = A[1] ^ A[6] ^ A[11] ^ A[16] ^ A[21],  \
+                   c2 = A[2] ^ A[7] ^ A[12] ^ A[17] ^ A[22], c3 = A[3] ^ A[8] ^ A[13] ^ A[18] ^ A[23],  \
+                   c4 = A[4] ^ A[9] ^ A[14] ^ A[19] ^ A[24];                                        \
+    const uint64_t d0 = c4 ^ rotl(c1, 1), d1 = c0 ^ rotl(c2, 1), d2 = c1 ^ rotl(c3, 1), d3 = c2 ^ rotl(c4, 1), \
+                   d4 = c3 ^ rotl(c0, 1);                                                           \
+    uint64_t b0, b1, b2, b3, b4;                                                                    \
+    b0 = A[0] ^ d0; b1 = rotl(A[6] ^ d1, 44); b2 = rotl(A[12] ^ d2, 43); b3 = rotl(A[18] ^ d3, 21); b4 = rotl(A[24] ^ d4, 14); \
+    E[0] = b0 ^ (~b1 & b2) ^ (rc); E[1] = b1 ^ (~b2 & b3); E[2] = b2 ^ (~b3 & b4); E[3] = b3 ^ (~b4 & b0); E[4] = b4 ^ (~b0 & b1); \
+    b0 = rotl(A[3] ^ d3, 28); b1 = rotl(A[9] ^ d4, 20); b2 = rotl(A[10] ^ d0, 3); b3 = rotl(A[16] ^ d1, 45); b4 = rotl(A[22] ^ d2, 61); \
+    E[5] = b0 ^ (~b1 & b2); E[6] = b1 ^ (~b2 & b3); E[7] = b2 ^ (~b3 & b4); E[8] = b3 ^ (~b4 & b0); E[9] = b4 ^ (~b0 & b1); \
+    b0 = rotl(A[1] ^ d1, 1); b1 = rotl(A[7] ^ d2, 6); b2 = rotl(A[13] ^ d3, 25); b3 = rotl(A[19] ^ d4, 8); b4 = rotl(A[20] ^ d0, 18); \
+    E[10] = b0 ^ (~b1 & b2); E[11] = b1 ^ (~b2 & b3); E[12] = b2 ^ (~b3 & b4); E[13] = b3 ^ (~b4 & b0); E[14] = b4 ^ (~b0 & b1); \
+    b0 = rotl(A[4] ^ d4, 27); b1 = rotl(A[5] ^ d0, 36); b2 = rotl(A[11] ^ d1, 10); b3 = rotl(A[17] ^ d2, 15); b4 = rotl(A[23] ^ d3, 56); \
+    E[15] = b0 ^ (~b1 & b2); E[16] = b1 ^ (~b2 & b3); E[17] = b2 ^ (~b3 & b4); E[18] = b3 ^ (~b4 & b0); E[19] = b4 ^ (~b0 & b1); \
+    b0 = rotl(A[2] ^ d2, 62); b1 = rotl(A[8] ^ d3, 55); b2 = rotl(A[14] ^ d4, 39); b3 = rotl(A[15] ^ d0, 41); b4 = rotl(A[21] ^ d1, 2); \
+    E[20] = b0 ^ (~b1 & b2); E[21] = b1 ^ (~b2 & b3); E[22] = b2 ^ (~b3 & b4); E[23] = b3 ^ (~b4 & b0); E[24] = b4 ^ (~b0 & b1); \
+  }
+
 void keccak_f1600(uint8_t* bytes) {
   static const uint64_t RC[24] = {
       0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
@@ -32,37 +54,15 @@ void keccak_f1600(uint8_t* bytes) {
       0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
       0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
       0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-  static const int ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14, 27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-  static const int PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4, 15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
-  uint64_t a[25];
-  for (int i = 0; i < 25; ++i) {            // lanes are little-endian 64-bit words, lane index x + 5y
-    uint64_t v = 0;
-    for (int j = 7; j >= 0; --j) v = (v << 8) | bytes[8 * i + j];
-    a[i] = v;
+  uint64_t a[25], e[25];
+  memcpy(a, bytes, 200);                    // lanes are little-endian 64-bit words, lane index x + 5y
+  for (int round = 0; round < 24; round += 2) {
+    CG1_KECCAK_ROUND(a, e, RC[round]);
+    CG1_KECCAK_ROUND(e, a, RC[round + 1]);
   }
-  for (int round = 0; round < 24; ++round) {
-    uint64_t c[5];
-    for (int x = 0; x < 5; ++x) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];        // theta
-    for (int x = 0; x < 5; ++x) {
-      uint64_t d = c[(x + 4) % 5] ^ rotl(c[(x + 1) % 5], 1);
-      for (int y = 0; y < 25; y += 5) a[y + x] ^= d;
-    }
-    uint64_t cur = a[1];                                                                        // rho + pi
-    for (int t = 0; t < 24; ++t) {
-      int j = PIL[t];
-      uint64_t tmp = a[j];
-      a[j] = rotl(cur, ROT[t]);
-      cur = tmp;
-    }
-    for (int y = 0; y < 25; y += 5) {                                                           // chi
-      uint64_t r0 = a[y], r1 = a[y + 1], r2 = a[y + 2], r3 = a[y + 3], r4 = a[y + 4];
-      a[y] = r0 ^ (~r1 & r2); a[y + 1] = r1 ^ (~r2 & r3); a[y + 2] = r2 ^ (~r3 & r4);
-      a[y + 3] = r3 ^ (~r4 & r0); a[y + 4] = r4 ^ (~r0 & r1);
-    }
-    a[0] ^= RC[round];                                                                          // iota
-  }
-  for (int i = 0; i < 25; ++i) for (int j = 0; j < 8; ++j) bytes[8 * i + j] = (uint8_t)(a[i] >> (8 * j));
+  memcpy(bytes, a, 200);
 }
+#undef CG1_KECCAK_ROUND
 
 void run_f(Strobe& s) {                              // strobe.py:55-61
   s.st[s.pos] ^= s.pos_begin;
@@ -72,7 +72,15 @@ void run_f(Strobe& s) {                              // strobe.py:55-61
   s.pos = 0; s.pos_begin = 0;
 }
 void absorb(Strobe& s, const uint8_t* d, size_t n) {  // strobe.py:63-68
-  for (size_t i = 0; i < n; ++i) { s.st[s.pos++] ^= d[i]; if (s.pos == STROBE_R) run_f(s); }
+  while (n) {
+    size_t room = (size_t)STROBE_R - s.pos, k = n < room ? n : room;
+    uint8_t* dst = s.st + s.pos;
+    for (size_t i = 0; i < k; ++i) dst[i] ^= d[i];
+    s.pos = (uint8_t)(s.pos + k);
+    d += k;
+    n -= k;
+    if (s.pos == STROBE_R) run_f(s);
+  }
 }
 void overwrite(Strobe& s, const uint8_t* d, size_t n) {   // strobe.py:70-75
   for (size_t i = 0; i < n; ++i) { s.st[s.pos++] = d[i]; if (s.pos == STROBE_R) run_f(s); }

@@ -598,6 +598,15 @@ int cg1_d2h(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return CG1_OK;
 }
+// `rows` records of `width` bytes, `src_pitch` apart on the device, packed `dst_pitch` apart on the host
+int cg1_d2h_2d(cg1_ctx* ctx, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (rows == 0 || width == 0) return CG1_OK;
+  if (width > dst_pitch || width > src_pitch) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpy2D(dst, dst_pitch, src, src_pitch, width, rows, hipMemcpyDeviceToHost));
+  return CG1_OK;
+}
 int cg1_ctx_sync(cg1_ctx* ctx) {
   if (!ctx) return CG1_ERR_HIP;
   HIPCHK(hipSetDevice(ctx->device));

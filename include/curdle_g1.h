@@ -71,6 +71,8 @@ void* cg1_dev_malloc(cg1_ctx* ctx, size_t bytes);                    /* NULL on 
 void cg1_dev_free(cg1_ctx* ctx, void* p);
 int  cg1_h2d(cg1_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  cg1_d2h(cg1_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* strided gather: `rows` records of `width` bytes lying `src_pitch` apart on the device -> `dst_pitch` apart on the host */
+int  cg1_d2h_2d(cg1_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t width, size_t rows);
 int  cg1_ctx_sync(cg1_ctx* ctx);                                     /* hipDeviceSynchronize on the context's GPU */
 int  cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value);   /* "chunk_len" (L0), "seg_m", "profile" */
 
@@ -143,6 +145,56 @@ void cg1_merlin_append_list(uint8_t* state, const uint8_t* label, size_t label_l
 void cg1_merlin_challenge(uint8_t* state, const uint8_t* label, size_t label_len, uint8_t* out, size_t out_len);
 /* get_and_append_challenge: 32 LE bytes of a canonical non-zero Fr element, already re-appended */
 void cg1_merlin_challenge_scalar(uint8_t* state, const uint8_t* label, size_t label_len, uint8_t out32[32]);
+
+/* ---------------- batch verifier front-end of the shuffle argument (host C++) ----------
+ * Stands behind CurdleProofsProof.verify (curdleproofs/curdleproofs/curdleproofs.py:160-246) and its
+ * sub-verifiers same_perm.py:75-121, grand_prod.py:161-218, ipa.py:156-236, same_scalar.py:71-111,
+ * same_msm.py:146-227, on the wire format of WhiskShuffleProof.from_bytes (whisk_interface.py:64-69) and of the
+ * trackers (whisk_interface.py:96-100).  It does NOT verify by itself: it reduces each proof to the statement
+ *        sum_k own_scalars[k] * own_points[k]  +  sum_j crs_scalars[j] * crs_points[j]  ==  identity
+ * which the caller checks with cg1_batch_decompress_device + cg1_msm_device (many proofs merged: add the CRS
+ * scalar vectors) or cg1_msm_batched_device (independently).  Python driver: curdleproofs_pie_amd/shuffle_verifier.py.
+ *
+ * Layouts (ell trackers, n = ell + 4 = 2^lg):
+ *   crs bytes       (ell+9) x 48: vec_G | vec_H(4) | H | G_t | G_u | G_sum | H_sum  = CurdleproofsCrs.to_bytes (crs.py:92-101)
+ *   instance        4*ell x 48:   vec_R | vec_S | vec_T | vec_U (tracker r_G / k_r_G encodings, pre then post)
+ *   proof           cg1_shuffle_proof_bytes(): M | A | cm_T | cm_U | R | S | same_perm | same_scalar | same_msm
+ *   own points      cg1_shuffle_points_per_proof() = 4*ell + 19 + 10*lg encodings: the instance, then the proof's
+ *                   points in wire order; own scalars use the same indexing, crs scalars the crs-bytes indexing
+ *   weights         12 x scalar32 per proof: the random rho of each of the 8 accumulated checks
+ *                   (msm_accumulator.py:43) and of the 4 same-scalar equalities (same_scalar.py:108)
+ *   status          0 = prepared; CG1_SHUFFLE_* = rejected before any group arithmetic (its scalars are zeroed)
+ *   challenges      optional (may be NULL), for parity tests: alpha_p beta_p alpha_g beta_g alpha_ipa beta_ipa
+ *                   alpha_samescalar alpha_samemsm | gamma_ipa[lg] | gamma_samemsm[lg] | vec_a[ell]
+ */
+#define CG1_SHUFFLE_BAD_SCALAR   1   /* an Fr field of the proof is >= r   (Scalar.from_le_bytes raises, util.py:149-153) */
+#define CG1_SHUFFLE_BAD_POINT    2   /* A, cm_T.T_1, cm_U.T_1 or B does not decode (util.py:143-147)                     */
+#define CG1_SHUFFLE_T0_INFINITY  3   /* vec_T[0] is the identity (curdleproofs.py:173-174)                               */
+#define CG1_SHUFFLE_BAD_WEIGHT   4   /* a caller-supplied weight is >= r                                                  */
+typedef struct cg1_shuffle_crs cg1_shuffle_crs;
+cg1_shuffle_crs* cg1_shuffle_crs_create(const uint8_t* crs_bytes, size_t ell, size_t n_blinders);   /* NULL: bad sizes / encoding */
+void   cg1_shuffle_crs_destroy(cg1_shuffle_crs* crs);
+size_t cg1_shuffle_proof_bytes(const cg1_shuffle_crs* crs);
+size_t cg1_shuffle_points_per_proof(const cg1_shuffle_crs* crs);
+size_t cg1_shuffle_crs_points(const cg1_shuffle_crs* crs);
+size_t cg1_shuffle_challenges_per_proof(const cg1_shuffle_crs* crs);
+/* decoded96 (may be NULL): per proof, at decoded96 + i*decoded_stride, the 8 consecutive own points 4*ell+1 .. 4*ell+8
+ * (A T_1 T_2 U_1 U_2 R S B) in affine96 form as cg1_batch_decompress_device produced them (one strided D2H copy).
+ * Of these the verifier needs A, T_1, U_1, B as group elements (A' = A + T_1 + U_1, curdleproofs.py:204; D,
+ * grand_prod.py:186).  NULL: the host decodes those four itself (4 square roots per proof). */
+int cg1_shuffle_prepare(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
+                        const uint8_t* weights, const uint8_t* decoded96, size_t decoded_stride,
+                        uint8_t* out_points48, uint8_t* out_scalars32, uint8_t* out_crs_scalars32,
+                        int32_t* status, uint8_t* out_challenges32, int n_threads /* 0 = all cores */);
+/* just the gather step: every proof's own points (instance, then the proof's points in wire order) */
+int cg1_shuffle_gather_points(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
+                              uint8_t* out_points48);
+/* fold cg1_batch_decompress_device's per-point status bytes (n_proofs x points_per_proof) into status[]: a proof
+ * with an undecodable point becomes CG1_SHUFFLE_BAD_POINT and its scalars are zeroed (BufReader.read_g1, util.py:143-147) */
+int cg1_shuffle_apply_point_status(int32_t* status, const uint8_t* point_status, size_t n_proofs, size_t points_per_proof,
+                                   uint8_t* scalars32, uint8_t* crs_scalars32, size_t ncrs);
+/* out[j] = sum over proofs i with status[i] == 0 (status may be NULL = all) of crs_scalars[i][j]  (mod r) */
+int cg1_shuffle_sum_crs_scalars(const uint8_t* crs_scalars32, const int32_t* status, size_t n_proofs, size_t ncrs, uint8_t* out32);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,87 @@
+"""GPU tests of the batch shuffle verifier: verdicts on the golden proofs (tests/golden/shuffle_vectors.json, verdicts
+recorded from the reference's IsValidWhiskShuffleProof) through the C ABI -- GPU decompression + merged / independent MSMs."""
+import json
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold():
+    with open(os.path.join(ROOT, "tests", "golden", "shuffle_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from curdleproofs_pie_amd import _native as N
+
+    return N.default_context()
+
+
+def _items(case, variants):
+    from test_shuffle_verifier import apply_edits
+
+    return [apply_edits(case, x["edits"]) for x in variants]
+
+
+@pytest.mark.parametrize("mode", ["merged", "independent"])
+def test_golden_verdicts(gold, ctx, mode):
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    for case in gold["cases"]:
+        v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx)
+        got = v.verify_many(_items(case, case["variants"]), mode=mode, rng=random.Random(case["seed"]))
+        want = [x["accepts"] for x in case["variants"]]
+        assert got == want, [(x["name"], g, w, s) for x, g, w, s in zip(case["variants"], got, want, v.last_status) if g != w]
+
+
+def test_all_valid_batch_takes_the_merged_path(gold, ctx):
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    c5, c6 = gold["cases"][4], gold["cases"][5]
+    assert c5["ell"] == c6["ell"] == 124 and c5["crs"] != c6["crs"]
+    for case in (c5, c6):
+        v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx)
+        item = _items(case, [{"edits": []}])[0]
+        got = v.verify_many([item] * 64, rng=random.Random(1))
+        assert got == [True] * 64 and v.last_stats["merged_ok"] is True
+        # one bad proof in the batch: merged check fails, the fallback names exactly that one
+        bad = _items(case, [x for x in case["variants"] if x["name"] == "post_r[1] := other point"])[0]
+        batch = [item] * 20 + [bad] + [item] * 11
+        got = v.verify_many(batch, rng=random.Random(2))
+        assert v.last_stats["merged_ok"] is False
+        assert got == [True] * 20 + [False] + [True] * 11 and v.last_status[20] == 6
+        # a proof rejected before any group arithmetic (non-canonical Fr) does not spoil the merged check of the others
+        early = _items(case, [x for x in case["variants"] if x["name"] == "proof.x_final := r (non-canonical)"])[0]
+        got = v.verify_many([item] * 5 + [early] + [item] * 2, rng=random.Random(3))
+        assert got == [True] * 5 + [False] + [True] * 2 and v.last_stats["merged_ok"] is True and v.last_status[5] == 1
+
+
+def test_cross_crs_proof_is_rejected(gold, ctx):
+    """A valid proof checked against another CRS of the same size must fail (every CRS slot matters)."""
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    c5, c6 = gold["cases"][4], gold["cases"][5]
+    v = ShuffleBatchVerifier(bytes.fromhex(c6["crs"]), ctx)
+    assert v.verify_many(_items(c5, [{"edits": []}]), rng=random.Random(3)) == [False]
+
+
+def test_single_proof_wrapper_and_bad_shapes(gold, ctx):
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier, is_valid_whisk_shuffle_proof
+
+    case = gold["cases"][1]
+    pre, post, proof = _items(case, [{"edits": []}])[0]
+    assert is_valid_whisk_shuffle_proof(bytes.fromhex(case["crs"]), pre, post, proof, ctx) is True
+    assert is_valid_whisk_shuffle_proof(bytes.fromhex(case["crs"]), post, pre, proof, ctx) is False
+    v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx)
+    assert v.verify_many([(pre, post, proof + b"xx"), (pre, post, proof[:-1]), (pre[:-1], post, proof), (pre, post, proof)]) == [True, False, False, True]
+    assert v.verify_many([]) == []
