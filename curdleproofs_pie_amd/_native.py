@@ -69,6 +69,8 @@ cg1_dev_malloc = _proto("cg1_dev_malloc", c_void_p, c_void_p, c_size_t)
 cg1_dev_free = _proto("cg1_dev_free", None, c_void_p, c_void_p)
 cg1_h2d = _proto("cg1_h2d", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
 cg1_d2h = _proto("cg1_d2h", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
+cg1_host_alloc = _proto("cg1_host_alloc", c_void_p, c_void_p, c_size_t)
+cg1_host_free = _proto("cg1_host_free", None, c_void_p, c_void_p)
 cg1_d2h_2d = _proto("cg1_d2h_2d", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t)
 cg1_ctx_sync = _proto("cg1_ctx_sync", c_int, c_void_p)
 cg1_ctx_set_param = _proto("cg1_ctx_set_param", c_int, c_void_p, c_char_p, c_int)
@@ -106,8 +108,9 @@ cg1_shuffle_proof_bytes = _proto("cg1_shuffle_proof_bytes", c_size_t, c_void_p)
 cg1_shuffle_points_per_proof = _proto("cg1_shuffle_points_per_proof", c_size_t, c_void_p)
 cg1_shuffle_crs_points = _proto("cg1_shuffle_crs_points", c_size_t, c_void_p)
 cg1_shuffle_challenges_per_proof = _proto("cg1_shuffle_challenges_per_proof", c_size_t, c_void_p)
-cg1_shuffle_prepare = _proto("cg1_shuffle_prepare", c_int, c_void_p, c_size_t, _u8p, _u8p, _u8p, _buf, c_size_t, _buf, _buf, _buf, _buf, _buf, c_int)
-cg1_shuffle_gather_points = _proto("cg1_shuffle_gather_points", c_int, c_void_p, c_size_t, _u8p, _u8p, _buf)
+# (all pointer arguments c_void_p: bytes objects, ctypes buffers and raw addresses -- sub-ranges of a batch -- are accepted)
+cg1_shuffle_prepare = _proto("cg1_shuffle_prepare", c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int)
+cg1_shuffle_gather_points = _proto("cg1_shuffle_gather_points", c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p)
 cg1_shuffle_apply_point_status = _proto("cg1_shuffle_apply_point_status", c_int, _buf, _u8p, c_size_t, c_size_t, _buf, _buf, c_size_t)
 cg1_shuffle_sum_crs_scalars = _proto("cg1_shuffle_sum_crs_scalars", c_int, _buf, _buf, c_size_t, c_size_t, _buf)
 
@@ -119,9 +122,33 @@ EXPORTED_SYMBOLS = [
     "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
-    "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_ctx_sync", "cg1_ctx_set_param",
+    "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_host_alloc", "cg1_host_free", "cg1_ctx_sync", "cg1_ctx_set_param",
     "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
+
+
+class PinnedBuffer:
+    """Page-locked host memory owned by a Context; `.buf` is a ctypes char array over it (pass it to native calls)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        self.ptr = cg1_host_alloc(ctx.handle, max(1, self.nbytes))
+        if not self.ptr:
+            raise NativeError(f"hipHostMalloc of {nbytes} bytes failed")
+        self.buf = (ctypes.c_char * max(1, self.nbytes)).from_address(self.ptr)
+
+    def free(self) -> None:
+        if self.ptr and self.ctx.handle:
+            self.buf = None
+            cg1_host_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

@@ -598,6 +598,19 @@ int cg1_d2h(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
   return CG1_OK;
 }
+// page-locked host memory: H2D/D2H copies from it run at full PCIe rate (pageable memory is staged by the runtime)
+void* cg1_host_alloc(cg1_ctx* ctx, size_t bytes) {
+  if (!ctx) return nullptr;
+  void* p = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+  return p;
+}
+void cg1_host_free(cg1_ctx* ctx, void* p) {
+  if (!ctx || !p) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipHostFree(p);
+}
 // `rows` records of `width` bytes, `src_pitch` apart on the device, packed `dst_pitch` apart on the host
 int cg1_d2h_2d(cg1_ctx* ctx, void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t width, size_t rows) {
   if (!ctx) return CG1_ERR_HIP;

@@ -21,9 +21,14 @@
 //     regime-B MSMs when a batch fails and the culprit must be found).
 // Point decompression of everything but {A, T_1, U_1, B} and the MSM itself run on the GPU
 // (cg1_batch_decompress_device, cg1_msm_device / cg1_msm_batched_device); this file is host logic only.
+#include <sched.h>
+
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -178,6 +183,68 @@ void fold_scalars(const std::vector<fr>& gamma, std::vector<fr>& s) {
     s.swap(nx);
   }
 }
+
+// Persistent worker pool (spawning a thread per core per call costs more than a sub-batch of proofs).  Leaked on
+// purpose: its threads sleep on a condition variable until the process exits.
+class Pool {
+ public:
+  static Pool& get() {
+    static Pool* p = new Pool;
+    return *p;
+  }
+  size_t size() const { return threads_.size(); }
+  // run `job` on `nt` of the pool's threads (the caller's thread also takes part) and wait for all of them
+  void run(const std::function<void()>& job, size_t nt) {
+    std::lock_guard<std::mutex> serial(run_mutex_);
+    if (nt > threads_.size() + 1) nt = threads_.size() + 1;
+    {
+      std::lock_guard<std::mutex> lk(m_);
+      job_ = &job;
+      want_ = nt - 1;
+      pending_ = nt - 1;
+      ++generation_;
+    }
+    cv_work_.notify_all();
+    job();
+    std::unique_lock<std::mutex> lk(m_);
+    cv_done_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  Pool() {
+    size_t n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (size_t)CPU_COUNT(&set);
+    if (n == 0) n = std::thread::hardware_concurrency();
+    if (n == 0) n = 1;
+    if (n > 128) n = 128;
+    for (size_t i = 0; i + 1 < n; ++i) threads_.emplace_back([this, i] { loop(i); });
+    for (auto& t : threads_) t.detach();
+  }
+  void loop(size_t index) {
+    size_t seen = 0;
+    for (;;) {
+      const std::function<void()>* job = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_work_.wait(lk, [&] { return generation_ != seen; });
+        seen = generation_;
+        if (index < want_) job = job_;
+      }
+      if (job) {
+        (*job)();
+        std::lock_guard<std::mutex> lk(m_);
+        if (--pending_ == 0) cv_done_.notify_all();
+      }
+    }
+  }
+  std::vector<std::thread> threads_;
+  std::mutex m_, run_mutex_;
+  std::condition_variable cv_work_, cv_done_;
+  const std::function<void()>* job_ = nullptr;
+  size_t want_ = 0, pending_ = 0, generation_ = 0;
+};
 
 // One proof.  Returns 0 (prepared) or a CG1_SHUFFLE_* reject code.
 int prepare_one(const Crs& crs, const uint8_t* inst /* 4*ell*48 */, const uint8_t* proof, const uint8_t* weights /* 12*32 */,
@@ -476,15 +543,13 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint
       status[i] = rc;
     }
   };
-  size_t nt = n_threads > 0 ? (size_t)n_threads : std::thread::hardware_concurrency();
-  if (nt < 1) nt = 1;
-  if (nt > n_proofs) nt = n_proofs;
-  if (nt <= 1) {
+  if (n_threads == 1 || n_proofs <= 1) {
     work();
   } else {
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; ++t) th.emplace_back(work);
-    for (auto& t : th) t.join();
+    Pool& pool = Pool::get();
+    size_t nt = n_threads > 0 ? (size_t)n_threads : pool.size() + 1;
+    if (nt > n_proofs) nt = n_proofs;
+    pool.run(work, nt);
   }
   return CG1_OK;
 }

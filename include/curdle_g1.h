@@ -71,6 +71,9 @@ void* cg1_dev_malloc(cg1_ctx* ctx, size_t bytes);                    /* NULL on 
 void cg1_dev_free(cg1_ctx* ctx, void* p);
 int  cg1_h2d(cg1_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  cg1_d2h(cg1_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* page-locked host memory for staging buffers (copies from it run at full PCIe rate); NULL on failure */
+void* cg1_host_alloc(cg1_ctx* ctx, size_t bytes);
+void cg1_host_free(cg1_ctx* ctx, void* p);
 /* strided gather: `rows` records of `width` bytes lying `src_pitch` apart on the device -> `dst_pitch` apart on the host */
 int  cg1_d2h_2d(cg1_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t width, size_t rows);
 int  cg1_ctx_sync(cg1_ctx* ctx);                                     /* hipDeviceSynchronize on the context's GPU */

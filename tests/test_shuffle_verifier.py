@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 from curdleproofs_pie_amd import _native as N  # noqa: E402
 from curdleproofs_pie_amd.shuffle_verifier import REJECT_LENGTH, ShuffleBatchVerifier, ShuffleCrs  # noqa: E402
-from oracle import c_oracle  # noqa: E402
+from oracle.shuffle_check import host_decompress_affine, oracle_verdicts  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden", "shuffle_vectors.json")
 REF = "/root/reference/curdleproofs"
@@ -44,42 +44,6 @@ def apply_edits(case, edits):
     pre = trackers(bufs["pre_r"].hex(), bufs["pre_k"].hex())
     post = trackers(bufs["post_r"].hex(), bufs["post_k"].hex())
     return pre, post, bytes(bufs["proof"])
-
-
-def host_decompress_affine(data48: bytes, n: int):
-    """-> (affine96 bytes, per-point ok flags) with the host codec (cg1_decompress, unchecked)."""
-    out, ok = [], []
-    blob = ctypes.create_string_buffer(N.POINT_BYTES)
-    aff = ctypes.create_string_buffer(96)
-    for i in range(n):
-        rc = N.cg1_decompress(blob, data48[48 * i: 48 * i + 48], 0)
-        ok.append(rc == 0)
-        if rc == 0:
-            N.cg1_to_affine96(aff, blob.raw)
-            out.append(aff.raw)
-        else:
-            out.append(bytes(96))
-    return b"".join(out), ok
-
-
-def oracle_verdicts(v: ShuffleBatchVerifier, prep):
-    """Evaluate each proof's statement  sum own + sum crs == identity  with the CPU oracle."""
-    crs = v.crs
-    L, C = crs.points_per_proof, crs.ncrs
-    res = []
-    for i in range(prep.n):
-        if prep.status[i]:
-            res.append(False)
-            continue
-        pts, ok = host_decompress_affine(prep.points48.raw[i * L * 48: (i + 1) * L * 48], L)
-        if not all(ok):
-            res.append(False)
-            continue
-        points = pts + crs.affine96
-        scalars = prep.scalars32.raw[i * L * 32: (i + 1) * L * 32] + prep.crs_scalars32.raw[i * C * 32: (i + 1) * C * 32]
-        total = c_oracle.msm_bucket(points, scalars, L + C)
-        res.append(total == bytes(96))
-    return res
 
 
 def test_layout_sizes(gold):

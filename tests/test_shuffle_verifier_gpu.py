@@ -66,6 +66,19 @@ def test_all_valid_batch_takes_the_merged_path(gold, ctx):
         assert got == [True] * 5 + [False] + [True] * 2 and v.last_stats["merged_ok"] is True and v.last_status[5] == 1
 
 
+def test_pipelined_sub_batches_agree(gold, ctx):
+    """chunk < batch: GPU decompression of sub-batch k+1 overlaps the host front-end of sub-batch k; same verdicts."""
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    case = gold["cases"][3]
+    items = _items(case, case["variants"]) * 3
+    want = [x["accepts"] for x in case["variants"]] * 3
+    for chunk in (5, 16, 1000):
+        v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx, chunk=chunk)
+        assert v.verify_many(items, rng=random.Random(chunk)) == want
+        assert v.last_stats["pipelined"] == (chunk < len(items))
+
+
 def test_cross_crs_proof_is_rejected(gold, ctx):
     """A valid proof checked against another CRS of the same size must fail (every CRS slot matters)."""
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier

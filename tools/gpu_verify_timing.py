@@ -21,16 +21,21 @@ print("host cores:", os.cpu_count(), flush=True)
 for threads in (1, 0):
     v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx, threads=threads)
     item = apply_edits(case, [])
-    for n in (64, 1024):
+    for n in (64, 1024, 4096):
+        inst, proofs, _ = v.pack([item] * n)
         for mode in ("merged", "independent"):
-            best = None
-            for rep in range(3):
-                t0 = time.perf_counter()
-                ok = v.verify_many([item] * n, mode=mode)
-                dt = time.perf_counter() - t0
-                assert all(ok)
-                if best is None or dt < best[0]:
-                    best = (dt, dict(v.last_stats))
-            st = best[1]
-            print(f"threads={threads or 'all'} n={n} {mode}: {best[0]*1e3:.1f} ms -> {n/best[0]:.0f} proofs/s | " +
-                  " ".join(f"{k}={1e3*x:.1f}ms" for k, x in st.items() if k.endswith('_s')), flush=True)
+            for api in ("packed", "objects"):
+                best = None
+                for rep in range(3):
+                    t0 = time.perf_counter()
+                    if api == "packed":
+                        ok = [s == 0 for s in v.verify_packed(inst, proofs, n, mode=mode)]
+                    else:
+                        ok = v.verify_many([item] * n, mode=mode)
+                    dt = time.perf_counter() - t0
+                    assert all(ok)
+                    if best is None or dt < best[0]:
+                        best = (dt, dict(v.last_stats))
+                st = best[1]
+                print(f"threads={threads or 'all'} n={n} {mode} {api}: {best[0]*1e3:.1f} ms -> {n/best[0]:.0f} proofs/s | " +
+                      " ".join(f"{k}={1e3*x:.1f}ms" for k, x in st.items() if k.endswith('_s')), flush=True)
