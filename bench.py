@@ -58,8 +58,6 @@ def side_mode(args):
     ctx = N.Context(0)
     d_g = ctx.alloc(96)
     d_g.upload(raw96_gen())
-    if args.mode == "verify":
-        return verify_mode(args, ctx)
     if args.mode == "batched":
         M, n = 1024, 627                       # 5*ell + 7 at ell = 124 (Whisk N = 128), SURVEY 3.2
         tot = M * n
@@ -93,50 +91,84 @@ def side_mode(args):
                           "ms_per_step": el / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup}))
 
 
-def verify_mode(args, ctx):
-    """BASELINE config 3: Whisk shuffle verification (ell = 124 + 4 blinders = 128), a batch of 1024 proofs per step,
-    from wire bytes in host memory to verdicts.  Proofs are the golden fixtures cycled (tests/golden/shuffle_vectors.json:
-    made by the reference prover; no prover runs on the GPU box); every slot draws its own random weights."""
+def verify_mode(args, rank, local_rank, world):
+    """BASELINE config 3 (N = 1) / config 5's structure (N > 1, proof-per-GPU): Whisk shuffle verification
+    (ell = 124 + 4 blinders = 128), `--batch` proofs per GPU per step, from wire bytes in host memory to verdicts.
+    Proofs are the golden fixture cycled (tests/golden/shuffle_vectors.json: made by the reference prover; no prover
+    runs on the GPU box); every slot draws its own random weights.  Ranks share the host's cores evenly."""
+    from curdleproofs_pie_amd import _native as N
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
 
+    dist = torch = None
+    dev_index = 0 if args.same_device else local_rank
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
+    ctx = N.Context(dev_index)
+    cores = int(N.cg1_shuffle_default_threads())         # usable CPUs (affinity mask capped by the cgroup quota)
+    threads = max(1, cores // world)
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "tests", "golden", "shuffle_vectors.json")) as f:
         case = [c for c in json.load(f)["cases"] if c["ell"] == 124][0]
-    v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx)
+    v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx, threads=threads)
     n = args.batch
     inst1 = bytes.fromhex(case["pre_r"] + case["pre_k"] + case["post_r"] + case["post_k"])
     proof1 = bytes.fromhex(case["proof"])
     inst, proofs = inst1 * n, proof1 * n
+
+    def barrier_sync():
+        if world > 1:
+            dist.barrier()
+            if args.backend == "nccl":
+                torch.cuda.synchronize()
+        ctx.sync()
+
     for _ in range(args.warmup):
         assert not any(v.verify_packed(inst, proofs, n, mode=args.verify_mode))
     acc = {}
+    barrier_sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st = v.verify_packed(inst, proofs, n, mode=args.verify_mode)
         for k, x in v.last_stats.items():
             if k.endswith("_s"):
                 acc[k] = acc.get(k, 0.0) + x
+    barrier_sync()
     el = time.perf_counter() - t0
     assert not any(st)
-    # CPU port beside it: the same front-end on ONE core + the statement's MSM by the CPU oracle (bucket method)
-    from oracle.shuffle_check import oracle_verdicts
-    v1 = ShuffleBatchVerifier(v.crs, ctx, threads=1)
-    m = 4
-    t1 = time.perf_counter()
-    prep = v1.prepare(inst1 * m, proof1 * m, m)
-    assert oracle_verdicts(v1, prep) == [True] * m
-    cpu_dt = (time.perf_counter() - t1) / m
-    print(json.dumps({
-        "metric": "shuffle proofs verified/sec (Whisk ell=124+4 blinders, batch of %d per step, mode %s)" % (n, args.verify_mode),
-        "value": n * args.steps / el, "unit": "proofs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-        "data": "reference-prover fixture cycled, fresh random weights per slot; inputs are wire bytes in host memory (H2D included)",
-        "config": {"workload": "whisk_shuffle_verify ell=124 batch=%d" % n, "points_per_step": v.last_stats.get("points")},
-        "host_threads": os.cpu_count(), "phases_ms_per_step": {k[:-2]: 1e3 * x / args.steps for k, x in acc.items()},
-        "cpu_baseline": {"value": 1.0 / cpu_dt, "unit": "proofs/s", "cores": 1, "kind": "port",
-                         "sample": "%d proofs: native front-end on one core + CPU-oracle bucket MSM of the 726-term statement "
-                                   "(the reference's own Python verifier over our host C++ backend measured 0.27 s/proof in the "
-                                   "build container; it cannot run on the GPU box)" % m}}))
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank == 0:
+        # CPU port beside it: the same front-end on ONE core + the statement's MSM by the CPU oracle (bucket method)
+        from oracle.shuffle_check import oracle_verdicts
+        v1 = ShuffleBatchVerifier(v.crs, ctx, threads=1)
+        m = 4
+        t1 = time.perf_counter()
+        prep = v1.prepare(inst1 * m, proof1 * m, m)
+        assert oracle_verdicts(v1, prep) == [True] * m
+        cpu_dt = (time.perf_counter() - t1) / m
+        print(json.dumps({
+            "metric": "shuffle proofs verified/sec (Whisk ell=124+4 blinders, batch of %d per GPU per step, mode %s)" % (n, args.verify_mode),
+            "value": world * n * args.steps / el, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "reference-prover fixture cycled, fresh random weights per slot; inputs are wire bytes in host memory (H2D included)",
+            "config": {"workload": "whisk_shuffle_verify ell=124 batch=%d per GPU" % n, "points_per_step_per_gpu": v.last_stats.get("points"),
+                       "parallelism": "proof-per-GPU x%d, no data-path collective" % world},
+            "host_threads_per_rank": threads, "phases_ms_per_step_rank0": {k[:-2]: 1e3 * x / args.steps for k, x in acc.items()},
+            "cpu_baseline": {"value": 1.0 / cpu_dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+                             "sample": "%d proofs: native front-end on one core + CPU-oracle bucket MSM of the 726-term statement "
+                                       "(the reference's own Python verifier over our host C++ backend measured 0.27 s/proof in the "
+                                       "build container; it cannot run on the GPU box)" % m}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -174,6 +206,8 @@ def main():
 
     dist = None
     torch = None
+    if args.mode == "verify":
+        return verify_mode(args, rank, local_rank, world)
     if args.mode != "msm":
         return side_mode(args)
     dev_index = 0 if args.same_device else local_rank

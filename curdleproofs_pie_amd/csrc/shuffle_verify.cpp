@@ -26,6 +26,8 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -212,13 +214,33 @@ class Pool {
   }
 
  private:
-  Pool() {
+  // CPUs this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one (a
+  // container that sees 256 cores but owns 16 cores' worth of quota gets throttled, not faster, with 256 threads)
+  static size_t usable_cpus() {
     size_t n = 0;
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) n = (size_t)CPU_COUNT(&set);
     if (n == 0) n = std::thread::hardware_concurrency();
     if (n == 0) n = 1;
-    if (n > 128) n = 128;
+    long long quota = -1, period = 0;
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                         // cgroup v2: "<quota|max> <period>"
+      char q[32] = {0};
+      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+      fclose(f);
+    } else {
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+    }
+    if (quota > 0 && period > 0) {
+      size_t q = (size_t)((quota + period - 1) / period);
+      if (q >= 1 && q < n) n = q;
+    }
+    return n;
+  }
+  Pool() {
+    size_t n = usable_cpus();
+    if (const char* e = getenv("CURDLE_G1_THREADS")) { long v = atol(e); if (v >= 1) n = (size_t)v; }
+    if (n > 256) n = 256;
     for (size_t i = 0; i + 1 < n; ++i) threads_.emplace_back([this, i] { loop(i); });
     for (auto& t : threads_) t.detach();
   }
@@ -516,6 +538,10 @@ size_t cg1_shuffle_challenges_per_proof(const cg1_shuffle_crs* crs) {
   const Crs* c = reinterpret_cast<const Crs*>(crs);
   return 8 + 2 * c->lg + c->ell;
 }
+
+// worker threads cg1_shuffle_prepare uses with n_threads = 0 (usable CPUs: affinity mask capped by the cgroup CPU quota;
+// CURDLE_G1_THREADS overrides)
+size_t cg1_shuffle_default_threads(void) { return Pool::get().size() + 1; }
 
 int cg1_shuffle_prepare(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
                         const uint8_t* weights, const uint8_t* decoded96, size_t decoded_stride, uint8_t* out_points48, uint8_t* out_scalars32, uint8_t* out_crs_scalars32,

@@ -114,3 +114,42 @@ def sharded_msm_batch(jobs_affine, rank: int, world: int, group=None, compute=No
         for i, b in zip(idxs, blobs):
             out[i] = b
     return out
+
+
+def sharded_verify(verifier, instances: bytes, proofs: bytes, n: int, rank: int, world: int, group=None, mode: str = "merged",
+                   verify=None) -> List[int]:
+    """BASELINE config 5 (16 384 Whisk shuffle verifications over 8 GPUs): proof-per-GPU sharding.  Rank g verifies the
+    contiguous slice [g*n/world, (g+1)*n/world) of the packed batch with its own `ShuffleBatchVerifier` (one merged MSM
+    per rank); the per-proof status codes (0 = valid) are all-gathered so every rank returns the full list.
+    No data-path collective: the only exchange is that gather of one small integer per proof.
+
+    verify: callable(instances_slice, proofs_slice, m) -> list of m status ints; defaults to verifier.verify_packed
+            (the parameter exists so the gloo tests can exercise the slicing / gather logic on a CPU-only box).
+    """
+    crs = verifier.crs
+    inst_b, proof_b = 4 * crs.ell * 48, crs.proof_bytes
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world
+    if verify is None:
+        verify = lambda a, b, m: verifier.verify_packed(a, b, m, mode=mode)
+    mine = list(verify(instances[lo * inst_b: hi * inst_b], proofs[lo * proof_b: hi * proof_b], hi - lo)) if hi > lo else []
+    assert len(mine) == hi - lo
+    import torch.distributed as dist
+
+    if world == 1 or not dist.is_initialized():
+        return mine
+    import torch
+
+    # fixed-size tensor gather (n/world differs by at most one between ranks: pad to the maximum)
+    width = (n + world - 1) // world
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    local = torch.full((width,), -1, dtype=torch.int32, device=dev)
+    if mine:
+        local[: len(mine)] = torch.tensor(mine, dtype=torch.int32, device=dev)
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local, group=group)
+    out: List[int] = []
+    for g, t in enumerate(gathered):
+        cnt = (n * (g + 1)) // world - (n * g) // world
+        out.extend(int(x) for x in t[:cnt].cpu().tolist())
+    return out

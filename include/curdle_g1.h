@@ -189,6 +189,8 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8
                         const uint8_t* weights, const uint8_t* decoded96, size_t decoded_stride,
                         uint8_t* out_points48, uint8_t* out_scalars32, uint8_t* out_crs_scalars32,
                         int32_t* status, uint8_t* out_challenges32, int n_threads /* 0 = all cores */);
+/* threads used when n_threads = 0: usable CPUs (affinity mask capped by the cgroup CPU quota; env CURDLE_G1_THREADS overrides) */
+size_t cg1_shuffle_default_threads(void);
 /* just the gather step: every proof's own points (instance, then the proof's points in wire order) */
 int cg1_shuffle_gather_points(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
                               uint8_t* out_points48);

@@ -141,3 +141,54 @@ def test_two_rank_job_sharding(native_lib):
     (_, r0, truth), (_, r1, _) = got
     assert r0 == r1
     assert r0 == [O.g1_compress(O.g1_mul(O.G1_GEN, t % O.R)).hex() for t in truth]
+
+
+def _worker_verify(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import json
+    import random
+
+    import torch.distributed as dist
+
+    from curdleproofs_pie_amd.distributed import sharded_verify
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+    from oracle.shuffle_check import oracle_verdicts
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    with open(os.path.join(ROOT, "tests", "golden", "shuffle_vectors.json")) as f:
+        case = json.load(f)["cases"][1]
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_shuffle_verifier import apply_edits
+
+    variants = case["variants"][:3] + case["variants"][-4:]            # 7 proofs over 2 ranks: uneven slices (3 + 4)
+    v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), threads=2)
+    inst, proofs, _ = v.pack([apply_edits(case, x["edits"]) for x in variants])
+
+    def host_verify(a, b, m):          # CPU stand-in for the GPU half (test only): front-end + CPU-oracle MSM
+        prep = v.prepare(a, b, m, rng=random.Random(5 + rank))
+        return [0 if ok else 6 for ok in oracle_verdicts(v, prep)]
+
+    status = sharded_verify(v, inst, proofs, len(variants), rank, world, verify=host_verify)
+    q.put((rank, status, [x["accepts"] for x in variants]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_proof_sharding(native_lib):
+    """BASELINE config 5's structure: proofs sharded per rank, verdicts all-gathered (gloo; CPU stand-in for the GPU half)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_verify, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, s0, want), (_, s1, _) = got
+    assert s0 == s1 and len(s0) == len(want)
+    assert [s == 0 for s in s0] == want
