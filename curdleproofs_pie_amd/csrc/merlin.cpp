@@ -64,6 +64,56 @@ void keccak_f1600(uint8_t* bytes) {
 }
 #undef CG1_KECCAK_ROUND
 
+// ---- eight permutations at once: lane w of state k at a[w][k] (SoA), one 512-bit vector per lane index.
+// Written with compiler vector extensions; the same body is compiled twice -- for AVX-512 (vprolq / vpternlogq,
+// selected at run time) and for the baseline ISA.  Used by the batch front-end, which advances many independent
+// transcripts in step (csrc/shuffle_verify.cpp).
+typedef uint64_t v8u64 __attribute__((vector_size(64), aligned(8)));
+static inline __attribute__((always_inline)) v8u64 vrotl(v8u64 v, int n) { return (v << n) | (v >> (64 - n)); }
+
+#define CG1_KECCAK_ROUND_V(A, E, rc)                                                                \
+  {                                                                                                 \
+    const v8u64 c0 = A[0] ^ A[5] ^ A[10] ^ A[15] ^ A[20], c1 = A[1] ^ A[6] ^ A[11] ^ A[16] ^ A[21],    \
+                c2 = A[2] ^ A[7] ^ A[12] ^ A[17] ^ A[22], c3 = A[3] ^ A[8] ^ A[13] ^ A[18] ^ A[23],    \
+                c4 = A[4] ^ A[9] ^ A[14] ^ A[19] ^ A[24];                                           \
+    const v8u64 d0 = c4 ^ vrotl(c1, 1), d1 = c0 ^ vrotl(c2, 1), d2 = c1 ^ vrotl(c3, 1), d3 = c2 ^ vrotl(c4, 1), \
+                d4 = c3 ^ vrotl(c0, 1);                                                             \
+    v8u64 b0, b1, b2, b3, b4;                                                                       \
+    b0 = A[0] ^ d0; b1 = vrotl(A[6] ^ d1, 44); b2 = vrotl(A[12] ^ d2, 43); b3 = vrotl(A[18] ^ d3, 21); b4 = vrotl(A[24] ^ d4, 14); \
+    E[0] = b0 ^ (~b1 & b2) ^ (rc); E[1] = b1 ^ (~b2 & b3); E[2] = b2 ^ (~b3 & b4); E[3] = b3 ^ (~b4 & b0); E[4] = b4 ^ (~b0 & b1); \
+    b0 = vrotl(A[3] ^ d3, 28); b1 = vrotl(A[9] ^ d4, 20); b2 = vrotl(A[10] ^ d0, 3); b3 = vrotl(A[16] ^ d1, 45); b4 = vrotl(A[22] ^ d2, 61); \
+    E[5] = b0 ^ (~b1 & b2); E[6] = b1 ^ (~b2 & b3); E[7] = b2 ^ (~b3 & b4); E[8] = b3 ^ (~b4 & b0); E[9] = b4 ^ (~b0 & b1); \
+    b0 = vrotl(A[1] ^ d1, 1); b1 = vrotl(A[7] ^ d2, 6); b2 = vrotl(A[13] ^ d3, 25); b3 = vrotl(A[19] ^ d4, 8); b4 = vrotl(A[20] ^ d0, 18); \
+    E[10] = b0 ^ (~b1 & b2); E[11] = b1 ^ (~b2 & b3); E[12] = b2 ^ (~b3 & b4); E[13] = b3 ^ (~b4 & b0); E[14] = b4 ^ (~b0 & b1); \
+    b0 = vrotl(A[4] ^ d4, 27); b1 = vrotl(A[5] ^ d0, 36); b2 = vrotl(A[11] ^ d1, 10); b3 = vrotl(A[17] ^ d2, 15); b4 = vrotl(A[23] ^ d3, 56); \
+    E[15] = b0 ^ (~b1 & b2); E[16] = b1 ^ (~b2 & b3); E[17] = b2 ^ (~b3 & b4); E[18] = b3 ^ (~b4 & b0); E[19] = b4 ^ (~b0 & b1); \
+    b0 = vrotl(A[2] ^ d2, 62); b1 = vrotl(A[8] ^ d3, 55); b2 = vrotl(A[14] ^ d4, 39); b3 = vrotl(A[15] ^ d0, 41); b4 = vrotl(A[21] ^ d1, 2); \
+    E[20] = b0 ^ (~b1 & b2); E[21] = b1 ^ (~b2 & b3); E[22] = b2 ^ (~b3 & b4); E[23] = b3 ^ (~b4 & b0); E[24] = b4 ^ (~b0 & b1); \
+  }
+
+static inline __attribute__((always_inline)) void keccak_x8_body(uint64_t* lanes) {
+  static const uint64_t RC[24] = {
+      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+      0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+      0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+      0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  v8u64 a[25], e[25];
+  for (int i = 0; i < 25; ++i) memcpy(&a[i], lanes + 8 * i, 64);
+  for (int round = 0; round < 24; round += 2) {
+    const v8u64 r0 = {RC[round], RC[round], RC[round], RC[round], RC[round], RC[round], RC[round], RC[round]};
+    const uint64_t q = RC[round + 1];
+    const v8u64 r1 = {q, q, q, q, q, q, q, q};
+    CG1_KECCAK_ROUND_V(a, e, r0);
+    CG1_KECCAK_ROUND_V(e, a, r1);
+  }
+  for (int i = 0; i < 25; ++i) memcpy(lanes + 8 * i, &a[i], 64);
+}
+#undef CG1_KECCAK_ROUND_V
+
+__attribute__((target("avx512f,avx512vl,avx512dq,avx512bw"))) void keccak_x8_avx512(uint64_t* lanes) { keccak_x8_body(lanes); }
+void keccak_x8_generic(uint64_t* lanes) { keccak_x8_body(lanes); }
+
 void run_f(Strobe& s) {                              // strobe.py:55-61
   s.st[s.pos] ^= s.pos_begin;
   s.st[s.pos + 1] ^= 0x04;
@@ -117,6 +167,14 @@ bool fr_canonical_nonzero(const uint8_t b[32]) {
 }  // namespace
 
 extern "C" {
+
+// eight Keccak-f[1600] permutations; lanes[25][8]: lane w of state k at lanes[8*w + k]
+void cg1_keccak_f1600_x8(uint64_t* lanes) {
+  static const bool have512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
+  if (have512) keccak_x8_avx512(lanes); else keccak_x8_generic(lanes);
+}
+// one permutation of a 200-byte state (exported for tests / microbenchmarks)
+void cg1_keccak_f1600(uint8_t* state200) { keccak_f1600(state200); }
 
 // Strobe128.new(protocol_label)   strobe.py:23-36
 void cg1_strobe_new(uint8_t* state, const uint8_t* label, size_t len) {

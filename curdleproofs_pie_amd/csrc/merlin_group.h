@@ -1,0 +1,187 @@
+// G independent Merlin transcripts advanced IN STEP, their Keccak-f[1600] permutations batched eight at a time
+// (cg1_keccak_f1600_x8: one 512-bit vector per sponge lane).  Used by the batch shuffle-verifier front-end
+// (csrc/shuffle_verify.cpp): all proofs of a batch run the same sequence of transcript operations
+// (curdleproofs.py:176-180, same_perm.py:91-95, grand_prod.py:175-183, ipa.py:170-176,204-212, same_scalar.py:82-99,
+// same_msm.py:164-172,194-204), so the operation is common and only the sponge positions differ -- a transcript
+// needs a permutation where its own position wraps (strobe.py:63-68) or where an operation forces one
+// (strobe.py:103-105), and the rejection sampling of challenges (curdleproofs_transcript.py:15-25) repeats per
+// transcript.  Each operation is therefore a tiny program (header bytes, label, length, data, squeeze, check) that
+// every transcript executes until it needs a permutation; the pending ones are permuted together, then resumed.
+// Same bytes in, same bytes out as csrc/merlin.cpp's single-transcript functions (tests/test_merlin.py).
+#pragma once
+#include <cstdint>
+#include <cstring>
+
+#include "../../include/curdle_g1.h"
+
+namespace cg1m {
+
+constexpr int G = 16;                              // transcripts per group (two x8 permutation batches)
+constexpr int STROBE_R = 166;                      // strobe.py:4
+constexpr uint8_t FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_M = 16;
+
+struct Group {
+  alignas(64) uint64_t st[25][G];                  // sponge lane w of transcript k
+  uint8_t pos[G], pos_begin[G];
+  int count = 0;                                   // transcripts in use (<= G)
+
+  // MerlinTranscript(label) for `n` transcripts (merlin_transcript.py:6-9): identical so far, computed once
+  void init(const char* label, int n) {
+    uint8_t one[CG1_MERLIN_STATE_BYTES];
+    cg1_merlin_init(one, reinterpret_cast<const uint8_t*>(label), strlen(label));
+    count = n;
+    for (int w = 0; w < 25; ++w) {
+      uint64_t v;
+      memcpy(&v, one + 8 * w, 8);
+      for (int k = 0; k < G; ++k) st[w][k] = v;
+    }
+    for (int k = 0; k < G; ++k) { pos[k] = one[200]; pos_begin[k] = one[201]; }
+  }
+
+  // append_message(label, data[k]) on every transcript (merlin_transcript.py:11-15)
+  void append(const char* label, const uint8_t* const* data, uint32_t len) { run(label, data, nullptr, len, false); }
+  // the same message on every transcript
+  void append_same(const char* label, const uint8_t* data, uint32_t len) {
+    const uint8_t* p[G];
+    for (int k = 0; k < G; ++k) p[k] = data;
+    run(label, p, nullptr, len, false);
+  }
+  // get_and_append_challenge(label) on every transcript: out[k] = 32 LE bytes of a canonical non-zero Fr element
+  void challenge_scalar(const char* label, uint8_t (*out)[32]) { run(label, nullptr, out, 32, true); }
+
+ private:
+  uint8_t& byte_at(int k, unsigned p) { return reinterpret_cast<uint8_t*>(&st[p >> 3][k])[p & 7]; }
+
+  // strobe.py:55-61 up to (not including) the permutation itself
+  void pad(int k) {
+    byte_at(k, pos[k]) ^= pos_begin[k];
+    byte_at(k, pos[k] + 1u) ^= 0x04;
+    byte_at(k, STROBE_R + 1) ^= 0x80;
+  }
+  static bool fr_canonical_nonzero(const uint8_t b[32]) {
+    static const uint64_t R[4] = {0xffffffff00000001ull, 0x53bda402fffe5bfeull, 0x3339d80809a1d805ull, 0x73eda753299d7d48ull};
+    uint64_t w[4];
+    memcpy(w, b, 32);
+    if (!(w[0] | w[1] | w[2] | w[3])) return false;
+    for (int i = 3; i >= 0; --i)
+      if (w[i] != R[i]) return w[i] < R[i];
+    return false;
+  }
+
+  // One operation = one or two byte strings per transcript, absorbed a sponge lane at a time:
+  //   append:     [old pos_begin, M|A] label len32 [old pos_begin, A] data                       (strobe.py:89-101, 63-68)
+  //   challenge:  [.., M|A] label len32 [.., I|A|C] -> forced permutation -> squeeze 32 -> check;  retry from the start,
+  //               or, accepted:  [.., M|A] label len32 [.., A] out32
+  // The first byte of each 2-byte header is the transcript's pos_begin AT THAT MOMENT, so it is patched in when the
+  // cursor reaches it (a permutation in between resets it).  absorb() returns true when the transcript must be
+  // permuted before it can go on (padding already applied).
+  struct Str {
+    uint8_t b[160];             // + slack for the 8-byte loads
+    uint32_t total, patch2;     // header offsets: 0 and patch2
+  };
+  bool absorb(int k, Str& s, uint32_t& off) {
+    while (off < s.total) {
+      if (off == 0 || off == s.patch2) {                       // begin_op
+        s.b[off] = pos_begin[k];
+        pos_begin[k] = (uint8_t)(pos[k] + 1);
+      }
+      const unsigned p = pos[k], sh = p & 7u;
+      unsigned take = 8u - sh;
+      const uint32_t limit = (off < s.patch2) ? s.patch2 : s.total;   // stop at the next header: it is patched on arrival
+      if (take > limit - off) take = limit - off;
+      if (take > (unsigned)STROBE_R - p) take = (unsigned)STROBE_R - p;
+      uint64_t v;
+      memcpy(&v, s.b + off, 8);
+      if (take < 8) v &= (1ull << (8u * take)) - 1ull;
+      st[p >> 3][k] ^= v << (8u * sh);
+      off += take;
+      pos[k] = (uint8_t)(p + take);
+      if (pos[k] == STROBE_R) {
+        pad(k);
+        return true;
+      }
+    }
+    return false;
+  }
+  static void build(Str& s, const char* label, uint32_t llen, uint32_t len, uint8_t flags2, const uint8_t* data, uint32_t dlen) {
+    s.b[1] = FLAG_M | FLAG_A;
+    memcpy(s.b + 2, label, llen);
+    s.b[2 + llen] = (uint8_t)len; s.b[3 + llen] = (uint8_t)(len >> 8); s.b[4 + llen] = (uint8_t)(len >> 16); s.b[5 + llen] = (uint8_t)(len >> 24);
+    s.patch2 = 6 + llen;
+    s.b[s.patch2 + 1] = flags2;
+    if (dlen) memcpy(s.b + s.patch2 + 2, data, dlen);
+    s.total = s.patch2 + 2 + dlen;
+  }
+
+  void run(const char* label, const uint8_t* const* data, uint8_t (*out)[32], uint32_t len, bool challenge) {
+    const uint32_t llen = (uint32_t)strlen(label);
+    if (llen > 64 || len > 64) return;                           // protocol labels are <= 18 bytes, messages 32 or 48
+    Str str[G];
+    uint8_t pc[G];            // append: 0 string, 3 done.  challenge: 0 first string, 1 squeeze + check, 2 second string, 3 done
+    uint32_t off[G];
+    for (int k = 0; k < count; ++k) {
+      pc[k] = 0;
+      off[k] = 0;
+      if (challenge) build(str[k], label, llen, 32, FLAG_I | FLAG_A | FLAG_C, nullptr, 0);
+      else build(str[k], label, llen, len, FLAG_A, data[k], len);
+    }
+    for (;;) {
+      int pending[G], np = 0;
+      for (int k = 0; k < count; ++k) {
+        bool need = false;
+        while (pc[k] != 3 && !need) {
+          if (pc[k] == 0 || pc[k] == 2) {
+            need = absorb(k, str[k], off[k]);
+            if (need) break;
+            if (!challenge || pc[k] == 2) { pc[k] = 3; break; }
+            pc[k] = 1;                                            // first string done: PRF forces a permutation unless pos == 0
+            if (pos[k] != 0) { pad(k); need = true; }
+          } else {                                                // pc == 1: squeeze 32 bytes from a fresh block, then check
+            uint8_t* o = out[k];
+            if (pos[k] == 0) {
+              for (int wd = 0; wd < 4; ++wd) { memcpy(o + 8 * wd, &st[wd][k], 8); st[wd][k] = 0; }
+              pos[k] = 32;
+            } else {                                              // unreachable for 32-byte outputs; kept exact (strobe.py:77-87)
+              for (int i = 0; i < 32; ++i) { uint8_t& b = byte_at(k, pos[k]); o[i] = b; b = 0; ++pos[k]; }
+            }
+            off[k] = 0;
+            if (fr_canonical_nonzero(o)) {
+              build(str[k], label, llen, 32, FLAG_A, o, 32);
+              pc[k] = 2;
+            } else {
+              pc[k] = 0;                                          // retry: same first string (headers are re-patched)
+            }
+          }
+        }
+        if (need) pending[np++] = k;
+      }
+      if (np == 0) return;
+      permute(pending, np);
+      for (int i = 0; i < np; ++i) { pos[pending[i]] = 0; pos_begin[pending[i]] = 0; }
+    }
+  }
+
+  // Keccak-f on the listed transcripts, eight per call
+  void permute(const int* idx, int n) {
+    alignas(64) uint64_t lanes[25 * 8];
+    for (int base = 0; base < n; base += 8) {
+      const int m = n - base < 8 ? n - base : 8;
+      if (m == 8 && idx[base + 7] - idx[base] == 7 && (idx[base] & 7) == 0) {         // a whole aligned half: no repacking
+        const int c0 = idx[base];
+        for (int w = 0; w < 25; ++w) memcpy(lanes + 8 * w, &st[w][c0], 64);
+        cg1_keccak_f1600_x8(lanes);
+        for (int w = 0; w < 25; ++w) memcpy(&st[w][c0], lanes + 8 * w, 64);
+        continue;
+      }
+      for (int w = 0; w < 25; ++w) {
+        for (int j = 0; j < m; ++j) lanes[8 * w + j] = st[w][idx[base + j]];
+        for (int j = m; j < 8; ++j) lanes[8 * w + j] = 0;
+      }
+      cg1_keccak_f1600_x8(lanes);
+      for (int w = 0; w < 25; ++w)
+        for (int j = 0; j < m; ++j) st[w][idx[base + j]] = lanes[8 * w + j];
+    }
+  }
+};
+
+}  // namespace cg1m

@@ -23,6 +23,7 @@
 // (cg1_batch_decompress_device, cg1_msm_device / cg1_msm_batched_device); this file is host logic only.
 #include <sched.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdint>
@@ -37,6 +38,7 @@
 #include "../../include/curdle_g1.h"
 #include "fr.h"
 #include "host_g1.h"
+#include "merlin_group.h"
 
 using namespace cg1fr;
 using cg1h::jac;
@@ -498,9 +500,273 @@ int prepare_one(const Crs& crs, const uint8_t* inst /* 4*ell*48 */, const uint8_
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The same front-end for up to cg1m::G proofs at once: identical arithmetic per proof, but the transcripts advance in
+// step so that their Keccak permutations run eight at a time (csrc/merlin_group.h).  Output bytes are identical to
+// prepare_one's (tests/test_shuffle_verifier.py::test_grouped_front_end_matches_single).
+struct ProofWork {
+  int status = 0;
+  uint8_t* pts = nullptr;
+  fr r_p, c_fin, d_fin, z_k, z_t, z_u, x_fin, rho[12];
+  Aff aA, aT1, aU1, aB;
+  fr alpha_p, beta_p, gprod, alpha_g, beta_g, beta_inv, inner_prod, alpha_i, beta_i, alpha_s, alpha_m;
+  std::vector<fr> a, u, gam, gam_inv, s, s_inv, gm, gm_inv, sm;
+  uint8_t D48[48], Ap48[48];
+};
+
+void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const uint8_t* const* proof, const uint8_t* const* weights,
+                   const uint8_t* const* decoded, uint8_t* const* out_points, uint8_t* const* out_scalars,
+                   uint8_t* const* out_crs_scalars, uint8_t* const* out_challenges, int32_t* const* status_out) {
+  const size_t ell = crs.ell, lg = crs.lg, n = ell + NB;
+  const Layout L(ell, lg);
+  ProofWork w[cg1m::G];
+  static const uint8_t zero48[48] = {0};
+
+  // ---- parse (as prepare_one); a proof rejected here keeps running on harmless values and is zeroed at the end
+  for (int k = 0; k < cnt; ++k) {
+    ProofWork& q = w[k];
+    q.pts = out_points[k];
+    memcpy(q.pts, inst[k], 4 * ell * 48);
+    const uint8_t* p = proof[k];
+    uint8_t* o = q.pts + L.base() * 48;
+    auto pts = [&](size_t m) { memcpy(o, p, 48 * m); o += 48 * m; p += 48 * m; };
+    bool ok = true;
+    auto sc = [&](fr& dst) { if (!fr_from_le32(p, dst)) { ok = false; dst = fr_zero(); } p += 32; };
+    pts(10); sc(q.r_p);
+    pts(2 + 4 * lg); sc(q.c_fin); sc(q.d_fin);
+    pts(4); sc(q.z_k); sc(q.z_t); sc(q.z_u);
+    pts(3 + 6 * lg); sc(q.x_fin);
+    if (!ok) q.status = CG1_SHUFFLE_BAD_SCALAR;
+    else if (q.pts[L.T(0) * 48] & 0x40) q.status = CG1_SHUFFLE_T0_INFINITY;
+    for (int j = 0; j < 12; ++j)
+      if (!fr_from_le32(weights[k] + 32 * j, q.rho[j])) { q.rho[j] = fr_zero(); if (!q.status) q.status = CG1_SHUFFLE_BAD_WEIGHT; }
+    auto dec = [&](size_t idx) { return decoded && decoded[k] ? decoded[k] + 96 * (idx - L.A()) : nullptr; };
+    auto pt = [&](size_t idx, Aff& dst) {
+      if (!decode_point(q.pts + idx * 48, dec(idx), dst)) {
+        dst.inf = true; dst.x = cg1h::fe_zero(); dst.y = cg1h::fe_zero();
+        if (!q.status) q.status = CG1_SHUFFLE_BAD_POINT;
+      }
+    };
+    if (q.status == 0 || q.status == CG1_SHUFFLE_BAD_WEIGHT) { pt(L.A(), q.aA); pt(L.T1(), q.aT1); pt(L.U1(), q.aU1); pt(L.B(), q.aB); }
+    else { q.aA.inf = q.aT1.inf = q.aU1.inf = q.aB.inf = true; }
+  }
+
+  cg1m::Group tr;
+  tr.init("curdleproofs", cnt);
+  const uint8_t* ptrs[cg1m::G];
+  uint8_t tmp[cg1m::G][32];
+  auto point = [&](const char* label, size_t idx) {            // own wire point idx of every proof
+    for (int k = 0; k < cnt; ++k) ptrs[k] = w[k].pts + idx * 48;
+    tr.append(label, ptrs, 48);
+  };
+  auto scalar = [&](const char* label, fr ProofWork::*m) {
+    for (int k = 0; k < cnt; ++k) { fr_to_le32(w[k].*m, tmp[k]); ptrs[k] = tmp[k]; }
+    tr.append(label, ptrs, 32);
+  };
+  auto challenge = [&](const char* label, fr ProofWork::*m) {
+    tr.challenge_scalar(label, tmp);
+    for (int k = 0; k < cnt; ++k) fr_from_le32(tmp[k], w[k].*m);
+  };
+
+  // ---- curdleproofs.py:176-180
+  for (size_t i = 0; i < 4 * ell; ++i) point("curdleproofs_step1", i);
+  point("curdleproofs_step1", L.M());
+  for (int k = 0; k < cnt; ++k) w[k].a.resize(ell);
+  for (size_t i = 0; i < ell; ++i) {
+    tr.challenge_scalar("curdleproofs_vec_a", tmp);
+    for (int k = 0; k < cnt; ++k) fr_from_le32(tmp[k], w[k].a[i]);
+  }
+  // ---- same_perm.py:91-98
+  point("same_perm_step1", L.A());
+  point("same_perm_step1", L.M());
+  for (size_t i = 0; i < ell; ++i) {
+    for (int k = 0; k < cnt; ++k) { fr_to_le32(w[k].a[i], tmp[k]); ptrs[k] = tmp[k]; }
+    tr.append("same_perm_step1", ptrs, 32);
+  }
+  challenge("same_perm_alpha", &ProofWork::alpha_p);
+  challenge("same_perm_beta", &ProofWork::beta_p);
+  for (int k = 0; k < cnt; ++k) {
+    ProofWork& q = w[k];
+    q.gprod = fr_one();
+    fr t = q.beta_p;
+    for (size_t i = 0; i < ell; ++i) { q.gprod = fr_mul(q.gprod, fr_add(q.a[i], t)); t = fr_add(t, q.alpha_p); }
+  }
+  // ---- grand_prod.py:175-199
+  point("gprod_step1", L.B());
+  scalar("gprod_step1", &ProofWork::gprod);
+  challenge("gprod_alpha", &ProofWork::alpha_g);
+  point("gprod_step2", L.C());
+  scalar("gprod_step2", &ProofWork::r_p);
+  challenge("gprod_beta", &ProofWork::beta_g);
+  for (int k = 0; k < cnt; ++k) {
+    ProofWork& q = w[k];
+    q.beta_inv = fr_inv(q.beta_g);
+    q.u.resize(n);
+    fr pw = q.beta_inv;
+    for (size_t i = 0; i < ell; ++i) { q.u[i] = pw; pw = fr_mul(pw, q.beta_inv); }
+    for (size_t i = ell; i < n; ++i) q.u[i] = pw;
+    jac two[2] = {cg1h::jac_identity(), cg1h::jac_identity()};
+    crs.g_sum.mul_into(two[0], fr_neg(q.beta_inv));
+    crs.h_sum.mul_into(two[0], q.alpha_g);
+    madd_aff(two[0], q.aB);
+    madd_aff(two[1], q.aA); madd_aff(two[1], q.aT1); madd_aff(two[1], q.aU1);
+    cg1h::fe xs[2], ys[2];
+    uint8_t inf[2];
+    cg1h::jac_batch_to_affine(two, 2, xs, ys, inf);
+    cg1h::g1_compress_affine(xs[0], ys[0], inf[0] != 0, q.D48);
+    cg1h::g1_compress_affine(xs[1], ys[1], inf[1] != 0, q.Ap48);
+    const fr beta_ell = fr_pow_u64(q.beta_g, ell);
+    q.inner_prod = fr_sub(fr_add(fr_mul(q.r_p, fr_mul(beta_ell, q.beta_g)), fr_mul(q.gprod, beta_ell)), fr_one());
+  }
+  // ---- ipa.py:204-212, 170-176
+  point("ipa_step1", L.C());
+  for (int k = 0; k < cnt; ++k) ptrs[k] = w[k].D48;
+  tr.append("ipa_step1", ptrs, 48);
+  scalar("ipa_step1", &ProofWork::inner_prod);
+  point("ipa_step1", L.Bc());
+  point("ipa_step1", L.Bd());
+  challenge("ipa_alpha", &ProofWork::alpha_i);
+  challenge("ipa_beta", &ProofWork::beta_i);
+  for (int k = 0; k < cnt; ++k) { w[k].gam.resize(lg); w[k].gm.resize(lg); }
+  for (size_t j = 0; j < lg; ++j) {
+    point("ipa_loop", L.LC(j)); point("ipa_loop", L.LD(j)); point("ipa_loop", L.RC(j)); point("ipa_loop", L.RD(j));
+    tr.challenge_scalar("ipa_gamma", tmp);
+    for (int k = 0; k < cnt; ++k) fr_from_le32(tmp[k], w[k].gam[j]);
+  }
+  // ---- same_scalar.py:82-99
+  {
+    const size_t order[10] = {L.Rp(), L.Sp(), L.T1(), L.T2(), L.U1(), L.U2(), L.cmA1(), L.cmA2(), L.cmB1(), L.cmB2()};
+    for (size_t i = 0; i < 10; ++i) point("sameexp_points", order[i]);
+  }
+  challenge("same_scalar_alpha", &ProofWork::alpha_s);
+  // ---- curdleproofs.py:204-224 + same_msm.py:194-204, 164-172
+  uint8_t Z48[48];
+  memset(Z48, 0, 48);
+  Z48[0] = 0xC0;
+  for (int k = 0; k < cnt; ++k) ptrs[k] = w[k].Ap48;
+  tr.append("same_msm_step1", ptrs, 48);
+  point("same_msm_step1", L.T2());
+  point("same_msm_step1", L.U2());
+  for (size_t i = 0; i < ell; ++i) point("same_msm_step1", L.T(i));
+  tr.append_same("same_msm_step1", Z48, 48); tr.append_same("same_msm_step1", Z48, 48);
+  tr.append_same("same_msm_step1", crs.H48(), 48); tr.append_same("same_msm_step1", Z48, 48);
+  for (size_t i = 0; i < ell; ++i) point("same_msm_step1", L.U(i));
+  tr.append_same("same_msm_step1", Z48, 48); tr.append_same("same_msm_step1", Z48, 48);
+  tr.append_same("same_msm_step1", Z48, 48); tr.append_same("same_msm_step1", crs.H48(), 48);
+  point("same_msm_step1", L.Ba()); point("same_msm_step1", L.Bt()); point("same_msm_step1", L.Bu());
+  challenge("same_msm_alpha", &ProofWork::alpha_m);
+  for (size_t j = 0; j < lg; ++j) {
+    point("same_msm_loop", L.LA(j)); point("same_msm_loop", L.LT(j)); point("same_msm_loop", L.LU(j));
+    point("same_msm_loop", L.RA(j)); point("same_msm_loop", L.RT(j)); point("same_msm_loop", L.RU(j));
+    tr.challenge_scalar("same_msm_gamma", tmp);
+    for (int k = 0; k < cnt; ++k) fr_from_le32(tmp[k], w[k].gm[j]);
+  }
+  (void)zero48;
+
+  // ---- the scalar rows (all equations as in prepare_one)
+  for (int k = 0; k < cnt; ++k) {
+    ProofWork& q = w[k];
+    *status_out[k] = q.status;
+    if (q.status) {
+      memset(out_scalars[k], 0, L.count() * 32);
+      memset(out_crs_scalars[k], 0, L.ncrs() * 32);
+      continue;
+    }
+    std::vector<fr> sc(L.count(), fr_zero()), cs(L.ncrs(), fr_zero());
+    auto add = [](fr& dst, const fr& v) { dst = fr_add(dst, v); };
+    auto sub = [](fr& dst, const fr& v) { dst = fr_sub(dst, v); };
+    const fr* rho = q.rho;
+    // E1
+    add(sc[L.B()], rho[0]); sub(sc[L.A()], rho[0]); sub(sc[L.M()], fr_mul(rho[0], q.alpha_p));
+    {
+      const fr t = fr_mul(rho[0], q.beta_p);
+      for (size_t i = 0; i < ell; ++i) sub(cs[L.cG(i)], t);
+    }
+    q.gam_inv = q.gam;
+    fr_batch_inv(q.gam_inv.data(), lg);
+    fold_scalars(q.gam, q.s);
+    fold_scalars(q.gam_inv, q.s_inv);
+    {   // E2
+      const fr wt = rho[1];
+      for (size_t j = 0; j < lg; ++j) { add(sc[L.LC(j)], fr_mul(wt, q.gam[j])); add(sc[L.RC(j)], fr_mul(wt, q.gam_inv[j])); }
+      add(sc[L.Bc()], wt);
+      add(sc[L.C()], fr_mul(wt, q.alpha_i));
+      const fr hcoef = fr_mul(q.beta_i, fr_sub(fr_mul(fr_sqr(q.alpha_i), q.inner_prod), fr_mul(q.c_fin, q.d_fin)));
+      add(cs[L.cH()], fr_mul(wt, hcoef));
+      const fr wc = fr_mul(wt, q.c_fin);
+      for (size_t i = 0; i < n; ++i) sub(cs[i], fr_mul(wc, q.s[i]));
+    }
+    {   // E3
+      const fr wt = rho[2];
+      for (size_t j = 0; j < lg; ++j) { add(sc[L.LD(j)], fr_mul(wt, q.gam[j])); add(sc[L.RD(j)], fr_mul(wt, q.gam_inv[j])); }
+      add(sc[L.Bd()], wt);
+      const fr wa = fr_mul(wt, q.alpha_i);
+      add(sc[L.B()], wa);
+      sub(cs[L.cGsum()], fr_mul(wa, q.beta_inv));
+      add(cs[L.cHsum()], fr_mul(wa, q.alpha_g));
+      const fr wd = fr_mul(wt, q.d_fin);
+      for (size_t i = 0; i < n; ++i) sub(cs[i], fr_mul(wd, fr_mul(q.s_inv[i], q.u[i])));
+    }
+    {   // same-scalar
+      const fr w1 = rho[8], w2 = rho[9], w3 = rho[10], w4 = rho[11];
+      add(cs[L.cGt()], fr_mul(w1, q.z_t)); sub(sc[L.cmA1()], w1); sub(sc[L.T1()], fr_mul(w1, q.alpha_s));
+      add(sc[L.Rp()], fr_mul(w2, q.z_k)); add(cs[L.cH()], fr_mul(w2, q.z_t)); sub(sc[L.cmA2()], w2); sub(sc[L.T2()], fr_mul(w2, q.alpha_s));
+      add(cs[L.cGu()], fr_mul(w3, q.z_u)); sub(sc[L.cmB1()], w3); sub(sc[L.U1()], fr_mul(w3, q.alpha_s));
+      add(sc[L.Sp()], fr_mul(w4, q.z_k)); add(cs[L.cH()], fr_mul(w4, q.z_u)); sub(sc[L.cmB2()], w4); sub(sc[L.U2()], fr_mul(w4, q.alpha_s));
+    }
+    q.gm_inv = q.gm;
+    fr_batch_inv(q.gm_inv.data(), lg);
+    fold_scalars(q.gm, q.sm);
+    {   // E4-E6
+      const fr w4 = rho[3], w5 = rho[4], w6 = rho[5];
+      for (size_t j = 0; j < lg; ++j) {
+        add(sc[L.LA(j)], fr_mul(w4, q.gm[j])); add(sc[L.RA(j)], fr_mul(w4, q.gm_inv[j]));
+        add(sc[L.LT(j)], fr_mul(w5, q.gm[j])); add(sc[L.RT(j)], fr_mul(w5, q.gm_inv[j]));
+        add(sc[L.LU(j)], fr_mul(w6, q.gm[j])); add(sc[L.RU(j)], fr_mul(w6, q.gm_inv[j]));
+      }
+      add(sc[L.Ba()], w4); add(sc[L.Bt()], w5); add(sc[L.Bu()], w6);
+      const fr w4a = fr_mul(w4, q.alpha_m);
+      add(sc[L.A()], w4a); add(sc[L.T1()], w4a); add(sc[L.U1()], w4a);
+      add(sc[L.T2()], fr_mul(w5, q.alpha_m));
+      add(sc[L.U2()], fr_mul(w6, q.alpha_m));
+      const fr x4 = fr_mul(w4, q.x_fin), x5 = fr_mul(w5, q.x_fin), x6 = fr_mul(w6, q.x_fin);
+      for (size_t i = 0; i < ell; ++i) {
+        sub(cs[L.cG(i)], fr_mul(x4, q.sm[i]));
+        sub(sc[L.T(i)], fr_mul(x5, q.sm[i]));
+        sub(sc[L.U(i)], fr_mul(x6, q.sm[i]));
+      }
+      sub(cs[L.cHv(0)], fr_mul(x4, q.sm[ell])); sub(cs[L.cHv(1)], fr_mul(x4, q.sm[ell + 1]));
+      sub(cs[L.cGt()], fr_mul(x4, q.sm[ell + 2])); sub(cs[L.cGu()], fr_mul(x4, q.sm[ell + 3]));
+      sub(cs[L.cH()], fr_mul(x5, q.sm[ell + 2]));
+      sub(cs[L.cH()], fr_mul(x6, q.sm[ell + 3]));
+    }
+    {   // E7, E8
+      const fr w7 = rho[6], w8 = rho[7];
+      add(sc[L.Rp()], w7); add(sc[L.Sp()], w8);
+      for (size_t i = 0; i < ell; ++i) { sub(sc[L.R(i)], fr_mul(w7, q.a[i])); sub(sc[L.S(i)], fr_mul(w8, q.a[i])); }
+    }
+    for (size_t i = 0; i < L.count(); ++i) fr_to_le32(sc[i], out_scalars[k] + 32 * i);
+    for (size_t i = 0; i < L.ncrs(); ++i) fr_to_le32(cs[i], out_crs_scalars[k] + 32 * i);
+    if (out_challenges && out_challenges[k]) {
+      uint8_t* o = out_challenges[k];
+      const fr head[8] = {q.alpha_p, q.beta_p, q.alpha_g, q.beta_g, q.alpha_i, q.beta_i, q.alpha_s, q.alpha_m};
+      for (const fr& c : head) { fr_to_le32(c, o); o += 32; }
+      for (size_t j = 0; j < lg; ++j) { fr_to_le32(q.gam[j], o); o += 32; }
+      for (size_t j = 0; j < lg; ++j) { fr_to_le32(q.gm[j], o); o += 32; }
+      for (size_t i = 0; i < ell; ++i) { fr_to_le32(q.a[i], o); o += 32; }
+    }
+  }
+}
+
+std::atomic<int> g_grouped{1};
+
 }  // namespace
 
 extern "C" {
+
+// 1 (default): proofs are prepared cg1m::G at a time with batched Keccak permutations; 0: one transcript at a time
+void cg1_shuffle_set_grouped(int on) { g_grouped.store(on ? 1 : 0); }
+
 
 cg1_shuffle_crs* cg1_shuffle_crs_create(const uint8_t* crs_bytes, size_t ell, size_t n_blinders) {
   if (n_blinders != NB || ell == 0) return nullptr;
@@ -552,10 +818,30 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint
   const Layout L(crs.ell, crs.lg);
   const size_t inst_b = 4 * crs.ell * 48, proof_b = proof_wire_bytes(crs.lg), nch = 8 + 2 * crs.lg + crs.ell;
   std::atomic<size_t> next{0};
+  const bool grouped = g_grouped.load() != 0;
+  const size_t per_item = grouped ? (size_t)cg1m::G : 1, n_items = (n_proofs + per_item - 1) / per_item;
   auto work = [&]() {
     for (;;) {
-      size_t i = next.fetch_add(1);
-      if (i >= n_proofs) return;
+      const size_t item = next.fetch_add(1);
+      if (item >= n_items) return;
+      if (grouped) {
+        const size_t lo = item * per_item, cnt = std::min(per_item, n_proofs - lo);
+        const uint8_t *in[cg1m::G], *pr[cg1m::G], *we[cg1m::G], *de[cg1m::G];
+        uint8_t *pts[cg1m::G], *scs[cg1m::G], *ccs[cg1m::G], *chs[cg1m::G];
+        int32_t* sts[cg1m::G];
+        for (size_t k = 0; k < cnt; ++k) {
+          const size_t i = lo + k;
+          in[k] = instances + i * inst_b; pr[k] = proofs + i * proof_b; we[k] = weights + i * 12 * 32;
+          de[k] = decoded96 ? decoded96 + i * decoded_stride : nullptr;
+          pts[k] = out_points48 + i * L.count() * 48; scs[k] = out_scalars32 + i * L.count() * 32;
+          ccs[k] = out_crs_scalars32 + i * L.ncrs() * 32;
+          chs[k] = out_challenges32 ? out_challenges32 + i * nch * 32 : nullptr;
+          sts[k] = status + i;
+        }
+        prepare_group(crs, (int)cnt, in, pr, we, de, pts, scs, ccs, chs, sts);
+        continue;
+      }
+      const size_t i = item;
       uint8_t* pts = out_points48 + i * L.count() * 48;
       uint8_t* scs = out_scalars32 + i * L.count() * 32;
       uint8_t* ccs = out_crs_scalars32 + i * L.ncrs() * 32;
@@ -569,12 +855,12 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint
       status[i] = rc;
     }
   };
-  if (n_threads == 1 || n_proofs <= 1) {
+  if (n_threads == 1 || n_items <= 1) {
     work();
   } else {
     Pool& pool = Pool::get();
     size_t nt = n_threads > 0 ? (size_t)n_threads : pool.size() + 1;
-    if (nt > n_proofs) nt = n_proofs;
+    if (nt > n_items) nt = n_items;
     pool.run(work, nt);
   }
   return CG1_OK;

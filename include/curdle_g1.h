@@ -136,6 +136,8 @@ int cg1_probe_madd(cg1_ctx* ctx, const void* d_points_affine96, size_t npts, siz
  * keccak.py:16-66} and curdleproofs/curdleproofs/curdleproofs_transcript.py:7-28.
  * `state` is a caller-owned CG1_MERLIN_STATE_BYTES blob; copying the blob forks the transcript. */
 #define CG1_MERLIN_STATE_BYTES 208
+void cg1_keccak_f1600(uint8_t* state200);              /* keccak.py:16-66, one permutation */
+void cg1_keccak_f1600_x8(uint64_t* lanes);               /* eight states at once, lane w of state k at lanes[8*w + k] (AVX-512 when present) */
 void cg1_strobe_new(uint8_t* state, const uint8_t* protocol_label, size_t len);                 /* Strobe128.new */
 int  cg1_strobe_meta_ad(uint8_t* state, const uint8_t* data, size_t len, int more);
 int  cg1_strobe_ad(uint8_t* state, const uint8_t* data, size_t len, int more);
@@ -189,6 +191,9 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8
                         const uint8_t* weights, const uint8_t* decoded96, size_t decoded_stride,
                         uint8_t* out_points48, uint8_t* out_scalars32, uint8_t* out_crs_scalars32,
                         int32_t* status, uint8_t* out_challenges32, int n_threads /* 0 = all cores */);
+/* 1 (default): cg1_shuffle_prepare advances 16 proofs' transcripts in step, their Keccak-f permutations eight at a time
+ * (AVX-512 when present); 0: one transcript at a time.  Same output bytes either way. */
+void cg1_shuffle_set_grouped(int on);
 /* threads used when n_threads = 0: usable CPUs (affinity mask capped by the cgroup CPU quota; env CURDLE_G1_THREADS overrides) */
 size_t cg1_shuffle_default_threads(void);
 /* just the gather step: every proof's own points (instance, then the proof's points in wire order) */

@@ -216,3 +216,47 @@ def test_decoded_window_path_matches_host_decode(gold):
             # an undecodable A/T_1/U_1/B shows up as an all-zero record on the decoded path; the GPU's point status rejects it
             assert a.status[i] in (1, 2, 3)
     assert a.crs_scalars32.raw == b.crs_scalars32.raw or any(a.status[i] == 2 for i in range(n))
+
+
+def test_grouped_front_end_matches_single(gold):
+    """16 transcripts in step with batched (x8, AVX-512 when present) Keccak == one transcript at a time, byte for byte,
+    for group sizes that do not divide evenly and for batches mixing valid, tampered and early-rejected proofs."""
+    for case_idx, n in ((0, 1), (1, 7), (1, 17), (2, 33), (4, 3)):
+        case = gold["cases"][case_idx]
+        v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), threads=2)
+        var = case["variants"]
+        items = [apply_edits(case, var[i % len(var)]["edits"]) for i in range(n)]
+        inst, proofs, _ = v.pack(items)
+        w = v.draw_weights(n, random.Random(n))
+        outs = []
+        for grouped in (0, 1):
+            N.cg1_shuffle_set_grouped(grouped)
+            try:
+                p = v.prepare(inst, proofs, n, weights=w, want_challenges=True)
+            finally:
+                N.cg1_shuffle_set_grouped(1)
+            ok = [i for i in range(n) if p.status[i] == 0]
+            C = v.crs.challenges_per_proof * 32
+            outs.append((list(p.status), p.points48.raw, p.scalars32.raw, p.crs_scalars32.raw, [p.challenges.raw[i * C: (i + 1) * C] for i in ok]))
+        assert outs[0] == outs[1]
+
+
+def test_keccak_x8_matches_single():
+    rng = random.Random(3)
+    states = [bytes(rng.getrandbits(8) for _ in range(200)) for _ in range(8)]
+    want = []
+    for s in states:
+        b = ctypes.create_string_buffer(s, 200)
+        N.cg1_keccak_f1600(b)
+        want.append(b.raw)
+    lanes = (ctypes.c_uint64 * 200)()
+    for k, s in enumerate(states):
+        for w in range(25):
+            lanes[8 * w + k] = int.from_bytes(s[8 * w: 8 * w + 8], "little")
+    N.cg1_keccak_f1600_x8(lanes)
+    for k in range(8):
+        assert b"".join(int(lanes[8 * w + k]).to_bytes(8, "little") for w in range(25)) == want[k]
+    # known answer: Keccak-f[1600] of the all-zero state (first lane), keccak.py:16-66
+    z = ctypes.create_string_buffer(200)
+    N.cg1_keccak_f1600(z)
+    assert z.raw[:8].hex() == "e7dde140798f25f1"
