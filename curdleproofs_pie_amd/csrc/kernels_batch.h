@@ -51,8 +51,11 @@ __global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ 
 // One lane per point: parse the ZCash-format encoding (util.py:35-36 -> G1Point.from_compressed_bytes[_unchecked]),
 // y = sqrt(x^3 + 4) by exponentiation, sign select, optional subgroup test  [z^2]P == phi(P) + P.
 // out: affine96 (zeros = identity), status: 0 ok, CG1_ERR_ENCODING / _NOT_ON_CURVE / _NOT_IN_SUBGROUP.
+// CHECK is a template parameter: the unchecked instantiation (the reference's default, util.py:35-36) must not carry the
+// register footprint of the subgroup test's scalar multiplication (256 VGPRs + spills, 1 wave/SIMD when it did).
+template <bool CHECK>
 __global__ void __launch_bounds__(128) k_batch_decompress(const uint8_t* __restrict__ in48, uint32_t* __restrict__ out_raw,
-                                                          uint8_t* __restrict__ status, uint32_t n, int check_subgroup) {
+                                                          uint8_t* __restrict__ status, uint32_t n) {
   uint32_t i = blockIdx.x * 128 + threadIdx.x;
   if (i >= n) return;
   const uint8_t* b = in48 + 48ull * i;
@@ -93,7 +96,7 @@ __global__ void __launch_bounds__(128) k_batch_decompress(const uint8_t* __restr
     }
     y = fp_to_mont(fp_from_words(yw));
   }
-  if (check_subgroup) {
+  if (CHECK) {
     constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
     fp beta; for (int k = 0; k < NL; ++k) beta.l[k] = bt[k];
     xyzz acc = xyzz_identity();

@@ -755,8 +755,12 @@ int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_af
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(cg1::k_batch_decompress, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                     (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n, check_subgroup);
+  if (check_subgroup)
+    hipLaunchKernelGGL(cg1::k_batch_decompress<true>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                       (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
+  else
+    hipLaunchKernelGGL(cg1::k_batch_decompress<false>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                       (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   return CG1_OK;

@@ -105,15 +105,17 @@ class Prepared:
 
 
 class ShuffleBatchVerifier:
-    def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256):
+    def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 512):
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
         self.chunk = chunk                  # sub-batch of the decompress / front-end pipeline
         self._gpu_thread = None
         self._gpu_jobs = None
-        self._bufs = {}
+        self._slots = [None, None, None]
+        self._next_slot = 0
         self.last_stats = {}
+        self.last_status = []
 
     # ---------------------------------------------------------------- host half
     def pack(self, items) -> Tuple[bytes, bytes, List[int]]:
@@ -173,14 +175,38 @@ class ShuffleBatchVerifier:
             self._ctx = N.default_context()
         return self._ctx
 
-    def _device_buffers(self, n: int):
-        crs = self.crs
+    def _gpu_submit(self, fn) -> None:
+        """All GPU work of the verifier runs, in submission order, on ONE persistent thread (a thread's first HIP call
+        is expensive, and a context takes one call at a time)."""
+        import queue
+        import threading
+
+        if self._gpu_thread is None:
+            self._gpu_jobs = queue.Queue()
+
+            def loop(jobs=self._gpu_jobs):
+                while True:
+                    job = jobs.get()
+                    if job is None:
+                        return
+                    job()
+
+            self._gpu_thread = threading.Thread(target=loop, daemon=True)
+            self._gpu_thread.start()
+        self._gpu_jobs.put(fn)
+
+    def _slot(self, n: int) -> dict:
+        """Buffers of one batch in flight (3 slots rotate: MSM of batch k-1, front-end of k, decompression of k+1)."""
+        crs, ctx = self.crs, self.ctx
         L, C = crs.points_per_proof, crs.ncrs
-        b = self._bufs.get(n)
-        if b is None:
-            self._bufs.clear()
-            ctx = self.ctx
+        idx = self._next_slot
+        self._next_slot = (idx + 1) % 3
+        b = self._slots[idx]
+        if b is not None and b["busy"] is not None:
+            b["busy"].wait()                                  # its previous batch must have left the GPU
+        if b is None or b["cap"] < n:
             b = {
+                "cap": n, "busy": None,
                 "wire": ctx.alloc(n * L * 48),
                 "pts": ctx.alloc((n * L + C) * 96),          # own points of all proofs, then the CRS points
                 "pstat": ctx.alloc(n * L),
@@ -192,18 +218,15 @@ class ShuffleBatchVerifier:
                     "decoded": N.PinnedBuffer(ctx, n * 768),
                 },
             }
-            b["pts"].upload(crs.affine96, n * L * 96)
-            self._bufs[n] = b
+            self._slots[idx] = b
         return b
 
-    def decompress_on_gpu(self, instances: bytes, proofs: bytes, n: int, lo: int = 0, hi: Optional[int] = None):
-        """Gather the own points of proofs [lo, hi) of an n-proof batch, decompress them on the GPU (they stay there for
-        the MSM) and bring back the per-point verdicts + the 8-point window the host front-end wants."""
+    def _decompress_range(self, b: dict, instances, proofs, n: int, lo: int, hi: int) -> None:
+        """GPU thread: gather the own points of proofs [lo, hi), H2D, decompress (they stay on the device for the MSM),
+        bring back the per-point verdicts and the 8-point window the host front-end wants."""
         crs, ctx = self.crs, self.ctx
         L = crs.points_per_proof
-        hi = n if hi is None else hi
         m = hi - lo
-        b = self._device_buffers(n)
         h = b["host"]
         wire = h["wire"].ptr + lo * L * 48
         ctx.check(N.cg1_shuffle_gather_points(crs.handle, m, _addr(instances) + lo * 4 * crs.ell * 48,
@@ -213,158 +236,168 @@ class ShuffleBatchVerifier:
                                                 b["pstat"].ptr + lo * L, m * L, 0))
         ctx.check(N.cg1_d2h(ctx.handle, h["pstat"].ptr + lo * L, b["pstat"].ptr + lo * L, m * L))
         ctx.check(N.cg1_d2h_2d(ctx.handle, h["decoded"].ptr + lo * 768, 768, b["pts"].ptr + (lo * L + 4 * crs.ell + 1) * 96, L * 96, 768, m))
-        return h["pstat"].buf, h["decoded"].buf
 
-    def check_prepared(self, prep: Prepared, mode: str = "merged", points_on_device: bool = False) -> List[int]:
-        """Run the group arithmetic for a Prepared batch.  Returns the final per-proof status (0 = valid)."""
+    def _begin(self, batch, mode: str, rng) -> dict:
+        """Stage 1 of a batch (asynchronous): claim a slot and queue the GPU decompression of its sub-batches."""
+        import queue
+        import threading
         import time
 
-        crs, ctx, n = self.crs, self.ctx, prep.n
+        instances, proofs, n = batch[0], batch[1], batch[2]
+        crs = self.crs
         L, C = crs.points_per_proof, crs.ncrs
-        if n == 0:
-            return []
-        t0 = time.perf_counter()
-        b = self._device_buffers(n)
-        if not points_on_device:
-            ctx.check(N.cg1_h2d(ctx.handle, b["wire"].ptr, prep.points48, n * L * 48))
-            ctx.check(N.cg1_batch_decompress_device(ctx.handle, b["wire"].ptr, b["pts"].ptr, b["pstat"].ptr, n * L, 0))
-            pstat = b["pstat"].download(n * L)
-            ctx.check(N.cg1_shuffle_apply_point_status(prep.status, pstat, n, L, prep.scalars32, prep.crs_scalars32, C))
-        t1 = time.perf_counter()
-        status = [int(prep.status[i]) for i in range(n)]
-        live = [i for i in range(n) if status[i] == 0]
-        merged_ok = None
-        if live and mode == "merged":
-            crs_sum = ctypes.create_string_buffer(C * 32)
-            ctx.check(N.cg1_shuffle_sum_crs_scalars(prep.crs_scalars32, prep.status, n, C, crs_sum))
-            if len(prep.scalars32) >= (n * L + C) * 32:          # staging buffer: CRS row right behind, one copy
-                ctypes.memmove(ctypes.addressof(prep.scalars32) + n * L * 32, crs_sum, C * 32)
-                ctx.check(N.cg1_h2d(ctx.handle, b["sc"].ptr, prep.scalars32, (n * L + C) * 32))
-            else:
-                ctx.check(N.cg1_h2d(ctx.handle, b["sc"].ptr, prep.scalars32, n * L * 32))
-                ctx.check(N.cg1_h2d(ctx.handle, b["sc"].ptr + n * L * 32, crs_sum, C * 32))
-            blob = ctx.msm_device(b["pts"], b["sc"], n * L + C)
-            merged_ok = bool(N.cg1_is_identity(blob))
-        t2 = time.perf_counter()
-        if live and not merged_ok:
-            # independent: P_i over the proof's own points, Q_i over the CRS points; valid iff P_i + Q_i = 0
-            ctx.check(N.cg1_h2d(ctx.handle, b["sc"].ptr, prep.scalars32, n * L * 32))
-            own = ctx.msm_batched_device(b["pts"], b["sc"], [i * L for i in range(n + 1)])
-            rep_pts = ctx.alloc(n * C * 96)
-            rep_sc = ctx.alloc(n * C * 32)
-            rep_pts.upload(crs.affine96 * n)
-            ctx.check(N.cg1_h2d(ctx.handle, rep_sc.ptr, prep.crs_scalars32, n * C * 32))
-            shared = ctx.msm_batched_device(rep_pts, rep_sc, [i * C for i in range(n + 1)])
-            tmp = ctypes.create_string_buffer(N.POINT_BYTES)
-            for i in live:
-                N.cg1_add(tmp, own[i], shared[i])
-                if not N.cg1_is_identity(tmp.raw):
-                    status[i] = REJECT_EQUATION
-        t3 = time.perf_counter()
-        self.last_stats.update({"decompress_s": t1 - t0, "merged_msm_s": t2 - t1, "independent_s": t3 - t2, "merged_ok": merged_ok,
-                                "n": n, "points": n * L + C})
-        return status
+        assert n >= 1 and len(instances) == n * 4 * crs.ell * 48 and len(proofs) == n * crs.proof_bytes
+        weights = batch[4] if len(batch) > 4 and batch[4] is not None else self.draw_weights(n, rng)
+        assert len(weights) == n * N_WEIGHTS * 32
+        b = self._slot(n)
+        tk = {"slot": b, "n": n, "instances": instances, "proofs": proofs, "weights": weights, "mode": mode,
+              "pre_status": batch[3] if len(batch) > 3 else None, "chunks": queue.Queue(), "done": threading.Event(),
+              "bounds": [(lo, min(lo + self.chunk, n)) for lo in range(0, n, self.chunk)], "error": None, "t0": time.perf_counter()}
+        b["busy"] = tk["done"]
 
-    def verify_many(self, items, mode: str = "merged", rng=None) -> List[bool]:
-        """[IsValidWhiskShuffleProof(crs, pre, post, proof) for (pre, post, proof) in items] (whisk_interface.py:72-87)."""
-        import time
-
-        items = list(items)
-        if not items:
-            return []
-        t0 = time.perf_counter()
-        inst, proofs, pre_status = self.pack(items)
-        t1 = time.perf_counter()
-        status = self.verify_packed(inst, proofs, len(items), mode=mode, rng=rng, pre_status=pre_status)
-        self.last_stats["pack_s"] = t1 - t0
-        self.last_stats["total_s"] = time.perf_counter() - t0
-        return [s == 0 for s in status]
-
-    def verify_packed(self, instances: bytes, proofs: bytes, n: int, mode: str = "merged", rng=None, weights=None,
-                      pre_status: Optional[Sequence[int]] = None) -> List[int]:
-        """The batch in wire form: `instances` = n x (vec_R | vec_S | vec_T | vec_U) encodings, `proofs` = n x
-        crs.proof_bytes.  Returns the per-proof status (0 = valid, else a reject code of REJECT_NAMES)."""
-        import time
-
-        crs, ctx = self.crs, self.ctx
-        L, C = crs.points_per_proof, crs.ncrs
-        t1 = time.perf_counter()
-        if weights is None:
-            weights = self.draw_weights(n, rng)
-        assert len(instances) == n * 4 * crs.ell * 48 and len(proofs) == n * crs.proof_bytes and len(weights) == n * N_WEIGHTS * 32
-        t2 = t2b = time.perf_counter()
-        bounds = [(lo, min(lo + self.chunk, n)) for lo in range(0, n, self.chunk)]
-        if len(bounds) <= 1:
-            pstat, decoded = self.decompress_on_gpu(instances, proofs, n)
-            t2b = time.perf_counter()
-            prep = self.prepare(instances, proofs, n, weights=weights, decoded=decoded, staging=self._device_buffers(n)["host"])
-        else:
-            # two-stage pipeline over sub-batches: a worker thread drives the GPU (gather, H2D, decompress, D2H) while
-            # this thread runs the native front-end (all cores) on the sub-batches already decoded
-            import queue
-            import threading
-
-            host = self._device_buffers(n)["host"]
-            pstat, decoded = host["pstat"].buf, host["decoded"].buf
-            done: "queue.Queue" = queue.Queue()
-
-            def gpu_stage():
-                try:
-                    for lo, hi in bounds:
-                        self.decompress_on_gpu(instances, proofs, n, lo, hi)
-                        done.put((lo, hi))
-                except BaseException as e:                      # surfaced in the consumer
-                    done.put(e)
-                finally:
-                    done.put(None)
-
-            if self._gpu_thread is None:                       # persistent: a thread's first HIP call is expensive
-                self._gpu_jobs = queue.Queue()
-
-                def loop(jobs=self._gpu_jobs):
-                    while True:
-                        job = jobs.get()
-                        if job is None:
-                            return
-                        job()
-
-                self._gpu_thread = threading.Thread(target=loop, daemon=True)
-                self._gpu_thread.start()
-            self._gpu_jobs.put(gpu_stage)
-            prep = Prepared(crs, n, False, host)
-            finished = False
+        def gpu_stage(tk=tk, b=b):
             try:
-                for _ in bounds:
-                    r = done.get()
-                    if r is None:
-                        finished = True
-                        raise N.NativeError("GPU stage ended early")
-                    if isinstance(r, BaseException):
-                        raise r
-                    lo, hi = r
-                    rc = N.cg1_shuffle_prepare(crs.handle, hi - lo, _addr(instances) + lo * 4 * crs.ell * 48,
-                                               _addr(proofs) + lo * crs.proof_bytes, _addr(weights) + lo * N_WEIGHTS * 32,
-                                               host["decoded"].ptr + lo * 768, 768, host["wire"].ptr + lo * L * 48,
-                                               host["sc"].ptr + lo * L * 32, ctypes.addressof(prep.crs_scalars32) + lo * C * 32,
-                                               ctypes.addressof(prep.status) + lo * 4, None, self.threads)
-                    if rc:
-                        raise N.NativeError(f"cg1_shuffle_prepare failed ({rc})")
-            finally:
-                while not finished and done.get() is not None:     # wait for the GPU stage before touching its buffers
-                    pass
-        ctx.check(N.cg1_shuffle_apply_point_status(prep.status, pstat, n, L, prep.scalars32, prep.crs_scalars32, C))
-        for i, s in enumerate(pre_status or ()):
+                if b.get("crs_at") != n:                       # CRS points sit right behind the batch's own points
+                    b["pts"].upload(crs.affine96, n * L * 96)
+                    b["crs_at"] = n
+                for lo, hi in tk["bounds"]:
+                    self._decompress_range(b, instances, proofs, n, lo, hi)
+                    tk["chunks"].put((lo, hi))
+            except BaseException as e:                          # surfaced in the consumer
+                tk["chunks"].put(e)
+
+        self._gpu_submit(gpu_stage)
+        return tk
+
+    def _front_end(self, tk: dict) -> None:
+        """Stage 2 (caller's thread, all cores through the native pool): the front-end of each sub-batch as soon as the
+        GPU has decoded it; then point verdicts, early rejects, and the summed CRS row."""
+        import time
+
+        crs = self.crs
+        L, C = crs.points_per_proof, crs.ncrs
+        b, n = tk["slot"], tk["n"]
+        host = b["host"]
+        t0 = time.perf_counter()
+        prep = Prepared(crs, n, False, host)
+        tk["prep"] = prep
+        for _ in tk["bounds"]:
+            r = tk["chunks"].get()
+            if isinstance(r, BaseException):
+                tk["error"] = r
+                tk["done"].set()
+                raise r
+            lo, hi = r
+            rc = N.cg1_shuffle_prepare(crs.handle, hi - lo, _addr(tk["instances"]) + lo * 4 * crs.ell * 48,
+                                       _addr(tk["proofs"]) + lo * crs.proof_bytes, _addr(tk["weights"]) + lo * N_WEIGHTS * 32,
+                                       host["decoded"].ptr + lo * 768, 768, host["wire"].ptr + lo * L * 48,
+                                       host["sc"].ptr + lo * L * 32, ctypes.addressof(prep.crs_scalars32) + lo * C * 32,
+                                       ctypes.addressof(prep.status) + lo * 4, None, self.threads)
+            if rc:
+                tk["done"].set()
+                raise N.NativeError(f"cg1_shuffle_prepare failed ({rc})")
+        self.ctx.check(N.cg1_shuffle_apply_point_status(prep.status, host["pstat"].buf, n, L, prep.scalars32, prep.crs_scalars32, C))
+        for i, s in enumerate(tk["pre_status"] or ()):
             if s:
                 prep.status[i] = s
                 ctypes.memset(ctypes.addressof(prep.scalars32) + i * L * 32, 0, L * 32)
                 ctypes.memset(ctypes.addressof(prep.crs_scalars32) + i * C * 32, 0, C * 32)
-        t3 = time.perf_counter()
-        # (pipelined batches: gpu_decompress_s is hidden inside prepare_s)
-        self.last_stats = {"weights_s": t2 - t1, "gpu_decompress_s": t2b - t2, "prepare_s": t3 - t2b, "pipelined": len(bounds) > 1}
-        status = self.check_prepared(prep, mode, points_on_device=True)
-        self.last_status = status
-        self.last_stats["total_s"] = time.perf_counter() - t1
-        return status
+        crs_sum = ctypes.create_string_buffer(C * 32)
+        self.ctx.check(N.cg1_shuffle_sum_crs_scalars(prep.crs_scalars32, prep.status, n, C, crs_sum))
+        ctypes.memmove(host["sc"].ptr + n * L * 32, crs_sum, C * 32)
+        tk["front_end_s"] = time.perf_counter() - t0
+
+    def _enqueue_msm(self, tk: dict) -> None:
+        """Stage 3 (asynchronous, GPU thread): scalars H2D, the merged MSM, and -- if it is not the identity, or in mode
+        "independent" -- the per-proof MSMs that name the invalid proofs."""
+        import time
+
+        crs, ctx = self.crs, self.ctx
+        L, C = crs.points_per_proof, crs.ncrs
+        b, n, prep = tk["slot"], tk["n"], tk["prep"]
+
+        def gpu_stage():
+            try:
+                t0 = time.perf_counter()
+                status = [int(prep.status[i]) for i in range(n)]
+                live = [i for i in range(n) if status[i] == 0]
+                merged_ok = None
+                ctx.check(N.cg1_h2d(ctx.handle, b["sc"].ptr, b["host"]["sc"].ptr, (n * L + C) * 32))
+                if live and tk["mode"] == "merged":
+                    merged_ok = bool(N.cg1_is_identity(ctx.msm_device(b["pts"], b["sc"], n * L + C)))
+                t1 = time.perf_counter()
+                if live and not merged_ok:
+                    # independent: P_i over the proof's own points, Q_i over the CRS points; valid iff P_i + Q_i = 0
+                    own = ctx.msm_batched_device(b["pts"], b["sc"], [i * L for i in range(n + 1)])
+                    rep_pts, rep_sc = ctx.alloc(n * C * 96), ctx.alloc(n * C * 32)
+                    rep_pts.upload(crs.affine96 * n)
+                    ctx.check(N.cg1_h2d(ctx.handle, rep_sc.ptr, prep.crs_scalars32, n * C * 32))
+                    shared = ctx.msm_batched_device(rep_pts, rep_sc, [i * C for i in range(n + 1)])
+                    rep_pts.free()
+                    rep_sc.free()
+                    tmp = ctypes.create_string_buffer(N.POINT_BYTES)
+                    for i in live:
+                        N.cg1_add(tmp, own[i], shared[i])
+                        if not N.cg1_is_identity(tmp.raw):
+                            status[i] = REJECT_EQUATION
+                tk["status"] = status
+                tk["stats"] = {"merged_msm_s": t1 - t0, "independent_s": time.perf_counter() - t1, "merged_ok": merged_ok,
+                               "front_end_s": tk.get("front_end_s", 0.0), "n": n, "points": n * L + C, "pipelined": len(tk["bounds"]) > 1}
+            except BaseException as e:
+                tk["error"] = e
+            finally:
+                tk["done"].set()
+
+        self._gpu_submit(gpu_stage)
+
+    def _finish(self, tk: dict) -> List[int]:
+        import time
+
+        tk["done"].wait()
+        if tk["error"] is not None:
+            raise tk["error"]
+        self.last_status = tk["status"]
+        self.last_stats = dict(tk["stats"])
+        self.last_stats["total_s"] = time.perf_counter() - tk["t0"]
+        return tk["status"]
+
+    def verify_stream(self, batches, mode: str = "merged", rng=None):
+        """Verify a sequence of batches, three stages overlapped across batches: while the host front-end works on batch k,
+        the GPU finishes the MSM of batch k-1 and already decompresses batch k+1.
+        `batches` yields (instances, proofs, n[, pre_status[, weights]]); yields one status list (0 = valid) per batch."""
+        it = iter(batches)
+        cur = next(it, None)
+        if cur is None:
+            return
+        tk = self._begin(cur, mode, rng)
+        pending = None
+        while tk is not None:
+            nxt = next(it, None)
+            tk_next = self._begin(nxt, mode, rng) if nxt is not None else None      # prefetch: decompression of the next batch
+            self._front_end(tk)
+            self._enqueue_msm(tk)
+            if pending is not None:
+                yield self._finish(pending)
+            pending, tk = tk, tk_next
+        if pending is not None:
+            yield self._finish(pending)
+
+    def verify_packed(self, instances: bytes, proofs: bytes, n: int, mode: str = "merged", rng=None, weights=None,
+                      pre_status: Optional[Sequence[int]] = None) -> List[int]:
+        """One batch in wire form: `instances` = n x (vec_R | vec_S | vec_T | vec_U) encodings, `proofs` = n x
+        crs.proof_bytes.  Returns the per-proof status (0 = valid, else a reject code of REJECT_NAMES)."""
+        if n == 0:
+            return []
+        return next(self.verify_stream([(instances, proofs, n, pre_status, weights)], mode=mode, rng=rng))
+
+    def verify_many(self, items, mode: str = "merged", rng=None) -> List[bool]:
+        """[IsValidWhiskShuffleProof(crs, pre, post, proof) for (pre, post, proof) in items] (whisk_interface.py:72-87)."""
+        items = list(items)
+        if not items:
+            return []
+        inst, proofs, pre_status = self.pack(items)
+        status = self.verify_packed(inst, proofs, len(items), mode=mode, rng=rng, pre_status=pre_status)
+        return [s == 0 for s in status]
 
 
 def is_valid_whisk_shuffle_proof(crs, pre_shuffle_trackers, post_shuffle_trackers, whisk_shuffle_proof_bytes, ctx=None) -> bool:

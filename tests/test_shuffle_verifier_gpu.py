@@ -79,6 +79,26 @@ def test_pipelined_sub_batches_agree(gold, ctx):
         assert v.last_stats["pipelined"] == (chunk < len(items))
 
 
+def test_stream_of_batches(gold, ctx):
+    """verify_stream overlaps decompression / front-end / MSM of consecutive batches (three rotating buffer slots);
+    batches of different sizes, some with invalid proofs: each batch gets exactly its own verdicts, in order."""
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    case = gold["cases"][2]
+    v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx, chunk=4)
+    good = _items(case, [{"edits": []}])[0]
+    variants = case["variants"]
+    batches, want = [], []
+    for b in range(7):
+        items = [good] * (3 + b) + _items(case, variants[b: b + 2]) + [good] * (b % 3)
+        inst, proofs, pre = v.pack(items)
+        batches.append((inst, proofs, len(items), pre))
+        want.append([True] * (3 + b) + [x["accepts"] for x in variants[b: b + 2]] + [True] * (b % 3))
+    got = [[s == 0 for s in st] for st in v.verify_stream(batches, rng=random.Random(8))]
+    assert got == want
+    assert list(v.verify_stream([])) == []
+
+
 def test_cross_crs_proof_is_rejected(gold, ctx):
     """A valid proof checked against another CRS of the same size must fail (every CRS slot matters)."""
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier

@@ -25,3 +25,13 @@ for grouped in (0, 1):
             print(f"grouped={grouped} threads={threads or 'all'} chunk={chunk}: mean {1e3*sum(ts)/len(ts):.1f} ms  min {1e3*ts[0]:.1f}  max {1e3*ts[-1]:.1f}  -> {n*len(ts)/sum(ts):.0f} proofs/s | "
                   + " ".join(f"{k}={1e3*x:.1f}" for k, x in v.last_stats.items() if k.endswith('_s')), flush=True)
 N.cg1_shuffle_set_grouped(1)
+for chunk in (128, 256, 512):
+    v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx, chunk=chunk)
+    list(v.verify_stream([(inst, proofs, n)] * 2))
+    K = 12
+    t0 = time.perf_counter()
+    for st in v.verify_stream(((inst, proofs, n) for _ in range(K))):
+        assert not any(st)
+    dt = time.perf_counter() - t0
+    print(f"stream of {K} batches, chunk={chunk}: {1e3*dt/K:.1f} ms per batch -> {n*K/dt:.0f} proofs/s | last: "
+          + " ".join(f"{k}={1e3*x:.1f}" for k, x in v.last_stats.items() if k.endswith('_s')), flush=True)
