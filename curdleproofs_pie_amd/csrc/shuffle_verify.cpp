@@ -866,6 +866,44 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint
   return CG1_OK;
 }
 
+// ---- Whisk tracker-opening proofs (opening.py:21-79; IsValidWhiskOpeningProof, whisk_interface.py:147-169), batched the
+// same way: proof of knowledge of k with k_r_G = k * r_G and k_G = k * G.  The reference checks
+//     s*G + c*k_G == A   and   s*r_G + c*k_r_G == B        (opening.py:74-77)
+// with c drawn from the transcript; here both equalities of every proof, weighted by two random rho, become scalars over
+// the proof's own points [k_G, k_r_G, r_G, A, B] and over the generator G (whose scalars add up across proofs).
+//   trackers: n x (r_G | k_r_G) encodings; k_commitments: n x 48; proofs: n x 128 (A | B | s); weights: n x 2 x 32.
+int cg1_opening_prepare(size_t n, const uint8_t* trackers, const uint8_t* k_commitments, const uint8_t* proofs, const uint8_t* weights,
+                        uint8_t* out_points48, uint8_t* out_scalars32, uint8_t* out_g_scalars32, int32_t* status) {
+  if (n && (!trackers || !k_commitments || !proofs || !weights || !out_points48 || !out_scalars32 || !out_g_scalars32 || !status))
+    return CG1_ERR_ARG;
+  uint8_t G48[48];
+  cg1h::g1_compress(cg1h::jac_generator(), G48);
+  for (size_t i = 0; i < n; ++i) {
+    const uint8_t *rG = trackers + 96 * i, *krG = rG + 48, *kG = k_commitments + 48 * i, *A = proofs + 128 * i, *B = A + 48;
+    uint8_t* pts = out_points48 + 5 * 48 * i;
+    memcpy(pts, kG, 48); memcpy(pts + 48, krG, 48); memcpy(pts + 96, rG, 48); memcpy(pts + 144, A, 48); memcpy(pts + 192, B, 48);
+    uint8_t* sc = out_scalars32 + 5 * 32 * i;
+    uint8_t* gs = out_g_scalars32 + 32 * i;
+    memset(sc, 0, 5 * 32);
+    memset(gs, 0, 32);
+    fr s_, r1, r2;
+    if (!fr_from_le32(A + 96, s_)) { status[i] = CG1_SHUFFLE_BAD_SCALAR; continue; }
+    if (!fr_from_le32(weights + 64 * i, r1) || !fr_from_le32(weights + 64 * i + 32, r2)) { status[i] = CG1_SHUFFLE_BAD_WEIGHT; continue; }
+    Transcript tr("whisk_opening_proof");
+    const uint8_t* order[6] = {kG, G48, krG, rG, A, B};
+    for (const uint8_t* p : order) tr.point("tracker_opening_proof", p);
+    const fr c = tr.challenge("tracker_opening_proof_challenge");
+    fr_to_le32(fr_mul(r1, c), sc);                 // k_G
+    fr_to_le32(fr_mul(r2, c), sc + 32);            // k_r_G
+    fr_to_le32(fr_mul(r2, s_), sc + 64);           // r_G
+    fr_to_le32(fr_neg(r1), sc + 96);               // A
+    fr_to_le32(fr_neg(r2), sc + 128);              // B
+    fr_to_le32(fr_mul(r1, s_), gs);                // G
+    status[i] = 0;
+  }
+  return CG1_OK;
+}
+
 // Only the first step of cg1_shuffle_prepare: the proofs' own points in layout order (what the GPU decompresses).
 int cg1_shuffle_gather_points(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
                               uint8_t* out_points48) {

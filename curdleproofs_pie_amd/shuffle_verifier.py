@@ -44,12 +44,15 @@ def _addr(b) -> int:
 
 def _tracker_bytes(trackers) -> Tuple[bytes, bytes]:
     """Sequence of WhiskTracker-likes (r_G, k_r_G attributes; whisk_interface.py:24-30) or (r_G, k_r_G) pairs."""
-    rs, ks = [], []
-    for t in trackers:
-        r, k = (t.r_G, t.k_r_G) if hasattr(t, "r_G") else t
-        rs.append(bytes(r))
-        ks.append(bytes(k))
-    return b"".join(rs), b"".join(ks)
+    trackers = list(trackers)
+    if trackers and hasattr(trackers[0], "r_G"):
+        rs, ks = [t.r_G for t in trackers], [t.k_r_G for t in trackers]
+    else:
+        rs, ks = [t[0] for t in trackers], [t[1] for t in trackers]
+    try:
+        return b"".join(rs), b"".join(ks)                 # bytes-likes (BLSPubkey is a bytes subclass)
+    except TypeError:
+        return b"".join(bytes(r) for r in rs), b"".join(bytes(k) for k in ks)
 
 
 class ShuffleCrs:
@@ -131,7 +134,8 @@ class ShuffleBatchVerifier:
                 qr, qk = _tracker_bytes(post)
             except Exception:
                 pr = pk = qr = qk = b""
-            ok = len(pr) == len(pk) == len(qr) == len(qk) == 48 * ell and len(proof) >= pb
+            ok = (len(pr) == len(pk) == len(qr) == len(qk) == 48 * ell and len(proof) >= pb
+                  and len(pre) == len(post) == ell)
             if ok:
                 inst.append(pr + pk + qr + qk)        # vec_R | vec_S | vec_T | vec_U
                 proofs.append(proof[:pb])             # trailing bytes are never read by BufReader (util.py:138-153)
@@ -404,3 +408,88 @@ def is_valid_whisk_shuffle_proof(crs, pre_shuffle_trackers, post_shuffle_tracker
     """Drop-in for IsValidWhiskShuffleProof (whisk_interface.py:72-87) -- a batch of one."""
     v = crs if isinstance(crs, ShuffleBatchVerifier) else ShuffleBatchVerifier(crs, ctx)
     return v.verify_many([(pre_shuffle_trackers, post_shuffle_trackers, whisk_shuffle_proof_bytes)])[0]
+
+
+class OpeningBatchVerifier:
+    """Many `IsValidWhiskOpeningProof(tracker, k_commitment, proof)` calls (whisk_interface.py:147-169) as one GPU MSM of
+    5 n + 1 terms: both equalities of every proof (opening.py:74-77) under fresh random weights, points decompressed on
+    the GPU.  If the merged check fails, one 5-term MSM per proof (plus its generator term on the host) names the culprits."""
+
+    PROOF_BYTES = 128                       # A | B | s   (opening.py:94-99)
+
+    def __init__(self, ctx: Optional["N.Context"] = None):
+        self._ctx = ctx
+        g = ctypes.create_string_buffer(N.POINT_BYTES)
+        N.cg1_generator(g)
+        aff = ctypes.create_string_buffer(96)
+        N.cg1_to_affine96(aff, g.raw)
+        self._g_blob, self._g96 = g.raw, aff.raw
+        self.last_status: List[int] = []
+
+    @property
+    def ctx(self) -> "N.Context":
+        if self._ctx is None:
+            self._ctx = N.default_context()
+        return self._ctx
+
+    def prepare(self, items, rng=None):
+        """items: (tracker, k_commitment, proof_bytes); tracker = WhiskTracker-like or (r_G, k_r_G).  Host half only."""
+        items = list(items)
+        n = len(items)
+        tr, kc, pf, pre = [], [], [], []
+        for t, k, p in items:
+            r, kr = (t.r_G, t.k_r_G) if hasattr(t, "r_G") else t
+            r, kr, k, p = bytes(r), bytes(kr), bytes(k), bytes(p)
+            ok = len(r) == len(kr) == len(k) == 48 and len(p) >= self.PROOF_BYTES       # BufReader ignores trailing bytes
+            tr.append(r + kr if ok else bytes(96)); kc.append(k if ok else bytes(48)); pf.append(p[:128] if ok else bytes(128))
+            pre.append(0 if ok else REJECT_LENGTH)
+        if rng is None:
+            raw = bytearray(secrets.token_bytes(64 * n))
+            raw[31::32] = bytes(b & 0x3F for b in raw[31::32])
+            weights = bytes(raw)
+        else:
+            weights = b"".join(rng.randint(1, FR_MODULUS - 1).to_bytes(32, "little") for _ in range(2 * n))
+        out = {"n": n, "points48": ctypes.create_string_buffer(max(1, 240 * n)), "scalars32": ctypes.create_string_buffer(max(1, 160 * n)),
+               "g_scalars32": ctypes.create_string_buffer(max(1, 32 * n)), "status": (ctypes.c_int32 * max(1, n))()}
+        rc = N.cg1_opening_prepare(n, b"".join(tr), b"".join(kc), b"".join(pf), weights, out["points48"], out["scalars32"],
+                                   out["g_scalars32"], out["status"])
+        if rc:
+            raise N.NativeError(f"cg1_opening_prepare failed ({rc})")
+        for i, s in enumerate(pre):
+            if s:
+                out["status"][i] = s
+                ctypes.memset(ctypes.addressof(out["scalars32"]) + 160 * i, 0, 160)
+                ctypes.memset(ctypes.addressof(out["g_scalars32"]) + 32 * i, 0, 32)
+        return out
+
+    def verify_many(self, items, rng=None) -> List[bool]:
+        prep = self.prepare(items, rng)
+        n = prep["n"]
+        if n == 0:
+            return []
+        ctx = self.ctx
+        d_wire, d_pts, d_stat, d_sc = ctx.alloc(240 * n), ctx.alloc(96 * (5 * n + 1)), ctx.alloc(5 * n), ctx.alloc(32 * (5 * n + 1))
+        d_wire.upload(prep["points48"].raw[: 240 * n])
+        ctx.check(N.cg1_batch_decompress_device(ctx.handle, d_wire.ptr, d_pts.ptr, d_stat.ptr, 5 * n, 0))
+        d_pts.upload(self._g96, 96 * 5 * n)
+        ctx.check(N.cg1_shuffle_apply_point_status(prep["status"], d_stat.download(5 * n), n, 5, prep["scalars32"], prep["g_scalars32"], 1))
+        g_sum = ctypes.create_string_buffer(32)
+        ctx.check(N.cg1_shuffle_sum_crs_scalars(prep["g_scalars32"], prep["status"], n, 1, g_sum))
+        d_sc.upload(prep["scalars32"].raw[: 160 * n] + g_sum.raw)
+        status = [int(prep["status"][i]) for i in range(n)]
+        live = [i for i in range(n) if status[i] == 0]
+        if live and not N.cg1_is_identity(ctx.msm_device(d_pts, d_sc, 5 * n + 1)):
+            own = ctx.msm_batched_device(d_pts, d_sc, [5 * i for i in range(n + 1)])
+            tmp = ctypes.create_string_buffer(N.POINT_BYTES)
+            for i in live:
+                N.cg1_mul(tmp, self._g_blob, prep["g_scalars32"].raw[32 * i: 32 * i + 32])
+                N.cg1_add(tmp, tmp.raw, own[i])
+                if not N.cg1_is_identity(tmp.raw):
+                    status[i] = REJECT_EQUATION
+        self.last_status = status
+        return [s == 0 for s in status]
+
+
+def is_valid_whisk_opening_proof(tracker, k_commitment, tracker_proof, ctx=None) -> bool:
+    """Drop-in for IsValidWhiskOpeningProof (whisk_interface.py:147-160) -- a batch of one."""
+    return OpeningBatchVerifier(ctx).verify_many([(tracker, k_commitment, tracker_proof)])[0]

@@ -206,6 +206,15 @@ int cg1_shuffle_apply_point_status(int32_t* status, const uint8_t* point_status,
 /* out[j] = sum over proofs i with status[i] == 0 (status may be NULL = all) of crs_scalars[i][j]  (mod r) */
 int cg1_shuffle_sum_crs_scalars(const uint8_t* crs_scalars32, const int32_t* status, size_t n_proofs, size_t ncrs, uint8_t* out32);
 
+/* Whisk tracker-opening proofs in batches: IsValidWhiskOpeningProof (whisk_interface.py:147-169) ->
+ * TrackerOpeningProof.verify (opening.py:60-79), wire format opening.py:94-106.  Own points per proof, in order:
+ * k_G, k_r_G, r_G, A, B (5 encodings / 5 scalars); out_g_scalars32 holds each proof's scalar on the generator G
+ * (add them up with cg1_shuffle_sum_crs_scalars(..., ncrs = 1)).  status: 0 or CG1_SHUFFLE_BAD_SCALAR / _BAD_WEIGHT;
+ * undecodable points are found by cg1_batch_decompress_device (apply with cg1_shuffle_apply_point_status, 5 points per proof). */
+int cg1_opening_prepare(size_t n, const uint8_t* trackers96 /* r_G | k_r_G */, const uint8_t* k_commitments48, const uint8_t* proofs128,
+                        const uint8_t* weights /* n x 2 x scalar32 */, uint8_t* out_points48, uint8_t* out_scalars32,
+                        uint8_t* out_g_scalars32, int32_t* status);
+
 #ifdef __cplusplus
 }
 #endif
