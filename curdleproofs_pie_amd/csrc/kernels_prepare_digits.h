@@ -3,28 +3,41 @@
 #pragma once
 
 // ------------------------------------------------------------------ k_prepare_points
+// 96-B affine record -> 128-B Montgomery record.  A block moves its 256 records through LDS so that both the reads
+// (24.6 KB) and the writes (32 KB) are whole contiguous lines; a lane-strided access touched 64 lines per instruction
+// (3.5 TB/s effective; this kernel runs over ALL N * 2^20 points on every rank of a window-sharded MSM).
 __global__ void __launch_bounds__(256) k_prepare_points(const uint32_t* __restrict__ raw, PreparedPoint* __restrict__ out,
                                                         uint8_t* __restrict__ inf_flag, uint32_t n) {
-  uint32_t i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const uint4* q = reinterpret_cast<const uint4*>(raw + 24ull * i);
-  uint32_t w[24];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) { uint4 v = q[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
-  uint32_t any = 0;
-#pragma unroll
-  for (int k = 0; k < 24; ++k) any |= w[k];
-  fp x = fp_to_mont(fp_from_words(w));
-  fp y = fp_to_mont(fp_from_words(w + 12));
+  __shared__ uint4 stage[256 * 8];                       // 32 KB: input (6 uint4 per record), then output (8 per record)
+  const uint32_t base = blockIdx.x * 256u, t = threadIdx.x;
+  const uint32_t cnt = (n - base < 256u) ? n - base : 256u;
+  const uint4* src = reinterpret_cast<const uint4*>(raw + 24ull * base);
+  for (uint32_t j = t; j < cnt * 6u; j += 256u) stage[j] = src[j];
+  __syncthreads();
   uint32_t o[32];
+  if (t < cnt) {
+    uint32_t w[24];
 #pragma unroll
-  for (int k = 0; k < NL; ++k) { o[k] = x.l[k]; o[NL + k] = y.l[k]; }
-  o[28] = any ? 0u : 1u;               // (0,0) is not on the curve: it encodes the identity
-  inf_flag[i] = any ? 0 : 1;           // compact copy: the digit kernels must not touch the 128-B records
-  o[29] = o[30] = o[31] = 0;
-  uint4* d = reinterpret_cast<uint4*>(out + i);
+    for (int k = 0; k < 6; ++k) { uint4 v = stage[t * 6u + k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+    uint32_t any = 0;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) d[k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+    for (int k = 0; k < 24; ++k) any |= w[k];
+    fp x = fp_to_mont(fp_from_words(w));
+    fp y = fp_to_mont(fp_from_words(w + 12));
+#pragma unroll
+    for (int k = 0; k < NL; ++k) { o[k] = x.l[k]; o[NL + k] = y.l[k]; }
+    o[28] = any ? 0u : 1u;               // (0,0) is not on the curve: it encodes the identity
+    inf_flag[base + t] = any ? 0 : 1;    // compact copy: the digit kernels must not touch the 128-B records
+    o[29] = o[30] = o[31] = 0;
+  }
+  __syncthreads();                       // everyone has consumed its input record
+  if (t < cnt) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) stage[t * 8u + k] = make_uint4(o[4 * k], o[4 * k + 1], o[4 * k + 2], o[4 * k + 3]);
+  }
+  __syncthreads();
+  uint4* dst = reinterpret_cast<uint4*>(out + base);
+  for (uint32_t j = t; j < cnt * 8u; j += 256u) dst[j] = stage[j];
 }
 
 // ------------------------------------------------------------------ signed digit recoding

@@ -108,7 +108,7 @@ class Prepared:
 
 
 class ShuffleBatchVerifier:
-    def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 512):
+    def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256):
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
