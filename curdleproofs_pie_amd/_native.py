@@ -84,6 +84,7 @@ cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p,
 cg1_batch_mul_add_device = _proto("cg1_batch_mul_add_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
 cg1_batch_mul_add = _proto("cg1_batch_mul_add", c_int, c_void_p, _u8p, c_size_t, _u8p, c_size_t, _u8p, _buf, c_size_t)
 cg1_batch_decompress_device = _proto("cg1_batch_decompress_device", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int)
+cg1_batch_compress_device = _proto("cg1_batch_compress_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
 cg1_batch_decompress_gpu = _proto("cg1_batch_decompress_gpu", c_int, c_void_p, _u8p, _buf, c_size_t, c_int, POINTER(c_size_t))
 cg1_gen_scalars_device = _proto("cg1_gen_scalars_device", c_int, c_void_p, c_void_p, c_size_t, c_uint64)
 cg1_probe_madd = _proto("cg1_probe_madd", c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_int, POINTER(c_float))
@@ -128,7 +129,7 @@ EXPORTED_SYMBOLS = [
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_host_alloc", "cg1_host_free", "cg1_ctx_sync", "cg1_ctx_set_param",
-    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
+    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 
 

@@ -51,6 +51,27 @@ __global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ 
 // One lane per point: parse the ZCash-format encoding (util.py:35-36 -> G1Point.from_compressed_bytes[_unchecked]),
 // y = sqrt(x^3 + 4) by exponentiation, sign select, optional subgroup test  [z^2]P == phi(P) + P.
 // out: affine96 (zeros = identity), status: 0 ok, CG1_ERR_ENCODING / _NOT_ON_CURVE / _NOT_IN_SUBGROUP.
+// ------------------------------------------------------------------ batched 48-byte G1 compression
+// affine96 (x || y little-endian standard form, zeros = identity) -> ZCash-format encoding (util.py:27-28 ->
+// G1Point.to_compressed_bytes): big-endian x, bit 7 compressed, bit 6 infinity, bit 5 "y > (p-1)/2".  No field
+// arithmetic: the inputs are already affine (k_batch_mul / k_batch_decompress produce this form).
+__global__ void __launch_bounds__(256) k_batch_compress(const uint32_t* __restrict__ in_raw, uint8_t* __restrict__ out48, uint32_t n) {
+  uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t* src = in_raw + 24ull * i;
+  uint32_t w[24], any = 0;
+  for (int k = 0; k < 24; ++k) { w[k] = src[k]; any |= w[k]; }
+  uint8_t* o = out48 + 48ull * i;
+  if (!any) { o[0] = 0xC0; for (int k = 1; k < 48; ++k) o[k] = 0; return; }
+  bool is_large = false, decided = false;       // y > (p-1)/2 ?
+  for (int j = 11; j >= 0 && !decided; --j) if (w[12 + j] != W_P_MINUS_1_HALF[j]) { is_large = w[12 + j] > W_P_MINUS_1_HALF[j]; decided = true; }
+  for (int j = 0; j < 12; ++j) {                // little-endian words -> big-endian bytes
+    uint32_t v = w[11 - j];
+    o[4 * j] = (uint8_t)(v >> 24); o[4 * j + 1] = (uint8_t)(v >> 16); o[4 * j + 2] = (uint8_t)(v >> 8); o[4 * j + 3] = (uint8_t)v;
+  }
+  o[0] |= (uint8_t)(0x80 | (is_large ? 0x20 : 0));
+}
+
 // CHECK is a template parameter: the unchecked instantiation (the reference's default, util.py:35-36) must not carry the
 // register footprint of the subgroup test's scalar multiplication (256 VGPRs + spills, 1 wave/SIMD when it did).
 template <bool CHECK>

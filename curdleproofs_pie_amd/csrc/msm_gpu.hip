@@ -765,6 +765,17 @@ int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_af
   HIPCHK(hipGetLastError());
   return CG1_OK;
 }
+int cg1_batch_compress_device(cg1_ctx* ctx, const void* d_in_affine96, void* d_out48, size_t n) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) return CG1_OK;
+  if (n >= (1ull << 31)) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(cg1::k_batch_compress, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream,
+                     (const uint32_t*)d_in_affine96, (uint8_t*)d_out48, (uint32_t)n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
 // host buffers: returns CG1_OK if every encoding is valid, else the first failing status with *bad_index set
 int cg1_batch_decompress_gpu(cg1_ctx* ctx, const uint8_t* in48, uint8_t* out_affine96, size_t n, int check_subgroup, size_t* bad_index) {
   if (!ctx) return CG1_ERR_HIP;

@@ -111,6 +111,21 @@ def batch_from_compressed(encodings: Iterable[bytes], checked: bool = False) -> 
     return _blobs_from_affine96(raw, len(enc))
 
 
+def batch_to_compressed(points: Iterable[G1Point]) -> List[bytes]:
+    """[p.to_compressed_bytes() for p in points] (util.py:27-28, points_projective_to_bytes util.py:31-32): ONE batched
+    normalisation on the host (a single field inversion) and the encoding itself on the GPU (k_batch_compress)."""
+    pts = list(points)
+    if not pts:
+        return []
+    ctx = N.default_context()
+    n = len(pts)
+    d_in, d_out = ctx.alloc(96 * n), ctx.alloc(48 * n)
+    d_in.upload(points_to_affine96(pts))
+    ctx.check(N.cg1_batch_compress_device(ctx.handle, d_in.ptr, d_out.ptr, n))
+    raw = d_out.download(48 * n)
+    return [raw[48 * i: 48 * i + 48] for i in range(n)]
+
+
 class MSMAccumulator:
     """Random-linear-combination batching of `C == MSM(bases, scalars)` checks (msm_accumulator.py:32-68).
 

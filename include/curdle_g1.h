@@ -124,6 +124,9 @@ int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t nbase,
  * Host variant: CG1_OK iff all n encodings are valid, else the first failing status and *bad_index. */
 int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup);
 int cg1_batch_decompress_gpu(cg1_ctx* ctx, const uint8_t* in48, uint8_t* out_affine96, size_t n, int check_subgroup, size_t* bad_index);
+/* Batched compression on the GPU: n affine96 records (as cg1_batch_mul_add_device / cg1_batch_decompress_device produce
+ * them; zeros = identity) -> n compressed48 (to_compressed_bytes, util.py:27-28,120).  All device pointers. */
+int cg1_batch_compress_device(cg1_ctx* ctx, const void* d_in_affine96, void* d_out48, size_t n);
 /* deterministic synthetic scalars, uniform in [1, r-1] (util.py:21-24 distribution), from a 64-bit seed
  * (splitmix64 + rejection), device memory */
 int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out_scalars32, size_t n, uint64_t seed);

@@ -119,6 +119,20 @@ def test_batch_mul_patterns(api):
     assert batch_mul([], []) == []
 
 
+def test_batch_to_compressed(api):
+    """GPU batched compression == to_compressed_bytes, incl. identity and both sign flags; round trip through the GPU decoder."""
+    A, U = api
+    from curdleproofs_pie_amd.msm_accumulator import batch_from_compressed, batch_to_compressed
+
+    random.seed(10)
+    pts = [U.get_random_point() for _ in range(300)] + [U.Z1, U.G1, -U.G1]
+    want = [bytes(p.to_compressed_bytes()) for p in pts]
+    got = batch_to_compressed(pts)
+    assert got == want
+    assert batch_from_compressed(got) == pts
+    assert batch_to_compressed([]) == []
+
+
 def test_batch_from_compressed(api):
     """GPU batched decompression == the host decoder, incl. identity, both sign branches and rejections."""
     A, U = api
