@@ -61,6 +61,19 @@ __device__ __forceinline__ xyzz load_sum(const PointSum* src) {
 }
 
 
+__device__ __forceinline__ xyzz shfl_xyzz(const xyzz& a, int src_lane) {        // a as held by lane src_lane of the wave
+  xyzz r;
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    r.X.l[i] = __shfl(a.X.l[i], src_lane, 64);
+    r.Y.l[i] = __shfl(a.Y.l[i], src_lane, 64);
+    r.ZZ.l[i] = __shfl(a.ZZ.l[i], src_lane, 64);
+    r.ZZZ.l[i] = __shfl(a.ZZZ.l[i], src_lane, 64);
+  }
+  r.inf = __shfl(a.inf, src_lane, 64);
+  return r;
+}
+
 __device__ __forceinline__ xyzz shfl_down_xyzz(const xyzz& a, int delta) {
   xyzz r;
 #pragma unroll

@@ -97,11 +97,34 @@ __device__ __forceinline__ xyzz bucket_sum(const uint32_t* __restrict__ choff, c
   return acc;
 }
 
+// Shuffle tree over the `lanes` partial sums of one row / column (lane `part` of the group starting at wave lane
+// `base`).  The levels that have at most lanes/4 additions left run as QUAD-lane additions (g1_quad.h): the 4 lanes of
+// quad v fetch both operands and share the field multiplications (4.5 instead of 14.5 multiply-times per level).
+// The result ends in the group's first lane.
+__device__ __forceinline__ xyzz group_tree(xyzz acc, uint32_t lanes, uint32_t part, uint32_t base, int use_quad) {
+  uint32_t delta = lanes >> 1;
+  for (; delta >= 1 && (!use_quad || delta * 4u > lanes); delta >>= 1) {
+    xyzz o = shfl_down_xyzz(acc, (int)delta);
+    if (part < delta) acc = xyzz_add(acc, o);
+  }
+  uint32_t stride = 1;                                   // value v is held by lane base + v*stride (all 4 lanes of quad v once stride == 4)
+  const uint32_t q = part & 3u, quad = part >> 2;
+  for (; delta >= 1; delta >>= 1) {
+    const uint32_t v = quad < delta ? quad : 0u;          // idle quads recompute pair 0 (same control flow, result unused)
+    const xyzz a = shfl_xyzz(acc, (int)(base + v * stride));
+    const xyzz b = shfl_xyzz(acc, (int)(base + (v + delta) * stride));
+    acc = quad_add(a, b, q);
+    stride = 4;
+  }
+  return acc;
+}
+
 __global__ void __launch_bounds__(256, 2) k_rowcol(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
                                                 const uint8_t* __restrict__ combined, PointSum* __restrict__ rowsum,
                                                 PointSum* __restrict__ colsum, uint32_t nlw, uint32_t hb, uint32_t lb,
-                                                uint32_t nrow_blocks) {
+                                                uint32_t nrow_blocks, int use_quad) {
   const uint32_t R = 1u << hb, Cn = 1u << lb;
+  const uint32_t lane = threadIdx.x & 63u;
   if (blockIdx.x < nrow_blocks) {
     const uint32_t lpr = Cn < 32u ? Cn : 32u, serial = Cn / lpr;
     const uint32_t gr = blockIdx.x * (256u / lpr) + threadIdx.x / lpr;     // global row = lw * R + h
@@ -110,10 +133,7 @@ __global__ void __launch_bounds__(256, 2) k_rowcol(const uint32_t* __restrict__ 
     xyzz acc = xyzz_identity();
     if (live)
       for (uint32_t t = 0; t < serial; ++t) acc = xyzz_add(acc, bucket_sum(choff, sums, combined, gr * Cn + part * serial + t));
-    for (uint32_t delta = lpr >> 1; delta >= 1; delta >>= 1) {
-      xyzz o = shfl_down_xyzz(acc, (int)delta);
-      if (part < delta) acc = xyzz_add(acc, o);
-    }
+    acc = group_tree(acc, lpr, part, lane - part, use_quad && lpr >= 4u);
     if (live && part == 0) store_sum(rowsum + gr, acc);
   } else {
     const uint32_t lpc = R < 16u ? R : 16u, serial = R / lpc;
@@ -124,10 +144,7 @@ __global__ void __launch_bounds__(256, 2) k_rowcol(const uint32_t* __restrict__ 
     xyzz acc = xyzz_identity();
     if (live)
       for (uint32_t t = 0; t < serial; ++t) acc = xyzz_add(acc, bucket_sum(choff, sums, combined, (lw * R + part * serial + t) * Cn + l));
-    for (uint32_t delta = lpc >> 1; delta >= 1; delta >>= 1) {
-      xyzz o = shfl_down_xyzz(acc, (int)delta);
-      if (part < delta) acc = xyzz_add(acc, o);
-    }
+    acc = group_tree(acc, lpc, part, lane - part, use_quad && lpc >= 4u);
     if (live && part == 0) store_sum(colsum + gc, acc);
   }
 }

@@ -296,7 +296,7 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     PointSum* rowsum = ctx->d_segrun;                     // reuse the segment buffers (>= nb_total records each)
     PointSum* colsum = ctx->d_segtot;
     hipLaunchKernelGGL(k_rowcol, dim3(nrow_blocks + ncol_blocks), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
-                       rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks);
+                       rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks, ctx->quad);
     HIPCHK(hipEventRecord(ctx->ev[6], st));
     if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(512), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
     else hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
