@@ -35,6 +35,7 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include "g1_xyzz.h"
 #include "g1_quad.h"
 #include "host_g1.h"
@@ -69,6 +70,7 @@ struct Ctx {
   size_t cap_digits = 0, cap_part = 0, cap_blockcnt = 0;
   int use_partition_sort = 1;
   int stage_sort = 1;                   // LDS-staged, line-coalesced writes in k_part_scatter / k_bin_sort (A/B switch)
+  int host_split = 1;                   // host Horner tail on two threads (A/B switch)
   int quad = 1;                         // quad-lane EC ops in the latency-bound kernels (A/B switch)
   int reduce_2d = 1;                    // 1: k_rowcol + k_small_tree; 0: k_seg_reduce + k_bit_tree (A/B switch)
   uint32_t* d_heavy = nullptr; size_t cap_heavy = 0;         // [0] count, then heavy bucket ids
@@ -326,22 +328,39 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   ctx->host_ms[1] = std::chrono::duration<float, std::milli>(h2 - h1).count();
   ctx->host_ms[2] = std::chrono::duration<float, std::milli>(t0 - h2).count();
   int lm = 0; while ((1u << lm) < m) ++lm;
-  cg1h::jac acc = cg1h::jac_identity();
   const int top_w = rank + (nlw - 1) * world;
-  for (int e = c * top_w + c - 2; e >= 0; --e) {
-    acc = cg1h::jac_dbl(acc);
-    const int w = e / c, r = e % c;
-    if (w % world != rank) continue;
-    const PointWords* row = ctx->h_out + (size_t)(w / world) * nitems;
-    if (r == 0) acc = cg1h::jac_add(acc, jac_from_words(row[0]));
-    if (use2d) {
-      //   e(T0) = c w;  e(column bit k) = c w + k (k < lb);  e(row bit k) = c w + lb + k (k < hb)
-      if (r < (int)lb2) acc = cg1h::jac_add(acc, jac_from_words(row[1 + hb2 + r]));
-      else if (r - (int)lb2 < (int)hb2) acc = cg1h::jac_add(acc, jac_from_words(row[1 + (r - lb2)]));
-    } else {
-      //   e(T_w) = c w;  e(Y_{w,b}) = c w + log2(m) + b
-      if (r >= lm && r - lm < nbits) acc = cg1h::jac_add(acc, jac_from_words(row[1 + (r - lm)]));
+  // horner(lo, hi) = sum_{e in [lo, hi]} 2^(e - lo) * (points of weight 2^e)
+  auto horner = [&](int lo, int hi) {
+    cg1h::jac a = cg1h::jac_identity();
+    for (int e = hi; e >= lo; --e) {
+      a = cg1h::jac_dbl(a);
+      const int w = e / c, r = e % c;
+      if (w % world != rank) continue;
+      const PointWords* row = ctx->h_out + (size_t)(w / world) * nitems;
+      if (r == 0) a = cg1h::jac_add(a, jac_from_words(row[0]));
+      if (use2d) {
+        //   e(T0) = c w;  e(column bit k) = c w + k (k < lb);  e(row bit k) = c w + lb + k (k < hb)
+        if (r < (int)lb2) a = cg1h::jac_add(a, jac_from_words(row[1 + hb2 + r]));
+        else if (r - (int)lb2 < (int)hb2) a = cg1h::jac_add(a, jac_from_words(row[1 + (r - lb2)]));
+      } else {
+        //   e(T_w) = c w;  e(Y_{w,b}) = c w + log2(m) + b
+        if (r >= lm && r - lm < nbits) a = cg1h::jac_add(a, jac_from_words(row[1 + (r - lm)]));
+      }
     }
+    return a;
+  };
+  const int e_top = c * top_w + c - 2;
+  cg1h::jac acc;
+  if (ctx->host_split && e_top >= 96) {
+    // two host threads: the low half of the exponent range on a helper while this thread does the high half and
+    // then its e_mid doublings (255 doublings + 129 additions on the critical path instead of 255 + 256)
+    const int e_mid = (e_top + 1) / 2;
+    auto low = std::async(std::launch::async, horner, 0, e_mid - 1);
+    acc = horner(e_mid, e_top);
+    for (int k = 0; k < e_mid; ++k) acc = cg1h::jac_dbl(acc);
+    acc = cg1h::jac_add(acc, low.get());
+  } else {
+    acc = horner(0, e_top);
   }
   result = acc;
   ctx->host_tail_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -633,6 +652,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "quad")) { ctx->quad = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "reduce_2d")) { ctx->reduce_2d = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
+  if (!strcmp(name, "host_split")) { ctx->host_split = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
     int v = value ? 1 : 0;
     HIPCHK(hipSetDevice(ctx->device));

@@ -219,14 +219,14 @@ def test_pipeline_variants_agree(native_lib, golden):
         s32 = b"".join(rng.choice([rng.randint(0, O.R - 1), 7, O.R - 1]).to_bytes(32, "little") for _ in range(n))
         want = C.compress(C.compute_msm(p96, s32, n))
         for params in ({"partition_sort": 0}, {"chunk_len": 1}, {"chunk_len": 7}, {"chunk_len": 4096}, {"seg_m": 1},
-                       {"seg_m": 2}, {"seg_m": 16}, {"wave_agg": 0}, {"stage_sort": 0}, {"partition_sort": 0, "chunk_len": 3, "seg_m": 8},
+                       {"seg_m": 2}, {"seg_m": 16}, {"wave_agg": 0}, {"stage_sort": 0}, {"host_split": 0}, {"partition_sort": 0, "chunk_len": 3, "seg_m": 8},
                        {"reduce_2d": 0}, {"reduce_2d": 0, "seg_m": 8}, {"quad": 0}):
             for k, v in params.items():
                 c2.set_param(k, v)
             for c in (0, 4, 5, 6, 9, 16):
                 assert gpu_msm(N, c2, p96, s32, n, window_c=c) == want, (params, c)
             for k in params:   # back to defaults
-                c2.set_param(k, {"partition_sort": 1, "chunk_len": 8, "seg_m": 4, "wave_agg": 1, "stage_sort": 1, "reduce_2d": 1, "quad": 1}[k])
+                c2.set_param(k, {"partition_sort": 1, "chunk_len": 8, "seg_m": 4, "wave_agg": 1, "stage_sort": 1, "host_split": 1, "reduce_2d": 1, "quad": 1}[k])
     finally:
         c2.close()
 
