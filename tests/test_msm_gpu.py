@@ -142,6 +142,30 @@ def test_full_size_2_20_closed_form_and_linearity(native_lib, ctx):
         assert p96[96 * i: 96 * i + 96] == C.scalar_mul(raw96(O.G1_GEN), kb[32 * i: 32 * i + 32])
 
 
+def test_config4_full_size_2_22_window_shards(native_lib, ctx):
+    """BASELINE config 4: one MSM of 2^22 terms, window buckets sharded over 8 ranks (here: the 8 per-rank partials
+    computed one after another on this GPU).  Closed form: points k_i*G, so MSM == (sum k_i s_i mod r) * G exactly;
+    the 8 window-shard partials must add up to exactly that point, and so must the 8 point-shard partials."""
+    N = native_lib
+    n = 1 << 22
+    dk, dg, dp, ds = ctx.alloc(32 * n), ctx.alloc(96), ctx.alloc(96 * n), ctx.alloc(32 * n)
+    ctx.gen_scalars_device(dk, n, 41); ctx.gen_scalars_device(ds, n, 42)
+    dg.upload(raw96(O.G1_GEN))
+    ctx.batch_mul_device(dg, 1, dk, dp, n)
+    kb, sb = dk.download(), ds.download()
+    acc = 0
+    for i in range(n):
+        acc += int.from_bytes(kb[32 * i: 32 * i + 32], "little") * int.from_bytes(sb[32 * i: 32 * i + 32], "little")
+    want = O.g1_compress(O.g1_mul(O.G1_GEN, acc % O.R))
+    assert compress_blob(N, ctx.msm_device(dp, ds, n)) == want
+    from curdleproofs_pie_amd.distributed import sum_blobs
+    parts = [ctx.msm_device(dp, ds, n, window_c=16, shard_rank=g, shard_world=8) for g in range(8)]
+    assert compress_blob(N, sum_blobs(parts)) == want
+    m = n // 8
+    parts = [ctx.msm_device(dp.ptr + 96 * m * g, ds.ptr + 32 * m * g, m) for g in range(8)]
+    assert compress_blob(N, sum_blobs(parts)) == want
+
+
 def test_batch_mul_variable_base(native_lib, ctx):
     rng = random.Random(9)
     n = 37
