@@ -126,11 +126,13 @@ __global__ void __launch_bounds__(256) k_part_scatter(const uint16_t* __restrict
 constexpr uint32_t BIN_STAGE = 12288;     // entries of a bin staged in LDS (48 KB) so sorted[] is written as full lines
 __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
                                                   uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted,
-                                                  uint32_t nbins_total, uint32_t nslices, uint32_t sub_bits, int use_stage) {
+                                                  uint32_t nbins_total, uint32_t nslices, uint32_t sub_bits, int use_stage,
+                                                  const uint8_t* __restrict__ bigflag) {
   __shared__ uint32_t cnt[256];
   __shared__ uint32_t cur[256];
   __shared__ uint32_t stage[BIN_STAGE];
   const uint32_t g = blockIdx.x;
+  if (bigflag[g]) return;                                          // sorted by k_big_count / k_big_scatter (many blocks)
   const uint32_t start = block_base[(size_t)g * nslices];
   const uint32_t end = block_base[(size_t)(g + 1) * nslices];     // element [nbins_total*nslices] holds the grand total
   cnt[threadIdx.x] = 0;
@@ -166,6 +168,88 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ p
   if (staged) {                                                      // scattered inside LDS, streamed out in order
     __syncthreads();
     for (uint32_t o = threadIdx.x; start + o < end; o += 256) sorted[start + o] = stage[o];
+  }
+}
+
+// ---- giant bins.  Skewed scalars (all-equal, tiny ranges, recoding-carry windows) put up to ALL n entries of a window
+// into one bin, and one block sorting a million entries takes milliseconds.  Bins above BIG_MIN entries are listed
+// (k_big_list, up to BIG_CAP of them; the rest stay with k_bin_sort) and each is sorted by BIG_S blocks over equal
+// slices of its entries: per-slice LDS histograms (k_big_count), then every block derives its own offsets from the
+// BIG_S histograms of its bin and scatters (k_big_scatter).  Fixed grids (blocks beyond the list exit at once), no
+// host round trip.
+constexpr uint32_t BIG_MIN = 4u * BIN_STAGE, BIG_CAP = 64, BIG_S = 64;
+
+__global__ void __launch_bounds__(256) k_big_list(const uint32_t* __restrict__ block_base, uint32_t nbins_total, uint32_t nslices,
+                                                  uint32_t* __restrict__ bigcount, uint32_t* __restrict__ biglist,
+                                                  uint8_t* __restrict__ bigflag, int enable) {
+  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+  if (g >= nbins_total) return;
+  const uint32_t size = block_base[(size_t)(g + 1) * nslices] - block_base[(size_t)g * nslices];
+  uint8_t flag = 0;
+  if (enable && size > BIG_MIN) {
+    const uint32_t slot = atomicAdd(bigcount, 1u);
+    if (slot < BIG_CAP) { biglist[slot] = g; flag = 1; }
+  }
+  bigflag[g] = flag;
+}
+
+__global__ void __launch_bounds__(256) k_big_count(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
+                                                   uint32_t nslices, const uint32_t* __restrict__ bigcount,
+                                                   const uint32_t* __restrict__ biglist, uint32_t* __restrict__ bighist) {
+  __shared__ uint32_t cnt[256];
+  const uint32_t slot = blockIdx.x, s = blockIdx.y;
+  const uint32_t nbig = *bigcount < BIG_CAP ? *bigcount : BIG_CAP;
+  if (slot >= nbig) return;
+  const uint32_t g = biglist[slot];
+  const uint32_t start = block_base[(size_t)g * nslices], size = block_base[(size_t)(g + 1) * nslices] - start;
+  const uint32_t lo = start + (uint32_t)((uint64_t)size * s / BIG_S), hi = start + (uint32_t)((uint64_t)size * (s + 1) / BIG_S);
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t span = ((hi - lo + 255u) / 256u) * 256u;          // whole waves iterate together
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const bool live = lo + o < hi;
+    lds_ranked_inc(cnt, live ? (part[lo + o] >> 24) : 0u, live);
+  }
+  __syncthreads();
+  bighist[((size_t)slot * BIG_S + s) * 256u + threadIdx.x] = cnt[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) k_big_scatter(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
+                                                     uint32_t nslices, uint32_t sub_bits, const uint32_t* __restrict__ bigcount,
+                                                     const uint32_t* __restrict__ biglist, const uint32_t* __restrict__ bighist,
+                                                     uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t cur[256];
+  const uint32_t slot = blockIdx.x, s = blockIdx.y;
+  const uint32_t nbig = *bigcount < BIG_CAP ? *bigcount : BIG_CAP;
+  if (slot >= nbig) return;
+  const uint32_t g = biglist[slot];
+  const uint32_t start = block_base[(size_t)g * nslices], size = block_base[(size_t)(g + 1) * nslices] - start;
+  const uint32_t lo = start + (uint32_t)((uint64_t)size * s / BIG_S), hi = start + (uint32_t)((uint64_t)size * (s + 1) / BIG_S);
+  uint32_t total = 0, before = 0;                                   // of sub-bucket threadIdx.x: whole bin / slices before mine
+  for (uint32_t s2 = 0; s2 < BIG_S; ++s2) {
+    const uint32_t v = bighist[((size_t)slot * BIG_S + s2) * 256u + threadIdx.x];
+    if (s2 < s) before += v;
+    total += v;
+  }
+  cur[threadIdx.x] = total;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? cur[threadIdx.x - d] : 0u;
+    __syncthreads();
+    cur[threadIdx.x] += u;
+    __syncthreads();
+  }
+  const uint32_t excl = cur[threadIdx.x] - total;
+  __syncthreads();
+  cur[threadIdx.x] = start + excl + before;
+  if (s == 0 && threadIdx.x < (1u << sub_bits)) hist[((size_t)g << sub_bits) + threadIdx.x] = total;
+  __syncthreads();
+  const uint32_t span = ((hi - lo + 255u) / 256u) * 256u;
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const bool live = lo + o < hi;
+    const uint32_t v = live ? part[lo + o] : 0u;
+    const uint32_t pos = lds_ranked_inc(cur, v >> 24, live);
+    if (live) sorted[pos] = (v & 0x7fffffu) | ((v >> 23 & 1u) << 31);
   }
 }
 

@@ -68,6 +68,8 @@ struct Ctx {
   PointSum* d_partial = nullptr; size_t cap_partial = 0;
   uint16_t* d_digits = nullptr; uint32_t* d_part = nullptr; uint32_t* d_blockcnt = nullptr; uint32_t* d_ublocktot = nullptr;
   size_t cap_digits = 0, cap_part = 0, cap_blockcnt = 0;
+  uint32_t *d_bigcount = nullptr, *d_biglist = nullptr, *d_bighist = nullptr; uint8_t* d_bigflag = nullptr; size_t cap_bigflag = 0;
+  int big_bins = 1;                     // giant bins of skewed scalars sorted by many blocks (A/B switch)
   int use_partition_sort = 1;
   int stage_sort = 1;                   // LDS-staged, line-coalesced writes in k_part_scatter / k_bin_sort (A/B switch)
   int host_split = 1;                   // host Horner tail on two threads (A/B switch)
@@ -101,6 +103,7 @@ static void free_bufs(Ctx* c) {
   F(c->d_sums); F(c->d_segrun); F(c->d_segtot); F(c->d_out); F(c->d_order); F(c->d_lenhist); F(c->d_partial);
   c->cap_partial = 0;
   F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot); F(c->d_boffs); F(c->d_gsum); F(c->d_bout);
+  F(c->d_bigcount); F(c->d_biglist); F(c->d_bighist); F(c->d_bigflag); c->cap_bigflag = 0;
   if (c->h_bout) { (void)hipHostFree(c->h_bout); c->h_bout = nullptr; }
   c->cap_boffs = c->cap_gsum = c->cap_bout = 0;
   c->cap_digits = c->cap_part = c->cap_blockcnt = 0;
@@ -169,6 +172,16 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
       if (ctx->d_part) (void)hipFree(ctx->d_part);
       HIPCHK(hipMalloc(&ctx->d_part, (entries + 1) * 4));
       ctx->cap_part = entries;
+    }
+    if (!ctx->d_bigcount) {
+      HIPCHK(hipMalloc(&ctx->d_bigcount, 16));
+      HIPCHK(hipMalloc(&ctx->d_biglist, BIG_CAP * 4));
+      HIPCHK(hipMalloc(&ctx->d_bighist, (size_t)BIG_CAP * BIG_S * 256 * 4));
+    }
+    if (nlw * 128 > ctx->cap_bigflag) {
+      if (ctx->d_bigflag) (void)hipFree(ctx->d_bigflag);
+      HIPCHK(hipMalloc(&ctx->d_bigflag, nlw * 128 + 16));
+      ctx->cap_bigflag = nlw * 128;
     }
     if (nbc > ctx->cap_blockcnt) {
       if (ctx->d_blockcnt) (void)hipFree(ctx->d_blockcnt);
@@ -261,7 +274,14 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     hipLaunchKernelGGL(k_uscan3, dim3(ublk), dim3(256), 0, st, ctx->d_ublocktot, ctx->d_blockcnt, nbc);
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_part_scatter, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, ctx->d_part, n32, nslices, nbins, sub_bits, ctx->stage_sort);
-    hipLaunchKernelGGL(k_bin_sort, dim3((uint32_t)nlw * nbins), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, ctx->d_hist, ctx->d_sorted, (uint32_t)nlw * nbins, nslices, sub_bits, ctx->stage_sort);
+    const uint32_t nbt = (uint32_t)nlw * nbins;
+    HIPCHK(hipMemsetAsync(ctx->d_bigcount, 0, 4, st));
+    hipLaunchKernelGGL(k_big_list, dim3((nbt + 255) / 256), dim3(256), 0, st, ctx->d_blockcnt, nbt, nslices, ctx->d_bigcount, ctx->d_biglist, ctx->d_bigflag, ctx->big_bins);
+    hipLaunchKernelGGL(k_bin_sort, dim3(nbt), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, ctx->d_hist, ctx->d_sorted, nbt, nslices, sub_bits, ctx->stage_sort, ctx->d_bigflag);
+    if (ctx->big_bins && n32 > BIG_MIN) {                          // a bin cannot exceed n entries
+      hipLaunchKernelGGL(k_big_count, dim3(BIG_CAP, BIG_S), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, nslices, ctx->d_bigcount, ctx->d_biglist, ctx->d_bighist);
+      hipLaunchKernelGGL(k_big_scatter, dim3(BIG_CAP, BIG_S), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, nslices, sub_bits, ctx->d_bigcount, ctx->d_biglist, ctx->d_bighist, ctx->d_hist, ctx->d_sorted);
+    }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
@@ -652,6 +672,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "quad")) { ctx->quad = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "reduce_2d")) { ctx->reduce_2d = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
+  if (!strcmp(name, "big_bins")) { ctx->big_bins = value != 0; return CG1_OK; }
   if (!strcmp(name, "host_split")) { ctx->host_split = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
     int v = value ? 1 : 0;

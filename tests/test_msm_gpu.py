@@ -106,7 +106,9 @@ def test_structured_scalars(native_lib, ctx, logn):
     p96 = dp.download()
     k_int = [int.from_bytes(ks[32 * i: 32 * i + 32], "little") for i in range(n)]
     beta = rng.randint(1, O.R - 1)
-    for name, sc in (("all_equal", [beta] * n), ("sigma", list(range(n))), ("all_max", [O.R - 1] * n)):
+    two = [(3, O.R - 5)[i & 1] for i in range(n)]                      # two hot buckets per window (+3 and -5's digits)
+    few = [rng.randrange(1 << 20) << 16 for _ in range(n)]            # windows 1 and 2 only: window 2 has 16 buckets
+    for name, sc in (("all_equal", [beta] * n), ("sigma", list(range(n))), ("all_max", [O.R - 1] * n), ("two_values", two), ("few_bits", few)):
         s32 = b"".join(s.to_bytes(32, "little") for s in sc)
         # closed form: points are k_i * G, so the MSM is (sum k_i s_i mod r) * G
         tot = sum(k * s for k, s in zip(k_int, sc)) % O.R
@@ -243,14 +245,14 @@ def test_pipeline_variants_agree(native_lib, golden):
         s32 = b"".join(rng.choice([rng.randint(0, O.R - 1), 7, O.R - 1]).to_bytes(32, "little") for _ in range(n))
         want = C.compress(C.compute_msm(p96, s32, n))
         for params in ({"partition_sort": 0}, {"chunk_len": 1}, {"chunk_len": 7}, {"chunk_len": 4096}, {"seg_m": 1},
-                       {"seg_m": 2}, {"seg_m": 16}, {"wave_agg": 0}, {"stage_sort": 0}, {"host_split": 0}, {"partition_sort": 0, "chunk_len": 3, "seg_m": 8},
+                       {"seg_m": 2}, {"seg_m": 16}, {"wave_agg": 0}, {"stage_sort": 0}, {"host_split": 0}, {"big_bins": 0}, {"partition_sort": 0, "chunk_len": 3, "seg_m": 8},
                        {"reduce_2d": 0}, {"reduce_2d": 0, "seg_m": 8}, {"quad": 0}):
             for k, v in params.items():
                 c2.set_param(k, v)
             for c in (0, 4, 5, 6, 9, 16):
                 assert gpu_msm(N, c2, p96, s32, n, window_c=c) == want, (params, c)
             for k in params:   # back to defaults
-                c2.set_param(k, {"partition_sort": 1, "chunk_len": 8, "seg_m": 4, "wave_agg": 1, "stage_sort": 1, "host_split": 1, "reduce_2d": 1, "quad": 1}[k])
+                c2.set_param(k, {"partition_sort": 1, "chunk_len": 8, "seg_m": 4, "wave_agg": 1, "stage_sort": 1, "host_split": 1, "big_bins": 1, "reduce_2d": 1, "quad": 1}[k])
     finally:
         c2.close()
 
