@@ -374,17 +374,26 @@ class ShuffleBatchVerifier:
         if cur is None:
             return
         tk = self._begin(cur, mode, rng)
-        pending = None
-        while tk is not None:
-            nxt = next(it, None)
-            tk_next = self._begin(nxt, mode, rng) if nxt is not None else None      # prefetch: decompression of the next batch
-            self._front_end(tk)
-            self._enqueue_msm(tk)
+        pending = tk_next = None
+        try:
+            while tk is not None:
+                nxt = next(it, None)
+                tk_next = self._begin(nxt, mode, rng) if nxt is not None else None      # prefetch: decompression of the next batch
+                self._front_end(tk)
+                self._enqueue_msm(tk)
+                if pending is not None:
+                    done, pending = pending, None
+                    yield self._finish(done)
+                pending, tk, tk_next = tk, tk_next, None
             if pending is not None:
-                yield self._finish(pending)
-            pending, tk = tk, tk_next
-        if pending is not None:
-            yield self._finish(pending)
+                done, pending = pending, None
+                yield self._finish(done)
+        finally:
+            # abandoned mid-way (an error, or the consumer stopped iterating): release the buffer slots of the batches
+            # still in flight once the GPU thread has drained what was queued for them
+            left = [t for t in (pending, tk, tk_next) if t is not None and not t["done"].is_set()]
+            if left:
+                self._gpu_submit(lambda: [t["done"].set() for t in left])
 
     def verify_packed(self, instances: bytes, proofs: bytes, n: int, mode: str = "merged", rng=None, weights=None,
                       pre_status: Optional[Sequence[int]] = None) -> List[int]:

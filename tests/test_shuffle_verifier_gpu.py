@@ -97,6 +97,12 @@ def test_stream_of_batches(gold, ctx):
     got = [[s == 0 for s in st] for st in v.verify_stream(batches, rng=random.Random(8))]
     assert got == want
     assert list(v.verify_stream([])) == []
+    # a consumer that stops early must not strand the buffer slots of the batches still in flight
+    for _ in range(4):
+        gen = v.verify_stream(batches, rng=random.Random(9))
+        assert [s == 0 for s in next(gen)] == want[0]
+        gen.close()
+    assert [[s == 0 for s in st] for st in v.verify_stream(batches[:4], rng=random.Random(10))] == want[:4]
 
 
 def test_cross_crs_proof_is_rejected(gold, ctx):
