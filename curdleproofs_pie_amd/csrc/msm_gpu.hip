@@ -57,6 +57,8 @@ namespace cg1 {
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;    // H2D staging copies that overlap kernels on `stream` (cg1_h2d_async / cg1_copy_fence)
+  hipEvent_t copy_ev = nullptr;
   char err[256] = {0};
   // capacity
   size_t cap_n = 0, cap_nb = 0, cap_chunks = 0, cap_entries = 0, cap_out = 0;
@@ -603,6 +605,8 @@ cg1_ctx* cg1_ctx_create(int device) {
   cg1_ctx* ctx = new cg1_ctx();
   ctx->device = device;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+  if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
   for (int i = 0; i <= CG1_NPHASE; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return nullptr; }
   return ctx;
 }
@@ -614,6 +618,8 @@ void cg1_ctx_destroy(cg1_ctx* ctx) {
   if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
   for (int i = 0; i <= CG1_NPHASE; ++i) (void)hipEventDestroy(ctx->ev[i]);
   (void)hipStreamDestroy(ctx->stream);
+  if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   delete ctx;
 }
 const char* cg1_ctx_error(const cg1_ctx* ctx) { return ctx ? ctx->err : "null context (no GPU visible?)"; }
@@ -635,6 +641,24 @@ int cg1_d2h(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return CG1_ERR_HIP;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+  return CG1_OK;
+}
+// Asynchronous H2D on the context's copy stream (src must be page-locked for the copy to overlap kernels), and the
+// fence that orders everything queued on the copy stream so far before whatever is launched next on the compute
+// stream.  Neither blocks the host.  cg1_h2d_async touches only the copy stream: it may be called from a second
+// thread while another thread runs kernels on this context.
+int cg1_h2d_async(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (bytes == 0) return CG1_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  return CG1_OK;
+}
+int cg1_copy_fence(cg1_ctx* ctx) {
+  if (!ctx) return CG1_ERR_HIP;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipEventRecord(ctx->copy_ev, ctx->copy_stream));
+  HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->copy_ev, 0));
   return CG1_OK;
 }
 // page-locked host memory: H2D/D2H copies from it run at full PCIe rate (pageable memory is staged by the runtime)
@@ -803,6 +827,21 @@ int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_af
     hipLaunchKernelGGL(cg1::k_batch_decompress<false>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
                        (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
+// same launch as cg1_batch_decompress_device without waiting for it (pair with cg1_ctx_sync)
+int cg1_batch_decompress_enqueue(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) return CG1_OK;
+  if (n >= (1ull << 31)) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (check_subgroup)
+    hipLaunchKernelGGL(cg1::k_batch_decompress<true>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                       (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
+  else
+    hipLaunchKernelGGL(cg1::k_batch_decompress<false>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                       (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
   HIPCHK(hipGetLastError());
   return CG1_OK;
 }

@@ -33,6 +33,7 @@ N_WEIGHTS = 12
 REJECT_NAMES = {0: "prepared", 1: "bad scalar encoding", 2: "bad point encoding", 3: "vec_T[0] is infinity", 4: "bad weight",
                 5: "bad length", 6: "verification equation failed"}
 REJECT_LENGTH, REJECT_EQUATION = 5, 6
+_CLEAR_TOP2 = bytes(b & 0x3F for b in range(256))
 
 
 def _addr(b) -> int:
@@ -102,8 +103,13 @@ class Prepared:
         else:
             self.points48 = ctypes.create_string_buffer(max(1, n * L * 48))
             self.scalars32 = ctypes.create_string_buffer(max(1, n * L * 32))
-        self.crs_scalars32 = ctypes.create_string_buffer(max(1, n * C * 32))
-        self.status = (ctypes.c_int32 * max(1, n))()
+        if staging is not None and staging.get("crs_scalars") is not None and len(staging["crs_scalars"]) >= n * C * 32:
+            self.crs_scalars32, self.status = staging["crs_scalars"], staging["status"]      # every byte is rewritten by prepare
+        else:
+            self.crs_scalars32 = ctypes.create_string_buffer(max(1, n * C * 32))
+            self.status = (ctypes.c_int32 * max(1, n))()
+            if staging is not None:
+                staging["crs_scalars"], staging["status"] = self.crs_scalars32, self.status
         self.challenges = ctypes.create_string_buffer(n * crs.challenges_per_proof * 32) if want_challenges and n else None
 
 
@@ -151,7 +157,7 @@ class ShuffleBatchVerifier:
         proof survives a batch with probability ~2^-254); with `rng` (tests): rng.randint(1, r-1) like util.py:21-24."""
         if rng is None:
             raw = bytearray(secrets.token_bytes(32 * N_WEIGHTS * n))
-            raw[31::32] = bytes(b & 0x3F for b in raw[31::32])          # < 2^254 < r: canonical without rejection
+            raw[31::32] = raw[31::32].translate(_CLEAR_TOP2)            # < 2^254 < r: canonical without rejection
             return bytes(raw)
         return b"".join(rng.randint(1, FR_MODULUS - 1).to_bytes(32, "little") for _ in range(N_WEIGHTS * n))
 
@@ -225,19 +231,28 @@ class ShuffleBatchVerifier:
             self._slots[idx] = b
         return b
 
-    def _decompress_range(self, b: dict, instances, proofs, n: int, lo: int, hi: int) -> None:
-        """GPU thread: gather the own points of proofs [lo, hi), H2D, decompress (they stay on the device for the MSM),
-        bring back the per-point verdicts and the 8-point window the host front-end wants."""
+    def _stage_in(self, b: dict, instances, proofs, lo: int, hi: int) -> None:
+        """GPU thread: gather the own points of proofs [lo, hi) into page-locked memory and queue their H2D copy on the
+        context's copy stream (it overlaps the decompression kernel of the previous sub-batch)."""
         crs, ctx = self.crs, self.ctx
         L = crs.points_per_proof
-        m = hi - lo
-        h = b["host"]
-        wire = h["wire"].ptr + lo * L * 48
-        ctx.check(N.cg1_shuffle_gather_points(crs.handle, m, _addr(instances) + lo * 4 * crs.ell * 48,
+        wire = b["host"]["wire"].ptr + lo * L * 48
+        ctx.check(N.cg1_shuffle_gather_points(crs.handle, hi - lo, _addr(instances) + lo * 4 * crs.ell * 48,
                                               _addr(proofs) + lo * crs.proof_bytes, wire))
-        ctx.check(N.cg1_h2d(ctx.handle, b["wire"].ptr + lo * L * 48, wire, m * L * 48))
-        ctx.check(N.cg1_batch_decompress_device(ctx.handle, b["wire"].ptr + lo * L * 48, b["pts"].ptr + lo * L * 96,
-                                                b["pstat"].ptr + lo * L, m * L, 0))
+        ctx.check(N.cg1_h2d_async(ctx.handle, b["wire"].ptr + lo * L * 48, wire, (hi - lo) * L * 48))
+
+    def _decompress_launch(self, b: dict, lo: int, hi: int) -> None:
+        """GPU thread: once the sub-batch's copy has landed, launch its decompression (points stay on the device for the MSM)."""
+        ctx, L = self.ctx, self.crs.points_per_proof
+        ctx.check(N.cg1_copy_fence(ctx.handle))
+        ctx.check(N.cg1_batch_decompress_enqueue(ctx.handle, b["wire"].ptr + lo * L * 48, b["pts"].ptr + lo * L * 96,
+                                                 b["pstat"].ptr + lo * L, (hi - lo) * L, 0))
+
+    def _decompress_collect(self, b: dict, lo: int, hi: int) -> None:
+        """GPU thread: wait for the kernel, bring back the per-point verdicts and the 8-point window the front-end wants."""
+        crs, ctx = self.crs, self.ctx
+        L, h, m = crs.points_per_proof, b["host"], hi - lo
+        ctx.sync()
         ctx.check(N.cg1_d2h(ctx.handle, h["pstat"].ptr + lo * L, b["pstat"].ptr + lo * L, m * L))
         ctx.check(N.cg1_d2h_2d(ctx.handle, h["decoded"].ptr + lo * 768, 768, b["pts"].ptr + (lo * L + 4 * crs.ell + 1) * 96, L * 96, 768, m))
 
@@ -251,8 +266,8 @@ class ShuffleBatchVerifier:
         crs = self.crs
         L, C = crs.points_per_proof, crs.ncrs
         assert n >= 1 and len(instances) == n * 4 * crs.ell * 48 and len(proofs) == n * crs.proof_bytes
-        weights = batch[4] if len(batch) > 4 and batch[4] is not None else self.draw_weights(n, rng)
-        assert len(weights) == n * N_WEIGHTS * 32
+        weights = batch[4] if len(batch) > 4 else None       # None: drawn on the GPU thread while the first kernel runs
+        assert weights is None or len(weights) == n * N_WEIGHTS * 32
         b = self._slot(n)
         tk = {"slot": b, "n": n, "instances": instances, "proofs": proofs, "weights": weights, "mode": mode,
               "pre_status": batch[3] if len(batch) > 3 else None, "chunks": queue.Queue(), "done": threading.Event(),
@@ -264,8 +279,15 @@ class ShuffleBatchVerifier:
                 if b.get("crs_at") != n:                       # CRS points sit right behind the batch's own points
                     b["pts"].upload(crs.affine96, n * L * 96)
                     b["crs_at"] = n
-                for lo, hi in tk["bounds"]:
-                    self._decompress_range(b, instances, proofs, n, lo, hi)
+                bounds = tk["bounds"]
+                self._stage_in(b, instances, proofs, *bounds[0])
+                for i, (lo, hi) in enumerate(bounds):              # copy of sub-batch i+1 overlaps the kernel of sub-batch i
+                    self._decompress_launch(b, lo, hi)
+                    if tk["weights"] is None:
+                        tk["weights"] = self.draw_weights(n, rng)
+                    if i + 1 < len(bounds):
+                        self._stage_in(b, instances, proofs, *bounds[i + 1])
+                    self._decompress_collect(b, lo, hi)
                     tk["chunks"].put((lo, hi))
             except BaseException as e:                          # surfaced in the consumer
                 tk["chunks"].put(e)
@@ -309,6 +331,8 @@ class ShuffleBatchVerifier:
         crs_sum = ctypes.create_string_buffer(C * 32)
         self.ctx.check(N.cg1_shuffle_sum_crs_scalars(prep.crs_scalars32, prep.status, n, C, crs_sum))
         ctypes.memmove(host["sc"].ptr + n * L * 32, crs_sum, C * 32)
+        # scalars to the device on the copy stream, from this thread, while the GPU thread is busy with other batches
+        self.ctx.check(N.cg1_h2d_async(self.ctx.handle, b["sc"].ptr, host["sc"].ptr, (n * L + C) * 32))
         tk["front_end_s"] = time.perf_counter() - t0
 
     def _enqueue_msm(self, tk: dict) -> None:
@@ -326,7 +350,7 @@ class ShuffleBatchVerifier:
                 status = [int(prep.status[i]) for i in range(n)]
                 live = [i for i in range(n) if status[i] == 0]
                 merged_ok = None
-                ctx.check(N.cg1_h2d(ctx.handle, b["sc"].ptr, b["host"]["sc"].ptr, (n * L + C) * 32))
+                ctx.check(N.cg1_copy_fence(ctx.handle))          # the scalars queued by _front_end
                 if live and tk["mode"] == "merged":
                     merged_ok = bool(N.cg1_is_identity(ctx.msm_device(b["pts"], b["sc"], n * L + C)))
                 t1 = time.perf_counter()

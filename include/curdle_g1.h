@@ -71,6 +71,10 @@ void* cg1_dev_malloc(cg1_ctx* ctx, size_t bytes);                    /* NULL on 
 void cg1_dev_free(cg1_ctx* ctx, void* p);
 int  cg1_h2d(cg1_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  cg1_d2h(cg1_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+/* asynchronous H2D on the context's copy stream (src page-locked to overlap kernels); cg1_copy_fence orders everything
+ * queued there so far before the next launch on the compute stream.  Neither blocks the host. */
+int  cg1_h2d_async(cg1_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int  cg1_copy_fence(cg1_ctx* ctx);
 /* page-locked host memory for staging buffers (copies from it run at full PCIe rate); NULL on failure */
 void* cg1_host_alloc(cg1_ctx* ctx, size_t bytes);
 void cg1_host_free(cg1_ctx* ctx, void* p);
@@ -123,6 +127,7 @@ int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t nbase,
  * Device variant: per-point status byte (0 ok, CG1_ERR_ENCODING, _NOT_ON_CURVE, _NOT_IN_SUBGROUP), affine96 out.
  * Host variant: CG1_OK iff all n encodings are valid, else the first failing status and *bad_index. */
 int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup);
+int cg1_batch_decompress_enqueue(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup);  /* no wait: pair with cg1_ctx_sync */
 int cg1_batch_decompress_gpu(cg1_ctx* ctx, const uint8_t* in48, uint8_t* out_affine96, size_t n, int check_subgroup, size_t* bad_index);
 /* Batched compression on the GPU: n affine96 records (as cg1_batch_mul_add_device / cg1_batch_decompress_device produce
  * them; zeros = identity) -> n compressed48 (to_compressed_bytes, util.py:27-28,120).  All device pointers. */
