@@ -21,7 +21,7 @@ constexpr int STROBE_R = 166;                      // strobe.py:4
 constexpr uint8_t FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_M = 16;
 
 struct Group {
-  alignas(64) uint64_t st[25][G];                  // sponge lane w of transcript k
+  alignas(64) uint8_t st[G][208];                  // the 200-byte sponge of transcript k (+ slack for 8-byte accesses)
   uint8_t pos[G], pos_begin[G];
   int count = 0;                                   // transcripts in use (<= G)
 
@@ -30,12 +30,12 @@ struct Group {
     uint8_t one[CG1_MERLIN_STATE_BYTES];
     cg1_merlin_init(one, reinterpret_cast<const uint8_t*>(label), strlen(label));
     count = n;
-    for (int w = 0; w < 25; ++w) {
-      uint64_t v;
-      memcpy(&v, one + 8 * w, 8);
-      for (int k = 0; k < G; ++k) st[w][k] = v;
+    for (int k = 0; k < G; ++k) {
+      memcpy(st[k], one, 200);
+      memset(st[k] + 200, 0, 8);
+      pos[k] = one[200];
+      pos_begin[k] = one[201];
     }
-    for (int k = 0; k < G; ++k) { pos[k] = one[200]; pos_begin[k] = one[201]; }
   }
 
   // append_message(label, data[k]) on every transcript (merlin_transcript.py:11-15)
@@ -50,7 +50,7 @@ struct Group {
   void challenge_scalar(const char* label, uint8_t (*out)[32]) { run(label, nullptr, out, 32, true); }
 
  private:
-  uint8_t& byte_at(int k, unsigned p) { return reinterpret_cast<uint8_t*>(&st[p >> 3][k])[p & 7]; }
+  uint8_t& byte_at(int k, unsigned p) { return st[k][p]; }
 
   // strobe.py:55-61 up to (not including) the permutation itself
   void pad(int k) {
@@ -80,20 +80,36 @@ struct Group {
     uint32_t total, patch2;     // header offsets: 0 and patch2
   };
   bool absorb(int k, Str& s, uint32_t& off) {
+    if (off == 0 && (unsigned)pos[k] + s.total < (unsigned)STROBE_R) {
+      // the whole string fits before the sponge position wraps (the common case): both headers are known up front
+      // (the second begin_op sees the pos_begin the first one set), one unaligned XOR pass, no permutation
+      const unsigned p = pos[k];
+      s.b[0] = pos_begin[k];
+      s.b[s.patch2] = (uint8_t)(p + 1);
+      pos_begin[k] = (uint8_t)(p + s.patch2 + 1);
+      uint8_t* dst = st[k] + p;
+      for (uint32_t i = 0; i < s.total; i += 8) {          // s.b has slack; bytes past `total` are masked off
+        uint64_t v, d;
+        memcpy(&v, s.b + i, 8);
+        if (s.total - i < 8) v &= (1ull << (8u * (s.total - i))) - 1ull;
+        memcpy(&d, dst + i, 8);
+        d ^= v;
+        memcpy(dst + i, &d, 8);
+      }
+      off = s.total;
+      pos[k] = (uint8_t)(p + s.total);
+      return false;
+    }
     while (off < s.total) {
       if (off == 0 || off == s.patch2) {                       // begin_op
         s.b[off] = pos_begin[k];
         pos_begin[k] = (uint8_t)(pos[k] + 1);
       }
-      const unsigned p = pos[k], sh = p & 7u;
-      unsigned take = 8u - sh;
+      const unsigned p = pos[k];
       const uint32_t limit = (off < s.patch2) ? s.patch2 : s.total;   // stop at the next header: it is patched on arrival
-      if (take > limit - off) take = limit - off;
+      unsigned take = limit - off;
       if (take > (unsigned)STROBE_R - p) take = (unsigned)STROBE_R - p;
-      uint64_t v;
-      memcpy(&v, s.b + off, 8);
-      if (take < 8) v &= (1ull << (8u * take)) - 1ull;
-      st[p >> 3][k] ^= v << (8u * sh);
+      for (unsigned i = 0; i < take; ++i) st[k][p + i] ^= s.b[off + i];
       off += take;
       pos[k] = (uint8_t)(p + take);
       if (pos[k] == STROBE_R) {
@@ -139,7 +155,8 @@ struct Group {
           } else {                                                // pc == 1: squeeze 32 bytes from a fresh block, then check
             uint8_t* o = out[k];
             if (pos[k] == 0) {
-              for (int wd = 0; wd < 4; ++wd) { memcpy(o + 8 * wd, &st[wd][k], 8); st[wd][k] = 0; }
+              memcpy(o, st[k], 32);
+              memset(st[k], 0, 32);
               pos[k] = 32;
             } else {                                              // unreachable for 32-byte outputs; kept exact (strobe.py:77-87)
               for (int i = 0; i < 32; ++i) { uint8_t& b = byte_at(k, pos[k]); o[i] = b; b = 0; ++pos[k]; }
@@ -161,25 +178,20 @@ struct Group {
     }
   }
 
-  // Keccak-f on the listed transcripts, eight per call
+  // Keccak-f on the listed transcripts, eight per call (sponge lanes transposed into one vector per lane index)
   void permute(const int* idx, int n) {
     alignas(64) uint64_t lanes[25 * 8];
     for (int base = 0; base < n; base += 8) {
       const int m = n - base < 8 ? n - base : 8;
-      if (m == 8 && idx[base + 7] - idx[base] == 7 && (idx[base] & 7) == 0) {         // a whole aligned half: no repacking
-        const int c0 = idx[base];
-        for (int w = 0; w < 25; ++w) memcpy(lanes + 8 * w, &st[w][c0], 64);
-        cg1_keccak_f1600_x8(lanes);
-        for (int w = 0; w < 25; ++w) memcpy(&st[w][c0], lanes + 8 * w, 64);
-        continue;
-      }
-      for (int w = 0; w < 25; ++w) {
-        for (int j = 0; j < m; ++j) lanes[8 * w + j] = st[w][idx[base + j]];
-        for (int j = m; j < 8; ++j) lanes[8 * w + j] = 0;
+      for (int j = 0; j < 8; ++j) {
+        const uint8_t* src = st[idx[base + (j < m ? j : 0)]];          // unused vector slots repeat transcript 0 of the batch
+        for (int w = 0; w < 25; ++w) memcpy(&lanes[8 * w + j], src + 8 * w, 8);
       }
       cg1_keccak_f1600_x8(lanes);
-      for (int w = 0; w < 25; ++w)
-        for (int j = 0; j < m; ++j) st[w][idx[base + j]] = lanes[8 * w + j];
+      for (int j = 0; j < m; ++j) {
+        uint8_t* dst = st[idx[base + j]];
+        for (int w = 0; w < 25; ++w) memcpy(dst + 8 * w, &lanes[8 * w + j], 8);
+      }
     }
   }
 };

@@ -514,6 +514,18 @@ struct ProofWork {
   uint8_t D48[48], Ap48[48];
 };
 
+#ifdef CG1_FE_PROFILE
+#include <chrono>
+std::atomic<long long> g_prof[6];                 // ns: parse+decode, transcript, fr (between), ec, rows, total
+struct ProfTimer {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  long long lap() { auto n = std::chrono::steady_clock::now(); long long d = std::chrono::duration_cast<std::chrono::nanoseconds>(n - t).count(); t = n; return d; }
+};
+#define PROF_LAP(i) g_prof[i] += prof.lap()
+#else
+#define PROF_LAP(i)
+#endif
+
 void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const uint8_t* const* proof, const uint8_t* const* weights,
                    const uint8_t* const* decoded, uint8_t* const* out_points, uint8_t* const* out_scalars,
                    uint8_t* const* out_crs_scalars, uint8_t* const* out_challenges, int32_t* const* status_out) {
@@ -521,6 +533,9 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
   const Layout L(ell, lg);
   ProofWork w[cg1m::G];
   static const uint8_t zero48[48] = {0};
+#ifdef CG1_FE_PROFILE
+  ProfTimer prof;
+#endif
 
   // ---- parse (as prepare_one); a proof rejected here keeps running on harmless values and is zeroed at the end
   for (int k = 0; k < cnt; ++k) {
@@ -551,6 +566,7 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
     else { q.aA.inf = q.aT1.inf = q.aU1.inf = q.aB.inf = true; }
   }
 
+  PROF_LAP(0);
   cg1m::Group tr;
   tr.init("curdleproofs", cnt);
   const uint8_t* ptrs[cg1m::G];
@@ -585,12 +601,14 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
   }
   challenge("same_perm_alpha", &ProofWork::alpha_p);
   challenge("same_perm_beta", &ProofWork::beta_p);
+  PROF_LAP(1);
   for (int k = 0; k < cnt; ++k) {
     ProofWork& q = w[k];
     q.gprod = fr_one();
     fr t = q.beta_p;
     for (size_t i = 0; i < ell; ++i) { q.gprod = fr_mul(q.gprod, fr_add(q.a[i], t)); t = fr_add(t, q.alpha_p); }
   }
+  PROF_LAP(2);
   // ---- grand_prod.py:175-199
   point("gprod_step1", L.B());
   scalar("gprod_step1", &ProofWork::gprod);
@@ -598,26 +616,41 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
   point("gprod_step2", L.C());
   scalar("gprod_step2", &ProofWork::r_p);
   challenge("gprod_beta", &ProofWork::beta_g);
-  for (int k = 0; k < cnt; ++k) {
-    ProofWork& q = w[k];
-    q.beta_inv = fr_inv(q.beta_g);
-    q.u.resize(n);
-    fr pw = q.beta_inv;
-    for (size_t i = 0; i < ell; ++i) { q.u[i] = pw; pw = fr_mul(pw, q.beta_inv); }
-    for (size_t i = ell; i < n; ++i) q.u[i] = pw;
-    jac two[2] = {cg1h::jac_identity(), cg1h::jac_identity()};
-    crs.g_sum.mul_into(two[0], fr_neg(q.beta_inv));
-    crs.h_sum.mul_into(two[0], q.alpha_g);
-    madd_aff(two[0], q.aB);
-    madd_aff(two[1], q.aA); madd_aff(two[1], q.aT1); madd_aff(two[1], q.aU1);
-    cg1h::fe xs[2], ys[2];
-    uint8_t inf[2];
-    cg1h::jac_batch_to_affine(two, 2, xs, ys, inf);
-    cg1h::g1_compress_affine(xs[0], ys[0], inf[0] != 0, q.D48);
-    cg1h::g1_compress_affine(xs[1], ys[1], inf[1] != 0, q.Ap48);
-    const fr beta_ell = fr_pow_u64(q.beta_g, ell);
-    q.inner_prod = fr_sub(fr_add(fr_mul(q.r_p, fr_mul(beta_ell, q.beta_g)), fr_mul(q.gprod, beta_ell)), fr_one());
+  PROF_LAP(1);
+  {
+    // the group's field inversions share ONE inversion each (Montgomery's trick): beta^-1 of every proof here, the
+    // Z coordinates of every proof's D and A' below, all challenge inverses after the transcript
+    fr binv[cg1m::G];
+    for (int k = 0; k < cnt; ++k) binv[k] = w[k].beta_g;
+    fr_batch_inv(binv, (size_t)cnt);
+    jac pts2[2 * cg1m::G];
+    for (int k = 0; k < cnt; ++k) {
+      ProofWork& q = w[k];
+      q.beta_inv = binv[k];
+      q.u.resize(n);
+      fr pw = q.beta_inv;
+      for (size_t i = 0; i < ell; ++i) { q.u[i] = pw; pw = fr_mul(pw, q.beta_inv); }
+      for (size_t i = ell; i < n; ++i) q.u[i] = pw;
+      jac& d = pts2[2 * k];
+      jac& ap = pts2[2 * k + 1];
+      d = cg1h::jac_identity();
+      ap = cg1h::jac_identity();
+      crs.g_sum.mul_into(d, fr_neg(q.beta_inv));
+      crs.h_sum.mul_into(d, q.alpha_g);
+      madd_aff(d, q.aB);
+      madd_aff(ap, q.aA); madd_aff(ap, q.aT1); madd_aff(ap, q.aU1);
+      const fr beta_ell = fr_pow_u64(q.beta_g, ell);
+      q.inner_prod = fr_sub(fr_add(fr_mul(q.r_p, fr_mul(beta_ell, q.beta_g)), fr_mul(q.gprod, beta_ell)), fr_one());
+    }
+    cg1h::fe xs[2 * cg1m::G], ys[2 * cg1m::G];
+    uint8_t inf[2 * cg1m::G];
+    cg1h::jac_batch_to_affine(pts2, 2 * (size_t)cnt, xs, ys, inf);
+    for (int k = 0; k < cnt; ++k) {
+      cg1h::g1_compress_affine(xs[2 * k], ys[2 * k], inf[2 * k] != 0, w[k].D48);
+      cg1h::g1_compress_affine(xs[2 * k + 1], ys[2 * k + 1], inf[2 * k + 1] != 0, w[k].Ap48);
+    }
   }
+  PROF_LAP(3);
   // ---- ipa.py:204-212, 170-176
   point("ipa_step1", L.C());
   for (int k = 0; k < cnt; ++k) ptrs[k] = w[k].D48;
@@ -662,6 +695,17 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
     for (int k = 0; k < cnt; ++k) fr_from_le32(tmp[k], w[k].gm[j]);
   }
   (void)zero48;
+  PROF_LAP(1);
+  {
+    std::vector<fr> all(2 * lg * (size_t)cnt);
+    for (int k = 0; k < cnt; ++k)
+      for (size_t j = 0; j < lg; ++j) { all[(2 * k) * lg + j] = w[k].gam[j]; all[(2 * k + 1) * lg + j] = w[k].gm[j]; }
+    fr_batch_inv(all.data(), all.size());
+    for (int k = 0; k < cnt; ++k) {
+      w[k].gam_inv.assign(all.begin() + (2 * k) * lg, all.begin() + (2 * k + 1) * lg);
+      w[k].gm_inv.assign(all.begin() + (2 * k + 1) * lg, all.begin() + (2 * k + 2) * lg);
+    }
+  }
 
   // ---- the scalar rows (all equations as in prepare_one)
   for (int k = 0; k < cnt; ++k) {
@@ -682,8 +726,6 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
       const fr t = fr_mul(rho[0], q.beta_p);
       for (size_t i = 0; i < ell; ++i) sub(cs[L.cG(i)], t);
     }
-    q.gam_inv = q.gam;
-    fr_batch_inv(q.gam_inv.data(), lg);
     fold_scalars(q.gam, q.s);
     fold_scalars(q.gam_inv, q.s_inv);
     {   // E2
@@ -714,8 +756,6 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
       add(cs[L.cGu()], fr_mul(w3, q.z_u)); sub(sc[L.cmB1()], w3); sub(sc[L.U1()], fr_mul(w3, q.alpha_s));
       add(sc[L.Sp()], fr_mul(w4, q.z_k)); add(cs[L.cH()], fr_mul(w4, q.z_u)); sub(sc[L.cmB2()], w4); sub(sc[L.U2()], fr_mul(w4, q.alpha_s));
     }
-    q.gm_inv = q.gm;
-    fr_batch_inv(q.gm_inv.data(), lg);
     fold_scalars(q.gm, q.sm);
     {   // E4-E6
       const fr w4 = rho[3], w5 = rho[4], w6 = rho[5];
@@ -756,11 +796,17 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
       for (size_t i = 0; i < ell; ++i) { fr_to_le32(q.a[i], o); o += 32; }
     }
   }
+  PROF_LAP(4);
 }
 
 std::atomic<int> g_grouped{1};
 
 }  // namespace
+#ifdef CG1_FE_PROFILE
+extern "C" void cg1_shuffle_profile(double out_ms[6]) { for (int i = 0; i < 6; ++i) out_ms[i] = g_prof[i].exchange(0) * 1e-6; }
+#endif
+namespace {
+}
 
 extern "C" {
 
