@@ -73,6 +73,7 @@ cg1_host_alloc = _proto("cg1_host_alloc", c_void_p, c_void_p, c_size_t)
 cg1_host_free = _proto("cg1_host_free", None, c_void_p, c_void_p)
 cg1_h2d_async = _proto("cg1_h2d_async", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
 cg1_copy_fence = _proto("cg1_copy_fence", c_int, c_void_p)
+cg1_stream_sync = _proto("cg1_stream_sync", c_int, c_void_p)
 cg1_d2h_2d = _proto("cg1_d2h_2d", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t)
 cg1_ctx_sync = _proto("cg1_ctx_sync", c_int, c_void_p)
 cg1_ctx_set_param = _proto("cg1_ctx_set_param", c_int, c_void_p, c_char_p, c_int)
@@ -131,7 +132,7 @@ EXPORTED_SYMBOLS = [
     "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
-    "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_h2d_async", "cg1_copy_fence", "cg1_batch_decompress_enqueue", "cg1_host_alloc", "cg1_host_free", "cg1_ctx_sync", "cg1_ctx_set_param",
+    "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_h2d_async", "cg1_copy_fence", "cg1_stream_sync", "cg1_batch_decompress_enqueue", "cg1_host_alloc", "cg1_host_free", "cg1_ctx_sync", "cg1_ctx_set_param",
     "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 

@@ -654,6 +654,13 @@ int cg1_h2d_async(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
   HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
   return CG1_OK;
 }
+// wait for the context's compute stream only (cg1_ctx_sync waits for the whole device, other contexts included)
+int cg1_stream_sync(cg1_ctx* ctx) {
+  if (!ctx) return CG1_ERR_HIP;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return CG1_OK;
+}
 int cg1_copy_fence(cg1_ctx* ctx) {
   if (!ctx) return CG1_ERR_HIP;
   HIPCHK(hipSetDevice(ctx->device));

@@ -119,8 +119,9 @@ class ShuffleBatchVerifier:
         self._ctx = ctx
         self.threads = threads
         self.chunk = chunk                  # sub-batch of the decompress / front-end pipeline
-        self._gpu_thread = None
-        self._gpu_jobs = None
+        self._gpu_threads = [None, None]
+        self._gpu_jobs = [None, None]
+        self._ctx_msm = None
         self._slots = [None, None, None]
         self._next_slot = 0
         self.last_stats = {}
@@ -185,25 +186,33 @@ class ShuffleBatchVerifier:
             self._ctx = N.default_context()
         return self._ctx
 
-    def _gpu_submit(self, fn) -> None:
-        """All GPU work of the verifier runs, in submission order, on ONE persistent thread (a thread's first HIP call
-        is expensive, and a context takes one call at a time)."""
+    @property
+    def ctx_msm(self) -> "N.Context":
+        """A second context on the same GPU for the MSM stage: its kernels, its host Horner tail and its dependent reduce
+        kernels then overlap the decompression of the next batch (which runs on `ctx` from another thread)."""
+        if self._ctx_msm is None:
+            self._ctx_msm = N.Context(self.ctx.device)
+        return self._ctx_msm
+
+    def _gpu_submit(self, fn, lane: int = 0) -> None:
+        """GPU work runs on two persistent threads (a thread's first HIP call is expensive; a context takes one call at
+        a time): lane 0 drives `ctx` (staging + decompression, in submission order), lane 1 drives `ctx_msm` (MSMs)."""
         import queue
         import threading
 
-        if self._gpu_thread is None:
-            self._gpu_jobs = queue.Queue()
+        if self._gpu_threads[lane] is None:
+            jobs = self._gpu_jobs[lane] = queue.Queue()
 
-            def loop(jobs=self._gpu_jobs):
+            def loop(jobs=jobs):
                 while True:
                     job = jobs.get()
                     if job is None:
                         return
                     job()
 
-            self._gpu_thread = threading.Thread(target=loop, daemon=True)
-            self._gpu_thread.start()
-        self._gpu_jobs.put(fn)
+            self._gpu_threads[lane] = threading.Thread(target=loop, daemon=True)
+            self._gpu_threads[lane].start()
+        self._gpu_jobs[lane].put(fn)
 
     def _slot(self, n: int) -> dict:
         """Buffers of one batch in flight (3 slots rotate: MSM of batch k-1, front-end of k, decompression of k+1)."""
@@ -252,7 +261,7 @@ class ShuffleBatchVerifier:
         """GPU thread: wait for the kernel, bring back the per-point verdicts and the 8-point window the front-end wants."""
         crs, ctx = self.crs, self.ctx
         L, h, m = crs.points_per_proof, b["host"], hi - lo
-        ctx.sync()
+        ctx.check(N.cg1_stream_sync(ctx.handle))                  # this context's kernel only: the MSM context keeps running
         ctx.check(N.cg1_d2h(ctx.handle, h["pstat"].ptr + lo * L, b["pstat"].ptr + lo * L, m * L))
         ctx.check(N.cg1_d2h_2d(ctx.handle, h["decoded"].ptr + lo * 768, 768, b["pts"].ptr + (lo * L + 4 * crs.ell + 1) * 96, L * 96, 768, m))
 
@@ -332,7 +341,7 @@ class ShuffleBatchVerifier:
         self.ctx.check(N.cg1_shuffle_sum_crs_scalars(prep.crs_scalars32, prep.status, n, C, crs_sum))
         ctypes.memmove(host["sc"].ptr + n * L * 32, crs_sum, C * 32)
         # scalars to the device on the copy stream, from this thread, while the GPU thread is busy with other batches
-        self.ctx.check(N.cg1_h2d_async(self.ctx.handle, b["sc"].ptr, host["sc"].ptr, (n * L + C) * 32))
+        self.ctx_msm.check(N.cg1_h2d_async(self.ctx_msm.handle, b["sc"].ptr, host["sc"].ptr, (n * L + C) * 32))
         tk["front_end_s"] = time.perf_counter() - t0
 
     def _enqueue_msm(self, tk: dict) -> None:
@@ -340,7 +349,7 @@ class ShuffleBatchVerifier:
         "independent" -- the per-proof MSMs that name the invalid proofs."""
         import time
 
-        crs, ctx = self.crs, self.ctx
+        crs, ctx = self.crs, self.ctx_msm
         L, C = crs.points_per_proof, crs.ncrs
         b, n, prep = tk["slot"], tk["n"], tk["prep"]
 
@@ -376,7 +385,7 @@ class ShuffleBatchVerifier:
             finally:
                 tk["done"].set()
 
-        self._gpu_submit(gpu_stage)
+        self._gpu_submit(gpu_stage, lane=1)
 
     def _finish(self, tk: dict) -> List[int]:
         import time
@@ -417,7 +426,7 @@ class ShuffleBatchVerifier:
             # still in flight once the GPU thread has drained what was queued for them
             left = [t for t in (pending, tk, tk_next) if t is not None and not t["done"].is_set()]
             if left:
-                self._gpu_submit(lambda: [t["done"].set() for t in left])
+                self._gpu_submit(lambda: self._gpu_submit(lambda: [t["done"].set() for t in left], lane=1))
 
     def verify_packed(self, instances: bytes, proofs: bytes, n: int, mode: str = "merged", rng=None, weights=None,
                       pre_status: Optional[Sequence[int]] = None) -> List[int]:

@@ -75,6 +75,7 @@ int  cg1_d2h(cg1_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
  * queued there so far before the next launch on the compute stream.  Neither blocks the host. */
 int  cg1_h2d_async(cg1_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int  cg1_copy_fence(cg1_ctx* ctx);
+int  cg1_stream_sync(cg1_ctx* ctx);                                  /* this context's compute stream only */
 /* page-locked host memory for staging buffers (copies from it run at full PCIe rate); NULL on failure */
 void* cg1_host_alloc(cg1_ctx* ctx, size_t bytes);
 void cg1_host_free(cg1_ctx* ctx, void* p);

@@ -11,9 +11,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 inst = bytes.fromhex(case["pre_r"] + case["pre_k"] + case["post_r"] + case["post_k"]) * n
 proofs = bytes.fromhex(case["proof"]) * n
 print("default threads:", N.cg1_shuffle_default_threads(), "batch", n, flush=True)
-for grouped in (0, 1):
+for grouped in (1,):
     N.cg1_shuffle_set_grouped(grouped)
-    for threads in (1, 8, 0):
+    for threads in (1, 0):
         for chunk in (256, 1 << 20):
             v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx, threads=threads, chunk=chunk)
             v.verify_packed(inst, proofs, n)
@@ -25,7 +25,7 @@ for grouped in (0, 1):
             print(f"grouped={grouped} threads={threads or 'all'} chunk={chunk}: mean {1e3*sum(ts)/len(ts):.1f} ms  min {1e3*ts[0]:.1f}  max {1e3*ts[-1]:.1f}  -> {n*len(ts)/sum(ts):.0f} proofs/s | "
                   + " ".join(f"{k}={1e3*x:.1f}" for k, x in v.last_stats.items() if k.endswith('_s')), flush=True)
 N.cg1_shuffle_set_grouped(1)
-for chunk in (128, 256, 512):
+for chunk in (256, 512, 1024, 256, 512, 1024):
     v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx, chunk=chunk)
     list(v.verify_stream([(inst, proofs, n)] * 2))
     K = 12
