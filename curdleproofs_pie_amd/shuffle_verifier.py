@@ -214,30 +214,41 @@ class ShuffleBatchVerifier:
             self._gpu_threads[lane].start()
         self._gpu_jobs[lane].put(fn)
 
-    def _slot(self, n: int) -> dict:
-        """Buffers of one batch in flight (3 slots rotate: MSM of batch k-1, front-end of k, decompression of k+1)."""
+    def _alloc_slot(self, n: int) -> dict:
         crs, ctx = self.crs, self.ctx
         L, C = crs.points_per_proof, crs.ncrs
+        return {
+            "cap": n, "busy": None,
+            "wire": ctx.alloc(n * L * 48),
+            "pts": ctx.alloc((n * L + C) * 96),              # own points of all proofs, then the CRS points
+            "pstat": ctx.alloc(n * L),
+            "sc": ctx.alloc((n * L + C) * 32),
+            "host": {                                        # page-locked staging
+                "wire": N.PinnedBuffer(ctx, n * L * 48),
+                "sc": N.PinnedBuffer(ctx, (n * L + C) * 32),
+                "pstat": N.PinnedBuffer(ctx, n * L),
+                "decoded": N.PinnedBuffer(ctx, n * 768),
+            },
+        }
+
+    def _slot(self, n: int) -> dict:
+        """Buffers of one batch in flight (3 slots rotate: MSM of batch k-1, front-end of k, decompression of k+1).
+        All three are allocated together the first time a batch size is seen (page-locking tens of MB takes
+        milliseconds: not something to meet again in the middle of a stream)."""
         idx = self._next_slot
         self._next_slot = (idx + 1) % 3
         b = self._slots[idx]
         if b is not None and b["busy"] is not None:
             b["busy"].wait()                                  # its previous batch must have left the GPU
         if b is None or b["cap"] < n:
-            b = {
-                "cap": n, "busy": None,
-                "wire": ctx.alloc(n * L * 48),
-                "pts": ctx.alloc((n * L + C) * 96),          # own points of all proofs, then the CRS points
-                "pstat": ctx.alloc(n * L),
-                "sc": ctx.alloc((n * L + C) * 32),
-                "host": {                                    # page-locked staging
-                    "wire": N.PinnedBuffer(ctx, n * L * 48),
-                    "sc": N.PinnedBuffer(ctx, (n * L + C) * 32),
-                    "pstat": N.PinnedBuffer(ctx, n * L),
-                    "decoded": N.PinnedBuffer(ctx, n * 768),
-                },
-            }
-            self._slots[idx] = b
+            for j in range(3):
+                o = self._slots[j]
+                if o is None or (o["cap"] < n and (o["busy"] is None or o["busy"].is_set())):
+                    self._slots[j] = self._alloc_slot(n)
+            b = self._slots[idx]
+            if b["cap"] < n:                                  # was still busy above: wait, then replace
+                b["busy"].wait()
+                b = self._slots[idx] = self._alloc_slot(n)
         return b
 
     def _stage_in(self, b: dict, instances, proofs, lo: int, hi: int) -> None:
