@@ -59,6 +59,8 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;    // H2D staging copies that overlap kernels on `stream` (cg1_h2d_async / cg1_copy_fence)
   hipEvent_t copy_ev = nullptr;
+  hipEvent_t sync_ev = nullptr;         // blocking-sync event: waits sleep on an interrupt instead of spinning a core
+  int blocking_sync = 0;
   char err[256] = {0};
   // capacity
   size_t cap_n = 0, cap_nb = 0, cap_chunks = 0, cap_entries = 0, cap_out = 0;
@@ -227,6 +229,18 @@ int pick_window(size_t n) {
   return 16;                     // t = 15
 }
 
+// Wait for the context's compute stream.  blocking_sync: sleep until the GPU signals (an event created with
+// hipEventBlockingSync) and leave the core to the front-end threads; default: the runtime's spinning wait (lowest latency).
+static int wait_stream(Ctx* ctx) {
+  if (ctx->blocking_sync) {
+    HIPCHK(hipEventRecord(ctx->sync_ev, ctx->stream));
+    HIPCHK(hipEventSynchronize(ctx->sync_ev));
+    return CG1_OK;
+  }
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return CG1_OK;
+}
+
 int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
   result = cg1h::jac_identity();
   if (n == 0) return CG1_OK;
@@ -335,7 +349,7 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)nlw * nitems * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
-  HIPCHK(hipStreamSynchronize(st));
+  { int wrc = wait_stream(ctx); if (wrc) return wrc; }
   HIPCHK(hipGetLastError());
   auto h2 = std::chrono::steady_clock::now();
   if (ctx->profile)
@@ -486,7 +500,7 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, M * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
-  HIPCHK(hipStreamSynchronize(st));
+  { int wrc = wait_stream(ctx); if (wrc) return wrc; }
   HIPCHK(hipGetLastError());
   auto h2 = std::chrono::steady_clock::now();
   if (ctx->profile)
@@ -606,7 +620,8 @@ cg1_ctx* cg1_ctx_create(int device) {
   ctx->device = device;
   if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
   if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess) { delete ctx; return nullptr; }
+      hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { delete ctx; return nullptr; }
   for (int i = 0; i <= CG1_NPHASE; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return nullptr; }
   return ctx;
 }
@@ -619,6 +634,7 @@ void cg1_ctx_destroy(cg1_ctx* ctx) {
   for (int i = 0; i <= CG1_NPHASE; ++i) (void)hipEventDestroy(ctx->ev[i]);
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
+  if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   delete ctx;
 }
@@ -658,8 +674,7 @@ int cg1_h2d_async(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
 int cg1_stream_sync(cg1_ctx* ctx) {
   if (!ctx) return CG1_ERR_HIP;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  return CG1_OK;
+  return cg1::wait_stream(ctx);
 }
 int cg1_copy_fence(cg1_ctx* ctx) {
   if (!ctx) return CG1_ERR_HIP;
@@ -703,6 +718,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "quad")) { ctx->quad = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "reduce_2d")) { ctx->reduce_2d = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
+  if (!strcmp(name, "blocking_sync")) { ctx->blocking_sync = value != 0; return CG1_OK; }
   if (!strcmp(name, "big_bins")) { ctx->big_bins = value != 0; return CG1_OK; }
   if (!strcmp(name, "host_split")) { ctx->host_split = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
