@@ -105,10 +105,22 @@ static inline bool fr_from_le32(const uint8_t* b, fr& out) {
   out = fr_mul(a, r2);
   return true;
 }
+// out of Montgomery form: four reduction rounds only (half the work of a multiplication by 1)
 static inline void fr_to_le32(const fr& a, uint8_t* b) {
-  fr one{{1, 0, 0, 0}};
-  fr s = fr_mul(a, one);
-  memcpy(b, s.l, 32);
+  uint64_t t[4] = {a.l[0], a.l[1], a.l[2], a.l[3]};
+  for (int i = 0; i < 4; ++i) {
+    const uint64_t m = t[0] * cg1::H_FR_INV;
+    u128 c = (u128)m * cg1::H_FR[0] + t[0];
+    c >>= 64;
+    for (int j = 1; j < 4; ++j) {
+      c += (u128)m * cg1::H_FR[j] + t[j];
+      t[j - 1] = (uint64_t)c;
+      c >>= 64;
+    }
+    t[3] = (uint64_t)c;
+  }
+  if (geq_r(t)) sub_r(t);                 // t < r already for canonical input; kept for safety
+  memcpy(b, t, 32);
 }
 
 static inline fr fr_pow_u64(fr base, uint64_t e) {
