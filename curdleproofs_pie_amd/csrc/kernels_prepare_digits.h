@@ -69,12 +69,14 @@ __device__ __forceinline__ void load_scalar(const uint32_t* scalars, uint32_t i,
 
 // counts per (local window, bucket); skips zero digits and identity points
 __global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
-                                              uint32_t* __restrict__ hist, uint32_t n, int c, int nwin, int rank, int world) {
+                                              uint32_t* __restrict__ hist, uint32_t n, int c, int nwin, int rank, int world,
+                                              uint32_t* __restrict__ bad_flag) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   if (inf_flag[i]) return;
   DigitIter it; it.c = c;
   load_scalar(scalars, i, it);
+  if (it.s[7] >> 31) *bad_flag = 1u;
   const uint32_t NB = 1u << (c - 1);
   for (int w = 0; w < nwin; ++w) {
     int d = it.next(w);

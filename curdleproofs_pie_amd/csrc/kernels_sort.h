@@ -42,12 +42,14 @@ __device__ __forceinline__ uint32_t lds_ranked_inc(uint32_t* ctr, uint32_t key, 
 }
 
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
-                                                uint16_t* __restrict__ digits, uint32_t n, int c, int nwin, int rank, int world) {
+                                                uint16_t* __restrict__ digits, uint32_t n, int c, int nwin, int rank, int world,
+                                                uint32_t* __restrict__ bad_flag) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const bool inf = inf_flag[i] != 0;
   DigitIter it; it.c = c;
   load_scalar(scalars, i, it);
+  if (it.s[7] >> 31) *bad_flag = 1u;              // >= 2^255: the signed-digit recoding would carry out of the top window
   for (int w = 0; w < nwin; ++w) {
     int d = it.next(w);
     if ((w % world) != rank) continue;

@@ -204,8 +204,8 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
   if (nout > ctx->cap_out) {
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
-    HIPCHK(hipMalloc(&ctx->d_out, nout * sizeof(PointWords)));
-    HIPCHK(hipHostMalloc(&ctx->h_out, nout * sizeof(PointWords)));
+    HIPCHK(hipMalloc(&ctx->d_out, (nout + 1) * sizeof(PointWords)));      // + one record: the input-validation flag word
+    HIPCHK(hipHostMalloc(&ctx->h_out, (nout + 1) * sizeof(PointWords)));
     ctx->cap_out = nout;
   }
   return CG1_OK;
@@ -275,6 +275,9 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   HIPCHK(hipEventRecord(ctx->ev[0], st));
   hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32);
   HIPCHK(hipEventRecord(ctx->ev[1], st));
+  const size_t nout_words = (size_t)nlw * nitems;
+  uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // set by the digit kernels: a scalar >= 2^255
+  HIPCHK(hipMemsetAsync(bad_flag, 0, 4, st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
     // ---- two-level partition sort: no global atomics
@@ -282,7 +285,7 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     const uint32_t sub_bits = bb < 8u ? bb : 8u, nbins = 1u << (bb - sub_bits);
     const uint32_t nslices = (n32 + PART_TILE - 1) / PART_TILE;
     const uint32_t nbc = (uint32_t)nlw * nbins * nslices;
-    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, n32, c, nwin, rank, world);
+    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, n32, c, nwin, rank, world, bad_flag);
     hipLaunchKernelGGL(k_part_count, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, n32, nslices, nbins, sub_bits);
     const uint32_t ublk = (nbc + SCAN_ITEMS - 1) / SCAN_ITEMS;
     hipLaunchKernelGGL(k_uscan1, dim3(ublk), dim3(256), 0, st, ctx->d_blockcnt, ctx->d_ublocktot, nbc);
@@ -305,7 +308,7 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   } else {
     // ---- global-atomic counting sort (any n < 2^31)
     HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
-    hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_hist, n32, c, nwin, rank, world);
+    hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_hist, n32, c, nwin, rank, world, bad_flag);
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
@@ -346,11 +349,15 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw, S), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_partial, J);
     hipLaunchKernelGGL(k_bit_tree_final, dim3((uint32_t)(nitems * nlw)), dim3(64), 0, st, ctx->d_partial, ctx->d_out, S);
   }
-  HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, (size_t)nlw * nitems * sizeof(PointWords), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, ((size_t)nlw * nitems + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
   { int wrc = wait_stream(ctx); if (wrc) return wrc; }
   HIPCHK(hipGetLastError());
+  if (*reinterpret_cast<const uint32_t*>(ctx->h_out + nout_words)) {
+    snprintf(ctx->err, sizeof ctx->err, "a scalar is >= 2^255: scalar32 must be a canonical Fr element (< r)");
+    return CG1_ERR_ENCODING;
+  }
   auto h2 = std::chrono::steady_clock::now();
   if (ctx->profile)
     for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
@@ -454,8 +461,8 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   if (M > ctx->cap_bout) {
     if (ctx->d_bout) (void)hipFree(ctx->d_bout);
     if (ctx->h_bout) (void)hipHostFree(ctx->h_bout);
-    HIPCHK(hipMalloc(&ctx->d_bout, M * sizeof(PointWords)));
-    HIPCHK(hipHostMalloc(&ctx->h_bout, M * sizeof(PointWords)));
+    HIPCHK(hipMalloc(&ctx->d_bout, (M + 1) * sizeof(PointWords)));         // + one record: the input-validation flag word
+    HIPCHK(hipHostMalloc(&ctx->h_bout, (M + 1) * sizeof(PointWords)));
     ctx->cap_bout = M;
   }
   if (N * nwin > ctx->cap_digits) {
@@ -470,7 +477,9 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   HIPCHK(hipEventRecord(ctx->ev[0], st));
   hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, N32);
   HIPCHK(hipEventRecord(ctx->ev[1], st));
-  hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, N32, c, (int)nwin, 0, 1);
+  uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_bout + M);
+  HIPCHK(hipMemsetAsync(bad_flag, 0, 4, st));
+  hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, N32, c, (int)nwin, 0, 1, bad_flag);
   hipLaunchKernelGGL(k_group_count, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_hist, N32, NB, nwin);
   HIPCHK(hipEventRecord(ctx->ev[2], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
@@ -497,11 +506,15 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   HIPCHK(hipEventRecord(ctx->ev[6], st));
   if (ctx->quad) hipLaunchKernelGGL(k_msm_horner_quad, dim3((uint32_t)((M * 4 + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
   else hipLaunchKernelGGL(k_msm_horner, dim3((uint32_t)((M + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
-  HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, M * sizeof(PointWords), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, (M + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
   { int wrc = wait_stream(ctx); if (wrc) return wrc; }
   HIPCHK(hipGetLastError());
+  if (*reinterpret_cast<const uint32_t*>(ctx->h_bout + M)) {
+    snprintf(ctx->err, sizeof ctx->err, "a scalar is >= 2^255: scalar32 must be a canonical Fr element (< r)");
+    return CG1_ERR_ENCODING;
+  }
   auto h2 = std::chrono::steady_clock::now();
   if (ctx->profile)
     for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));

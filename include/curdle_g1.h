@@ -15,7 +15,8 @@
  *   - "point blob": 144 opaque bytes (host Jacobian X,Y,Z; 6x64-bit Montgomery limbs each).
  *   - "affine96": x || y, each a 48-byte little-endian integer < p in standard (non-Montgomery) form;
  *     the all-zero record encodes the identity ((0,0) is not on the curve).
- *   - "scalar32": 32-byte little-endian canonical Fr element (< r), as Scalar.to_le_bytes() returns.
+ *   - "scalar32": 32-byte little-endian canonical Fr element (< r), as Scalar.to_le_bytes() returns.  The MSM entry
+ *     points treat it as a plain integer and reject values >= 2^255 (CG1_ERR_ENCODING) instead of mis-summing them.
  *   - "compressed48": the 48-byte ZCash-format compression G1Point.to_compressed_bytes() returns.
  *   - device entry points fail with CG1_ERR_HIP when no GPU / HIP error; there is NO CPU fallback.
  */

@@ -322,6 +322,16 @@ def test_argument_errors_are_reported(native_lib, ctx):
         ctx.msm_batched_device(dp, ds, [0, 4], window_c=12)    # batched widths are 4..9
     with pytest.raises(N.NativeError):
         ctx.set_param("no_such_param", 1)
+    # scalars must fit the signed-digit recoding (< 2^255; canonical Fr elements always do): rejected, not mis-summed
+    dbad = ctx.alloc(32 * 4)
+    dbad.upload((5).to_bytes(32, "little") * 3 + (1 << 255).to_bytes(32, "little"))
+    with pytest.raises(N.NativeError, match="2\\^255"):
+        ctx.msm_device(dp, dbad, 4)
+    with pytest.raises(N.NativeError, match="2\\^255"):
+        ctx.msm_batched_device(dp, dbad, [0, 2, 4])
+    dok = ctx.alloc(32 * 4)
+    dok.upload((5).to_bytes(32, "little") * 3 + ((1 << 255) - 1).to_bytes(32, "little"))     # non-canonical but in range: plain integer
+    assert compress_blob(N, ctx.msm_device(dp, dok, 4)) == O.g1_compress(O.g1_mul(O.G1_GEN, (15 + (1 << 255) - 1) % O.R))
     # the context stays usable after errors
     want = O.g1_compress(O.g1_mul(O.G1_GEN, 20))
     assert compress_blob(N, ctx.msm_device(dp, ds, 4)) == want
