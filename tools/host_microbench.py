@@ -33,6 +33,17 @@ t = time.perf_counter()
 for _ in range(2000):
     N.cg1_mul(blob, g.raw, k)
 print(f"host scalar mul (4-bit windows): {(time.perf_counter() - t) / 2000 * 1e6:.1f} us")
+lanes = (ctypes.c_uint64 * 200)()
+t = time.perf_counter()
+for _ in range(20000):
+    N.cg1_keccak_f1600_x8(lanes)
+dt8 = (time.perf_counter() - t) / 20000
+st200 = ctypes.create_string_buffer(200)
+t = time.perf_counter()
+for _ in range(20000):
+    N.cg1_keccak_f1600(st200)
+dt1 = (time.perf_counter() - t) / 20000
+print(f"Keccak-f[1600]: one state {dt1 * 1e9:.0f} ns per call; eight states (AVX-512 when present) {dt8 * 1e9:.0f} ns per call = {dt8 * 1e9 / 8:.0f} ns per state (both incl. ~0.2 us of ctypes call overhead)")
 print("usable host threads (affinity mask capped by cgroup quota):", N.cg1_shuffle_default_threads(), " os.cpu_count:", os.cpu_count())
 for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):
     try:
