@@ -122,6 +122,7 @@ class ShuffleBatchVerifier:
         self._gpu_threads = [None, None]
         self._gpu_jobs = [None, None]
         self._ctx_msm = None
+        self.prefetch_big = True            # two large decompress launches for batches decoded a batch ahead (A/B switch)
         self._slots = [None, None, None]
         self._next_slot = 0
         self.last_stats = {}
@@ -276,8 +277,10 @@ class ShuffleBatchVerifier:
         ctx.check(N.cg1_d2h(ctx.handle, h["pstat"].ptr + lo * L, b["pstat"].ptr + lo * L, m * L))
         ctx.check(N.cg1_d2h_2d(ctx.handle, h["decoded"].ptr + lo * 768, 768, b["pts"].ptr + (lo * L + 4 * crs.ell + 1) * 96, L * 96, 768, m))
 
-    def _begin(self, batch, mode: str, rng) -> dict:
-        """Stage 1 of a batch (asynchronous): claim a slot and queue the GPU decompression of its sub-batches."""
+    def _begin(self, batch, mode: str, rng, prefetched: bool = False) -> dict:
+        """Stage 1 of a batch (asynchronous): claim a slot and queue the GPU decompression of its sub-batches.
+        prefetched: the batch is decoded a whole batch ahead of its front-end, so small sub-batches buy nothing and
+        two large launches fill the GPU better (2 x 2.3 ms instead of 4 x 1.4 ms per 1024 proofs)."""
         import queue
         import threading
         import time
@@ -291,7 +294,9 @@ class ShuffleBatchVerifier:
         b = self._slot(n)
         tk = {"slot": b, "n": n, "instances": instances, "proofs": proofs, "weights": weights, "mode": mode,
               "pre_status": batch[3] if len(batch) > 3 else None, "chunks": queue.Queue(), "done": threading.Event(),
-              "bounds": [(lo, min(lo + self.chunk, n)) for lo in range(0, n, self.chunk)], "error": None, "t0": time.perf_counter()}
+              "error": None, "t0": time.perf_counter()}
+        step = max(self.chunk, (n + 1) // 2) if (prefetched and self.prefetch_big) else self.chunk
+        tk["bounds"] = [(lo, min(lo + step, n)) for lo in range(0, n, step)]
         b["busy"] = tk["done"]
 
         def gpu_stage(tk=tk, b=b):
@@ -422,7 +427,7 @@ class ShuffleBatchVerifier:
         try:
             while tk is not None:
                 nxt = next(it, None)
-                tk_next = self._begin(nxt, mode, rng) if nxt is not None else None      # prefetch: decompression of the next batch
+                tk_next = self._begin(nxt, mode, rng, prefetched=True) if nxt is not None else None    # decompression of the next batch
                 self._front_end(tk)
                 self._enqueue_msm(tk)
                 if pending is not None:
