@@ -76,30 +76,10 @@ struct Group {
   // cursor reaches it (a permutation in between resets it).  absorb() returns true when the transcript must be
   // permuted before it can go on (padding already applied).
   struct Str {
-    uint8_t b[160];             // + slack for the 8-byte loads
+    uint8_t b[168];             // header (<= 40) + data (<= 64) + slack for the 8-byte loads
     uint32_t total, patch2;     // header offsets: 0 and patch2
   };
   bool absorb(int k, Str& s, uint32_t& off) {
-    if (off == 0 && (unsigned)pos[k] + s.total < (unsigned)STROBE_R) {
-      // the whole string fits before the sponge position wraps (the common case): both headers are known up front
-      // (the second begin_op sees the pos_begin the first one set), one unaligned XOR pass, no permutation
-      const unsigned p = pos[k];
-      s.b[0] = pos_begin[k];
-      s.b[s.patch2] = (uint8_t)(p + 1);
-      pos_begin[k] = (uint8_t)(p + s.patch2 + 1);
-      uint8_t* dst = st[k] + p;
-      for (uint32_t i = 0; i < s.total; i += 8) {          // s.b has slack; bytes past `total` are masked off
-        uint64_t v, d;
-        memcpy(&v, s.b + i, 8);
-        if (s.total - i < 8) v &= (1ull << (8u * (s.total - i))) - 1ull;
-        memcpy(&d, dst + i, 8);
-        d ^= v;
-        memcpy(dst + i, &d, 8);
-      }
-      off = s.total;
-      pos[k] = (uint8_t)(p + s.total);
-      return false;
-    }
     while (off < s.total) {
       if (off == 0 || off == s.patch2) {                       // begin_op
         s.b[off] = pos_begin[k];
@@ -129,26 +109,76 @@ struct Group {
     s.total = s.patch2 + 2 + dlen;
   }
 
+  // The common case of a string, without materialising it: header part (one template per operation, the two pos_begin
+  // bytes patched into a local copy) and data part XORed straight from their sources in 8-byte steps.  Only possible
+  // when the whole string fits before the sponge position wraps; false = use the general path.
+  bool absorb_fast(int k, const Str& hdr, const uint8_t* data, uint32_t dlen) {
+    const unsigned p = pos[k], hlen = hdr.total;
+    if (p + hlen + dlen >= (unsigned)STROBE_R || (dlen & 7u)) return false;
+    uint64_t h[6];                                            // hlen <= 2 + 32 + 4 + 2 = 40 <= 48
+    memcpy(h, hdr.b, 48);
+    reinterpret_cast<uint8_t*>(h)[0] = pos_begin[k];
+    reinterpret_cast<uint8_t*>(h)[hdr.patch2] = (uint8_t)(p + 1);
+    pos_begin[k] = (uint8_t)(p + hdr.patch2 + 1);
+    uint8_t* dst = st[k] + p;
+    for (unsigned i = 0; i < hlen; i += 8) {
+      uint64_t v = h[i >> 3], d;
+      if (hlen - i < 8) v &= (1ull << (8u * (hlen - i))) - 1ull;
+      memcpy(&d, dst + i, 8);
+      d ^= v;
+      memcpy(dst + i, &d, 8);
+    }
+    dst += hlen;
+    for (unsigned i = 0; i < dlen; i += 8) {
+      uint64_t v, d;
+      memcpy(&v, data + i, 8);
+      memcpy(&d, dst + i, 8);
+      d ^= v;
+      memcpy(dst + i, &d, 8);
+    }
+    pos[k] = (uint8_t)(p + hlen + dlen);
+    return true;
+  }
+
   void run(const char* label, const uint8_t* const* data, uint8_t (*out)[32], uint32_t len, bool challenge) {
     const uint32_t llen = (uint32_t)strlen(label);
-    if (llen > 64 || len > 64) return;                           // protocol labels are <= 18 bytes, messages 32 or 48
-    Str str[G];
+    if (llen > 32 || len > 64) return;                           // protocol labels are <= 18 bytes, messages 32 or 48
+    Str hdr1, hdr2;                                              // header templates: this operation's first / second string
+    if (challenge) {
+      build(hdr1, label, llen, 32, FLAG_I | FLAG_A | FLAG_C, nullptr, 0);
+      build(hdr2, label, llen, 32, FLAG_A, nullptr, 0);
+    } else {
+      build(hdr1, label, llen, len, FLAG_A, nullptr, 0);
+    }
+    Str str[G];               // materialised only for a transcript whose string straddles a sponge wrap
+    bool built[G];
     uint8_t pc[G];            // append: 0 string, 3 done.  challenge: 0 first string, 1 squeeze + check, 2 second string, 3 done
     uint32_t off[G];
-    for (int k = 0; k < count; ++k) {
-      pc[k] = 0;
-      off[k] = 0;
-      if (challenge) build(str[k], label, llen, 32, FLAG_I | FLAG_A | FLAG_C, nullptr, 0);
-      else build(str[k], label, llen, len, FLAG_A, data[k], len);
-    }
+    for (int k = 0; k < count; ++k) { pc[k] = 0; off[k] = 0; built[k] = false; }
     for (;;) {
       int pending[G], np = 0;
       for (int k = 0; k < count; ++k) {
         bool need = false;
         while (pc[k] != 3 && !need) {
           if (pc[k] == 0 || pc[k] == 2) {
-            need = absorb(k, str[k], off[k]);
-            if (need) break;
+            const Str& hdr = pc[k] == 2 ? hdr2 : hdr1;
+            const uint8_t* dptr = pc[k] == 2 ? out[k] : (challenge ? nullptr : data[k]);
+            const uint32_t dlen = pc[k] == 2 ? 32u : (challenge ? 0u : len);
+            if (off[k] == 0 && !built[k] && absorb_fast(k, hdr, dptr, dlen)) {
+              need = false;
+            } else {
+              if (!built[k]) {
+                memcpy(str[k].b, hdr.b, 48);
+                if (dlen) memcpy(str[k].b + hdr.total, dptr, dlen);
+                str[k].total = hdr.total + dlen;
+                str[k].patch2 = hdr.patch2;
+                built[k] = true;
+              }
+              need = absorb(k, str[k], off[k]);
+              if (need) break;
+            }
+            built[k] = false;
+            off[k] = 0;
             if (!challenge || pc[k] == 2) { pc[k] = 3; break; }
             pc[k] = 1;                                            // first string done: PRF forces a permutation unless pos == 0
             if (pos[k] != 0) { pad(k); need = true; }
@@ -161,13 +191,7 @@ struct Group {
             } else {                                              // unreachable for 32-byte outputs; kept exact (strobe.py:77-87)
               for (int i = 0; i < 32; ++i) { uint8_t& b = byte_at(k, pos[k]); o[i] = b; b = 0; ++pos[k]; }
             }
-            off[k] = 0;
-            if (fr_canonical_nonzero(o)) {
-              build(str[k], label, llen, 32, FLAG_A, o, 32);
-              pc[k] = 2;
-            } else {
-              pc[k] = 0;                                          // retry: same first string (headers are re-patched)
-            }
+            pc[k] = fr_canonical_nonzero(o) ? 2 : 0;              // accepted: append it; else retry the first string
           }
         }
         if (need) pending[np++] = k;
