@@ -14,6 +14,17 @@
 
 #include "../../include/curdle_g1.h"
 
+#ifdef CG1_FE_PROFILE
+#include <atomic>
+#include <chrono>
+extern std::atomic<long long> g_tr_prof[4];        // ns in gather, keccak x8, scatter; number of x8 calls
+#define TR_NOW() std::chrono::steady_clock::now()
+#define TR_ADD(i, a, b) g_tr_prof[i] += std::chrono::duration_cast<std::chrono::nanoseconds>((b) - (a)).count()
+#else
+#define TR_NOW() 0
+#define TR_ADD(i, a, b) (void)0
+#endif
+
 namespace cg1m {
 
 constexpr int G = 16;                              // transcripts per group (two x8 permutation batches)
@@ -207,15 +218,24 @@ struct Group {
     alignas(64) uint64_t lanes[25 * 8];
     for (int base = 0; base < n; base += 8) {
       const int m = n - base < 8 ? n - base : 8;
+      auto t0 = TR_NOW();
       for (int j = 0; j < 8; ++j) {
         const uint8_t* src = st[idx[base + (j < m ? j : 0)]];          // unused vector slots repeat transcript 0 of the batch
         for (int w = 0; w < 25; ++w) memcpy(&lanes[8 * w + j], src + 8 * w, 8);
       }
+      auto t1 = TR_NOW();
       cg1_keccak_f1600_x8(lanes);
+      auto t2 = TR_NOW();
       for (int j = 0; j < m; ++j) {
         uint8_t* dst = st[idx[base + j]];
         for (int w = 0; w < 25; ++w) memcpy(dst + 8 * w, &lanes[8 * w + j], 8);
       }
+      auto t3 = TR_NOW();
+      TR_ADD(0, t0, t1); TR_ADD(1, t1, t2); TR_ADD(2, t2, t3);
+#ifdef CG1_FE_PROFILE
+      g_tr_prof[3] += 1;
+#endif
+      (void)t0; (void)t1; (void)t2; (void)t3;
     }
   }
 };

@@ -803,7 +803,9 @@ std::atomic<int> g_grouped{1};
 
 }  // namespace
 #ifdef CG1_FE_PROFILE
+std::atomic<long long> g_tr_prof[4];
 extern "C" void cg1_shuffle_profile(double out_ms[6]) { for (int i = 0; i < 6; ++i) out_ms[i] = g_prof[i].exchange(0) * 1e-6; }
+extern "C" void cg1_transcript_profile(double out[4]) { for (int i = 0; i < 3; ++i) out[i] = g_tr_prof[i].exchange(0) * 1e-6; out[3] = (double)g_tr_prof[3].exchange(0); }
 #endif
 namespace {
 }

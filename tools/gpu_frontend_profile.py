@@ -27,8 +27,12 @@ prof = N.lib.cg1_shuffle_profile
 out = (ctypes.c_double * 6)()
 v.prepare(inst, proofs, n, weights=w, decoded=dec * n)
 prof(out)
+N.lib.cg1_transcript_profile((ctypes.c_double * 4)())
 t0 = time.perf_counter(); v.prepare(inst, proofs, n, weights=w, decoded=dec * n); dt = time.perf_counter() - t0
 prof(out)
+tp = (ctypes.c_double * 4)()
+N.lib.cg1_transcript_profile(tp)
+print(f"  transcript detail: {tp[3] / n:.0f} x8 permutation calls per proof; per proof: gather {1e3 * tp[0] / n:.1f} us, Keccak x8 {1e3 * tp[1] / n:.1f} us, scatter {1e3 * tp[2] / n:.1f} us (incl. ~25 ns of timer overhead per call and part)")
 names = ["parse+decode", "transcript", "fr between", "ec (D, A')", "scalar rows", "-"]
 print(f"front-end, one thread: {1e6 * dt / n:.1f} us per proof")
 for nm, x in zip(names, out):
