@@ -462,10 +462,32 @@ class ShuffleBatchVerifier:
         return [s == 0 for s in status]
 
 
+_verifier_cache: dict = {}
+
+
+def verifier_for(crs, ctx=None) -> ShuffleBatchVerifier:
+    """One ShuffleBatchVerifier per (CRS bytes, context), kept across calls: creating one decodes the CRS and builds the
+    fixed-base tables of G_sum / H_sum (tens of milliseconds)."""
+    if isinstance(crs, ShuffleBatchVerifier):
+        return crs
+    data = crs.bytes if isinstance(crs, ShuffleCrs) else (bytes(crs.to_bytes()) if hasattr(crs, "to_bytes") else bytes(crs))
+    key = (data, id(ctx))
+    v = _verifier_cache.get(key)
+    if v is None:
+        if len(_verifier_cache) >= 4:
+            _verifier_cache.pop(next(iter(_verifier_cache)))
+        v = _verifier_cache[key] = ShuffleBatchVerifier(crs if isinstance(crs, ShuffleCrs) else data, ctx)
+    return v
+
+
 def is_valid_whisk_shuffle_proof(crs, pre_shuffle_trackers, post_shuffle_trackers, whisk_shuffle_proof_bytes, ctx=None) -> bool:
     """Drop-in for IsValidWhiskShuffleProof (whisk_interface.py:72-87) -- a batch of one."""
-    v = crs if isinstance(crs, ShuffleBatchVerifier) else ShuffleBatchVerifier(crs, ctx)
-    return v.verify_many([(pre_shuffle_trackers, post_shuffle_trackers, whisk_shuffle_proof_bytes)])[0]
+    return verifier_for(crs, ctx).verify_many([(pre_shuffle_trackers, post_shuffle_trackers, whisk_shuffle_proof_bytes)])[0]
+
+
+def are_valid_whisk_shuffle_proofs(crs, items, ctx=None) -> List[bool]:
+    """[IsValidWhiskShuffleProof(crs, pre, post, proof) for (pre, post, proof) in items] in one batch."""
+    return verifier_for(crs, ctx).verify_many(items)
 
 
 class OpeningBatchVerifier:
