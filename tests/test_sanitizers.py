@@ -21,6 +21,35 @@ def test_host_code_under_asan_ubsan():
     assert "sanitize ok" in r.stdout
 
 
+def _shuffle_case_blob(tmp_path):
+    import json
+    import struct
+
+    with open(os.path.join(ROOT, "tests", "golden", "shuffle_vectors.json")) as f:
+        case = json.load(f)["cases"][1]
+    blob = tmp_path / "case.bin"
+    blob.write_bytes(struct.pack("<Q", case["ell"]) + bytes.fromhex(case["crs"]) +
+                     bytes.fromhex(case["pre_r"] + case["pre_k"] + case["post_r"] + case["post_k"]) + bytes.fromhex(case["proof"]))
+    return blob
+
+
+def test_shuffle_front_end_under_tsan(tmp_path):
+    """Race detection: the native worker pool + grouped transcripts under ThreadSanitizer (same driver, 1 and 4 threads)."""
+    blob = _shuffle_case_blob(tmp_path)
+    out_dir = os.path.join(ROOT, "tests", "native", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "tsan_shuffle")
+    csrc = os.path.join(ROOT, "curdleproofs_pie_amd", "csrc")
+    src = [os.path.join(ROOT, "tests", "native", "sanitize_shuffle.cpp"), os.path.join(csrc, "shuffle_verify.cpp"),
+           os.path.join(csrc, "host_g1.cpp"), os.path.join(csrc, "merlin.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-fno-omit-frame-pointer", "-Wno-psabi",
+                           *src, "-o", exe])
+    r = subprocess.run([exe, str(blob)], capture_output=True, text=True, timeout=600,
+                       env={**os.environ, "TSAN_OPTIONS": "halt_on_error=1"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "sanitize ok" in r.stdout
+
+
 def test_shuffle_front_end_under_asan_ubsan(tmp_path):
     """csrc/shuffle_verify.cpp (+ fr.h, host_g1.cpp, merlin.cpp): golden proof, bit flips and garbage, 1 and 4 threads."""
     import json
