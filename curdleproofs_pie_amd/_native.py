@@ -97,6 +97,7 @@ cg1_probe_madd = _proto("cg1_probe_madd", c_int, c_void_p, c_void_p, c_size_t, c
 MERLIN_STATE_BYTES = 208
 cg1_keccak_f1600 = _proto("cg1_keccak_f1600", None, _buf)
 cg1_keccak_f1600_x8 = _proto("cg1_keccak_f1600_x8", None, _buf)
+cg1_keccak_f1600_x8_states = _proto("cg1_keccak_f1600_x8_states", None, c_void_p, c_int)
 cg1_strobe_new = _proto("cg1_strobe_new", None, _buf, _u8p, c_size_t)
 cg1_strobe_meta_ad = _proto("cg1_strobe_meta_ad", c_int, _buf, _u8p, c_size_t, c_int)
 cg1_strobe_ad = _proto("cg1_strobe_ad", c_int, _buf, _u8p, c_size_t, c_int)
@@ -127,7 +128,7 @@ cg1_shuffle_sum_crs_scalars = _proto("cg1_shuffle_sum_crs_scalars", c_int, _buf,
 EXPORTED_SYMBOLS = [
     "cg1_shuffle_crs_create", "cg1_shuffle_crs_destroy", "cg1_shuffle_proof_bytes", "cg1_shuffle_points_per_proof",
     "cg1_shuffle_crs_points", "cg1_shuffle_challenges_per_proof", "cg1_opening_prepare", "cg1_shuffle_prepare", "cg1_shuffle_set_grouped", "cg1_shuffle_default_threads", "cg1_shuffle_gather_points", "cg1_shuffle_apply_point_status", "cg1_shuffle_sum_crs_scalars",
-    "cg1_keccak_f1600", "cg1_keccak_f1600_x8", "cg1_strobe_new", "cg1_strobe_meta_ad", "cg1_strobe_ad", "cg1_strobe_prf", "cg1_strobe_key", "cg1_merlin_init",
+    "cg1_keccak_f1600", "cg1_keccak_f1600_x8", "cg1_keccak_f1600_x8_states", "cg1_strobe_new", "cg1_strobe_meta_ad", "cg1_strobe_ad", "cg1_strobe_prf", "cg1_strobe_key", "cg1_merlin_init",
     "cg1_merlin_append", "cg1_merlin_append_list", "cg1_merlin_challenge", "cg1_merlin_challenge_scalar",
     "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",

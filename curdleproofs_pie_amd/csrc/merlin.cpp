@@ -69,7 +69,7 @@ void keccak_f1600(uint8_t* bytes) {
 // selected at run time) and for the baseline ISA.  Used by the batch front-end, which advances many independent
 // transcripts in step (csrc/shuffle_verify.cpp).
 typedef uint64_t v8u64 __attribute__((vector_size(64), aligned(8)));
-static inline __attribute__((always_inline)) v8u64 vrotl(v8u64 v, int n) { return (v << n) | (v >> (64 - n)); }
+#define vrotl(v, n) (((v) << (n)) | ((v) >> (64 - (n))))      // a macro: vector arguments must not cross a target("avx512f") boundary
 
 #define CG1_KECCAK_ROUND_V(A, E, rc)                                                                \
   {                                                                                                 \
@@ -109,10 +109,70 @@ static inline __attribute__((always_inline)) void keccak_x8_body(uint64_t* lanes
   }
   for (int i = 0; i < 25; ++i) memcpy(lanes + 8 * i, &a[i], 64);
 }
-#undef CG1_KECCAK_ROUND_V
-
 __attribute__((target("avx512f,avx512vl,avx512dq,avx512bw"))) void keccak_x8_avx512(uint64_t* lanes) { keccak_x8_body(lanes); }
 void keccak_x8_generic(uint64_t* lanes) { keccak_x8_body(lanes); }
+
+}  // namespace
+#include <immintrin.h>
+namespace {
+
+// 8 x 8 transpose of 64-bit elements: rows r[0..7] -> columns (an involution: the same routine goes both ways)
+__attribute__((target("avx512f"))) static inline void transpose8x8(__m512i r[8]) {
+  const __m512i t0 = _mm512_unpacklo_epi64(r[0], r[1]), t1 = _mm512_unpackhi_epi64(r[0], r[1]);
+  const __m512i t2 = _mm512_unpacklo_epi64(r[2], r[3]), t3 = _mm512_unpackhi_epi64(r[2], r[3]);
+  const __m512i t4 = _mm512_unpacklo_epi64(r[4], r[5]), t5 = _mm512_unpackhi_epi64(r[4], r[5]);
+  const __m512i t6 = _mm512_unpacklo_epi64(r[6], r[7]), t7 = _mm512_unpackhi_epi64(r[6], r[7]);
+  const __m512i u0 = _mm512_shuffle_i64x2(t0, t2, 0x88), u1 = _mm512_shuffle_i64x2(t0, t2, 0xdd);
+  const __m512i u2 = _mm512_shuffle_i64x2(t4, t6, 0x88), u3 = _mm512_shuffle_i64x2(t4, t6, 0xdd);
+  const __m512i u4 = _mm512_shuffle_i64x2(t1, t3, 0x88), u5 = _mm512_shuffle_i64x2(t1, t3, 0xdd);
+  const __m512i u6 = _mm512_shuffle_i64x2(t5, t7, 0x88), u7 = _mm512_shuffle_i64x2(t5, t7, 0xdd);
+  r[0] = _mm512_shuffle_i64x2(u0, u2, 0x88); r[4] = _mm512_shuffle_i64x2(u0, u2, 0xdd);
+  r[2] = _mm512_shuffle_i64x2(u1, u3, 0x88); r[6] = _mm512_shuffle_i64x2(u1, u3, 0xdd);
+  r[1] = _mm512_shuffle_i64x2(u4, u6, 0x88); r[5] = _mm512_shuffle_i64x2(u4, u6, 0xdd);
+  r[3] = _mm512_shuffle_i64x2(u5, u7, 0x88); r[7] = _mm512_shuffle_i64x2(u5, u7, 0xdd);
+}
+
+// Eight 200-byte sponges where they lie (array-of-states): load + transpose in registers, permute, transpose back.
+// Avoids the 2 x 200 scalar moves per call of a staging buffer (and their failed store-to-load forwarding).
+__attribute__((target("avx512f,avx512vl,avx512dq,avx512bw"))) void keccak_x8_aos_avx512(uint8_t* const st[8], int live) {
+  static const uint64_t RC[24] = {
+      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+      0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+      0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+      0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  v8u64 a[25], e[25];
+  for (int b = 0; b < 3; ++b) {
+    __m512i r[8];
+    for (int j = 0; j < 8; ++j) r[j] = _mm512_loadu_si512(st[j] + 64 * b);
+    transpose8x8(r);
+    for (int j = 0; j < 8; ++j) a[8 * b + j] = (v8u64)r[j];
+  }
+  {
+    uint64_t last[8];
+    for (int j = 0; j < 8; ++j) memcpy(&last[j], st[j] + 192, 8);
+    memcpy(&a[24], last, 64);
+  }
+  for (int round = 0; round < 24; round += 2) {
+    const v8u64 r0 = {RC[round], RC[round], RC[round], RC[round], RC[round], RC[round], RC[round], RC[round]};
+    const uint64_t q = RC[round + 1];
+    const v8u64 r1 = {q, q, q, q, q, q, q, q};
+    CG1_KECCAK_ROUND_V(a, e, r0);
+    CG1_KECCAK_ROUND_V(e, a, r1);
+  }
+  for (int b = 0; b < 3; ++b) {
+    __m512i r[8];
+    for (int j = 0; j < 8; ++j) r[j] = (__m512i)a[8 * b + j];
+    transpose8x8(r);
+    for (int j = 0; j < live; ++j) _mm512_storeu_si512(st[j] + 64 * b, r[j]);
+  }
+  {
+    uint64_t last[8];
+    memcpy(last, &a[24], 64);
+    for (int j = 0; j < live; ++j) memcpy(st[j] + 192, &last[j], 8);
+  }
+}
+#undef CG1_KECCAK_ROUND_V
 
 void run_f(Strobe& s) {                              // strobe.py:55-61
   s.st[s.pos] ^= s.pos_begin;
@@ -172,6 +232,27 @@ extern "C" {
 void cg1_keccak_f1600_x8(uint64_t* lanes) {
   static const bool have512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
   if (have512) keccak_x8_avx512(lanes); else keccak_x8_generic(lanes);
+}
+// Permute `live` (1..8) 200-byte sponges in place, given by address.  AVX-512: loaded, transposed and stored in
+// registers; otherwise through a staging buffer and cg1_keccak_f1600_x8's baseline build.
+void cg1_keccak_f1600_x8_states(uint8_t* const* states, int live) {
+  static const bool have512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl");
+  if (live < 1) return;
+  if (live > 8) live = 8;
+  if (have512) {
+    uint8_t* st[8];
+    for (int j = 0; j < 8; ++j) st[j] = states[j < live ? j : 0];
+    keccak_x8_aos_avx512(st, live);
+    return;
+  }
+  alignas(64) uint64_t lanes[25 * 8];
+  for (int j = 0; j < 8; ++j) {
+    const uint8_t* src = states[j < live ? j : 0];
+    for (int w = 0; w < 25; ++w) memcpy(&lanes[8 * w + j], src + 8 * w, 8);
+  }
+  keccak_x8_generic(lanes);
+  for (int j = 0; j < live; ++j)
+    for (int w = 0; w < 25; ++w) memcpy(states[j] + 8 * w, &lanes[8 * w + j], 8);
 }
 // one permutation of a 200-byte state (exported for tests / microbenchmarks)
 void cg1_keccak_f1600(uint8_t* state200) { keccak_f1600(state200); }

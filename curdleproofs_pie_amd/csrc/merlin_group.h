@@ -213,29 +213,20 @@ struct Group {
     }
   }
 
-  // Keccak-f on the listed transcripts, eight per call (sponge lanes transposed into one vector per lane index)
+  // Keccak-f on the listed transcripts, eight per call, where the sponges lie
   void permute(const int* idx, int n) {
-    alignas(64) uint64_t lanes[25 * 8];
     for (int base = 0; base < n; base += 8) {
       const int m = n - base < 8 ? n - base : 8;
+      uint8_t* ptr[8];
+      for (int j = 0; j < m; ++j) ptr[j] = st[idx[base + j]];
       auto t0 = TR_NOW();
-      for (int j = 0; j < 8; ++j) {
-        const uint8_t* src = st[idx[base + (j < m ? j : 0)]];          // unused vector slots repeat transcript 0 of the batch
-        for (int w = 0; w < 25; ++w) memcpy(&lanes[8 * w + j], src + 8 * w, 8);
-      }
+      cg1_keccak_f1600_x8_states(ptr, m);
       auto t1 = TR_NOW();
-      cg1_keccak_f1600_x8(lanes);
-      auto t2 = TR_NOW();
-      for (int j = 0; j < m; ++j) {
-        uint8_t* dst = st[idx[base + j]];
-        for (int w = 0; w < 25; ++w) memcpy(dst + 8 * w, &lanes[8 * w + j], 8);
-      }
-      auto t3 = TR_NOW();
-      TR_ADD(0, t0, t1); TR_ADD(1, t1, t2); TR_ADD(2, t2, t3);
+      TR_ADD(1, t0, t1);
 #ifdef CG1_FE_PROFILE
       g_tr_prof[3] += 1;
 #endif
-      (void)t0; (void)t1; (void)t2; (void)t3;
+      (void)t0; (void)t1;
     }
   }
 };

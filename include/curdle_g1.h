@@ -148,6 +148,7 @@ int cg1_probe_madd(cg1_ctx* ctx, const void* d_points_affine96, size_t npts, siz
 #define CG1_MERLIN_STATE_BYTES 208
 void cg1_keccak_f1600(uint8_t* state200);              /* keccak.py:16-66, one permutation */
 void cg1_keccak_f1600_x8(uint64_t* lanes);               /* eight states at once, lane w of state k at lanes[8*w + k] (AVX-512 when present) */
+void cg1_keccak_f1600_x8_states(uint8_t* const* states200, int live);   /* 1..8 sponges permuted where they lie */
 void cg1_strobe_new(uint8_t* state, const uint8_t* protocol_label, size_t len);                 /* Strobe128.new */
 int  cg1_strobe_meta_ad(uint8_t* state, const uint8_t* data, size_t len, int more);
 int  cg1_strobe_ad(uint8_t* state, const uint8_t* data, size_t len, int more);

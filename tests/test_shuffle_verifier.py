@@ -256,6 +256,12 @@ def test_keccak_x8_matches_single():
     N.cg1_keccak_f1600_x8(lanes)
     for k in range(8):
         assert b"".join(int(lanes[8 * w + k]).to_bytes(8, "little") for w in range(25)) == want[k]
+    # sponges permuted where they lie (AVX-512: in-register transposes), any number 1..8 of them
+    for live in (1, 3, 8):
+        bufs = [ctypes.create_string_buffer(s, 200) for s in states[:live]]
+        ptrs = (ctypes.c_void_p * live)(*[ctypes.addressof(b) for b in bufs])
+        N.cg1_keccak_f1600_x8_states(ptrs, live)
+        assert [b.raw for b in bufs] == want[:live]
     # known answer: Keccak-f[1600] of the all-zero state (first lane), keccak.py:16-66
     z = ctypes.create_string_buffer(200)
     N.cg1_keccak_f1600(z)
