@@ -77,6 +77,18 @@ struct Ctx {
   int use_partition_sort = 1;
   int stage_sort = 1;                   // LDS-staged, line-coalesced writes in k_part_scatter / k_bin_sort (A/B switch)
   int host_split = 1;                   // host Horner tail on two threads (A/B switch)
+  int split2 = 0;                       // one large MSM as two window halves on two streams (A/B switch; measured: no gain --
+                                        // k_accumulate owns every VGPR of the chip, so the other half's kernels cannot co-run)
+  struct Ctx* child = nullptr;          // second pipeline (own stream + scratch) of the split
+  hipEvent_t prep_ev = nullptr;         // "prepared points are ready" for the child
+  struct Pending {                      // what msm_finish needs from msm_enqueue
+    bool active = false;
+    int c = 0, rank = 0, world = 1, nlw = 0, nbits = 0;
+    uint32_t m = 1, lb2 = 0, hb2 = 0, nitems = 0;
+    bool use2d = true;
+    size_t nout_words = 0;
+    std::chrono::steady_clock::time_point h0, h1;
+  } pend;
   int quad = 1;                         // quad-lane EC ops in the latency-bound kernels (A/B switch)
   int reduce_2d = 1;                    // 1: k_rowcol + k_small_tree; 0: k_seg_reduce + k_bit_tree (A/B switch)
   uint32_t* d_heavy = nullptr; size_t cap_heavy = 0;         // [0] count, then heavy bucket ids
@@ -115,10 +127,10 @@ static void free_bufs(Ctx* c) {
   c->cap_n = c->cap_nb = c->cap_chunks = c->cap_entries = c->cap_out = 0;
 }
 
-static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems, uint32_t L) {
+static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems, uint32_t L, bool own_points = true) {
   size_t entries = n * nlw;
   size_t chunks = nb_total + entries / L + 1;
-  if (n > ctx->cap_n) {
+  if (own_points && n > ctx->cap_n) {
     if (ctx->d_pts) (void)hipFree(ctx->d_pts);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     HIPCHK(hipMalloc(&ctx->d_pts, n * sizeof(PreparedPoint)));
@@ -241,13 +253,13 @@ static int wait_stream(Ctx* ctx) {
   return CG1_OK;
 }
 
-int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
-  result = cg1h::jac_identity();
-  if (n == 0) return CG1_OK;
-  if (n >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "n too large"); return CG1_ERR_ARG; }
-  if (world < 1 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
-  if (c <= 0) c = pick_window(n);
-  if (c < 4 || c > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
+// Enqueue the whole launch chain of this context's share of an MSM (windows w = rank mod world) up to the D2H of the
+// window sums; nothing waits.  shared_pts / shared_flags: prepared points of ANOTHER context (ready once wait_ev has
+// fired) instead of preparing them again; prepared_ev: recorded on this stream as soon as this context's are ready.
+static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world,
+                       const PreparedPoint* shared_pts, const uint8_t* shared_flags, hipEvent_t wait_ev, hipEvent_t prepared_ev,
+                       hipEvent_t accumulate_after = nullptr) {
+  ctx->pend.active = false;
   HIPCHK(hipSetDevice(ctx->device));
   const int nwin = 255 / c + 1;
   const int nlw = (nwin - rank + world - 1) / world;           // windows w = rank, rank+world, ...
@@ -266,14 +278,21 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   // (window-sharded ranks, skew, thin top windows) are re-joined by k_bucket_fold (<= 16 chunks) / k_heavy_combine.
   uint32_t L0 = ctx->L0;
   while (L0 < 65536u && ((uint64_t)n * (uint64_t)nlw >> 18) > (uint64_t)L0) L0 <<= 1;
-  int rc = ensure(ctx, n, nb_total, nlw, nitems, L0);
+  int rc = ensure(ctx, n, nb_total, nlw, nitems, L0, shared_pts == nullptr);
   if (rc) return rc;
   hipStream_t st = ctx->stream;
   const uint32_t n32 = (uint32_t)n;
   const uint32_t gn = (n32 + 255) / 256;
   auto h0 = std::chrono::steady_clock::now();
+  const PreparedPoint* pts = shared_pts ? shared_pts : ctx->d_pts;
+  const uint8_t* flags = shared_pts ? shared_flags : ctx->d_flags;
   HIPCHK(hipEventRecord(ctx->ev[0], st));
-  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32);
+  if (shared_pts) {
+    HIPCHK(hipStreamWaitEvent(st, wait_ev, 0));
+  } else {
+    hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32);
+    if (prepared_ev) HIPCHK(hipEventRecord(prepared_ev, st));
+  }
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   const size_t nout_words = (size_t)nlw * nitems;
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // set by the digit kernels: a scalar >= 2^255
@@ -285,7 +304,7 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
     const uint32_t sub_bits = bb < 8u ? bb : 8u, nbins = 1u << (bb - sub_bits);
     const uint32_t nslices = (n32 + PART_TILE - 1) / PART_TILE;
     const uint32_t nbc = (uint32_t)nlw * nbins * nslices;
-    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, n32, c, nwin, rank, world, bad_flag);
+    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_digits, n32, c, nwin, rank, world, bad_flag);
     hipLaunchKernelGGL(k_part_count, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, n32, nslices, nbins, sub_bits);
     const uint32_t ublk = (nbc + SCAN_ITEMS - 1) / SCAN_ITEMS;
     hipLaunchKernelGGL(k_uscan1, dim3(ublk), dim3(256), 0, st, ctx->d_blockcnt, ctx->d_ublocktot, nbc);
@@ -308,13 +327,13 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   } else {
     // ---- global-atomic counting sort (any n < 2^31)
     HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
-    hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_hist, n32, c, nwin, rank, world, bad_flag);
+    hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, n32, c, nwin, rank, world, bad_flag);
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     HIPCHK(hipEventRecord(ctx->ev[3], st));
-    hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, c, nwin, rank, world);
+    hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, c, nwin, rank, world);
   }
   HIPCHK(hipMemsetAsync(ctx->d_lenhist, 0, LEN_BINS * 4, st));
   HIPCHK(hipMemsetAsync(ctx->d_heavy, 0, 4, st));
@@ -325,7 +344,8 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS);
   hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
   HIPCHK(hipEventRecord(ctx->ev[4], st));
-  hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
+  if (accumulate_after) HIPCHK(hipStreamWaitEvent(st, accumulate_after, 0));     // the other half's k_accumulate goes first
+  hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, pts, ctx->d_sums);
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
   hipLaunchKernelGGL(k_bucket_fold, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total);
@@ -352,6 +372,24 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, ((size_t)nlw * nitems + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
+  Ctx::Pending& pd = ctx->pend;
+  pd.active = true; pd.c = c; pd.rank = rank; pd.world = world; pd.nlw = nlw; pd.nbits = nbits; pd.m = m; pd.lb2 = lb2; pd.hb2 = hb2;
+  pd.nitems = nitems; pd.use2d = use2d; pd.nout_words = nout_words; pd.h0 = h0; pd.h1 = h1;
+  return CG1_OK;
+}
+
+// Wait for what msm_enqueue queued on this context, then the host Horner tail over its windows.
+static int msm_finish(Ctx* ctx, cg1h::jac& result) {
+  result = cg1h::jac_identity();
+  if (!ctx->pend.active) return CG1_OK;
+  const Ctx::Pending pd = ctx->pend;
+  ctx->pend.active = false;
+  const int c = pd.c, rank = pd.rank, world = pd.world, nlw = pd.nlw, nbits = pd.nbits;
+  const uint32_t m = pd.m, lb2 = pd.lb2, hb2 = pd.hb2, nitems = pd.nitems;
+  const bool use2d = pd.use2d;
+  const size_t nout_words = pd.nout_words;
+  const auto h0 = pd.h0, h1 = pd.h1;
+  HIPCHK(hipSetDevice(ctx->device));
   { int wrc = wait_stream(ctx); if (wrc) return wrc; }
   HIPCHK(hipGetLastError());
   if (*reinterpret_cast<const uint32_t*>(ctx->h_out + nout_words)) {
@@ -407,6 +445,61 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   }
   result = acc;
   ctx->host_tail_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  ctx->host_ms[3] = ctx->host_tail_ms;
+  return CG1_OK;
+}
+
+static Ctx* split_child(Ctx* ctx) {
+  if (ctx->child) return ctx->child;
+  Ctx* ch = new Ctx();
+  ch->device = ctx->device;
+  int least = 0, greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+  bool ok = hipStreamCreateWithPriority(&ch->stream, hipStreamNonBlocking, least) == hipSuccess;   // the parent's half goes first
+  ok = ok && hipEventCreateWithFlags(&ch->sync_ev, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
+  for (int i = 0; ok && i <= CG1_NPHASE; ++i) ok = hipEventCreate(&ch->ev[i]) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&ctx->prep_ev, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { delete ch; return nullptr; }                      // (leaks the partial objects of a failed device: the caller falls back)
+  ctx->child = ch;
+  return ch;
+}
+
+constexpr size_t SPLIT_MIN_N = 1u << 18;
+
+// One MSM.  With split2 = 1 (off by default) a large single-GPU call runs as TWO half-pipelines: the odd windows on this
+// context's stream, the even ones on a low-priority child stream sharing the prepared points, the second k_accumulate
+// ordered after the first, so that the first half's reduce tail and host Horner could hide under the second half's
+// k_accumulate.  Measured on MI355X at 2^20: 3.31-3.53 ms vs 3.30-3.39 ms unsplit -- two waves of k_accumulate hold all
+// 512 VGPRs of a SIMD, nothing else becomes resident next to it, the halves serialise and the launch chain doubles.
+int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
+  result = cg1h::jac_identity();
+  if (n == 0) return CG1_OK;
+  if (n >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "n too large"); return CG1_ERR_ARG; }
+  if (world < 1 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
+  if (c <= 0) c = pick_window(n);
+  if (c < 4 || c > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
+  Ctx* ch = (ctx->split2 && world == 1 && n >= SPLIT_MIN_N && n <= PART_MAX_N && ctx->use_partition_sort) ? split_child(ctx) : nullptr;
+  if (!ch) {
+    int rc = msm_enqueue(ctx, d_points96, d_scalars32, n, c, rank, world, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    return msm_finish(ctx, result);
+  }
+  ch->L0 = ctx->L0; ch->seg_m = ctx->seg_m; ch->profile = ctx->profile; ch->stage_sort = ctx->stage_sort; ch->quad = ctx->quad;
+  ch->reduce_2d = ctx->reduce_2d; ch->host_split = ctx->host_split; ch->big_bins = ctx->big_bins; ch->blocking_sync = ctx->blocking_sync;
+  ch->use_partition_sort = ctx->use_partition_sort;
+  int rc = msm_enqueue(ctx, d_points96, d_scalars32, n, c, 1, 2, nullptr, nullptr, nullptr, ctx->prep_ev);
+  if (rc) return rc;
+  rc = msm_enqueue(ch, d_points96, d_scalars32, n, c, 0, 2, ctx->d_pts, ctx->d_flags, ctx->prep_ev, nullptr, ctx->ev[5]);
+  cg1h::jac ra, rb;
+  int rc_a = msm_finish(ctx, ra);                                // always drain both streams, even after an error
+  int rc_b = rc ? rc : msm_finish(ch, rb);
+  if (rc) { (void)hipStreamSynchronize(ch->stream); }
+  if (rc_a) return rc_a;
+  if (rc_b) { snprintf(ctx->err, sizeof ctx->err, "%s", ch->err); return rc_b; }
+  result = cg1h::jac_add(ra, rb);
+  for (int i = 0; i < CG1_NPHASE; ++i) ctx->phase_ms[i] += ch->phase_ms[i];     // kernel time of both halves (they overlap in wall time)
+  ctx->host_tail_ms += ch->host_tail_ms;
+  ctx->host_ms[0] += ch->host_ms[0];
   ctx->host_ms[3] = ctx->host_tail_ms;
   return CG1_OK;
 }
@@ -641,6 +734,16 @@ cg1_ctx* cg1_ctx_create(int device) {
 void cg1_ctx_destroy(cg1_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->child) {
+    cg1::Ctx* ch = ctx->child;
+    cg1::free_bufs(ch);
+    for (int i = 0; i <= CG1_NPHASE; ++i) (void)hipEventDestroy(ch->ev[i]);
+    if (ch->sync_ev) (void)hipEventDestroy(ch->sync_ev);
+    (void)hipStreamDestroy(ch->stream);
+    delete ch;
+    ctx->child = nullptr;
+  }
+  if (ctx->prep_ev) (void)hipEventDestroy(ctx->prep_ev);
   cg1::free_bufs(ctx);
   if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
   if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
@@ -733,6 +836,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "blocking_sync")) { ctx->blocking_sync = value != 0; return CG1_OK; }
   if (!strcmp(name, "big_bins")) { ctx->big_bins = value != 0; return CG1_OK; }
+  if (!strcmp(name, "split2")) { ctx->split2 = value != 0; return CG1_OK; }
   if (!strcmp(name, "host_split")) { ctx->host_split = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
     int v = value ? 1 : 0;
