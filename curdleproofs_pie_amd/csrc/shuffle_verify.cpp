@@ -926,7 +926,7 @@ int cg1_opening_prepare(size_t n, const uint8_t* trackers, const uint8_t* k_comm
     return CG1_ERR_ARG;
   uint8_t G48[48];
   cg1h::g1_compress(cg1h::jac_generator(), G48);
-  for (size_t i = 0; i < n; ++i) {
+  auto one = [&](size_t i) {
     const uint8_t *rG = trackers + 96 * i, *krG = rG + 48, *kG = k_commitments + 48 * i, *A = proofs + 128 * i, *B = A + 48;
     uint8_t* pts = out_points48 + 5 * 48 * i;
     memcpy(pts, kG, 48); memcpy(pts + 48, krG, 48); memcpy(pts + 96, rG, 48); memcpy(pts + 144, A, 48); memcpy(pts + 192, B, 48);
@@ -935,8 +935,8 @@ int cg1_opening_prepare(size_t n, const uint8_t* trackers, const uint8_t* k_comm
     memset(sc, 0, 5 * 32);
     memset(gs, 0, 32);
     fr s_, r1, r2;
-    if (!fr_from_le32(A + 96, s_)) { status[i] = CG1_SHUFFLE_BAD_SCALAR; continue; }
-    if (!fr_from_le32(weights + 64 * i, r1) || !fr_from_le32(weights + 64 * i + 32, r2)) { status[i] = CG1_SHUFFLE_BAD_WEIGHT; continue; }
+    if (!fr_from_le32(A + 96, s_)) { status[i] = CG1_SHUFFLE_BAD_SCALAR; return; }
+    if (!fr_from_le32(weights + 64 * i, r1) || !fr_from_le32(weights + 64 * i + 32, r2)) { status[i] = CG1_SHUFFLE_BAD_WEIGHT; return; }
     Transcript tr("whisk_opening_proof");
     const uint8_t* order[6] = {kG, G48, krG, rG, A, B};
     for (const uint8_t* p : order) tr.point("tracker_opening_proof", p);
@@ -948,6 +948,21 @@ int cg1_opening_prepare(size_t n, const uint8_t* trackers, const uint8_t* k_comm
     fr_to_le32(fr_neg(r2), sc + 128);              // B
     fr_to_le32(fr_mul(r1, s_), gs);                // G
     status[i] = 0;
+  };
+  if (n < 256) {
+    for (size_t i = 0; i < n; ++i) one(i);
+  } else {                                                    // slices of 64 proofs over the worker pool
+    std::atomic<size_t> next{0};
+    const size_t items = (n + 63) / 64;
+    std::function<void()> work = [&]() {
+      for (;;) {
+        const size_t it = next.fetch_add(1);
+        if (it >= items) return;
+        for (size_t i = it * 64; i < std::min(n, it * 64 + 64); ++i) one(i);
+      }
+    };
+    Pool& pool = Pool::get();
+    pool.run(work, std::min(items, pool.size() + 1));
   }
   return CG1_OK;
 }

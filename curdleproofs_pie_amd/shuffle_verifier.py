@@ -516,22 +516,35 @@ class OpeningBatchVerifier:
         """items: (tracker, k_commitment, proof_bytes); tracker = WhiskTracker-like or (r_G, k_r_G).  Host half only."""
         items = list(items)
         n = len(items)
-        tr, kc, pf, pre = [], [], [], []
-        for t, k, p in items:
-            r, kr = (t.r_G, t.k_r_G) if hasattr(t, "r_G") else t
-            r, kr, k, p = bytes(r), bytes(kr), bytes(k), bytes(p)
-            ok = len(r) == len(kr) == len(k) == 48 and len(p) >= self.PROOF_BYTES       # BufReader ignores trailing bytes
-            tr.append(r + kr if ok else bytes(96)); kc.append(k if ok else bytes(48)); pf.append(p[:128] if ok else bytes(128))
-            pre.append(0 if ok else REJECT_LENGTH)
+        trk = [it[0] for it in items]
+        rs = [t.r_G if hasattr(t, "r_G") else t[0] for t in trk]
+        krs = [t.k_r_G if hasattr(t, "k_r_G") else t[1] for t in trk]
+        ks = [it[1] for it in items]
+        ps = [it[2] for it in items]
+        try:
+            uniform = ({len(x) for x in rs} | {len(x) for x in krs} | {len(x) for x in ks}) <= {48} and {len(x) for x in ps} <= {self.PROOF_BYTES}
+        except TypeError:
+            uniform = False
+        if uniform:                                   # the common case: everything well-formed, packed without a per-item loop
+            trackers = b"".join(x for pair in zip(rs, krs) for x in pair)
+            kcs, pfs, pre = b"".join(ks), b"".join(ps), [0] * n
+        else:
+            tr, kc, pf, pre = [], [], [], []
+            for r, kr, k, p in zip(rs, krs, ks, ps):
+                r, kr, k, p = bytes(r), bytes(kr), bytes(k), bytes(p)
+                ok = len(r) == len(kr) == len(k) == 48 and len(p) >= self.PROOF_BYTES       # BufReader ignores trailing bytes
+                tr.append(r + kr if ok else bytes(96)); kc.append(k if ok else bytes(48)); pf.append(p[:128] if ok else bytes(128))
+                pre.append(0 if ok else REJECT_LENGTH)
+            trackers, kcs, pfs = b"".join(tr), b"".join(kc), b"".join(pf)
         if rng is None:
             raw = bytearray(secrets.token_bytes(64 * n))
-            raw[31::32] = bytes(b & 0x3F for b in raw[31::32])
+            raw[31::32] = raw[31::32].translate(_CLEAR_TOP2)
             weights = bytes(raw)
         else:
             weights = b"".join(rng.randint(1, FR_MODULUS - 1).to_bytes(32, "little") for _ in range(2 * n))
         out = {"n": n, "points48": ctypes.create_string_buffer(max(1, 240 * n)), "scalars32": ctypes.create_string_buffer(max(1, 160 * n)),
                "g_scalars32": ctypes.create_string_buffer(max(1, 32 * n)), "status": (ctypes.c_int32 * max(1, n))()}
-        rc = N.cg1_opening_prepare(n, b"".join(tr), b"".join(kc), b"".join(pf), weights, out["points48"], out["scalars32"],
+        rc = N.cg1_opening_prepare(n, trackers, kcs, pfs, weights, out["points48"], out["scalars32"],
                                    out["g_scalars32"], out["status"])
         if rc:
             raise N.NativeError(f"cg1_opening_prepare failed ({rc})")
