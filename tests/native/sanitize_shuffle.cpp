@@ -57,6 +57,21 @@ int main(int argc, char** argv) {
   size_t rejected = 0;
   for (size_t i = 0; i < n; ++i) rejected += st[i] != 0;
   printf("front-end rejected %zu of %zu\n", rejected, n);
+  {   // opening-proof front-end: 700 proofs of random bytes (pool path) -- statuses only, no crash / race
+    const size_t m = 700;
+    std::vector<uint8_t> trk(m * 96), kc(m * 48), pf(m * 128), w(m * 64), op(m * 240), os(m * 160), og(m * 32);
+    std::vector<int32_t> ost(m);
+    for (auto& b : trk) b = (uint8_t)rnd();
+    for (auto& b : kc) b = (uint8_t)rnd();
+    for (auto& b : pf) b = (uint8_t)rnd();
+    for (auto& b : w) b = (uint8_t)rnd();
+    for (size_t i = 31; i < w.size(); i += 32) w[i] &= 0x3f;
+    for (size_t i = 127; i < pf.size(); i += 256) pf[i] &= 0x3f;           // every other proof gets a canonical s
+    if (cg1_opening_prepare(m, trk.data(), kc.data(), pf.data(), w.data(), op.data(), os.data(), og.data(), ost.data())) return 1;
+    size_t okc = 0;
+    for (size_t i = 0; i < m; ++i) okc += ost[i] == 0;
+    printf("opening front-end prepared %zu of %zu\n", okc, m);
+  }
   cg1_shuffle_crs_destroy(crs);
   printf("sanitize ok\n");
   return 0;
