@@ -10,8 +10,10 @@ batch of synthetic input that is already resident in HBM: point preparation, sig
 sort, bucket accumulation, bucket reduction, D2H of the window sums and the host Horner tail are all inside
 the timed region.  Workload at N=1: BASELINE.json configs[1]'s shape at the metric's size -- one MSM of 2^20
 random G1 points (k_i*G) with scalars uniform in [1, r-1] (the reference's random_scalar, util.py:21-24).
-At N>1 (weak scaling): ONE MSM of N*2^20 terms whose signed-digit windows are sharded across the ranks
-(--shard windows, the north_star's decomposition) or whose points are (--shard points); the partial G1 sums
+At N>1 (weak scaling): ONE MSM of N*2^20 terms.  --shard hybrid (default): the signed-digit windows are sharded over
+2 window-bucket groups and the points over N/2 point groups (rank = window group + 2 * point group), so window buckets
+are sharded across GPUs as the north_star asks without every rank re-preparing all N*2^20 points; --shard windows:
+pure window sharding (every rank holds all points); --shard points: pure point sharding.  The partial G1 sums
 are all-gathered over RCCL and added on every rank.  value = total terms processed / max-over-ranks time.
 """
 import argparse
@@ -179,7 +181,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logn", type=int, default=20, help="log2 of terms per GPU")
     ap.add_argument("--window", type=int, default=16)
-    ap.add_argument("--shard", choices=["windows", "points"], default="windows")
+    ap.add_argument("--shard", choices=["hybrid", "windows", "points"], default="hybrid",
+                    help="N>1: hybrid = 2 window-bucket groups x N/2 point groups (default); windows / points = pure splits")
     ap.add_argument("--cpu-sample-logn", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--batch", type=int, default=1024, help="--mode verify: proofs per step")
@@ -226,10 +229,9 @@ def main():
     n_total = n_per_gpu * world
     c = args.window
     # ---- synthetic inputs, generated on the GPU and left resident in HBM
-    if args.shard == "windows":
-        n_local, seed_off = n_total, 0            # every rank holds the whole MSM
-    else:
-        n_local, seed_off = n_per_gpu, 1000 * rank  # this rank's shard of the points
+    from curdleproofs_pie_amd.distributed import shard_layout
+    w_rank, w_groups, p_rank, p_groups = shard_layout(rank, world, args.shard)
+    n_local, seed_off = n_total // p_groups, 1000 * p_rank      # this rank's point group (the whole MSM when p_groups == 1)
     d_k = ctx.alloc(32 * n_local)
     d_pts = ctx.alloc(96 * n_local)
     d_sc = ctx.alloc(32 * n_local)
@@ -243,10 +245,7 @@ def main():
     from curdleproofs_pie_amd.distributed import all_reduce_g1
 
     def step():
-        if args.shard == "windows":
-            part = ctx.msm_device(d_pts, d_sc, n_local, window_c=c, shard_rank=rank, shard_world=world)
-        else:
-            part = ctx.msm_device(d_pts, d_sc, n_local, window_c=c)
+        part = ctx.msm_device(d_pts, d_sc, n_local, window_c=c, shard_rank=w_rank, shard_world=w_groups)
         return all_reduce_g1(part) if world > 1 else part
 
     def barrier_sync():
@@ -286,7 +285,7 @@ def main():
         terms_per_launch = n_local
         achieved = 128.0 * terms_per_launch / (acc_ms * 1e-3) / 1e9
         nwin = 255 // c + 1
-        local_windows = (nwin + world - 1) // world if args.shard == "windows" else nwin
+        local_windows = (nwin + w_groups - 1) // w_groups
         mads = terms_per_launch * local_windows * 3542.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -309,8 +308,9 @@ def main():
             "dtype": "u32",
             "data": "synthetic: points k_i*G and scalars uniform in [1,r-1], splitmix64-seeded, generated on the GPU",
             "config": {"workload": f"single MSM of 2^{args.logn} x {world} BLS12-381 G1 terms, resident in HBM, "
-                                   f"{'window' if args.shard == 'windows' else 'point'}-sharded over {world} GPU(s)",
+                                   f"sharded over {world} GPU(s): {w_groups} window-bucket group(s) x {p_groups} point group(s)",
                        "terms_total": n_total, "terms_per_gpu": n_per_gpu, "window_c": c, "shard": args.shard,
+                       "parallelism": f"windows x{w_groups} . points x{p_groups}, one all-gather of {world} partial G1 sums",
                        "arithmetic": "381-bit Fp as 14 x 28-bit limbs in u32, Montgomery, 64-bit column accumulators (v_mad_u64_u32)",
                        "bit_exact_vs_oracle": "tests/test_msm_gpu.py"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

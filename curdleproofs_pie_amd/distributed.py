@@ -61,17 +61,40 @@ def all_reduce_g1(partial_blob: bytes, group=None, device: Optional[str] = None)
     return sum_blobs([raw[i * N.POINT_BYTES:(i + 1) * N.POINT_BYTES] for i in range(world)])
 
 
+def shard_layout(rank: int, world: int, mode: str = "hybrid", window_groups: int = 2):
+    """-> (window_rank, window_groups W, point_rank, point_groups P) with W * P == world.
+
+    "windows": W = world (every rank holds ALL points, owns the windows w = rank mod world) -- replicates the
+               per-point work (k_prepare_points, digit extraction) world times: 4.25 ms per rank at world = 8;
+    "points":  P = world (every rank holds 1/world of the points, all windows);
+    "hybrid":  W = window_groups (default 2) window-bucket groups x P = world / W point groups: window buckets are still
+               sharded across GPUs, but a rank only touches 1/P of the points (3.47 ms per rank at world = 8 on MI355X,
+               tools/gpu_shard_emulation.py).  Falls back to "windows" when world is not a multiple of window_groups."""
+    if mode == "windows" or (mode == "hybrid" and (world % window_groups or world < window_groups)):
+        return rank, world, 0, 1
+    if mode == "points":
+        return 0, 1, rank, world
+    if mode != "hybrid":
+        raise ValueError(f"unknown shard mode {mode!r}")
+    W = window_groups
+    return rank % W, W, rank // W, world // W
+
+
 def sharded_msm(ctx: "N.Context", d_points, d_scalars, n: int, rank: int, world: int, window_c: int = 16,
                 mode: str = "windows", group=None) -> bytes:
     """This rank's share of one MSM, then the G1 all-reduce.
 
     mode "windows": d_points/d_scalars hold ALL n terms on every rank.
     mode "points" : d_points/d_scalars hold only this rank's shard of n terms.
+    mode "hybrid" : d_points/d_scalars hold the n terms of this rank's point group (see shard_layout).
     """
     if mode == "windows":
         part = ctx.msm_device(d_points, d_scalars, n, window_c=window_c, shard_rank=rank, shard_world=world)
     elif mode == "points":
         part = ctx.msm_device(d_points, d_scalars, n, window_c=window_c)
+    elif mode == "hybrid":              # d_points/d_scalars hold this rank's POINT GROUP (n terms); windows split inside the group
+        wr, W, _, _ = shard_layout(rank, world, "hybrid")
+        part = ctx.msm_device(d_points, d_scalars, n, window_c=window_c, shard_rank=wr, shard_world=W)
     else:
         raise ValueError(f"unknown shard mode {mode!r}")
     return all_reduce_g1(part, group=group)

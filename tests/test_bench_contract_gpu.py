@@ -49,3 +49,4 @@ def test_two_rank_launch_prints_one_line():
         assert k in d, k
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["terms_total"] == 2 * (1 << 16)
+    assert d["config"]["parallelism"].startswith("windows x2 . points x1")

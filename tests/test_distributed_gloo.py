@@ -37,7 +37,14 @@ def _worker(rank, world, port, mode, q):
     bases = [G1Point() * Scalar(rng.randint(1, 2 ** 200)) for _ in range(n)]
     scalars = [rng.randint(0, 2 ** 255 - 20) for _ in range(n)]
     part = G1Point.identity()
-    if mode == "points":               # rank owns a contiguous slice of the terms
+    if mode == "hybrid":               # W window groups x P point groups (shard_layout): windows wr mod W of the point slice pr
+        from curdleproofs_pie_amd.distributed import shard_layout
+        wr, W, pr, P = shard_layout(rank, world, "hybrid")
+        lo, hi = pr * n // P, (pr + 1) * n // P
+        for b, s in zip(bases[lo:hi], scalars[lo:hi]):
+            mine = sum(((s >> (16 * w)) & 0xFFFF) << (16 * w) for w in range(16) if w % W == wr)
+            part = part + b * Scalar(mine)
+    elif mode == "points":             # rank owns a contiguous slice of the terms
         lo, hi = rank * n // world, (rank + 1) * n // world
         for b, s in zip(bases[lo:hi], scalars[lo:hi]):
             part = part + b * Scalar(s)
@@ -77,6 +84,36 @@ def test_two_rank_g1_all_reduce(native_lib, mode):
     scalars = [rng.randint(0, 2 ** 255 - 20) for _ in range(n)]
     want = O.g1_compress(O.g1_mul(O.G1_GEN, sum(k * (s % O.R) for k, s in zip(ks, scalars)) % O.R)).hex()
     assert got[0] == got[1] == want
+
+
+def test_four_rank_hybrid_all_reduce(native_lib):
+    """2 window groups x 2 point groups over 4 gloo ranks: every rank ends with the single-process result."""
+    import random
+
+    import torch.multiprocessing as mp
+
+    from curdleproofs_pie_amd.distributed import shard_layout
+    from oracle import bls12_381 as O
+
+    assert [shard_layout(r, 8, "hybrid") for r in range(8)] == [(r % 2, 2, r // 2, 4) for r in range(8)]
+    assert shard_layout(3, 8, "windows") == (3, 8, 0, 1) and shard_layout(3, 8, "points") == (0, 1, 3, 8)
+    assert shard_layout(2, 3, "hybrid") == (2, 3, 0, 1)                  # odd world: pure window sharding
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, "hybrid", q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(4))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = random.Random(2024)
+    n = 24
+    ks = [rng.randint(1, 2 ** 200) for _ in range(n)]
+    scalars = [rng.randint(0, 2 ** 255 - 20) for _ in range(n)]
+    want = O.g1_compress(O.g1_mul(O.G1_GEN, sum(k * (s % O.R) for k, s in zip(ks, scalars)) % O.R)).hex()
+    assert got[0] == got[1] == got[2] == got[3] == want
 
 
 def _worker_batch(rank, world, port, q):

@@ -147,7 +147,8 @@ def test_full_size_2_20_closed_form_and_linearity(native_lib, ctx):
 def test_config4_full_size_2_22_window_shards(native_lib, ctx):
     """BASELINE config 4: one MSM of 2^22 terms, window buckets sharded over 8 ranks (here: the 8 per-rank partials
     computed one after another on this GPU).  Closed form: points k_i*G, so MSM == (sum k_i s_i mod r) * G exactly;
-    the 8 window-shard partials must add up to exactly that point, and so must the 8 point-shard partials."""
+    the 8 window-shard partials must add up to exactly that point, and so must the 8 point-shard partials and the 8 partials
+    of the hybrid split (2 window groups x 4 point groups)."""
     N = native_lib
     n = 1 << 22
     dk, dg, dp, ds = ctx.alloc(32 * n), ctx.alloc(96), ctx.alloc(96 * n), ctx.alloc(32 * n)
@@ -165,6 +166,14 @@ def test_config4_full_size_2_22_window_shards(native_lib, ctx):
     assert compress_blob(N, sum_blobs(parts)) == want
     m = n // 8
     parts = [ctx.msm_device(dp.ptr + 96 * m * g, ds.ptr + 32 * m * g, m) for g in range(8)]
+    assert compress_blob(N, sum_blobs(parts)) == want
+    # bench.py's default split: 2 window-bucket groups x 4 point groups (distributed.shard_layout)
+    from curdleproofs_pie_amd.distributed import shard_layout
+    parts = []
+    for rank in range(8):
+        wr, W, pr, P = shard_layout(rank, 8, "hybrid")
+        q = n // P
+        parts.append(ctx.msm_device(dp.ptr + 96 * q * pr, ds.ptr + 32 * q * pr, q, window_c=16, shard_rank=wr, shard_world=W))
     assert compress_blob(N, sum_blobs(parts)) == want
 
 
