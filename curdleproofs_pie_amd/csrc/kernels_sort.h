@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ p
   __shared__ uint32_t cur[256];
   __shared__ uint32_t stage[BIN_STAGE];
   const uint32_t g = blockIdx.x;
-  if (bigflag[g]) return;                                          // sorted by k_big_count / k_big_scatter (many blocks)
+  if (bigflag[g]) return;                                          // oversize bin: sorted slice-wise (k_slice_*)
   const uint32_t start = block_base[(size_t)g * nslices];
   const uint32_t end = block_base[(size_t)(g + 1) * nslices];     // element [nbins_total*nslices] holds the grand total
   cnt[threadIdx.x] = 0;
@@ -173,38 +173,68 @@ __global__ void __launch_bounds__(256) k_bin_sort(const uint32_t* __restrict__ p
   }
 }
 
-// ---- giant bins.  Skewed scalars (all-equal, tiny ranges, recoding-carry windows) put up to ALL n entries of a window
-// into one bin, and one block sorting a million entries takes milliseconds.  Bins above BIG_MIN entries are listed
-// (k_big_list, up to BIG_CAP of them; the rest stay with k_bin_sort) and each is sorted by BIG_S blocks over equal
-// slices of its entries: per-slice LDS histograms (k_big_count), then every block derives its own offsets from the
-// BIG_S histograms of its bin and scatters (k_big_scatter).  Fixed grids (blocks beyond the list exit at once), no
-// host round trip.
-constexpr uint32_t BIG_MIN = 4u * BIN_STAGE, BIG_CAP = 64, BIG_S = 64;
+// ---- bins too large for k_bin_sort's LDS staging (> BIN_STAGE entries): n > 2^21 (uniform bins of 32 K - 64 K) and
+// skewed scalars (all-equal, tiny ranges, recoding-carry windows: up to ALL n entries of a window in one bin, which one
+// block would take milliseconds to sort).  Each such bin is cut into slices of <= BIN_STAGE entries, one block per slice:
+//   k_slice_plan     slices per bin + their exclusive scan (block -> (bin, slice) map), flags for k_bin_sort to skip
+//   k_slice_count    per-slice LDS histogram over the sub-bucket
+//   k_slice_prefix   one block per oversize bin: running sums across its slices (in place), per-bucket totals + bases
+//   k_slice_scatter  per slice: rank in LDS, stage, write whole runs -> sorted[]
+// Fixed upper-bound grids (blocks beyond the planned count exit at once); no host round trip.
+constexpr uint32_t SLICE = BIN_STAGE;
 
-__global__ void __launch_bounds__(256) k_big_list(const uint32_t* __restrict__ block_base, uint32_t nbins_total, uint32_t nslices,
-                                                  uint32_t* __restrict__ bigcount, uint32_t* __restrict__ biglist,
-                                                  uint8_t* __restrict__ bigflag, int enable) {
-  const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-  if (g >= nbins_total) return;
-  const uint32_t size = block_base[(size_t)(g + 1) * nslices] - block_base[(size_t)g * nslices];
-  uint8_t flag = 0;
-  if (enable && size > BIG_MIN) {
-    const uint32_t slot = atomicAdd(bigcount, 1u);
-    if (slot < BIG_CAP) { biglist[slot] = g; flag = 1; }
+__global__ void __launch_bounds__(256) k_slice_plan(const uint32_t* __restrict__ block_base, uint32_t nbins_total, uint32_t nslices,
+                                                    uint32_t* __restrict__ slice_base /* [nbins_total + 1] */,
+                                                    uint8_t* __restrict__ bigflag, int enable) {
+  __shared__ uint32_t part_sum[256];
+  // thread t owns bins [t*per, (t+1)*per): serial count, block scan of the 256 partial sums, serial write-back
+  const uint32_t per = (nbins_total + 255u) / 256u, g0 = threadIdx.x * per;
+  uint32_t mine = 0;
+  for (uint32_t g = g0; g < g0 + per && g < nbins_total; ++g) {
+    const uint32_t size = block_base[(size_t)(g + 1) * nslices] - block_base[(size_t)g * nslices];
+    mine += (enable && size > BIN_STAGE) ? (size + SLICE - 1u) / SLICE : 0u;
   }
-  bigflag[g] = flag;
+  part_sum[threadIdx.x] = mine;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? part_sum[threadIdx.x - d] : 0u;
+    __syncthreads();
+    part_sum[threadIdx.x] += u;
+    __syncthreads();
+  }
+  uint32_t run = part_sum[threadIdx.x] - mine;
+  for (uint32_t g = g0; g < g0 + per && g < nbins_total; ++g) {
+    const uint32_t size = block_base[(size_t)(g + 1) * nslices] - block_base[(size_t)g * nslices];
+    const uint32_t ns = (enable && size > BIN_STAGE) ? (size + SLICE - 1u) / SLICE : 0u;
+    slice_base[g] = run;
+    bigflag[g] = ns ? 1 : 0;
+    run += ns;
+  }
+  if (threadIdx.x == 255) slice_base[nbins_total] = part_sum[255];
 }
 
-__global__ void __launch_bounds__(256) k_big_count(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
-                                                   uint32_t nslices, const uint32_t* __restrict__ bigcount,
-                                                   const uint32_t* __restrict__ biglist, uint32_t* __restrict__ bighist) {
+// block b -> (bin g, slice s): the last g with slice_base[g] <= b (bins without slices share their successor's base)
+__device__ __forceinline__ bool slice_of_block(const uint32_t* __restrict__ slice_base, uint32_t nbins_total, uint32_t b,
+                                               uint32_t& g, uint32_t& s) {
+  if (b >= slice_base[nbins_total]) return false;
+  uint32_t lo = 0, hi = nbins_total;                    // invariant: slice_base[lo] <= b < slice_base[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (slice_base[mid] <= b) lo = mid; else hi = mid;
+  }
+  g = lo;
+  s = b - slice_base[lo];
+  return true;
+}
+
+__global__ void __launch_bounds__(256) k_slice_count(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
+                                                     uint32_t nbins_total, uint32_t nslices, const uint32_t* __restrict__ slice_base,
+                                                     uint32_t* __restrict__ slicehist) {
   __shared__ uint32_t cnt[256];
-  const uint32_t slot = blockIdx.x, s = blockIdx.y;
-  const uint32_t nbig = *bigcount < BIG_CAP ? *bigcount : BIG_CAP;
-  if (slot >= nbig) return;
-  const uint32_t g = biglist[slot];
-  const uint32_t start = block_base[(size_t)g * nslices], size = block_base[(size_t)(g + 1) * nslices] - start;
-  const uint32_t lo = start + (uint32_t)((uint64_t)size * s / BIG_S), hi = start + (uint32_t)((uint64_t)size * (s + 1) / BIG_S);
+  uint32_t g, s;
+  if (!slice_of_block(slice_base, nbins_total, blockIdx.x, g, s)) return;
+  const uint32_t start = block_base[(size_t)g * nslices], end = block_base[(size_t)(g + 1) * nslices];
+  const uint32_t lo = start + s * SLICE, hi = (lo + SLICE < end) ? lo + SLICE : end;
   cnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t span = ((hi - lo + 255u) / 256u) * 256u;          // whole waves iterate together
@@ -213,45 +243,82 @@ __global__ void __launch_bounds__(256) k_big_count(const uint32_t* __restrict__ 
     lds_ranked_inc(cnt, live ? (part[lo + o] >> 24) : 0u, live);
   }
   __syncthreads();
-  bighist[((size_t)slot * BIG_S + s) * 256u + threadIdx.x] = cnt[threadIdx.x];
+  slicehist[(size_t)blockIdx.x * 256u + threadIdx.x] = cnt[threadIdx.x];
 }
 
-__global__ void __launch_bounds__(256) k_big_scatter(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
-                                                     uint32_t nslices, uint32_t sub_bits, const uint32_t* __restrict__ bigcount,
-                                                     const uint32_t* __restrict__ biglist, const uint32_t* __restrict__ bighist,
-                                                     uint32_t* __restrict__ hist, uint32_t* __restrict__ sorted) {
-  __shared__ uint32_t cur[256];
-  const uint32_t slot = blockIdx.x, s = blockIdx.y;
-  const uint32_t nbig = *bigcount < BIG_CAP ? *bigcount : BIG_CAP;
-  if (slot >= nbig) return;
-  const uint32_t g = biglist[slot];
-  const uint32_t start = block_base[(size_t)g * nslices], size = block_base[(size_t)(g + 1) * nslices] - start;
-  const uint32_t lo = start + (uint32_t)((uint64_t)size * s / BIG_S), hi = start + (uint32_t)((uint64_t)size * (s + 1) / BIG_S);
-  uint32_t total = 0, before = 0;                                   // of sub-bucket threadIdx.x: whole bin / slices before mine
-  for (uint32_t s2 = 0; s2 < BIG_S; ++s2) {
-    const uint32_t v = bighist[((size_t)slot * BIG_S + s2) * 256u + threadIdx.x];
-    if (s2 < s) before += v;
-    total += v;
+// one block per bin; thread t = sub-bucket t.  slicehist[slice][t] becomes the number of entries of bucket t in the
+// EARLIER slices of the bin; subbase[g][t] = where bucket t of bin g starts in sorted[]; hist[] gets the bucket totals.
+__global__ void __launch_bounds__(256) k_slice_prefix(const uint32_t* __restrict__ block_base, uint32_t nslices, uint32_t sub_bits,
+                                                      const uint32_t* __restrict__ slice_base, const uint8_t* __restrict__ bigflag,
+                                                      uint32_t* __restrict__ slicehist, uint32_t* __restrict__ subbase,
+                                                      uint32_t* __restrict__ hist) {
+  __shared__ uint32_t tot[256];
+  const uint32_t g = blockIdx.x;
+  if (!bigflag[g]) return;
+  const uint32_t b0 = slice_base[g], b1 = slice_base[g + 1];
+  uint32_t run = 0;
+  for (uint32_t b = b0; b < b1; ++b) {
+    const size_t idx = (size_t)b * 256u + threadIdx.x;
+    const uint32_t v = slicehist[idx];
+    slicehist[idx] = run;
+    run += v;
   }
-  cur[threadIdx.x] = total;
+  tot[threadIdx.x] = run;
   __syncthreads();
   for (int d = 1; d < 256; d <<= 1) {
-    uint32_t u = ((int)threadIdx.x >= d) ? cur[threadIdx.x - d] : 0u;
+    uint32_t u = ((int)threadIdx.x >= d) ? tot[threadIdx.x - d] : 0u;
     __syncthreads();
-    cur[threadIdx.x] += u;
+    tot[threadIdx.x] += u;
     __syncthreads();
   }
-  const uint32_t excl = cur[threadIdx.x] - total;
-  __syncthreads();
-  cur[threadIdx.x] = start + excl + before;
-  if (s == 0 && threadIdx.x < (1u << sub_bits)) hist[((size_t)g << sub_bits) + threadIdx.x] = total;
+  subbase[(size_t)g * 256u + threadIdx.x] = block_base[(size_t)g * nslices] + tot[threadIdx.x] - run;
+  if (threadIdx.x < (1u << sub_bits)) hist[((size_t)g << sub_bits) + threadIdx.x] = run;
+}
+
+__global__ void __launch_bounds__(256) k_slice_scatter(const uint32_t* __restrict__ part, const uint32_t* __restrict__ block_base,
+                                                       uint32_t nbins_total, uint32_t nslices, const uint32_t* __restrict__ slice_base,
+                                                       const uint32_t* __restrict__ slicehist, const uint32_t* __restrict__ subbase,
+                                                       uint32_t* __restrict__ sorted) {
+  __shared__ uint32_t cnt[256];          // this slice's count per sub-bucket, then its exclusive scan (local base)
+  __shared__ uint32_t cur[256];          // local cursors
+  __shared__ uint32_t gdst[256];         // global destination of the slice's run of each sub-bucket
+  __shared__ uint32_t stage[SLICE];
+  uint32_t g, s;
+  if (!slice_of_block(slice_base, nbins_total, blockIdx.x, g, s)) return;
+  const uint32_t start = block_base[(size_t)g * nslices], end = block_base[(size_t)(g + 1) * nslices];
+  const uint32_t lo = start + s * SLICE, hi = (lo + SLICE < end) ? lo + SLICE : end;
+  cnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t span = ((hi - lo + 255u) / 256u) * 256u;
   for (uint32_t o = threadIdx.x; o < span; o += 256) {
     const bool live = lo + o < hi;
+    lds_ranked_inc(cnt, live ? (part[lo + o] >> 24) : 0u, live);
+  }
+  __syncthreads();
+  const uint32_t mine = cnt[threadIdx.x];
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? cnt[threadIdx.x - d] : 0u;
+    __syncthreads();
+    cnt[threadIdx.x] += u;
+    __syncthreads();
+  }
+  const uint32_t lbase = cnt[threadIdx.x] - mine;
+  __syncthreads();
+  cnt[threadIdx.x] = lbase;
+  cur[threadIdx.x] = lbase;
+  gdst[threadIdx.x] = subbase[(size_t)g * 256u + threadIdx.x] + slicehist[(size_t)blockIdx.x * 256u + threadIdx.x];
+  __syncthreads();
+  for (uint32_t o = threadIdx.x; o < span; o += 256) {
+    const bool live = lo + o < hi;
     const uint32_t v = live ? part[lo + o] : 0u;
     const uint32_t pos = lds_ranked_inc(cur, v >> 24, live);
-    if (live) sorted[pos] = (v & 0x7fffffu) | ((v >> 23 & 1u) << 31);
+    if (live) stage[pos] = v;
+  }
+  __syncthreads();
+  for (uint32_t o = threadIdx.x; o < hi - lo; o += 256) {           // consecutive o of one sub-bucket -> consecutive addresses
+    const uint32_t v = stage[o], k = v >> 24;
+    sorted[gdst[k] + (o - cnt[k])] = (v & 0x7fffffu) | ((v >> 23 & 1u) << 31);
   }
 }
 

@@ -72,7 +72,8 @@ struct Ctx {
   PointSum* d_partial = nullptr; size_t cap_partial = 0;
   uint16_t* d_digits = nullptr; uint32_t* d_part = nullptr; uint32_t* d_blockcnt = nullptr; uint32_t* d_ublocktot = nullptr;
   size_t cap_digits = 0, cap_part = 0, cap_blockcnt = 0;
-  uint32_t *d_bigcount = nullptr, *d_biglist = nullptr, *d_bighist = nullptr; uint8_t* d_bigflag = nullptr; size_t cap_bigflag = 0;
+  uint32_t *d_slice_base = nullptr, *d_slicehist = nullptr, *d_subbase = nullptr; uint8_t* d_bigflag = nullptr;
+  size_t cap_bigflag = 0, cap_slices = 0;
   int big_bins = 1;                     // giant bins of skewed scalars sorted by many blocks (A/B switch)
   int use_partition_sort = 1;
   int stage_sort = 1;                   // LDS-staged, line-coalesced writes in k_part_scatter / k_bin_sort (A/B switch)
@@ -119,7 +120,7 @@ static void free_bufs(Ctx* c) {
   F(c->d_sums); F(c->d_segrun); F(c->d_segtot); F(c->d_out); F(c->d_order); F(c->d_lenhist); F(c->d_partial);
   c->cap_partial = 0;
   F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot); F(c->d_boffs); F(c->d_gsum); F(c->d_bout);
-  F(c->d_bigcount); F(c->d_biglist); F(c->d_bighist); F(c->d_bigflag); c->cap_bigflag = 0;
+  F(c->d_slice_base); F(c->d_slicehist); F(c->d_subbase); F(c->d_bigflag); c->cap_bigflag = 0; c->cap_slices = 0;
   if (c->h_bout) { (void)hipHostFree(c->h_bout); c->h_bout = nullptr; }
   c->cap_boffs = c->cap_gsum = c->cap_bout = 0;
   c->cap_digits = c->cap_part = c->cap_blockcnt = 0;
@@ -189,15 +190,21 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
       HIPCHK(hipMalloc(&ctx->d_part, (entries + 1) * 4));
       ctx->cap_part = entries;
     }
-    if (!ctx->d_bigcount) {
-      HIPCHK(hipMalloc(&ctx->d_bigcount, 16));
-      HIPCHK(hipMalloc(&ctx->d_biglist, BIG_CAP * 4));
-      HIPCHK(hipMalloc(&ctx->d_bighist, (size_t)BIG_CAP * BIG_S * 256 * 4));
-    }
     if (nlw * 128 > ctx->cap_bigflag) {
-      if (ctx->d_bigflag) (void)hipFree(ctx->d_bigflag);
+      auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
+      F(ctx->d_bigflag); F(ctx->d_slice_base); F(ctx->d_subbase);
       HIPCHK(hipMalloc(&ctx->d_bigflag, nlw * 128 + 16));
+      HIPCHK(hipMalloc(&ctx->d_slice_base, (nlw * 128 + 1) * 4));
+      HIPCHK(hipMalloc(&ctx->d_subbase, nlw * 128 * 256 * 4));
       ctx->cap_bigflag = nlw * 128;
+    }
+    {
+      const size_t max_slices = entries / SLICE + nlw * 128 + 1;       // sum over bins of ceil(size / SLICE)
+      if (max_slices > ctx->cap_slices) {
+        if (ctx->d_slicehist) (void)hipFree(ctx->d_slicehist);
+        HIPCHK(hipMalloc(&ctx->d_slicehist, max_slices * 256 * 4));
+        ctx->cap_slices = max_slices;
+      }
     }
     if (nbc > ctx->cap_blockcnt) {
       if (ctx->d_blockcnt) (void)hipFree(ctx->d_blockcnt);
@@ -313,12 +320,13 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_part_scatter, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, ctx->d_part, n32, nslices, nbins, sub_bits, ctx->stage_sort);
     const uint32_t nbt = (uint32_t)nlw * nbins;
-    HIPCHK(hipMemsetAsync(ctx->d_bigcount, 0, 4, st));
-    hipLaunchKernelGGL(k_big_list, dim3((nbt + 255) / 256), dim3(256), 0, st, ctx->d_blockcnt, nbt, nslices, ctx->d_bigcount, ctx->d_biglist, ctx->d_bigflag, ctx->big_bins);
+    hipLaunchKernelGGL(k_slice_plan, dim3(1), dim3(256), 0, st, ctx->d_blockcnt, nbt, nslices, ctx->d_slice_base, ctx->d_bigflag, ctx->big_bins);
     hipLaunchKernelGGL(k_bin_sort, dim3(nbt), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, ctx->d_hist, ctx->d_sorted, nbt, nslices, sub_bits, ctx->stage_sort, ctx->d_bigflag);
-    if (ctx->big_bins && n32 > BIG_MIN) {                          // a bin cannot exceed n entries
-      hipLaunchKernelGGL(k_big_count, dim3(BIG_CAP, BIG_S), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, nslices, ctx->d_bigcount, ctx->d_biglist, ctx->d_bighist);
-      hipLaunchKernelGGL(k_big_scatter, dim3(BIG_CAP, BIG_S), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, nslices, sub_bits, ctx->d_bigcount, ctx->d_biglist, ctx->d_bighist, ctx->d_hist, ctx->d_sorted);
+    if (ctx->big_bins && n32 > BIN_STAGE) {                        // a bin cannot exceed n entries
+      const uint32_t max_slices = (uint32_t)(((size_t)n * (size_t)nlw) / SLICE + nbt + 1);
+      hipLaunchKernelGGL(k_slice_count, dim3(max_slices), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, nbt, nslices, ctx->d_slice_base, ctx->d_slicehist);
+      hipLaunchKernelGGL(k_slice_prefix, dim3(nbt), dim3(256), 0, st, ctx->d_blockcnt, nslices, sub_bits, ctx->d_slice_base, ctx->d_bigflag, ctx->d_slicehist, ctx->d_subbase, ctx->d_hist);
+      hipLaunchKernelGGL(k_slice_scatter, dim3(max_slices), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, nbt, nslices, ctx->d_slice_base, ctx->d_slicehist, ctx->d_subbase, ctx->d_sorted);
     }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
