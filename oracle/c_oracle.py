@@ -30,6 +30,9 @@ def lib():
         _lib.orc_scalar_mul.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
         _lib.orc_add.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_void_p]
         _lib.orc_compress.argtypes = [ctypes.c_char_p, ctypes.c_void_p]
+        _lib.orc_msm_bucket_mt.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        _lib.orc_decompress.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p]
+        _lib.orc_decompress.restype = ctypes.c_int
     return _lib
 
 
@@ -65,3 +68,20 @@ def compress(a96: bytes) -> bytes:
     out = ctypes.create_string_buffer(48)
     lib().orc_compress(a96, out)
     return out.raw
+
+
+def msm_bucket_mt(points96: bytes, scalars32: bytes, n: int, threads: int, c: int = 0) -> bytes:
+    """msm_bucket on `threads` host cores (OpenMP).  A stronger NON-reference baseline (the reference is single-threaded)."""
+    if c <= 0:
+        c = max(4, min(16, n.bit_length() - 3))
+    out = ctypes.create_string_buffer(96)
+    lib().orc_msm_bucket_mt(points96, scalars32, n, c, threads, out)
+    return out.raw
+
+
+def decompress(data48: bytes, check_subgroup: bool = False):
+    """-> (status, affine96): G1Point.from_compressed_bytes[_unchecked] (util.py:35-36); status 0 ok, 1 bad encoding,
+    2 not on the curve, 3 not in the subgroup."""
+    out = ctypes.create_string_buffer(96)
+    rc = lib().orc_decompress(bytes(data48), 1 if check_subgroup else 0, out)
+    return rc, out.raw

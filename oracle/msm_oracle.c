@@ -194,6 +194,50 @@ void orc_msm_bucket(const uint8_t* points96, const uint8_t* scalars32, size_t n,
   pt_to_affine96(total, out96);
   free(pts); free(buckets);
 }
+/* The same bucket method on `threads` host cores (OpenMP): the (window, point-slice) tasks are independent; their
+ * partial window sums are combined by one Horner pass.  A clearly-labelled NON-reference baseline for bench.py
+ * ("all host cores"); the reference itself is single-threaded. */
+void orc_msm_bucket_mt(const uint8_t* points96, const uint8_t* scalars32, size_t n, int c, int threads, uint8_t out96[96]) {
+  if (c < 2) c = 2;
+  if (c > 16) c = 16;
+  if (threads < 1) threads = 1;
+  const int nwin = (256 + c - 1) / c;
+  const size_t nb = (size_t)1 << c;
+  int nslice = (threads + nwin - 1) / nwin;
+  if ((size_t)nslice > n / 1024 + 1) nslice = (int)(n / 1024 + 1);
+  const int ntask = nwin * nslice;
+  pt* pts = (pt*)malloc((n ? n : 1) * sizeof(pt));
+  pt* part = (pt*)malloc((size_t)ntask * sizeof(pt));
+#pragma omp parallel for num_threads(threads) schedule(static)
+  for (long i = 0; i < (long)n; ++i) pts[i] = pt_from_affine96(points96 + 96 * (size_t)i);
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+  for (int t = 0; t < ntask; ++t) {
+    const int w = t / nslice, sl = t % nslice;
+    const size_t i0 = n * (size_t)sl / (size_t)nslice, i1 = n * (size_t)(sl + 1) / (size_t)nslice;
+    pt* buckets = (pt*)malloc(nb * sizeof(pt));
+    for (size_t b = 0; b < nb; ++b) buckets[b] = pt_identity();
+    for (size_t i = i0; i < i1; ++i) {
+      const uint8_t* k = scalars32 + 32 * i;
+      uint32_t d = 0;
+      for (int u = 0; u < c; ++u) {
+        int bit = w * c + u;
+        if (bit < 256 && ((k[bit >> 3] >> (bit & 7)) & 1)) d |= 1u << u;
+      }
+      if (d) buckets[d] = pt_add(buckets[d], pts[i]);
+    }
+    pt run = pt_identity(), acc = pt_identity();
+    for (size_t b = nb - 1; b >= 1; --b) { run = pt_add(run, buckets[b]); acc = pt_add(acc, run); }
+    part[t] = acc;
+    free(buckets);
+  }
+  pt total = pt_identity();
+  for (int w = nwin - 1; w >= 0; --w) {
+    for (int k = 0; k < c; ++k) total = pt_double(total);
+    for (int sl = 0; sl < nslice; ++sl) total = pt_add(total, part[w * nslice + sl]);
+  }
+  pt_to_affine96(total, out96);
+  free(pts); free(part);
+}
 void orc_scalar_mul(const uint8_t* point96, const uint8_t* scalar32, uint8_t out96[96]) {
   pt_to_affine96(pt_scalar_mul(pt_from_affine96(point96), scalar32), out96);
 }
@@ -219,4 +263,53 @@ void orc_compress(const uint8_t* a96, uint8_t out48[48]) {
   }
   out48[0] |= 0x80;
   if (larger) out48[0] |= 0x20;
+}
+
+/* 48-byte ZCash-format decompression: G1Point.from_compressed_bytes_unchecked (util.py:35-36) / from_compressed_bytes
+ * (checked, test_curdleproofs.py:171).  Restates oracle/bls12_381.py g1_decompress.  Returns 0 and the affine96
+ * record (zeros = identity), or 1 bad encoding / 2 x not on the curve / 3 not in the prime-order subgroup. */
+static const uint64_t SQRT_EXP[6] = {0xee7fbfffffffeaabULL, 0x07aaffffac54ffffULL, 0xd9cc34a83dac3d89ULL,
+                                     0xd91dd2e13ce144afULL, 0x92c6e9ed90d2eb35ULL, 0x0680447a8e5ff9a6ULL};   /* (p+1)/4 */
+static const uint64_t GROUP_ORDER[4] = {0xffffffff00000001ULL, 0x53bda402fffe5bfeULL, 0x3339d80809a1d805ULL, 0x73eda753299d7d48ULL};
+int orc_decompress(const uint8_t in48[48], int check_subgroup, uint8_t out96[96]) {
+  memset(out96, 0, 96);
+  const uint8_t flags = in48[0];
+  if (!(flags & 0x80)) return 1;
+  if ((flags & 0x40) && (flags & 0x20)) return 1;
+  uint8_t xle[48];
+  for (int i = 0; i < 48; ++i) xle[i] = in48[47 - i];
+  xle[47] &= 0x1f;
+  if (flags & 0x40) {
+    int any = 0;
+    for (int i = 0; i < 48; ++i) any |= xle[i];
+    return any ? 1 : 0;
+  }
+  uint64_t xw[6];
+  for (int i = 0; i < 6; ++i) { uint64_t w = 0; for (int j = 7; j >= 0; --j) w = (w << 8) | xle[8 * i + j]; xw[i] = w; }
+  if (ge_p(xw)) return 1;
+  fq x = fq_from_le(xle);
+  uint8_t four[48]; memset(four, 0, sizeof four); four[0] = 4;
+  fq rhs = fq_add(fq_mul(fq_mul(x, x), x), fq_from_le(four));
+  uint8_t one[48]; memset(one, 0, sizeof one); one[0] = 1;
+  fq y = fq_from_le(one);
+  for (int i = 383; i >= 0; --i) { y = fq_mul(y, y); if ((SQRT_EXP[i >> 6] >> (i & 63)) & 1) y = fq_mul(y, rhs); }
+  if (!fq_equal(fq_mul(y, y), rhs)) return 2;
+  uint8_t a96[96], enc[48];
+  memcpy(a96, xle, 48);
+  fq_to_le(y, a96 + 48);
+  orc_compress(a96, enc);
+  if (((enc[0] & 0x20) != 0) != ((flags & 0x20) != 0)) {
+    fq zero; memset(&zero, 0, sizeof zero);
+    fq_to_le(fq_sub(zero, y), a96 + 48);
+  }
+  if (check_subgroup) {
+    pt base = pt_from_affine96(a96), acc = pt_identity();
+    for (int bit = 254; bit >= 0; --bit) {
+      acc = pt_double(acc);
+      if ((GROUP_ORDER[bit >> 6] >> (bit & 63)) & 1) acc = pt_add(acc, base);
+    }
+    if (!fq_is_zero(acc.z)) return 3;
+  }
+  memcpy(out96, a96, 96);
+  return 0;
 }

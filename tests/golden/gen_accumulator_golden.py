@@ -7,9 +7,15 @@ with the left-hand side A_c it is compared with, for valid proofs and for the re
 (test_curdleproofs.py:643-670).  Only data is written: tests/golden/accumulator_vectors.json
 (compressed points 48 B hex, scalars 32 B LE hex).  The GPU tests recompute every MSM and compare with A_c.
 
-The curve arithmetic during generation is our host C++ (the wheel cannot run here), so these are
-protocol-shaped regression fixtures whose expected values are additionally re-derived by the CPU oracle in
-tests/test_accumulator_golden.py -- not an independent pin of the group law (that is tests/test_oracle_kat.py).
+The curve arithmetic during generation is the pure-Python CPU oracle (tests/golden/_backend.py; the wheel cannot run
+here), so nothing in the file comes out of product arithmetic; `--backend product` regenerates it over the product's host
+C++ and must give the same bytes (tests/test_golden_backends.py).  Not an independent pin of the group law (that is
+tests/test_oracle_kat.py).
+
+Also recorded ("sequences"): the complete `accumulate_check` call sequence of one verify (msm_accumulator.py:37-58) --
+per call the left-hand side C, every (base, scalar) pair as passed (identity bases included) and the random factor the
+reference drew -- followed by the accumulator's final state.  tests replay it through the product's MSMAccumulator on the
+GPU and through oracle.MSMAccumulator on the CPU.
 
     python tests/golden/gen_accumulator_golden.py
 """
@@ -18,14 +24,10 @@ import os
 import random
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.dont_write_bytecode = True
-sys.path.insert(0, ROOT)
-sys.path.insert(0, "/root/reference/curdleproofs")
-sys.path.insert(0, "/root/reference/merlin_transcripts")
-import curdleproofs_pie_amd.py_arkworks_bls12381 as backend  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _backend  # noqa: E402
 
-sys.modules["py_arkworks_bls12381"] = backend
+BACKEND_MODULE = _backend.inject()
 
 import curdleproofs.msm_accumulator as ref_acc  # noqa: E402
 from curdleproofs.crs import CurdleproofsCrs  # noqa: E402
@@ -33,7 +35,35 @@ from curdleproofs.curdleproofs import N_BLINDERS, CurdleProofsProof, shuffle_per
 from curdleproofs.util import get_random_point, random_scalar  # noqa: E402
 
 RECORDS = []
+CALLS = None                      # list of accumulate_check calls while a sequence is being recorded
 _orig_verify = ref_acc.MSMAccumulator.verify
+_orig_accumulate = ref_acc.MSMAccumulator.accumulate_check
+_orig_random_scalar = ref_acc.random_scalar
+_last_rho = []
+
+
+def _recording_random_scalar():
+    r = _orig_random_scalar()
+    _last_rho.append(r)
+    return r
+
+
+ref_acc.random_scalar = _recording_random_scalar
+
+
+def recording_accumulate(self, C, bases, scalars):
+    bases, scalars = list(bases), list(scalars)
+    del _last_rho[:]
+    _orig_accumulate(self, C, bases, scalars)
+    if CALLS is not None:
+        assert len(_last_rho) == 1            # exactly one draw per call (msm_accumulator.py:43)
+        CALLS.append({"C": bytes(C.to_compressed_bytes()).hex(),
+                      "bases": [bytes(b.to_compressed_bytes()).hex() for b in bases],
+                      "scalars": [bytes(x.to_le_bytes()).hex() for x in scalars],
+                      "rho": bytes(_last_rho[0].to_le_bytes()).hex()})
+
+
+ref_acc.MSMAccumulator.accumulate_check = recording_accumulate
 
 
 def recording_verify(self):
@@ -122,13 +152,29 @@ def run(N, seed, tamper):
     return new
 
 
+def record_sequence(N, seed, tamper):
+    global CALLS
+    CALLS = []
+    recs = run(N, seed, tamper)
+    calls, CALLS = CALLS, None
+    assert len(recs) == 1
+    final = recs[0]
+    return {"N": N, "seed": seed, "tamper": tamper, "calls": calls,
+            "final": {"bases": final["bases"], "scalars": final["scalars"], "A_c": final["A_c"], "accepts": final["accepts"]}}
+
+
 def main():
+    sequences = [record_sequence(128, 21, "none"), record_sequence(64, 22, "same_msm_x_final")]
+    for q in sequences:
+        print("sequence", q["N"], q["tamper"], [len(c["bases"]) for c in q["calls"]], "->", len(q["final"]["bases"]), q["final"]["accepts"])
+    del RECORDS[:]
     for N, seed, tamper in ((64, 1, "none"), (128, 2, "none"), (128, 3, "swap_R_S"), (64, 4, "wrong_k"),
                             (64, 5, "ipa_c_final"), (64, 6, "same_msm_x_final"), (128, 7, "ipa_c_final")):
         recs = run(N, seed, tamper)
         print(N, seed, tamper, "->", [(len(r["bases"]), r["accepts"]) for r in recs])
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "accumulator_vectors.json")
-    json.dump({"generator": "tests/golden/gen_accumulator_golden.py", "records": RECORDS}, open(out, "w"))
+    out = _backend.out_path("accumulator_vectors.json")
+    json.dump({"generator": "tests/golden/gen_accumulator_golden.py (G1Point/Scalar = %s)" % BACKEND_MODULE, "backend": BACKEND_MODULE,
+               "records": RECORDS, "sequences": sequences}, open(out, "w"), separators=(",", ":"))
     print("wrote", out, os.path.getsize(out), "bytes")
 
 

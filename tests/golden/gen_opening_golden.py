@@ -3,7 +3,7 @@
 
 Runs the reference's own entry points (/root/reference/curdleproofs/curdleproofs/whisk_interface.py:
 GenerateWhiskTrackerProof :172-190, IsValidWhiskOpeningProof :147-169), imported unmodified in the build container
-with our G1Point/Scalar module standing in for the missing Rust wheel, on seeded inputs.  Data only ->
+with a stand-in for the missing Rust wheel (tests/golden/_backend.py: the pure-Python CPU oracle by default), on seeded inputs.  Data only ->
 tests/golden/opening_vectors.json: per case the tracker, k_commitment, proof bytes, the challenge the reference
 verifier drew, and tampered variants each with the verdict IsValidWhiskOpeningProof returned.
 
@@ -60,9 +60,10 @@ def main():
         add("swap r_G <-> k_r_G", r_G=base["k_r_G"], k_r_G=base["r_G"])
         add("truncated proof", proof=proof[:-1])
         cases.append({**{k2: v.hex() for k2, v in base.items()}, "challenge": challenge, "variants": variants})
-    path = os.path.join(HERE, "opening_vectors.json")
+    path = G._backend.out_path("opening_vectors.json")
     with open(path, "w") as f:
-        json.dump({"generator": "tests/golden/gen_opening_golden.py (reference whisk_interface over our host backend)", "cases": cases}, f, separators=(",", ":"))
+        json.dump({"generator": "tests/golden/gen_opening_golden.py (reference whisk_interface; G1Point/Scalar = %s)" % G.BACKEND_MODULE,
+                   "backend": G.BACKEND_MODULE, "cases": cases}, f, separators=(",", ":"))
     print([(v["name"], v["accepts"]) for v in cases[0]["variants"]])
     print("wrote", path, os.path.getsize(path), "bytes")
 

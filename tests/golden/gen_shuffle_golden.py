@@ -3,8 +3,9 @@
 
 Runs the reference's own Whisk entry points (/root/reference/curdleproofs/curdleproofs/whisk_interface.py:
 GenerateWhiskShuffleProof :113-144, IsValidWhiskShuffleProof :72-109), imported unmodified in the build container
-with our G1Point/Scalar module standing in for the missing Rust wheel and the reference's own pure-Python Merlin,
-on seeded inputs.  Written to tests/golden/shuffle_vectors.json -- data only:
+with a stand-in for the missing Rust wheel (tests/golden/_backend.py: the pure-Python CPU oracle by default, so no
+byte of the fixture comes out of product arithmetic; `--backend product` for the byte-identity cross-check) and the
+reference's own pure-Python Merlin, on seeded inputs.  Written to tests/golden/shuffle_vectors.json -- data only:
 
   per case: ell, CRS bytes (crs.py:92-101), pre/post tracker encodings, proof bytes, every challenge the reference
   verifier drew (label + 32 LE bytes, in order), and a list of tampered variants (byte edits of the proof or the
@@ -21,14 +22,10 @@ import os
 import random
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.dont_write_bytecode = True
-sys.path.insert(0, ROOT)
-sys.path.insert(0, "/root/reference/curdleproofs")
-sys.path.insert(0, "/root/reference/merlin_transcripts")
-import curdleproofs_pie_amd.py_arkworks_bls12381 as backend  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _backend  # noqa: E402
 
-sys.modules["py_arkworks_bls12381"] = backend
+BACKEND_MODULE = _backend.inject()
 
 from curdleproofs.crs import CurdleproofsCrs  # noqa: E402
 from curdleproofs.curdleproofs_transcript import CurdleproofsTranscript  # noqa: E402
@@ -152,8 +149,9 @@ def run_case(ell, seed, n_variants):
 
 def main():
     cases = [run_case(4, 11, 12), run_case(12, 12, 16), run_case(28, 13, 10), run_case(60, 14, 8), run_case(124, 15, 8), run_case(124, 16, 0)]
-    out = {"generator": "tests/golden/gen_shuffle_golden.py (reference whisk_interface over our host backend)", "cases": cases}
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "shuffle_vectors.json")
+    out = {"generator": "tests/golden/gen_shuffle_golden.py (reference whisk_interface; G1Point/Scalar = %s)" % BACKEND_MODULE,
+           "backend": BACKEND_MODULE, "cases": cases}
+    path = _backend.out_path("shuffle_vectors.json")
     with open(path, "w") as f:
         json.dump(out, f, separators=(",", ":"))
     for c in cases:

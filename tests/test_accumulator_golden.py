@@ -65,3 +65,72 @@ def test_gpu_msm_on_real_accumulator_data(native_lib, records):
             assert out.raw == want
     finally:
         ctx.close()
+
+
+# ---------------------------------------------------------------- accumulate_check call sequences (msm_accumulator.py:37-58)
+@pytest.fixture(scope="module")
+def sequences():
+    seqs = json.load(open(os.path.join(ROOT, "tests", "golden", "accumulator_vectors.json")))["sequences"]
+    assert [(q["N"], len(q["calls"]), q["final"]["accepts"]) for q in seqs] == [(128, 8, True), (64, 8, False)]
+    return seqs
+
+
+class _Replay:
+    """Stands in for `random`: hands out the recorded random factors, one per accumulate_check (msm_accumulator.py:43)."""
+
+    def __init__(self, calls):
+        self.rhos = [int.from_bytes(bytes.fromhex(c["rho"]), "little") for c in calls]
+
+    def randint(self, lo, hi):
+        r = self.rhos.pop(0)
+        assert lo <= r <= hi
+        return r
+
+
+def test_oracle_accumulator_replays_reference_call_sequence(sequences):
+    """oracle.MSMAccumulator fed the reference's own 8 calls (C, bases incl. identities, scalars, rho) ends in exactly the
+    state the reference's accumulator ended in: same keys in the same order, same merged scalars, same A_c, same verdict."""
+    for q in sequences:
+        acc = O.MSMAccumulator(rng=_Replay(q["calls"]))
+        npairs = nident = 0
+        for c in q["calls"]:
+            bases = [O.g1_decompress(bytes.fromhex(h)) for h in c["bases"]]
+            npairs += len(bases)
+            nident += sum(1 for b in bases if b is None)
+            acc.accumulate_check(O.g1_decompress(bytes.fromhex(c["C"])), bases, [int.from_bytes(bytes.fromhex(h), "little") for h in c["scalars"]])
+        ell = q["N"] - 4
+        assert npairs == 3 * ell + 5 * q["N"] + 1 and nident == 6        # SURVEY 3.2: 1 013 pairs at N=128, 6 of them Z1
+        f = q["final"]
+        assert [k.hex() for k in acc.base_scalar_map.keys()] == f["bases"]
+        assert [v.to_bytes(32, "little").hex() for v in acc.base_scalar_map.values()] == f["scalars"]
+        assert O.g1_compress(O.jac_to_affine(acc.A_c)).hex() == f["A_c"]
+        pts = b"".join(raw96(O.g1_decompress(k)) for k in acc.base_scalar_map.keys())
+        sc = b"".join(v.to_bytes(32, "little") for v in acc.base_scalar_map.values())
+        assert (C.compress(C.msm_bucket(pts, sc, len(acc.base_scalar_map))).hex() == f["A_c"]) == f["accepts"]
+
+
+@pytest.mark.gpu
+def test_product_accumulator_replays_reference_call_sequence_on_gpu(native_lib, sequences, monkeypatch):
+    """The PRODUCT's MSMAccumulator (Python face -> C ABI -> HIP MSM) fed the same recorded calls: same merged map, same
+    A_c, verify() raises exactly when the reference's did."""
+    import curdleproofs_pie_amd.msm_accumulator as A
+    from curdleproofs_pie_amd.py_arkworks_bls12381 import G1Point, Scalar
+
+    for q in sequences:
+        rhos = [Scalar.from_le_bytes(bytes.fromhex(c["rho"])) for c in q["calls"]]
+        monkeypatch.setattr(A, "random_scalar", lambda rhos=rhos: rhos.pop(0))
+        acc = A.MSMAccumulator()
+        for c in q["calls"]:
+            acc.accumulate_check(G1Point.from_compressed_bytes_unchecked(bytes.fromhex(c["C"])),
+                                 [G1Point.from_compressed_bytes_unchecked(bytes.fromhex(h)) for h in c["bases"]],
+                                 [Scalar.from_le_bytes(bytes.fromhex(h)) for h in c["scalars"]])
+        assert not rhos                                               # exactly one draw per call
+        f = q["final"]
+        assert [k.hex() for k in acc.base_scalar_map.keys()] == f["bases"]
+        assert [e[0].to_bytes(32, "little").hex() for e in acc.base_scalar_map.values()] == f["scalars"]
+        assert bytes(acc.A_c.to_compressed_bytes()).hex() == f["A_c"]
+        if f["accepts"]:
+            acc.verify()
+        else:
+            with pytest.raises(AssertionError):
+                acc.verify()

@@ -33,6 +33,16 @@ def test_product_does_not_import_oracle():
                 assert "oracle" not in text.replace("test_oracle", ""), f"{f} mentions the oracle"
 
 
+def test_oracle_does_not_import_product():
+    """The checker stands on its own: no file under oracle/ imports (or names) the product package, so no oracle verdict
+    can be produced by the code under test."""
+    odir = os.path.join(ROOT, "oracle")
+    for f in os.listdir(odir):
+        if f.endswith((".py", ".c", ".h")) or f == "Makefile":
+            text = open(os.path.join(odir, f)).read()
+            assert "import curdleproofs_pie_amd" not in text and "from curdleproofs_pie_amd" not in text and "libcurdle_g1" not in text, f
+
+
 def test_msm_fails_loudly_without_gpu(native_lib):
     if native_lib.cg1_device_count() > 0:
         pytest.skip("a GPU is visible; the no-GPU failure mode is checked on the CPU box")

@@ -19,7 +19,7 @@ sys.path.insert(0, ROOT)
 
 from curdleproofs_pie_amd import _native as N  # noqa: E402
 from curdleproofs_pie_amd.shuffle_verifier import REJECT_LENGTH, ShuffleBatchVerifier, ShuffleCrs  # noqa: E402
-from oracle.shuffle_check import host_decompress_affine, oracle_verdicts  # noqa: E402
+from oracle.shuffle_check import decompress_affine, oracle_verdicts  # noqa: E402
 
 GOLD = os.path.join(ROOT, "tests", "golden", "shuffle_vectors.json")
 REF = "/root/reference/curdleproofs"
@@ -205,7 +205,7 @@ def test_decoded_window_path_matches_host_decode(gold):
     decoded = b""
     for i in range(n):
         lo = (i * L + 4 * v.crs.ell + 1) * 48
-        aff, _ok = host_decompress_affine(wire.raw[lo: lo + 8 * 48], 8)
+        aff, _ok = decompress_affine(wire.raw[lo: lo + 8 * 48], 8)
         decoded += aff
     b = v.prepare(inst, proofs, n, weights=w, decoded=decoded)
     for i in range(n):

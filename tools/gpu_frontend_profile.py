@@ -18,11 +18,11 @@ proofs = bytes.fromhex(case["proof"]) * n
 w = v.draw_weights(n)
 # decoded window from the host decoder (so the front-end skips its own square roots, as in the GPU flow)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from oracle.shuffle_check import host_decompress_affine
+from oracle.shuffle_check import decompress_affine
 L = v.crs.points_per_proof
 wire = ctypes.create_string_buffer(L * 48)
 N.cg1_shuffle_gather_points(v.crs.handle, 1, inst[: 4 * 124 * 48], proofs[: v.crs.proof_bytes], wire)
-dec, _ = host_decompress_affine(wire.raw[(4 * 124 + 1) * 48: (4 * 124 + 9) * 48], 8)
+dec, _ = decompress_affine(wire.raw[(4 * 124 + 1) * 48: (4 * 124 + 9) * 48], 8)
 prof = N.lib.cg1_shuffle_profile
 out = (ctypes.c_double * 6)()
 v.prepare(inst, proofs, n, weights=w, decoded=dec * n)
