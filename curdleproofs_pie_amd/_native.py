@@ -83,11 +83,16 @@ cg1_msm_batched_device = _proto("cg1_msm_batched_device", c_int, c_void_p, c_voi
 cg1_msm_batched = _proto("cg1_msm_batched", c_int, c_void_p, _u8p, _u8p, POINTER(ctypes.c_uint32), c_size_t, _buf)
 cg1_get_timings = _proto("cg1_get_timings", c_int, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_int))
 cg1_get_host_timings = _proto("cg1_get_host_timings", c_int, c_void_p, POINTER(c_float))
+cg1_get_last_counts = _proto("cg1_get_last_counts", c_int, c_void_p, POINTER(ctypes.c_uint32), POINTER(ctypes.c_uint32))
+cg1_timer_begin = _proto("cg1_timer_begin", c_int, c_void_p)
+cg1_timer_end = _proto("cg1_timer_end", c_int, c_void_p, POINTER(c_float))
 cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
 cg1_batch_mul_add_device = _proto("cg1_batch_mul_add_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
 cg1_batch_mul_add = _proto("cg1_batch_mul_add", c_int, c_void_p, _u8p, c_size_t, _u8p, c_size_t, _u8p, _buf, c_size_t)
 cg1_batch_decompress_device = _proto("cg1_batch_decompress_device", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int)
 cg1_batch_decompress_enqueue = _proto("cg1_batch_decompress_enqueue", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int)
+cg1_subgroup_flags_enqueue = _proto("cg1_subgroup_flags_enqueue", c_int, c_void_p, c_void_p, c_size_t, c_size_t, POINTER(ctypes.c_uint32), c_size_t, c_void_p)
+cg1_side_sync = _proto("cg1_side_sync", c_int, c_void_p)
 cg1_batch_compress_device = _proto("cg1_batch_compress_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t)
 cg1_batch_decompress_gpu = _proto("cg1_batch_decompress_gpu", c_int, c_void_p, _u8p, _buf, c_size_t, c_int, POINTER(c_size_t))
 cg1_gen_scalars_device = _proto("cg1_gen_scalars_device", c_int, c_void_p, c_void_p, c_size_t, c_uint64)
@@ -121,20 +126,22 @@ cg1_shuffle_prepare = _proto("cg1_shuffle_prepare", c_int, c_void_p, c_size_t, c
 cg1_opening_prepare = _proto("cg1_opening_prepare", c_int, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
 cg1_shuffle_set_grouped = _proto("cg1_shuffle_set_grouped", None, c_int)
 cg1_shuffle_default_threads = _proto("cg1_shuffle_default_threads", c_size_t)
+cg1_shuffle_exact_same_scalar = _proto("cg1_shuffle_exact_same_scalar", c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int))
+cg1_opening_exact = _proto("cg1_opening_exact", c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int))
 cg1_shuffle_gather_points = _proto("cg1_shuffle_gather_points", c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p)
 cg1_shuffle_apply_point_status = _proto("cg1_shuffle_apply_point_status", c_int, _buf, _u8p, c_size_t, c_size_t, _buf, _buf, c_size_t)
 cg1_shuffle_sum_crs_scalars = _proto("cg1_shuffle_sum_crs_scalars", c_int, _buf, _buf, c_size_t, c_size_t, _buf)
 
 EXPORTED_SYMBOLS = [
     "cg1_shuffle_crs_create", "cg1_shuffle_crs_destroy", "cg1_shuffle_proof_bytes", "cg1_shuffle_points_per_proof",
-    "cg1_shuffle_crs_points", "cg1_shuffle_challenges_per_proof", "cg1_opening_prepare", "cg1_shuffle_prepare", "cg1_shuffle_set_grouped", "cg1_shuffle_default_threads", "cg1_shuffle_gather_points", "cg1_shuffle_apply_point_status", "cg1_shuffle_sum_crs_scalars",
+    "cg1_shuffle_crs_points", "cg1_shuffle_challenges_per_proof", "cg1_opening_prepare", "cg1_shuffle_prepare", "cg1_shuffle_set_grouped", "cg1_shuffle_default_threads", "cg1_shuffle_gather_points", "cg1_shuffle_exact_same_scalar", "cg1_opening_exact", "cg1_subgroup_flags_enqueue", "cg1_side_sync", "cg1_shuffle_apply_point_status", "cg1_shuffle_sum_crs_scalars",
     "cg1_keccak_f1600", "cg1_keccak_f1600_x8", "cg1_keccak_f1600_x8_states", "cg1_strobe_new", "cg1_strobe_meta_ad", "cg1_strobe_ad", "cg1_strobe_prf", "cg1_strobe_key", "cg1_merlin_init",
     "cg1_merlin_append", "cg1_merlin_append_list", "cg1_merlin_challenge", "cg1_merlin_challenge_scalar",
     "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_h2d_async", "cg1_copy_fence", "cg1_stream_sync", "cg1_batch_decompress_enqueue", "cg1_host_alloc", "cg1_host_free", "cg1_ctx_sync", "cg1_ctx_set_param",
-    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
+    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_get_last_counts", "cg1_timer_begin", "cg1_timer_end", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 
 
@@ -253,6 +260,20 @@ class Context:
         self.check(cg1_msm_batched(self.handle, points_affine96, scalars32, arr, m, out))
         raw = out.raw
         return [raw[POINT_BYTES * j: POINT_BYTES * (j + 1)] for j in range(m)]
+
+    def last_counts(self) -> dict:
+        """Of the last MSM call: bucket entries (non-zero digits), chunks, and mixed additions = entries - chunks."""
+        e, c = ctypes.c_uint32(), ctypes.c_uint32()
+        cg1_get_last_counts(self.handle, ctypes.byref(e), ctypes.byref(c))
+        return {"entries": int(e.value), "chunks": int(c.value), "mixed_adds": int(e.value) - int(c.value)}
+
+    def timer_begin(self) -> None:
+        self.check(cg1_timer_begin(self.handle))
+
+    def timer_end(self) -> float:
+        ms = c_float()
+        self.check(cg1_timer_end(self.handle, ctypes.byref(ms)))
+        return float(ms.value)
 
     def timings(self) -> dict:
         ph = (c_float * NPHASE)()

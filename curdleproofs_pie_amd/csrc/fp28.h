@@ -50,22 +50,10 @@ CG1_KP_TAB(12)
 CG1_KP_TAB(32)
 #undef CG1_KP_TAB
 
-// acc + a*b.  hipcc re-associates every column into a fresh accumulator plus a 64-bit add of the shifted carry
-// (one extra half-rate v_lshl_add_u64 per column, ~6 % of a Montgomery product).  Pinning the dependent chain
-// with inline asm (-DCG1_ASM_MAD) was measured and is a LOSS on ROCm 7.2: the compiler pads every asm statement
-// with an s_nop, k_accumulate stays at 2.43 ms and the latency-bound kernels get 20-35 % slower
-// (same-box A/B, round 1).  Kept only as an experiment switch.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(CG1_ASM_MAD)
-__device__ __forceinline__ uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc");
-  return c;
-}
-// b is a compile-time constant (a limb of p): keep it in an SGPR
-__device__ __forceinline__ uint64_t mad64c(uint32_t a, uint32_t b, uint64_t c) {
-  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "s"(b) : "vcc");
-  return c;
-}
-#else
+// acc + a*b.  hipcc starts every column's MAD chain from zero and adds the shifted carry of the previous column with
+// one extra half-rate v_lshl_add_u64 (~6 % of a Montgomery product); it buys a shorter dependent chain.  Pinning the
+// chain with inline asm was measured in round 1 and is a loss on ROCm 7.2 (the hazard recogniser pads asm statements
+// with s_nop).
 CG1_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
 #if defined(CG1_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
   unsigned __int128 w = (unsigned __int128)a * b + c;
@@ -73,8 +61,7 @@ CG1_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
 #endif
   return (uint64_t)a * b + c;        // -> v_mad_u64_u32
 }
-CG1_HD uint64_t mad64c(uint32_t a, uint32_t b, uint64_t c) { return mad64(a, b, c); }
-#endif
+CG1_HD uint64_t mad64c(uint32_t a, uint32_t b, uint64_t c) { return mad64(a, b, c); }   // b: a limb of p (an SGPR constant)
 
 CG1_HD fp fp_zero() { fp r; for (int i = 0; i < NL; ++i) r.l[i] = 0; return r; }
 CG1_HD fp fp_one()  {                // Montgomery form of 1 (N-form)

@@ -72,6 +72,50 @@ __global__ void __launch_bounds__(256) k_batch_compress(const uint32_t* __restri
   o[0] |= (uint8_t)(0x80 | (is_large ? 0x20 : 0));
 }
 
+// P = (x, y) on the curve (Montgomery limbs, N-form) is in the prime-order subgroup G1  <=>  [z^2] P == phi(P) + P with
+// phi(x, y) = (beta x, y)  (the endomorphism acts on G1 as multiplication by z^2 - 1; on no other point of E(Fp) does it).
+// [z^2] P = [|z|] [|z|] P with |z| = 0xd201000000010000 (six set bits): 2 x (63 doublings + 5 additions) instead of the
+// 128 doublings + ~22 additions of a plain ladder over z^2.
+__device__ __forceinline__ bool g1_in_subgroup(const fp& x, const fp& y) {
+  constexpr uint64_t ZABS = 0xd201000000010000ull;
+  constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
+  fp beta; for (int k = 0; k < NL; ++k) beta.l[k] = bt[k];
+  xyzz q = xyzz_from_affine(x, y);                 // top bit of |z|
+#pragma unroll 1
+  for (int bit = 62; bit >= 0; --bit) {
+    q = xyzz_dbl(q);
+    if ((ZABS >> bit) & 1ull) q = xyzz_madd(q, x, y);
+  }
+  xyzz acc = q;
+#pragma unroll 1
+  for (int bit = 62; bit >= 0; --bit) {
+    acc = xyzz_dbl(acc);
+    if ((ZABS >> bit) & 1ull) acc = xyzz_add(acc, q);
+  }
+  const fp yneg = fp_neg<3>(y);
+  acc = xyzz_madd(acc, x, yneg);                   // - P
+  acc = xyzz_madd(acc, fp_mul(x, beta), yneg);     // - phi(P)
+  return acc.inf != 0;
+}
+
+// Subgroup flags for SELECTED points of each proof of a batch (affine96 standard-form words as k_batch_decompress wrote
+// them; `stride_pts` points per proof; the k = so.k points at offsets so.off[] of every proof): flags[proof * k + j] = 1 if
+// the point is NOT in G1.  The reference decodes unchecked (util.py:35-36) but asserts the same-scalar equalities EXACTLY
+// (same_scalar.py:108); batching them under random weights is only sound for points of G1, so the verifier needs to know.
+struct SgOffsets { uint32_t off[16]; uint32_t k; };
+__global__ void __launch_bounds__(64) k_subgroup_flags(const uint32_t* __restrict__ aff, uint32_t stride_pts, uint32_t n_proofs,
+                                                       SgOffsets so, uint8_t* __restrict__ flags) {
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t proof = t / so.k, j = t % so.k;
+  if (proof >= n_proofs) return;
+  const uint32_t* src = aff + 24ull * ((size_t)proof * stride_pts + so.off[j]);
+  uint32_t w[24], any = 0;
+  for (int k = 0; k < 24; ++k) { w[k] = src[k]; any |= w[k]; }
+  if (!any) { flags[t] = 0; return; }              // identity (or a point the decoder rejected: its proof is rejected anyway)
+  const fp x = fp_to_mont(fp_from_words(w)), y = fp_to_mont(fp_from_words(w + 12));
+  flags[t] = g1_in_subgroup(x, y) ? 0 : 1;
+}
+
 // CHECK is a template parameter: the unchecked instantiation (the reference's default, util.py:35-36) must not carry the
 // register footprint of the subgroup test's scalar multiplication (256 VGPRs + spills, 1 wave/SIMD when it did).
 template <bool CHECK>
@@ -118,17 +162,7 @@ __global__ void __launch_bounds__(128) k_batch_decompress(const uint8_t* __restr
     y = fp_to_mont(fp_from_words(yw));
   }
   if (CHECK) {
-    constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
-    fp beta; for (int k = 0; k < NL; ++k) beta.l[k] = bt[k];
-    xyzz acc = xyzz_identity();
-    for (int bit = 127; bit >= 0; --bit) {       // [z^2] P
-      acc = xyzz_dbl(acc);
-      if ((H_ZSQ[bit >> 6] >> (bit & 63)) & 1ull) acc = xyzz_madd(acc, x, y);
-    }
-    const fp yneg = fp_neg<3>(y);
-    acc = xyzz_madd(acc, x, yneg);               // - P
-    acc = xyzz_madd(acc, fp_mul(x, beta), yneg); // - phi(P)
-    if (!acc.inf) { status[i] = CG1_ERR_NOT_IN_SUBGROUP; return; }
+    if (!g1_in_subgroup(x, y)) { status[i] = CG1_ERR_NOT_IN_SUBGROUP; return; }
   }
   for (int k = 0; k < 12; ++k) { dst[k] = w[k]; dst[12 + k] = yw[k]; }
   status[i] = CG1_OK;

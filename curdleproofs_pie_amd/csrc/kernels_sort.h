@@ -557,8 +557,12 @@ __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__
 }
 
 // one block: len_cursor[k] = number of chunks with a LONGER key (descending order => longest chunks first)
-__global__ void __launch_bounds__(256) k_len_scan(const uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor) {
+// (also copies the call's totals -- sorted entries, chunks -- next to the input-validation flag word for the host)
+__global__ void __launch_bounds__(256) k_len_scan(const uint32_t* __restrict__ len_hist, uint32_t* __restrict__ len_cursor,
+                                                  const uint32_t* __restrict__ total_entries, const uint32_t* __restrict__ total_chunks,
+                                                  uint32_t* __restrict__ stats) {
   __shared__ uint32_t sh[LEN_BINS];
+  if (threadIdx.x == 0) { stats[1] = *total_entries; stats[2] = *total_chunks; }
   uint32_t rev = LEN_BINS - 1 - threadIdx.x;          // thread i handles key 255-i
   uint32_t v = len_hist[rev];
   sh[threadIdx.x] = v;

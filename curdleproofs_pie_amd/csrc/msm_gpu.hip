@@ -59,6 +59,8 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;    // H2D staging copies that overlap kernels on `stream` (cg1_h2d_async / cg1_copy_fence)
   hipEvent_t copy_ev = nullptr;
+  hipStream_t side_stream = nullptr;    // small latency-bound kernels that run BESIDE the compute stream (cg1_subgroup_flags_enqueue)
+  hipEvent_t side_ev = nullptr;
   hipEvent_t sync_ev = nullptr;         // blocking-sync event: waits sleep on an interrupt instead of spinning a core
   int blocking_sync = 0;
   char err[256] = {0};
@@ -78,10 +80,6 @@ struct Ctx {
   int use_partition_sort = 1;
   int stage_sort = 1;                   // LDS-staged, line-coalesced writes in k_part_scatter / k_bin_sort (A/B switch)
   int host_split = 1;                   // host Horner tail on two threads (A/B switch)
-  int split2 = 0;                       // one large MSM as two window halves on two streams (A/B switch; measured: no gain --
-                                        // k_accumulate owns every VGPR of the chip, so the other half's kernels cannot co-run)
-  struct Ctx* child = nullptr;          // second pipeline (own stream + scratch) of the split
-  hipEvent_t prep_ev = nullptr;         // "prepared points are ready" for the child
   struct Pending {                      // what msm_finish needs from msm_enqueue
     bool active = false;
     int c = 0, rank = 0, world = 1, nlw = 0, nbits = 0;
@@ -108,7 +106,8 @@ struct Ctx {
   float host_tail_ms = 0;
   float host_ms[4] = {0, 0, 0, 0};      // enqueue, wait-for-GPU, event readout, Horner tail
   int profile = 1;                      // read the per-phase hipEvents after each call
-  uint32_t last_chunks = 0, last_entries = 0;
+  uint32_t last_chunks = 0, last_entries = 0;   // of the last MSM call: non-zero digits sorted into buckets; chunks k_accumulate ran
+  hipEvent_t tm_ev[2] = {nullptr, nullptr};     // cg1_timer_begin / cg1_timer_end
   int last_c = 0;
   uint32_t L0 = 8;                      // MINIMUM chunk length; the per-call length grows with the entry count
   uint32_t seg_m = 4;
@@ -128,10 +127,10 @@ static void free_bufs(Ctx* c) {
   c->cap_n = c->cap_nb = c->cap_chunks = c->cap_entries = c->cap_out = 0;
 }
 
-static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems, uint32_t L, bool own_points = true) {
+static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems, uint32_t L) {
   size_t entries = n * nlw;
   size_t chunks = nb_total + entries / L + 1;
-  if (own_points && n > ctx->cap_n) {
+  if (n > ctx->cap_n) {
     if (ctx->d_pts) (void)hipFree(ctx->d_pts);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     HIPCHK(hipMalloc(&ctx->d_pts, n * sizeof(PreparedPoint)));
@@ -261,11 +260,8 @@ static int wait_stream(Ctx* ctx) {
 }
 
 // Enqueue the whole launch chain of this context's share of an MSM (windows w = rank mod world) up to the D2H of the
-// window sums; nothing waits.  shared_pts / shared_flags: prepared points of ANOTHER context (ready once wait_ev has
-// fired) instead of preparing them again; prepared_ev: recorded on this stream as soon as this context's are ready.
-static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world,
-                       const PreparedPoint* shared_pts, const uint8_t* shared_flags, hipEvent_t wait_ev, hipEvent_t prepared_ev,
-                       hipEvent_t accumulate_after = nullptr) {
+// window sums; nothing waits.
+static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world) {
   ctx->pend.active = false;
   HIPCHK(hipSetDevice(ctx->device));
   const int nwin = 255 / c + 1;
@@ -285,21 +281,16 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   // (window-sharded ranks, skew, thin top windows) are re-joined by k_bucket_fold (<= 16 chunks) / k_heavy_combine.
   uint32_t L0 = ctx->L0;
   while (L0 < 65536u && ((uint64_t)n * (uint64_t)nlw >> 18) > (uint64_t)L0) L0 <<= 1;
-  int rc = ensure(ctx, n, nb_total, nlw, nitems, L0, shared_pts == nullptr);
+  int rc = ensure(ctx, n, nb_total, nlw, nitems, L0);
   if (rc) return rc;
   hipStream_t st = ctx->stream;
   const uint32_t n32 = (uint32_t)n;
   const uint32_t gn = (n32 + 255) / 256;
   auto h0 = std::chrono::steady_clock::now();
-  const PreparedPoint* pts = shared_pts ? shared_pts : ctx->d_pts;
-  const uint8_t* flags = shared_pts ? shared_flags : ctx->d_flags;
+  const PreparedPoint* pts = ctx->d_pts;
+  const uint8_t* flags = ctx->d_flags;
   HIPCHK(hipEventRecord(ctx->ev[0], st));
-  if (shared_pts) {
-    HIPCHK(hipStreamWaitEvent(st, wait_ev, 0));
-  } else {
-    hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32);
-    if (prepared_ev) HIPCHK(hipEventRecord(prepared_ev, st));
-  }
+  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32);
   HIPCHK(hipEventRecord(ctx->ev[1], st));
   const size_t nout_words = (size_t)nlw * nitems;
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // set by the digit kernels: a scalar >= 2^255
@@ -349,10 +340,9 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0);
   const size_t max_chunks = nb_total + (n * (size_t)nlw) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
-  hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS);
+  hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
   hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
   HIPCHK(hipEventRecord(ctx->ev[4], st));
-  if (accumulate_after) HIPCHK(hipStreamWaitEvent(st, accumulate_after, 0));     // the other half's k_accumulate goes first
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, pts, ctx->d_sums);
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
@@ -400,9 +390,13 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   HIPCHK(hipSetDevice(ctx->device));
   { int wrc = wait_stream(ctx); if (wrc) return wrc; }
   HIPCHK(hipGetLastError());
-  if (*reinterpret_cast<const uint32_t*>(ctx->h_out + nout_words)) {
-    snprintf(ctx->err, sizeof ctx->err, "a scalar is >= 2^255: scalar32 must be a canonical Fr element (< r)");
-    return CG1_ERR_ENCODING;
+  {
+    const uint32_t* st_words = reinterpret_cast<const uint32_t*>(ctx->h_out + nout_words);    // [0] bad scalar, [1] entries, [2] chunks
+    ctx->last_entries = st_words[1]; ctx->last_chunks = st_words[2];
+    if (st_words[0]) {
+      snprintf(ctx->err, sizeof ctx->err, "a scalar is >= 2^255: scalar32 must be a canonical Fr element (< r)");
+      return CG1_ERR_ENCODING;
+    }
   }
   auto h2 = std::chrono::steady_clock::now();
   if (ctx->profile)
@@ -457,28 +451,7 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   return CG1_OK;
 }
 
-static Ctx* split_child(Ctx* ctx) {
-  if (ctx->child) return ctx->child;
-  Ctx* ch = new Ctx();
-  ch->device = ctx->device;
-  int least = 0, greatest = 0;
-  (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-  bool ok = hipStreamCreateWithPriority(&ch->stream, hipStreamNonBlocking, least) == hipSuccess;   // the parent's half goes first
-  ok = ok && hipEventCreateWithFlags(&ch->sync_ev, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
-  for (int i = 0; ok && i <= CG1_NPHASE; ++i) ok = hipEventCreate(&ch->ev[i]) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&ctx->prep_ev, hipEventDisableTiming) == hipSuccess;
-  if (!ok) { delete ch; return nullptr; }                      // (leaks the partial objects of a failed device: the caller falls back)
-  ctx->child = ch;
-  return ch;
-}
-
-constexpr size_t SPLIT_MIN_N = 1u << 18;
-
-// One MSM.  With split2 = 1 (off by default) a large single-GPU call runs as TWO half-pipelines: the odd windows on this
-// context's stream, the even ones on a low-priority child stream sharing the prepared points, the second k_accumulate
-// ordered after the first, so that the first half's reduce tail and host Horner could hide under the second half's
-// k_accumulate.  Measured on MI355X at 2^20: 3.31-3.53 ms vs 3.30-3.39 ms unsplit -- two waves of k_accumulate hold all
-// 512 VGPRs of a SIMD, nothing else becomes resident next to it, the halves serialise and the launch chain doubles.
+// One MSM: this context's share (windows w = rank mod world) of sum_i scalar_i * point_i.
 int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
   result = cg1h::jac_identity();
   if (n == 0) return CG1_OK;
@@ -486,30 +459,9 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   if (world < 1 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
   if (c <= 0) c = pick_window(n);
   if (c < 4 || c > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
-  Ctx* ch = (ctx->split2 && world == 1 && n >= SPLIT_MIN_N && n <= PART_MAX_N && ctx->use_partition_sort) ? split_child(ctx) : nullptr;
-  if (!ch) {
-    int rc = msm_enqueue(ctx, d_points96, d_scalars32, n, c, rank, world, nullptr, nullptr, nullptr, nullptr);
-    if (rc) return rc;
-    return msm_finish(ctx, result);
-  }
-  ch->L0 = ctx->L0; ch->seg_m = ctx->seg_m; ch->profile = ctx->profile; ch->stage_sort = ctx->stage_sort; ch->quad = ctx->quad;
-  ch->reduce_2d = ctx->reduce_2d; ch->host_split = ctx->host_split; ch->big_bins = ctx->big_bins; ch->blocking_sync = ctx->blocking_sync;
-  ch->use_partition_sort = ctx->use_partition_sort;
-  int rc = msm_enqueue(ctx, d_points96, d_scalars32, n, c, 1, 2, nullptr, nullptr, nullptr, ctx->prep_ev);
+  int rc = msm_enqueue(ctx, d_points96, d_scalars32, n, c, rank, world);
   if (rc) return rc;
-  rc = msm_enqueue(ch, d_points96, d_scalars32, n, c, 0, 2, ctx->d_pts, ctx->d_flags, ctx->prep_ev, nullptr, ctx->ev[5]);
-  cg1h::jac ra, rb;
-  int rc_a = msm_finish(ctx, ra);                                // always drain both streams, even after an error
-  int rc_b = rc ? rc : msm_finish(ch, rb);
-  if (rc) { (void)hipStreamSynchronize(ch->stream); }
-  if (rc_a) return rc_a;
-  if (rc_b) { snprintf(ctx->err, sizeof ctx->err, "%s", ch->err); return rc_b; }
-  result = cg1h::jac_add(ra, rb);
-  for (int i = 0; i < CG1_NPHASE; ++i) ctx->phase_ms[i] += ch->phase_ms[i];     // kernel time of both halves (they overlap in wall time)
-  ctx->host_tail_ms += ch->host_tail_ms;
-  ctx->host_ms[0] += ch->host_ms[0];
-  ctx->host_ms[3] = ctx->host_tail_ms;
-  return CG1_OK;
+  return msm_finish(ctx, result);
 }
 
 
@@ -595,7 +547,7 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0);
   const size_t max_chunks = nb_total + (N * (size_t)nwin) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
-  hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS);
+  hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
   hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
   HIPCHK(hipEventRecord(ctx->ev[4], st));
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
@@ -612,9 +564,13 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   auto h1 = std::chrono::steady_clock::now();
   { int wrc = wait_stream(ctx); if (wrc) return wrc; }
   HIPCHK(hipGetLastError());
-  if (*reinterpret_cast<const uint32_t*>(ctx->h_bout + M)) {
-    snprintf(ctx->err, sizeof ctx->err, "a scalar is >= 2^255: scalar32 must be a canonical Fr element (< r)");
-    return CG1_ERR_ENCODING;
+  {
+    const uint32_t* st_words = reinterpret_cast<const uint32_t*>(ctx->h_bout + M);
+    ctx->last_entries = st_words[1]; ctx->last_chunks = st_words[2];
+    if (st_words[0]) {
+      snprintf(ctx->err, sizeof ctx->err, "a scalar is >= 2^255: scalar32 must be a canonical Fr element (< r)");
+      return CG1_ERR_ENCODING;
+    }
   }
   auto h2 = std::chrono::steady_clock::now();
   if (ctx->profile)
@@ -742,16 +698,6 @@ cg1_ctx* cg1_ctx_create(int device) {
 void cg1_ctx_destroy(cg1_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->child) {
-    cg1::Ctx* ch = ctx->child;
-    cg1::free_bufs(ch);
-    for (int i = 0; i <= CG1_NPHASE; ++i) (void)hipEventDestroy(ch->ev[i]);
-    if (ch->sync_ev) (void)hipEventDestroy(ch->sync_ev);
-    (void)hipStreamDestroy(ch->stream);
-    delete ch;
-    ctx->child = nullptr;
-  }
-  if (ctx->prep_ev) (void)hipEventDestroy(ctx->prep_ev);
   cg1::free_bufs(ctx);
   if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
   if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
@@ -759,7 +705,10 @@ void cg1_ctx_destroy(cg1_ctx* ctx) {
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
   if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
+  for (int i = 0; i < 2; ++i) if (ctx->tm_ev[i]) (void)hipEventDestroy(ctx->tm_ev[i]);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
+  if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   delete ctx;
 }
 const char* cg1_ctx_error(const cg1_ctx* ctx) { return ctx ? ctx->err : "null context (no GPU visible?)"; }
@@ -844,7 +793,6 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "blocking_sync")) { ctx->blocking_sync = value != 0; return CG1_OK; }
   if (!strcmp(name, "big_bins")) { ctx->big_bins = value != 0; return CG1_OK; }
-  if (!strcmp(name, "split2")) { ctx->split2 = value != 0; return CG1_OK; }
   if (!strcmp(name, "host_split")) { ctx->host_split = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
     int v = value ? 1 : 0;
@@ -922,6 +870,30 @@ int cg1_get_timings(const cg1_ctx* ctx, float* phase_ms, float* host_tail_ms, in
   return CG1_OK;
 }
 
+int cg1_get_last_counts(const cg1_ctx* ctx, uint32_t* entries, uint32_t* chunks) {
+  if (!ctx) return CG1_ERR_ARG;
+  if (entries) *entries = ctx->last_entries;
+  if (chunks) *chunks = ctx->last_chunks;
+  return CG1_OK;
+}
+
+// hipEvent stopwatch on the context's compute stream: everything enqueued between begin and end is timed on the device
+int cg1_timer_begin(cg1_ctx* ctx) {
+  if (!ctx) return CG1_ERR_HIP;
+  HIPCHK(hipSetDevice(ctx->device));
+  for (int i = 0; i < 2; ++i) if (!ctx->tm_ev[i]) HIPCHK(hipEventCreate(&ctx->tm_ev[i]));
+  HIPCHK(hipEventRecord(ctx->tm_ev[0], ctx->stream));
+  return CG1_OK;
+}
+int cg1_timer_end(cg1_ctx* ctx, float* ms) {
+  if (!ctx || !ms || !ctx->tm_ev[0] || !ctx->tm_ev[1]) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipEventRecord(ctx->tm_ev[1], ctx->stream));
+  HIPCHK(hipEventSynchronize(ctx->tm_ev[1]));
+  HIPCHK(hipEventElapsedTime(ms, ctx->tm_ev[0], ctx->tm_ev[1]));
+  return CG1_OK;
+}
+
 int cg1_get_host_timings(const cg1_ctx* ctx, float host_ms[4]) {
   if (!ctx || !host_ms) return CG1_ERR_ARG;
   for (int i = 0; i < 4; ++i) host_ms[i] = ctx->host_ms[i];
@@ -991,6 +963,38 @@ int cg1_batch_decompress_enqueue(cg1_ctx* ctx, const void* d_in48, void* d_out_a
     hipLaunchKernelGGL(cg1::k_batch_decompress<false>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
                        (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
   HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
+// Subgroup flags of k selected points per proof (see k_subgroup_flags), on the context's SIDE stream: ordered after
+// everything enqueued on the compute stream so far (the decompression that produced the points), running beside what is
+// enqueued there next.  cg1_side_sync waits for it.
+int cg1_subgroup_flags_enqueue(cg1_ctx* ctx, const void* d_affine96, size_t stride_points, size_t n_proofs,
+                               const uint32_t* offsets, size_t k, void* d_flags) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n_proofs == 0 || k == 0) return CG1_OK;
+  if (!offsets || k > 16 || n_proofs * k >= (1ull << 31)) return CG1_ERR_ARG;
+  for (size_t j = 0; j < k; ++j) if (offsets[j] >= stride_points) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->side_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
+  }
+  HIPCHK(hipEventRecord(ctx->side_ev, ctx->stream));
+  HIPCHK(hipStreamWaitEvent(ctx->side_stream, ctx->side_ev, 0));
+  cg1::SgOffsets so;
+  for (size_t j = 0; j < 16; ++j) so.off[j] = j < k ? offsets[j] : 0u;
+  so.k = (uint32_t)k;
+  const size_t lanes = n_proofs * k;
+  hipLaunchKernelGGL(cg1::k_subgroup_flags, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, ctx->side_stream,
+                     (const uint32_t*)d_affine96, (uint32_t)stride_points, (uint32_t)n_proofs, so, (uint8_t*)d_flags);
+  HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
+int cg1_side_sync(cg1_ctx* ctx) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (!ctx->side_stream) return CG1_OK;
+  HIPCHK(hipSetDevice(ctx->device));
+  HIPCHK(hipStreamSynchronize(ctx->side_stream));
   return CG1_OK;
 }
 int cg1_batch_compress_device(cg1_ctx* ctx, const void* d_in_affine96, void* d_out48, size_t n) {

@@ -273,7 +273,8 @@ class Pool {
 // One proof.  Returns 0 (prepared) or a CG1_SHUFFLE_* reject code.
 int prepare_one(const Crs& crs, const uint8_t* inst /* 4*ell*48 */, const uint8_t* proof, const uint8_t* weights /* 12*32 */,
                 const uint8_t* decoded /* own points 4*ell+1 .. 4*ell+8 (A T_1 T_2 U_1 U_2 R S B) as affine96, or NULL */,
-                uint8_t* out_points, uint8_t* out_scalars, uint8_t* out_crs_scalars, uint8_t* out_challenges) {
+                uint8_t* out_points, uint8_t* out_scalars, uint8_t* out_crs_scalars, uint8_t* out_challenges,
+                fr* alpha_s_out = nullptr /* the same-scalar challenge (same_scalar.py:99) */) {
   const size_t ell = crs.ell, lg = crs.lg, n = ell + NB;
   const Layout L(ell, lg);
 
@@ -420,6 +421,7 @@ int prepare_one(const Crs& crs, const uint8_t* inst /* 4*ell*48 */, const uint8_
     for (size_t k = 0; k < 10; ++k) tr.point("sameexp_points", P(order[k]));
   }
   const fr alpha_s = tr.challenge("same_scalar_alpha");
+  if (alpha_s_out) *alpha_s_out = alpha_s;
   {
     // z_t G_t = cmA.T_1 + alpha T_1;   z_k R + z_t H = cmA.T_2 + alpha T_2;   same for (u, S, cmB, U)
     const fr w1 = rho[8], w2 = rho[9], w3 = rho[10], w4 = rho[11];
@@ -964,6 +966,67 @@ int cg1_opening_prepare(size_t n, const uint8_t* trackers, const uint8_t* k_comm
     Pool& pool = Pool::get();
     pool.run(work, std::min(items, pool.size() + 1));
   }
+  return CG1_OK;
+}
+
+// The equalities the reference asserts directly, evaluated EXACTLY (no random weights) with host group arithmetic, for
+// proofs that carry a point outside G1: random weights are only sound inside the prime-order subgroup (E(Fp) has points of
+// order 3, 11, ...), and the reference's own verdict on such a proof is the exact one.
+int cg1_shuffle_exact_same_scalar(const cg1_shuffle_crs* crs_, const uint8_t* instance, const uint8_t* proof, int* ok) {
+  if (!crs_ || !instance || !proof || !ok) return CG1_ERR_ARG;
+  *ok = 0;
+  const Crs& crs = *reinterpret_cast<const Crs*>(crs_);
+  const Layout L(crs.ell, crs.lg);
+  std::vector<uint8_t> pts(L.count() * 48), sc(L.count() * 32), cs(L.ncrs() * 32);
+  uint8_t w[12 * 32];
+  memset(w, 0, sizeof w);
+  for (int k = 0; k < 12; ++k) w[32 * k] = 1;                       // any valid weights: only alpha is wanted
+  fr alpha;
+  if (prepare_one(crs, instance, proof, w, nullptr, pts.data(), sc.data(), cs.data(), nullptr, &alpha) != 0) return CG1_OK;
+  fr z_k, z_t, z_u;
+  const uint8_t* zs = proof + 48 * (16 + 4 * crs.lg) + 32 * 3;      // M..C (10) r_p | B_c B_d L/R_C L/R_D (2+4lg) c d | cm_A cm_B (4) | z_k z_t z_u
+  if (!fr_from_le32(zs, z_k) || !fr_from_le32(zs + 32, z_t) || !fr_from_le32(zs + 64, z_u)) return CG1_OK;
+  auto dec = [&](const uint8_t* e, jac& out) { return cg1h::g1_decompress(e, false, out) == 0; };
+  auto P = [&](size_t idx) { return pts.data() + idx * 48; };
+  jac R, S, T1, T2, U1, U2, A1, A2, B1, B2, Gt, Gu, H;
+  if (!dec(P(L.Rp()), R) || !dec(P(L.Sp()), S) || !dec(P(L.T1()), T1) || !dec(P(L.T2()), T2) || !dec(P(L.U1()), U1) ||
+      !dec(P(L.U2()), U2) || !dec(P(L.cmA1()), A1) || !dec(P(L.cmA2()), A2) || !dec(P(L.cmB1()), B1) || !dec(P(L.cmB2()), B2) ||
+      !dec(crs.bytes.data() + L.cGt() * 48, Gt) || !dec(crs.bytes.data() + L.cGu() * 48, Gu) || !dec(crs.H48(), H))
+    return CG1_OK;
+  uint8_t a32[32], zk32[32], zt32[32], zu32[32];
+  fr_to_le32(alpha, a32); fr_to_le32(z_k, zk32); fr_to_le32(z_t, zt32); fr_to_le32(z_u, zu32);
+  using cg1h::jac_add; using cg1h::jac_mul; using cg1h::jac_eq;
+  // GroupCommitment.new(G, H, T, r) = (G r, T + H r)  (commitment.py:22-30); expected == cm + cm' alpha (same_scalar.py:101-108)
+  const bool e1 = jac_eq(jac_mul(Gt, zt32), jac_add(A1, jac_mul(T1, a32)));
+  const bool e2 = jac_eq(jac_add(jac_mul(R, zk32), jac_mul(H, zt32)), jac_add(A2, jac_mul(T2, a32)));
+  const bool e3 = jac_eq(jac_mul(Gu, zu32), jac_add(B1, jac_mul(U1, a32)));
+  const bool e4 = jac_eq(jac_add(jac_mul(S, zk32), jac_mul(H, zu32)), jac_add(B2, jac_mul(U2, a32)));
+  *ok = (e1 && e2 && e3 && e4) ? 1 : 0;
+  return CG1_OK;
+}
+
+int cg1_opening_exact(const uint8_t* tracker96, const uint8_t* k_commitment48, const uint8_t* proof128, int* ok) {
+  if (!tracker96 || !k_commitment48 || !proof128 || !ok) return CG1_ERR_ARG;
+  *ok = 0;
+  const uint8_t *rG = tracker96, *krG = tracker96 + 48, *kG = k_commitment48, *A = proof128, *B = proof128 + 48;
+  fr s_;
+  if (!fr_from_le32(proof128 + 96, s_)) return CG1_OK;
+  jac jrG, jkrG, jkG, jA, jB;
+  if (cg1h::g1_decompress(rG, false, jrG) || cg1h::g1_decompress(krG, false, jkrG) || cg1h::g1_decompress(kG, false, jkG) ||
+      cg1h::g1_decompress(A, false, jA) || cg1h::g1_decompress(B, false, jB))
+    return CG1_OK;
+  uint8_t G48[48];
+  cg1h::g1_compress(cg1h::jac_generator(), G48);
+  Transcript tr("whisk_opening_proof");
+  const uint8_t* order[6] = {kG, G48, krG, rG, A, B};
+  for (const uint8_t* p : order) tr.point("tracker_opening_proof", p);
+  const fr c = tr.challenge("tracker_opening_proof_challenge");
+  uint8_t c32[32], s32[32];
+  fr_to_le32(c, c32); fr_to_le32(s_, s32);
+  using cg1h::jac_add; using cg1h::jac_mul; using cg1h::jac_eq;
+  const bool e1 = jac_eq(jac_add(jac_mul(cg1h::jac_generator(), s32), jac_mul(jkG, c32)), jA);      // opening.py:73
+  const bool e2 = jac_eq(jac_add(jac_mul(jrG, s32), jac_mul(jkrG, c32)), jB);                       // opening.py:74
+  *ok = (e1 && e2) ? 1 : 0;
   return CG1_OK;
 }
 

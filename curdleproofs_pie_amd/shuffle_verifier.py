@@ -29,6 +29,7 @@ from . import _native as N
 FR_MODULUS = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001  # util.py:7
 N_BLINDERS = 4                                                                   # curdleproofs.py:26
 N_WEIGHTS = 12
+N_EXACT_POINTS = 10            # T_1 T_2 U_1 U_2 R S cm_A cm_B: the proof's points in the same-scalar equalities (same_scalar.py:82-108)
 
 REJECT_NAMES = {0: "prepared", 1: "bad scalar encoding", 2: "bad point encoding", 3: "vec_T[0] is infinity", 4: "bad weight",
                 5: "bad length", 6: "verification equation failed"}
@@ -44,12 +45,16 @@ def _addr(b) -> int:
 
 
 def _tracker_bytes(trackers) -> Tuple[bytes, bytes]:
-    """Sequence of WhiskTracker-likes (r_G, k_r_G attributes; whisk_interface.py:24-30) or (r_G, k_r_G) pairs."""
+    """Sequence of WhiskTracker-likes (r_G, k_r_G attributes; whisk_interface.py:24-30) or (r_G, k_r_G) pairs.
+    Every encoding must be exactly 48 bytes (the reference decodes them one by one, whisk_interface.py:96-100, and raises on
+    any other length): adjacent encodings of 47 and 49 bytes must not be re-split at 48-byte boundaries."""
     trackers = list(trackers)
     if trackers and hasattr(trackers[0], "r_G"):
         rs, ks = [t.r_G for t in trackers], [t.k_r_G for t in trackers]
     else:
         rs, ks = [t[0] for t in trackers], [t[1] for t in trackers]
+    if not all(len(x) == 48 for x in rs) or not all(len(x) == 48 for x in ks):
+        raise ValueError("tracker encoding is not 48 bytes")
     try:
         return b"".join(rs), b"".join(ks)                 # bytes-likes (BLSPubkey is a bytes subclass)
     except TypeError:
@@ -127,6 +132,36 @@ class ShuffleBatchVerifier:
         self._next_slot = 0
         self.last_stats = {}
         self.last_status = []
+        ell, lg = self.crs.ell, self.crs.lg
+        offs = [4 * ell + 2 + j for j in range(6)] + [4 * ell + 12 + 4 * lg + j for j in range(4)]
+        self._exact_offsets = (ctypes.c_uint32 * N_EXACT_POINTS)(*offs)
+
+    # ---------------------------------------------------------------- lifetime
+    def close(self) -> None:
+        """Stop the two GPU threads (after what is queued has drained) and release the buffer slots and the MSM context.
+        The verifier must not be used afterwards.  Idempotent; also run by __del__ and on cache eviction."""
+        for lane in (0, 1):
+            t, q = self._gpu_threads[lane], self._gpu_jobs[lane]
+            if t is not None:
+                q.put(None)
+                t.join()
+            self._gpu_threads[lane] = self._gpu_jobs[lane] = None
+        for i, b in enumerate(self._slots):
+            if b is not None:
+                for k in ("wire", "pts", "pstat", "sgflags", "sc"):
+                    b[k].free()
+                for h in b["host"].values():
+                    h.free()
+                self._slots[i] = None
+        if self._ctx_msm is not None:
+            self._ctx_msm.close()
+            self._ctx_msm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     # ---------------------------------------------------------------- host half
     def pack(self, items) -> Tuple[bytes, bytes, List[int]]:
@@ -223,6 +258,7 @@ class ShuffleBatchVerifier:
             "wire": ctx.alloc(n * L * 48),
             "pts": ctx.alloc((n * L + C) * 96),              # own points of all proofs, then the CRS points
             "pstat": ctx.alloc(n * L),
+            "sgflags": ctx.alloc(n * N_EXACT_POINTS),        # 1 = outside G1, for the points of the exactly-asserted equalities
             "sc": ctx.alloc((n * L + C) * 32),
             "host": {                                        # page-locked staging
                 "wire": N.PinnedBuffer(ctx, n * L * 48),
@@ -268,6 +304,9 @@ class ShuffleBatchVerifier:
         ctx.check(N.cg1_copy_fence(ctx.handle))
         ctx.check(N.cg1_batch_decompress_enqueue(ctx.handle, b["wire"].ptr + lo * L * 48, b["pts"].ptr + lo * L * 96,
                                                  b["pstat"].ptr + lo * L, (hi - lo) * L, 0))
+        # beside the next kernels (side stream): are the points of the exactly-asserted same-scalar equalities in G1?
+        ctx.check(N.cg1_subgroup_flags_enqueue(ctx.handle, b["pts"].ptr + lo * L * 96, L, hi - lo, self._exact_offsets,
+                                               N_EXACT_POINTS, b["sgflags"].ptr + lo * N_EXACT_POINTS))
 
     def _decompress_collect(self, b: dict, lo: int, hi: int) -> None:
         """GPU thread: wait for the kernel, bring back the per-point verdicts and the 8-point window the front-end wants."""
@@ -301,6 +340,7 @@ class ShuffleBatchVerifier:
 
         def gpu_stage(tk=tk, b=b):
             try:
+                t_dec = time.perf_counter()
                 if b.get("crs_at") != n:                       # CRS points sit right behind the batch's own points
                     b["pts"].upload(crs.affine96, n * L * 96)
                     b["crs_at"] = n
@@ -313,6 +353,7 @@ class ShuffleBatchVerifier:
                     if i + 1 < len(bounds):
                         self._stage_in(b, instances, proofs, *bounds[i + 1])
                     self._decompress_collect(b, lo, hi)
+                    tk["decompress_s"] = time.perf_counter() - t_dec   # staging + H2D + kernel + D2H of the batch's sub-batches
                     tk["chunks"].put((lo, hi))
             except BaseException as e:                          # surfaced in the consumer
                 tk["chunks"].put(e)
@@ -393,9 +434,25 @@ class ShuffleBatchVerifier:
                         N.cg1_add(tmp, own[i], shared[i])
                         if not N.cg1_is_identity(tmp.raw):
                             status[i] = REJECT_EQUATION
+                # Proofs carrying a point outside G1 in the same-scalar equalities: the reference asserts those exactly
+                # (same_scalar.py:108) and random weights are blind to a torsion defect with probability 1/3, so they
+                # are re-checked on the host without weights.  (None in honest traffic: one D2H of 10 bytes per proof.)
+                self.ctx.check(N.cg1_side_sync(self.ctx.handle))
+                flags = b["sgflags"].download(n * N_EXACT_POINTS)
+                n_exact = 0
+                if any(flags):
+                    ib, pb = 4 * crs.ell * 48, crs.proof_bytes
+                    ok = ctypes.c_int(0)
+                    for i in live:
+                        if status[i] == 0 and any(flags[i * N_EXACT_POINTS: (i + 1) * N_EXACT_POINTS]):
+                            n_exact += 1
+                            self.ctx.check(N.cg1_shuffle_exact_same_scalar(crs.handle, _addr(tk["instances"]) + i * ib,
+                                                                           _addr(tk["proofs"]) + i * pb, ctypes.byref(ok)))
+                            if not ok.value:
+                                status[i] = REJECT_EQUATION
                 tk["status"] = status
-                tk["stats"] = {"merged_msm_s": t1 - t0, "independent_s": time.perf_counter() - t1, "merged_ok": merged_ok,
-                               "front_end_s": tk.get("front_end_s", 0.0), "n": n, "points": n * L + C, "pipelined": len(tk["bounds"]) > 1}
+                tk["stats"] = {"merged_msm_s": t1 - t0, "exact_checks": n_exact, "independent_s": time.perf_counter() - t1, "merged_ok": merged_ok,
+                               "front_end_s": tk.get("front_end_s", 0.0), "decompress_s": tk.get("decompress_s", 0.0), "n": n, "points": n * L + C, "pipelined": len(tk["bounds"]) > 1}
             except BaseException as e:
                 tk["error"] = e
             finally:
@@ -475,7 +532,7 @@ def verifier_for(crs, ctx=None) -> ShuffleBatchVerifier:
     v = _verifier_cache.get(key)
     if v is None:
         if len(_verifier_cache) >= 4:
-            _verifier_cache.pop(next(iter(_verifier_cache)))
+            _verifier_cache.pop(next(iter(_verifier_cache))).close()
         v = _verifier_cache[key] = ShuffleBatchVerifier(crs if isinstance(crs, ShuffleCrs) else data, ctx)
     return v
 
@@ -542,7 +599,7 @@ class OpeningBatchVerifier:
             weights = bytes(raw)
         else:
             weights = b"".join(rng.randint(1, FR_MODULUS - 1).to_bytes(32, "little") for _ in range(2 * n))
-        out = {"n": n, "points48": ctypes.create_string_buffer(max(1, 240 * n)), "scalars32": ctypes.create_string_buffer(max(1, 160 * n)),
+        out = {"n": n, "proof_s": b"".join(pfs[128 * i + 96: 128 * i + 128] for i in range(n)), "points48": ctypes.create_string_buffer(max(1, 240 * n)), "scalars32": ctypes.create_string_buffer(max(1, 160 * n)),
                "g_scalars32": ctypes.create_string_buffer(max(1, 32 * n)), "status": (ctypes.c_int32 * max(1, n))()}
         rc = N.cg1_opening_prepare(n, trackers, kcs, pfs, weights, out["points48"], out["scalars32"],
                                    out["g_scalars32"], out["status"])
@@ -563,9 +620,15 @@ class OpeningBatchVerifier:
         ctx = self.ctx
         d_wire, d_pts, d_stat, d_sc = ctx.alloc(240 * n), ctx.alloc(96 * (5 * n + 1)), ctx.alloc(5 * n), ctx.alloc(32 * (5 * n + 1))
         d_wire.upload(prep["points48"].raw[: 240 * n])
-        ctx.check(N.cg1_batch_decompress_device(ctx.handle, d_wire.ptr, d_pts.ptr, d_stat.ptr, 5 * n, 0))
+        # Both equalities of an opening proof are asserted EXACTLY by the reference (opening.py:74-77) on points it decodes
+        # unchecked: weighting them randomly is sound only inside G1, so every point is decoded with the subgroup test.  A
+        # proof with a point outside G1 leaves the batch (its scalars are zeroed) and is decided by the exact host check.
+        ctx.check(N.cg1_batch_decompress_device(ctx.handle, d_wire.ptr, d_pts.ptr, d_stat.ptr, 5 * n, 1))
         d_pts.upload(self._g96, 96 * 5 * n)
-        ctx.check(N.cg1_shuffle_apply_point_status(prep["status"], d_stat.download(5 * n), n, 5, prep["scalars32"], prep["g_scalars32"], 1))
+        pstat = bytearray(d_stat.download(5 * n))
+        outside = [i for i in range(n) if N.ERR_NOT_IN_SUBGROUP in pstat[5 * i: 5 * i + 5]
+                   and not any(x not in (0, N.ERR_NOT_IN_SUBGROUP) for x in pstat[5 * i: 5 * i + 5])] if N.ERR_NOT_IN_SUBGROUP in pstat else []
+        ctx.check(N.cg1_shuffle_apply_point_status(prep["status"], bytes(pstat), n, 5, prep["scalars32"], prep["g_scalars32"], 1))
         g_sum = ctypes.create_string_buffer(32)
         ctx.check(N.cg1_shuffle_sum_crs_scalars(prep["g_scalars32"], prep["status"], n, 1, g_sum))
         d_sc.upload(prep["scalars32"].raw[: 160 * n] + g_sum.raw)
@@ -579,6 +642,13 @@ class OpeningBatchVerifier:
                 N.cg1_add(tmp, tmp.raw, own[i])
                 if not N.cg1_is_identity(tmp.raw):
                     status[i] = REJECT_EQUATION
+        ok = ctypes.c_int(0)
+        for i in outside:
+            if status[i] == 2:                       # rejected only for the subgroup flag: the exact equalities decide
+                trk = prep["points48"].raw[240 * i + 96: 240 * i + 144] + prep["points48"].raw[240 * i + 48: 240 * i + 96]
+                ctx.check(N.cg1_opening_exact(trk, prep["points48"].raw[240 * i: 240 * i + 48],
+                                              prep["points48"].raw[240 * i + 144: 240 * i + 240] + prep["proof_s"][32 * i: 32 * i + 32], ctypes.byref(ok)))
+                status[i] = 0 if ok.value else REJECT_EQUATION
         self.last_status = status
         return [s == 0 for s in status]
 

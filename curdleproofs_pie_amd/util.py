@@ -1,6 +1,8 @@
 """Boundary helpers of /root/reference/curdleproofs/curdleproofs/util.py that sit directly on the
-G1Point / Scalar backend.  Same names, same behaviour, same randomness source
-(Python's global `random`, so `random.seed(k)` reproduces the reference's draw order)."""
+G1Point / Scalar backend and that THIS package calls.  Same names, same behaviour, same
+randomness source (Python's global `random`, so `random.seed(k)` reproduces the reference's draw order).  The reference's
+pure-Python helpers (invert, scalar_pow, inner_product, BufReader, ...) are not restated: its callers keep using their own
+util.py over the injected backend (tests/test_reference_suite.py)."""
 from __future__ import annotations
 
 from random import randint
@@ -38,44 +40,5 @@ def field_to_bytes(field: Scalar) -> bytes:  # util.py:39-40
     return bytes(field.to_le_bytes())
 
 
-def invert(f: Scalar) -> Scalar:  # util.py:51-54
-    res = f.inverse()
-    assert res * f == Scalar(1)  # fail in case f == 0
-    return res
-
-
-def scalar_pow(f: Scalar, n: int) -> Scalar:  # util.py:57-64
-    result = Scalar(1)
-    while n != 0:
-        if n % 2 == 1:
-            result *= f
-        f *= f
-        n //= 2
-    return result
-
-
 def get_random_point() -> G1Point:  # util.py:67-68
     return G1 * random_scalar()
-
-
-def inner_product(a: List[Scalar], b: List[Scalar]) -> Scalar:  # util.py:85-87
-    assert len(a) == len(b)
-    return sum([a[i] * b[i] for i in range(0, len(a))], Scalar(0))
-
-
-class BufReader:  # util.py:138-153
-    def __init__(self, data):
-        self.data = data
-        self.ptr = 0
-
-    def read_g1(self) -> G1Point:
-        end_ptr = self.ptr + 48
-        p = point_projective_from_bytes(self.data[self.ptr:end_ptr])
-        self.ptr = end_ptr
-        return p
-
-    def read_fr(self) -> Scalar:
-        end_ptr = self.ptr + 32
-        p = Scalar.from_le_bytes(self.data[self.ptr:end_ptr])
-        self.ptr = end_ptr
-        return p

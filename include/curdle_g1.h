@@ -107,6 +107,13 @@ int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points_affine96, const uint8_t*
 /* per-phase GPU times (hipEvents on the context's stream) and host Horner tail of the last MSM call */
 int cg1_get_timings(const cg1_ctx* ctx, float phase_ms[CG1_NPHASE], float* host_tail_ms, int* window_c);
 
+/* work counts of the last MSM call: non-zero signed digits sorted into buckets (= bucket additions + first-entry copies)
+ * and the chunks k_accumulate ran (one copy each), so  mixed additions = entries - chunks */
+int cg1_get_last_counts(const cg1_ctx* ctx, uint32_t* entries, uint32_t* chunks);
+/* hipEvent stopwatch on the context's compute stream: device time of everything enqueued between begin and end */
+int cg1_timer_begin(cg1_ctx* ctx);
+int cg1_timer_end(cg1_ctx* ctx, float* ms);
+
 /* host-side wall times of the last MSM call: enqueue, wait-for-GPU, event readout, Horner tail (ms) */
 int cg1_get_host_timings(const cg1_ctx* ctx, float host_ms[4]);
 
@@ -131,6 +138,14 @@ int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t nbase,
 int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup);
 int cg1_batch_decompress_enqueue(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup);  /* no wait: pair with cg1_ctx_sync */
 int cg1_batch_decompress_gpu(cg1_ctx* ctx, const uint8_t* in48, uint8_t* out_affine96, size_t n, int check_subgroup, size_t* bad_index);
+/* Subgroup flags for k selected points of every proof of a decompressed batch (d_affine96: n_proofs x stride_points
+ * records; offsets[j] < stride_points, k <= 16): d_flags[proof * k + j] = 1 iff that point is on the curve but outside G1.
+ * The reference decodes unchecked (util.py:35-36) yet asserts the same-scalar equalities exactly (same_scalar.py:108);
+ * weighting them randomly is sound only for points of G1, so flagged proofs get the exact check below.  Runs on the
+ * context's side stream, ordered after what the compute stream holds so far; cg1_side_sync waits for it. */
+int cg1_subgroup_flags_enqueue(cg1_ctx* ctx, const void* d_affine96, size_t stride_points, size_t n_proofs,
+                               const uint32_t* offsets, size_t k, void* d_flags);
+int cg1_side_sync(cg1_ctx* ctx);
 /* Batched compression on the GPU: n affine96 records (as cg1_batch_mul_add_device / cg1_batch_decompress_device produce
  * them; zeros = identity) -> n compressed48 (to_compressed_bytes, util.py:27-28,120).  All device pointers. */
 int cg1_batch_compress_device(cg1_ctx* ctx, const void* d_in_affine96, void* d_out48, size_t n);
@@ -207,6 +222,12 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8
 void cg1_shuffle_set_grouped(int on);
 /* threads used when n_threads = 0: usable CPUs (affinity mask capped by the cgroup CPU quota; env CURDLE_G1_THREADS overrides) */
 size_t cg1_shuffle_default_threads(void);
+/* Exact (unweighted) evaluation on the host of the equalities the reference asserts directly, for proofs that carry a
+ * point outside G1 (cg1_subgroup_flags_enqueue / CG1_ERR_NOT_IN_SUBGROUP): the four same-scalar equalities of one shuffle
+ * proof (same_scalar.py:101-108; *ok = 1 iff all hold), and the two equalities of one tracker-opening proof
+ * (opening.py:73-76).  Points are decoded unchecked, scalars act as integers in [0, r), as in the reference. */
+int cg1_shuffle_exact_same_scalar(const cg1_shuffle_crs* crs, const uint8_t* instance, const uint8_t* proof, int* ok);
+int cg1_opening_exact(const uint8_t* tracker96 /* r_G | k_r_G */, const uint8_t* k_commitment48, const uint8_t* proof128, int* ok);
 /* just the gather step: every proof's own points (instance, then the proof's points in wire order) */
 int cg1_shuffle_gather_points(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
                               uint8_t* out_points48);

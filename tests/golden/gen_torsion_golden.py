@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Proofs that carry a point OUTSIDE the prime-order subgroup, with the reference verifier's verdicts.
+
+E(Fp): y^2 = x^3 + 4 has cofactor divisible by 3; T3 = (0, 2) has order 3.  The reference decodes points unchecked
+(util.py:35-36) and asserts the same-scalar equalities (same_scalar.py:101-108) and both opening-proof equalities
+(opening.py:73-76) EXACTLY, so its verdict on such a proof is deterministic; a verifier that batches those equalities
+under random weights w sees  w * T3 = O  whenever 3 | w.  Cases (reference classes, unmodified, over the pure-Python
+oracle backend of tests/golden/_backend.py; the provers are driven with a torsion component added where noted):
+
+  opening  "A + T3":      A := A + T3, s recomputed for the new challenge       -> reference REJECTS (A' != A by T3)
+  opening  "k_G + T3":    k_commitment := k_G + T3 and A := A + c*T3 (ground)   -> reference ACCEPTS (the defects cancel)
+  shuffle  "cm_A.T_1+T3": SameScalarProof.new sends cm_A.T_1 + T3               -> reference REJECTS
+plus the honest versions.  Data only -> tests/golden/torsion_vectors.json.
+
+    python tests/golden/gen_torsion_golden.py [--backend oracle|product]
+"""
+import json
+import os
+import random
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gen_shuffle_golden as G  # noqa: E402  (injects the backend, imports the reference)
+
+import curdleproofs.same_scalar as same_scalar  # noqa: E402
+from curdleproofs.curdleproofs_transcript import CurdleproofsTranscript  # noqa: E402
+from curdleproofs.opening import TrackerOpeningProof  # noqa: E402
+from curdleproofs.util import points_projective_to_bytes  # noqa: E402
+from curdleproofs.whisk_interface import IsValidWhiskOpeningProof  # noqa: E402
+from py_arkworks_bls12381 import G1Point, Scalar  # noqa: E402
+
+T3_BYTES = bytes([0x80]) + bytes(47)          # x = 0, the smaller root y = 2: a point of order 3
+
+
+def t3():
+    return G1Point.from_compressed_bytes_unchecked(T3_BYTES)
+
+
+def pb(p):
+    return bytes(G.point_projective_to_bytes(p))
+
+
+def opening_case(name, torsion_on):
+    k, r, blinder = G.random_scalar(), G.random_scalar(), G.random_scalar()
+    r_G = G.G1 * r
+    k_r_G, k_G = r_G * k, G.G1 * k
+    A, B = G.G1 * blinder, r_G * blinder
+    T = t3()
+    if torsion_on == "A":
+        A = A + T
+    if torsion_on == "k_G":
+        k_G = k_G + T
+    tries = [None]
+    if torsion_on == "k_G":                    # A := A + X with c * T3 == X: X depends on c mod 3, c depends on A: try all three
+        tries = [G1Point.identity(), T, T + T]
+    for X in tries:
+        A_try = A if X is None else A + X
+        tr = CurdleproofsTranscript(b"whisk_opening_proof")
+        tr.append_list(b"tracker_opening_proof", points_projective_to_bytes([k_G, G.G1, k_r_G, r_G, A_try, B]))
+        c = tr.get_and_append_challenge(b"tracker_opening_proof_challenge")
+        if X is None or T * c == X:
+            A = A_try
+            break
+    else:
+        return None                              # no X fits this blinder (probability (2/3)^3): the caller retries
+    s = blinder - c * k
+    proof = bytes(TrackerOpeningProof(A, B, s).to_bytes())
+    tracker = G.WhiskTracker(G.BLSPubkey(pb(r_G)), G.BLSPubkey(pb(k_r_G)))
+    accepts = bool(IsValidWhiskOpeningProof(tracker, G.BLSPubkey(pb(k_G)), proof))
+    return {"name": name, "r_G": pb(r_G).hex(), "k_r_G": pb(k_r_G).hex(), "k_commitment": pb(k_G).hex(), "proof": proof.hex(), "accepts": accepts}
+
+
+ARMED = [False, 0]
+_orig_gc_new = same_scalar.GroupCommitment.new.__func__
+_orig_ss_new = same_scalar.SameScalarProof.new.__func__
+
+
+def _gc_new(cls, crs_G, crs_H, T, r):
+    cm = _orig_gc_new(cls, crs_G, crs_H, T, r)
+    if ARMED[0]:
+        ARMED[1] += 1
+        if ARMED[1] == 1:                        # cm_A (same_scalar.py:44): send T_1 + T3
+            cm.T_1 = cm.T_1 + t3()
+    return cm
+
+
+def _ss_new(cls, *a, **kw):
+    if ARMED[0]:
+        ARMED[1] = 0
+        same_scalar.GroupCommitment.new = classmethod(_gc_new)
+    try:
+        return _orig_ss_new(cls, *a, **kw)
+    finally:
+        same_scalar.GroupCommitment.new = classmethod(_orig_gc_new)
+
+
+same_scalar.SameScalarProof.new = classmethod(_ss_new)
+
+
+def shuffle_case(name, ell, crs, torsion):
+    pre = G.make_trackers(ell)
+    ARMED[0] = torsion
+    try:
+        post, proof = G.GenerateWhiskShuffleProof(crs, pre)
+    finally:
+        ARMED[0] = False
+    pre_r, pre_k = G.cat(pre)
+    post_r, post_k = G.cat(post)
+    accepts = bool(G.IsValidWhiskShuffleProof(crs, pre, post, proof))
+    return {"name": name, "pre_r": pre_r.hex(), "pre_k": pre_k.hex(), "post_r": post_r.hex(), "post_k": post_k.hex(),
+            "proof": bytes(proof).hex(), "accepts": accepts}
+
+
+def main():
+    random.seed(333)
+    opening = []
+    for name, where in (("honest", None), ("A + T3 (s recomputed)", "A"), ("k_G + T3, A + c*T3", "k_G"), ("honest 2", None),
+                        ("k_G + T3, A + c*T3 (2)", "k_G"), ("A + T3 (2)", "A")):
+        case = None
+        while case is None:
+            case = opening_case(name, where)
+        opening.append(case)
+    ell = 12
+    crs = G.CurdleproofsCrs.new(ell, G.N_BLINDERS)
+    shuffle = {"ell": ell, "crs": bytes(crs.to_bytes()).hex(),
+               "cases": [shuffle_case("honest", ell, crs, False), shuffle_case("cm_A.T_1 + T3", ell, crs, True),
+                         shuffle_case("honest 2", ell, crs, False), shuffle_case("cm_A.T_1 + T3 (2)", ell, crs, True)]}
+    out = {"generator": "tests/golden/gen_torsion_golden.py (reference classes; G1Point/Scalar = %s)" % G.BACKEND_MODULE,
+           "backend": G.BACKEND_MODULE, "t3": T3_BYTES.hex(), "opening": opening, "shuffle": shuffle}
+    path = G._backend.out_path("torsion_vectors.json")
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+    print("opening:", [(c["name"], c["accepts"]) for c in opening])
+    print("shuffle:", [(c["name"], c["accepts"]) for c in shuffle["cases"]])
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

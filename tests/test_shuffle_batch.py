@@ -1,0 +1,72 @@
+"""BASELINE config 3 at its own size: a batch of 1024 Whisk shuffle verifications (ell = 124 + 4 blinders) made of the 64
+DISTINCT proofs of tests/golden/shuffle_batch_ell124.bin (reference prover, tests/golden/gen_shuffle_batch.py) with
+tampered proofs at known slots; verdicts must equal the ones the reference's IsValidWhiskShuffleProof
+(whisk_interface.py:72-87 -> curdleproofs.py:162-248) returned when the fixture was made.
+
+CPU: the native front-end's statements evaluated by the CPU oracle (all 12 tampered variants + 4 valid proofs).
+GPU: the product path -- verify_packed in both modes and verify_stream."""
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from batch_fixture import ShuffleBatch  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def fx():
+    f = ShuffleBatch()
+    assert f.count >= 64 and f.ell == 124 and len({p for p in f.proofs}) == f.count      # all distinct
+    assert [t["accepts"] for t in f.tampered].count(False) >= 10
+    return f
+
+
+def test_front_end_statements_match_reference_verdicts_cpu(native_lib, fx):
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+    from oracle.shuffle_check import oracle_verdicts
+
+    v = ShuffleBatchVerifier(fx.crs)
+    slots = {2 * i + 1: i for i in range(len(fx.tampered))}            # every tampered variant, valid proofs in between
+    n = 2 * len(fx.tampered) + 2
+    inst, proofs, want = fx.tiled(n, slots)
+    prep = v.prepare(inst, proofs, n, rng=random.Random(3))
+    assert oracle_verdicts(v, prep) == want
+
+
+SLOTS_1024 = {0: 0, 7: 3, 64: 1, 65: 4, 500: 2, 511: 6, 512: 7, 777: 8, 800: 9, 1000: 10, 1023: 5, 300: 11}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["merged", "independent"])
+def test_batch_1024_verdicts_equal_reference(native_lib, fx, mode):
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    v = ShuffleBatchVerifier(fx.crs, native_lib.Context(0))
+    inst, proofs, want = fx.tiled(1024, SLOTS_1024)
+    assert want.count(False) == 11
+    status = v.verify_packed(inst, proofs, 1024, mode=mode, rng=random.Random(5))
+    assert [s == 0 for s in status] == want
+    if mode == "merged":
+        assert v.last_stats["merged_ok"] is False                     # the merged check failed, culprits named by the fallback
+        clean, cproofs, cwant = fx.tiled(1024)
+        assert v.verify_packed(clean, cproofs, 1024, rng=random.Random(6)) == [0] * 1024
+        assert v.last_stats["merged_ok"] is True and v.last_stats["points"] == 1024 * v.crs.points_per_proof + v.crs.ncrs
+    v.close()
+
+
+@pytest.mark.gpu
+def test_stream_of_1024_batches(native_lib, fx):
+    """verify_stream: three consecutive 1024-proof batches (clean, tampered, clean) overlapped across the pipeline stages,
+    fresh OS-random weights (no rng): verdicts per batch equal the fixture's."""
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    v = ShuffleBatchVerifier(fx.crs, native_lib.Context(0))
+    clean = fx.tiled(1024)
+    bad = fx.tiled(1024, SLOTS_1024)
+    got = list(v.verify_stream([(clean[0], clean[1], 1024), (bad[0], bad[1], 1024), (clean[0], clean[1], 1024)]))
+    assert [[s == 0 for s in st] for st in got] == [clean[2], bad[2], clean[2]]
+    v.close()
