@@ -1,29 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py -- BLS12-381 G1 MSM throughput on MI355X (BASELINE.json metric: G1 scalar-muls/sec at MSM size 2^20).
+"""bench.py -- BASELINE.json's metric on MI355X: "BLS12-381 G1 scalar-muls/sec at MSM size 2^20; shuffle proofs verified/sec".
 
     python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one complete compute_MSM-equivalent call (msm_accumulator.py:6-12 of the reference) over one
-batch of synthetic input that is already resident in HBM: point preparation, signed-digit recode, counting
-sort, bucket accumulation, bucket reduction, D2H of the window sums and the host Horner tail are all inside
-the timed region.  Workload at N=1: BASELINE.json configs[1]'s shape at the metric's size -- one MSM of 2^20
-random G1 points (k_i*G) with scalars uniform in [1, r-1] (the reference's random_scalar, util.py:21-24).
-At N>1 (weak scaling): ONE MSM of N*2^20 terms.  --shard hybrid (default): the signed-digit windows are sharded over
-2 window-bucket groups and the points over N/2 point groups (rank = window group + 2 * point group), so window buckets
-are sharded across GPUs as the north_star asks without every rank re-preparing all N*2^20 points; --shard windows:
-pure window sharding (every rank holds all points); --shard points: pure point sharding.  The partial G1 sums
-are all-gathered over RCCL and added on every rank.  value = total terms processed / max-over-ranks time.
+HEADLINE (`value`): G1 scalar-muls/s.  A "step" is one complete compute_MSM-equivalent call (msm_accumulator.py:6-12 of
+the reference) over one batch of synthetic input that is already resident in HBM: point preparation, signed-digit recode,
+counting sort, bucket accumulation, bucket reduction, D2H of the window sums and the host Horner tail are all inside the
+timed region.  Workload at N=1: BASELINE.json configs[1]'s shape at the metric's size -- one MSM of 2^20 random G1 points
+(k_i*G) with scalars uniform in [1, r-1] (the reference's random_scalar, util.py:21-24).  At N>1 (weak scaling): ONE MSM of
+N*2^20 terms.  --shard hybrid (default): the signed-digit windows are sharded over 2 window-bucket groups and the points over
+N/2 point groups (rank = window group + 2 * point group); --shard windows: pure window sharding (every rank holds all
+points, what north_star names; also timed as `windows_only` in every N>1 line); --shard points: pure point sharding.  The
+partial G1 sums are all-gathered over RCCL and added on every rank.  value = total terms / max-over-ranks time.
+
+SECONDARY (same JSON line, key `secondary`, N=1): the metric's second half -- Whisk shuffle proofs verified/s
+(IsValidWhiskShuffleProof, whisk_interface.py:72-109 -> curdleproofs.py:162-248; BASELINE configs[2]): batches of 1024
+proofs (the 64 DISTINCT ell = 124 proofs of tests/golden/shuffle_batch_ell124.bin, made by the reference prover, tiled 16x,
+fresh random weights per slot) from wire bytes in host memory to verdicts, with per-phase times, its own cpu_baseline and the
+integer-MAD roofline of its dominant kernel k_batch_decompress.  `--mode verify` runs that part alone (and proof-per-GPU at N>1:
+BASELINE configs[4]'s structure).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+MAD_PEAK_T = 30.3          # chip-wide v_mad_u64_u32 rate, T lane-ops/s, measured on MI355X (profiles/r01_ubench_valu_rates.txt)
+MADS_PER_MADD = 3542       # XYZZ mixed add (g1_xyzz.h): 6 products x 392 + one fused double product x 588 + 2 squarings x 301
+MADS_MUL, MADS_SQR = 392, 301
+# one rank's share of ONE MSM of N x 2^20 terms, emulated on one GPU in round 1 (profiles/r01_v13_shard_emulation.txt), ms
+EMULATED_MS = {"hybrid": {1: 3.3, 2: 3.35, 4: 3.37, 8: 3.34}, "windows": {1: 3.3, 2: 3.35, 4: 3.58, 8: 4.03}, "points": {1: 3.3, 2: 3.21, 4: 3.18, 8: 3.17}}
 
 
 def raw96_gen():
@@ -32,25 +45,170 @@ def raw96_gen():
     return gx.to_bytes(48, "little") + gy.to_bytes(48, "little")
 
 
-def cpu_baseline(ctx, d_points, d_scalars, sample_n):
-    """The reference algorithm (naive per-term double-and-add loop) as restated by oracle/msm_oracle.c,
-    1 thread (the reference is single-threaded), on the first `sample_n` terms of the same workload."""
-    from oracle import c_oracle as C  # the only use of the oracle in bench.py: the reported CPU baseline
+def cpu_baseline(d_points, d_scalars, sample_n):
+    """The reference algorithm (naive per-term double-and-add loop) as restated by oracle/msm_oracle.c, 1 thread (the
+    reference is single-threaded), on the first `sample_n` terms of the same workload; beside it, clearly labelled
+    NON-reference baselines: the textbook bucket method on 1 core and on all host cores (OpenMP)."""
+    from oracle import c_oracle as C  # the only use of the oracle in the MSM leg: the reported CPU baseline
+
+    from curdleproofs_pie_amd import _native as N
 
     p = d_points.download(96 * sample_n)
     s = d_scalars.download(32 * sample_n)
     t0 = time.perf_counter()
-    C.compute_msm(p, s, sample_n)
+    naive = C.compute_msm(p, s, sample_n)
     dt = time.perf_counter() - t0
     t1 = time.perf_counter()
-    C.msm_bucket(p, s, sample_n)
+    b1 = C.msm_bucket(p, s, sample_n)
     dt_b = time.perf_counter() - t1
+    cores = int(N.cg1_shuffle_default_threads())          # usable CPUs: affinity mask capped by the cgroup quota
+    big = min(1 << 18, d_points.nbytes // 96)              # all-cores leg: a larger sample (the bucket method's rate grows with n)
+    pb, sb = d_points.download(96 * big), d_scalars.download(32 * big)
+    t2 = time.perf_counter()
+    bm = C.msm_bucket_mt(pb, sb, big, cores)
+    dt_m = time.perf_counter() - t2
+    assert naive == b1, "CPU oracle: naive loop and bucket method disagree"
     return {"value": sample_n / dt, "unit": "G1 scalar-muls/s", "cores": 1, "kind": "port",
-            "stronger_non_reference_baseline": {"what": "textbook bucket-method MSM in C (oracle/msm_oracle.c orc_msm_bucket), 1 core, "
-                                                        f"same {sample_n}-term sample (rate grows with n)", "value": sample_n / dt_b},
             "sample": f"naive reference loop (msm_accumulator.py:6-12 restated in C, 255-bit double-and-add + add per term) "
                       f"over the first {sample_n} terms of the same workload, {dt:.1f} s on one host core; "
-                      f"cost is linear in n so the 2^20 figure is this rate"}
+                      f"cost is linear in n so the 2^20 figure is this rate",
+            "stronger_non_reference_baselines": [
+                {"what": "textbook bucket-method MSM in C (oracle/msm_oracle.c orc_msm_bucket), same sample (rate grows with n)",
+                 "cores": 1, "value": sample_n / dt_b, "seconds": dt_b},
+                {"what": f"the same bucket method on all usable host cores (OpenMP, orc_msm_bucket_mt), first {big} terms",
+                 "cores": cores, "value": big / dt_m, "seconds": dt_m}]}
+
+
+# ---------------------------------------------------------------------------------------------- proofs verified / s
+def load_batch_fixture():
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from batch_fixture import ShuffleBatch
+
+    return ShuffleBatch()
+
+
+def decompress_mads_per_point():
+    """Algorithmic v_mad_u64_u32 of k_batch_decompress<false> per point (kernels_batch.h): x -> Montgomery (1 product),
+    x^3 + 4 (1 squaring + 1 product), y = rhs^((p+1)/4) (fp_sqrt_candidate: its squarings / products are counted from the
+    exponent by the same rule the kernel applies), y^2 == rhs (1 squaring + 1 product), y out of Montgomery form (1 product),
+    and one more Montgomery conversion for the half of the points whose sign bit asks for p - y."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from sqrt_chain import chain_cost
+
+    nsqr, nmul = chain_cost()
+    return (nsqr + 2) * MADS_SQR + (nmul + 4.5) * MADS_MUL, nsqr, nmul
+
+
+def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu_leg=True):
+    """Stream `steps` batches of `batch` distinct-proof slots through the GPU verifier; returns the `secondary` object."""
+    from curdleproofs_pie_amd import _native as N
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    fx = load_batch_fixture()
+    v = ShuffleBatchVerifier(fx.crs, ctx, threads=threads)
+    inst, proofs, want = fx.tiled(batch)
+    for _ in range(warmup):
+        assert not any(v.verify_packed(inst, proofs, batch, mode=verify_mode))
+    acc = {}
+    ctx.sync()
+    t0 = time.perf_counter()
+    # K steps as a stream: the three stages of consecutive batches overlap (GPU: decompress k+1 | host: front-end k |
+    # GPU: MSM k-1); every batch is verified completely inside the timed region
+    for st in v.verify_stream(((inst, proofs, batch) for _ in range(steps)), mode=verify_mode):
+        assert not any(st)
+        for k, x in v.last_stats.items():
+            if k.endswith("_s"):
+                acc[k] = acc.get(k, 0.0) + x
+    ctx.sync()
+    el = time.perf_counter() - t0
+    L, C = v.crs.points_per_proof, v.crs.ncrs
+    points = batch * L
+    # dominant GPU kernel, measured live: hipEvents on the context's stream around launches of k_batch_decompress over the
+    # batch's own wire points (the same launch the verifier issues, as one piece)
+    wire = N.PinnedBuffer(ctx, points * 48)
+    ctx.check(N.cg1_shuffle_gather_points(v.crs.handle, batch, inst, proofs, wire.ptr))
+    d_w, d_p, d_s = ctx.alloc(points * 48), ctx.alloc(points * 96), ctx.alloc(points)
+    ctx.check(N.cg1_h2d(ctx.handle, d_w.ptr, wire.ptr, points * 48))
+    reps = 5
+    ctx.check(N.cg1_batch_decompress_device(ctx.handle, d_w.ptr, d_p.ptr, d_s.ptr, points, 0))
+    ctx.timer_begin()
+    for _ in range(reps):
+        ctx.check(N.cg1_batch_decompress_enqueue(ctx.handle, d_w.ptr, d_p.ptr, d_s.ptr, points, 0))
+    dec_ms = ctx.timer_end() / reps
+    assert not any(d_s.download(points))
+    mads_pp, nsqr, nmul = decompress_mads_per_point()
+    out = {
+        "metric": "shuffle proofs verified/sec (Whisk ell=124+4 blinders, batches of %d, mode %s)" % (batch, verify_mode),
+        "value": batch * steps / el, "unit": "proofs/s", "ms_per_step": el / steps * 1e3, "steps": steps, "warmup": warmup,
+        "batch": batch, "distinct_proofs": fx.count, "higher_is_better": True,
+        "data": "tests/golden/shuffle_batch_ell124.bin: %d distinct proofs made by the reference prover over one CRS, tiled to the "
+                "batch, fresh OS-random weights per slot; inputs are wire bytes in host memory (H2D included)" % fx.count,
+        "points_per_step": points + C, "host_threads": threads,
+        "phases_ms_per_step": {"decompress_stage (H2D + k_batch_decompress + D2H, GPU thread)": 1e3 * acc.get("decompress_s", 0) / steps,
+                               "front_end (host: transcript + Fr algebra, all threads)": 1e3 * acc.get("front_end_s", 0) / steps,
+                               "merged_msm (one regime-A MSM of all points, GPU)": 1e3 * acc.get("merged_msm_s", 0) / steps,
+                               "note": "the three stages of consecutive batches overlap; they do not add up to ms_per_step"},
+        "roofline_int_mad": {"kernel": "k_batch_decompress<false>", "bound": "valu v_mad_u64_u32", "kernel_ms": dec_ms, "points_per_launch": points,
+                             "mads_per_point": mads_pp, "sqrt_chain": {"squarings": nsqr, "products": nmul},
+                             "achieved": mads_pp * points / (dec_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T, "unit": "T mad/s",
+                             "frac": mads_pp * points / (dec_ms * 1e-3) / (MAD_PEAK_T * 1e12)},
+    }
+    if cpu_leg:
+        # CPU port beside it: the same statement builder on ONE core + the statement's MSM by the CPU oracle (bucket method)
+        from oracle.shuffle_check import oracle_verdicts
+        v1 = ShuffleBatchVerifier(v.crs, ctx, threads=1)
+        m = 8
+        i1, p1, _ = fx.tiled(m)
+        t1 = time.perf_counter()
+        prep = v1.prepare(i1, p1, m)
+        assert oracle_verdicts(v1, prep) == [True] * m
+        cpu_dt = (time.perf_counter() - t1) / m
+        v1.close()
+        out["cpu_baseline"] = {"value": 1.0 / cpu_dt, "unit": "proofs/s", "cores": 1, "kind": "port",
+                               "sample": "%d distinct proofs: native front-end on one core + CPU-oracle decode and bucket MSM of each 726-term "
+                                         "statement (the reference's own Python verifier over our host C++ backend measured 0.27 s/proof in the "
+                                         "build container; it cannot run on the GPU box)" % m}
+    for b in (d_w, d_p, d_s, wire):
+        b.free()
+    v.close()
+    return out
+
+
+def verify_mode(args, rank, local_rank, world):
+    """BASELINE config 3 (N = 1) / config 5's structure (N > 1, proof-per-GPU): `--batch` proofs per GPU per step, from wire
+    bytes in host memory to verdicts.  Ranks share the host's cores evenly.  No data-path collective."""
+    from curdleproofs_pie_amd import _native as N
+
+    dist = torch = None
+    dev_index = 0 if args.same_device else local_rank
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            torch.cuda.set_device(dev_index)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend="gloo")
+    ctx = N.Context(dev_index)
+    cores = int(N.cg1_shuffle_default_threads())         # usable CPUs (affinity mask capped by the cgroup quota)
+    threads = max(1, cores // world)
+    if world > 1:
+        dist.barrier()
+    out = verify_measure(ctx, threads, args.steps, args.warmup, args.batch, args.verify_mode, cpu_leg=(rank == 0 and not args.no_cpu_baseline))
+    el = out["ms_per_step"] * args.steps / 1e3
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank == 0:
+        out.update({"value": world * args.batch * args.steps / el, "ms_per_step": el / args.steps * 1e3, "n_gpus": world, "scaling": "weak",
+                    "vs_baseline": None, "dtype": "u32",
+                    "config": {"workload": "whisk_shuffle_verify ell=124 batch=%d per GPU" % args.batch,
+                               "parallelism": "proof-per-GPU x%d, no data-path collective" % world}})
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def side_mode(args):
@@ -93,85 +251,23 @@ def side_mode(args):
                           "ms_per_step": el / args.steps * 1e3, "steps": args.steps, "warmup": args.warmup}))
 
 
-def verify_mode(args, rank, local_rank, world):
-    """BASELINE config 3 (N = 1) / config 5's structure (N > 1, proof-per-GPU): Whisk shuffle verification
-    (ell = 124 + 4 blinders = 128), `--batch` proofs per GPU per step, from wire bytes in host memory to verdicts.
-    Proofs are the golden fixture cycled (tests/golden/shuffle_vectors.json: made by the reference prover; no prover
-    runs on the GPU box); every slot draws its own random weights.  Ranks share the host's cores evenly."""
-    from curdleproofs_pie_amd import _native as N
-    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+# ---------------------------------------------------------------------------------------------- the MSM headline
+class Workload:
+    """Synthetic inputs of one rank, generated on the GPU and left resident in HBM: P_i = k_i * G (get_random_point,
+    util.py:67-68), scalars uniform in [1, r-1] (util.py:21-24), both splitmix64-seeded."""
 
-    dist = torch = None
-    dev_index = 0 if args.same_device else local_rank
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(dev_index)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend="gloo")
-    ctx = N.Context(dev_index)
-    cores = int(N.cg1_shuffle_default_threads())         # usable CPUs (affinity mask capped by the cgroup quota)
-    threads = max(1, cores // world)
-    here = os.path.dirname(os.path.abspath(__file__))
-    with open(os.path.join(here, "tests", "golden", "shuffle_vectors.json")) as f:
-        case = [c for c in json.load(f)["cases"] if c["ell"] == 124][0]
-    v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx, threads=threads)
-    n = args.batch
-    inst1 = bytes.fromhex(case["pre_r"] + case["pre_k"] + case["post_r"] + case["post_k"])
-    proof1 = bytes.fromhex(case["proof"])
-    inst, proofs = inst1 * n, proof1 * n
+    def __init__(self, ctx, d_g, n_local, seed, groups=(0,)):
+        self.n = n_local * len(groups)
+        d_k = ctx.alloc(32 * n_local)
+        self.d_pts, self.d_sc = ctx.alloc(96 * self.n), ctx.alloc(32 * self.n)
+        for j, g in enumerate(groups):          # point group g of the job; a window-only rank holds every group
+            ctx.gen_scalars_device(d_k, n_local, 0xC0FFEE + 7919 * seed + 1000 * g)
+            ctx.batch_mul_device(d_g, 1, d_k, self.d_pts.ptr + 96 * n_local * j, n_local)
+            ctx.gen_scalars_device(self.d_sc.ptr + 32 * n_local * j, n_local, 0xBEEF + 7919 * seed + 1000 * g)
+        d_k.free()
 
-    def barrier_sync():
-        if world > 1:
-            dist.barrier()
-            if args.backend == "nccl":
-                torch.cuda.synchronize()
-        ctx.sync()
-
-    for _ in range(args.warmup):
-        assert not any(v.verify_packed(inst, proofs, n, mode=args.verify_mode))
-    acc = {}
-    barrier_sync()
-    t0 = time.perf_counter()
-    # K steps as a stream: the three stages of consecutive batches overlap (GPU: decompress k+1 | host: front-end k |
-    # GPU: MSM k-1); every batch is verified completely inside the timed region
-    for st in v.verify_stream(((inst, proofs, n) for _ in range(args.steps)), mode=args.verify_mode):
-        assert not any(st)
-        for k, x in v.last_stats.items():
-            if k.endswith("_s"):
-                acc[k] = acc.get(k, 0.0) + x
-    barrier_sync()
-    el = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    if rank == 0:
-        # CPU port beside it: the same front-end on ONE core + the statement's MSM by the CPU oracle (bucket method)
-        from oracle.shuffle_check import oracle_verdicts
-        v1 = ShuffleBatchVerifier(v.crs, ctx, threads=1)
-        m = 4
-        t1 = time.perf_counter()
-        prep = v1.prepare(inst1 * m, proof1 * m, m)
-        assert oracle_verdicts(v1, prep) == [True] * m
-        cpu_dt = (time.perf_counter() - t1) / m
-        print(json.dumps({
-            "metric": "shuffle proofs verified/sec (Whisk ell=124+4 blinders, batch of %d per GPU per step, mode %s)" % (n, args.verify_mode),
-            "value": world * n * args.steps / el, "unit": "proofs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
-            "data": "reference-prover fixture cycled, fresh random weights per slot; inputs are wire bytes in host memory (H2D included)",
-            "config": {"workload": "whisk_shuffle_verify ell=124 batch=%d per GPU" % n, "points_per_step_per_gpu": v.last_stats.get("points"),
-                       "parallelism": "proof-per-GPU x%d, no data-path collective" % world},
-            "host_threads_per_rank": threads, "phases_ms_per_step_rank0": {k[:-2]: 1e3 * x / args.steps for k, x in acc.items()},
-            "cpu_baseline": {"value": 1.0 / cpu_dt, "unit": "proofs/s", "cores": 1, "kind": "port",
-                             "sample": "%d proofs: native front-end on one core + CPU-oracle bucket MSM of the 726-term statement "
-                                       "(the reference's own Python verifier over our host C++ backend measured 0.27 s/proof in the "
-                                       "build container; it cannot run on the GPU box)" % m}}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    def free(self):
+        self.d_pts.free(); self.d_sc.free()
 
 
 def main():
@@ -181,16 +277,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logn", type=int, default=20, help="log2 of terms per GPU")
     ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--seed", type=int, default=1, help="input seed of the timed region (seeds 1, 2, 3 are also reported side by side)")
     ap.add_argument("--shard", choices=["hybrid", "windows", "points"], default="hybrid",
                     help="N>1: hybrid = 2 window-bucket groups x N/2 point groups (default); windows / points = pure splits")
     ap.add_argument("--cpu-sample-logn", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=1024, help="--mode verify: proofs per step")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the proofs-verified/s object and the extra N>1 records")
+    ap.add_argument("--batch", type=int, default=1024, help="proofs per step (secondary metric / --mode verify)")
+    ap.add_argument("--verify-steps", type=int, default=20)
     ap.add_argument("--verify-mode", choices=["merged", "independent"], default="merged")
     ap.add_argument("--mode", choices=["msm", "batched", "pcie", "verify"], default="msm",
-                    help="msm: the headline metric (default). batched: BASELINE config 3's MSM content (1024 independent "
-                         "627-term accumulator MSMs per step, regime B). verify: BASELINE config 3 end to end (1024 Whisk shuffle proofs "
-                         "per step from wire bytes to verdicts). pcie: the headline MSM with inputs in HOST memory")
+                    help="msm: the driver's line (headline MSM + secondary proofs/s). batched: BASELINE config 3's MSM content (1024 independent "
+                         "627-term accumulator MSMs per step, regime B). verify: BASELINE config 3 end to end alone (and config 5's structure at "
+                         "N>1). pcie: the headline MSM with inputs in HOST memory")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="transport of the N>1 partial-sum exchange (nccl == RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
@@ -204,9 +303,10 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    from curdleproofs_pie_amd import _native as N
+    # build BEFORE the library is first loaded: a stale .so must not stay mapped under a fresh one
     from curdleproofs_pie_amd import build as B
     B.build(verbose=False)
+    from curdleproofs_pie_amd import _native as N
 
     dist = None
     torch = None
@@ -225,28 +325,11 @@ def main():
             dist.init_process_group(backend="gloo")
     ctx = N.Context(dev_index)
 
-    n_per_gpu = 1 << args.logn
-    n_total = n_per_gpu * world
+    from curdleproofs_pie_amd.distributed import all_reduce_g1, shard_layout
+
     c = args.window
-    # ---- synthetic inputs, generated on the GPU and left resident in HBM
-    from curdleproofs_pie_amd.distributed import shard_layout
-    w_rank, w_groups, p_rank, p_groups = shard_layout(rank, world, args.shard)
-    n_local, seed_off = n_total // p_groups, 1000 * p_rank      # this rank's point group (the whole MSM when p_groups == 1)
-    d_k = ctx.alloc(32 * n_local)
-    d_pts = ctx.alloc(96 * n_local)
-    d_sc = ctx.alloc(32 * n_local)
     d_g = ctx.alloc(96)
     d_g.upload(raw96_gen())
-    ctx.gen_scalars_device(d_k, n_local, 0xC0FFEE + seed_off)
-    ctx.batch_mul_device(d_g, 1, d_k, d_pts, n_local)       # P_i = k_i * G  (get_random_point, util.py:67-68)
-    ctx.gen_scalars_device(d_sc, n_local, 0xBEEF + seed_off)
-    d_k.free()
-
-    from curdleproofs_pie_amd.distributed import all_reduce_g1
-
-    def step():
-        part = ctx.msm_device(d_pts, d_sc, n_local, window_c=c, shard_rank=w_rank, shard_world=w_groups)
-        return all_reduce_g1(part) if world > 1 else part
 
     def barrier_sync():
         if world > 1:
@@ -255,78 +338,144 @@ def main():
                 torch.cuda.synchronize()
         ctx.sync()
 
-    results = []
-    for _ in range(args.warmup):
-        results.append(step())
-    phase_acc = {}
-    barrier_sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        results.append(step())
-        for k, v in ctx.timings().items():
-            phase_acc[k] = phase_acc.get(k, 0.0) + v
-    barrier_sync()
-    elapsed = time.perf_counter() - t0
-    same = all(N.cg1_eq(r, results[0]) for r in results[1:])
-    if not same:
-        sys.exit("bench.py: MSM results differ between steps")
+    def run(shard, n_per_gpu, seed, steps, warmup):
+        """One timed measurement: ONE MSM of world * n_per_gpu terms per step, sharded `shard`-wise.  Returns a dict with the
+        max-over-ranks time and what the audit needs."""
+        w_rank, w_groups, p_rank, p_groups = shard_layout(rank, world, shard)
+        n_group = n_per_gpu * world // p_groups            # terms of one point group (= of this rank)
+        wl = Workload(ctx, d_g, n_per_gpu, seed, groups=[p_rank * (world // p_groups) + j for j in range(world // p_groups)])
+        assert wl.n == n_group
+        ex = {"t": 0.0, "n": 0}
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def step():
+            part = ctx.msm_device(wl.d_pts, wl.d_sc, wl.n, window_c=c, shard_rank=w_rank, shard_world=w_groups)
+            if world == 1:
+                return part
+            t = time.perf_counter()
+            out = all_reduce_g1(part)
+            ex["t"] += time.perf_counter() - t
+            ex["n"] += 1
+            return out
+
+        results = [step() for _ in range(warmup)]
+        ex["t"], ex["n"] = 0.0, 0
+        phase_acc, counts = {}, None
+        barrier_sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            results.append(step())
+            for k, v in ctx.timings().items():
+                phase_acc[k] = phase_acc.get(k, 0.0) + v
+        barrier_sync()
+        elapsed = mine = time.perf_counter() - t0
+        counts = ctx.last_counts()
+        if not all(N.cg1_eq(r, results[0]) for r in results[1:]):
+            sys.exit("bench.py: MSM results differ between steps")
+        per_rank = [mine]
+        if world > 1:
+            dev = "cuda" if args.backend == "nccl" else "cpu"
+            t = torch.tensor([mine], dtype=torch.float64, device=dev)
+            g = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(g, t)
+            per_rank = [float(x.item()) for x in g]
+            elapsed = max(per_rank)
+        rec = {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "value": n_per_gpu * world * steps / elapsed,
+               "per_rank_ms_per_step": {"min": min(per_rank) / steps * 1e3, "max": max(per_rank) / steps * 1e3},
+               "phases_ms": {k: v / steps for k, v in phase_acc.items() if k != "window_c"}, "counts": counts,
+               "layout": (w_rank, w_groups, p_rank, p_groups), "n_local": wl.n,
+               "exchange_ms": (ex["t"] / ex["n"] * 1e3) if ex["n"] else None, "result": results[-1]}
+        wl.free()
+        return rec
+
+    n_per_gpu = 1 << args.logn
+    main_rec = run(args.shard, n_per_gpu, args.seed, args.steps, args.warmup)
+
+    extra = {}
+    if not args.no_secondary:
+        # the reference's input distribution at three seeds (SURVEY 8(d)): short side-by-side runs outside the timed region
+        seeds = {}
+        for s in (1, 2, 3):
+            seeds[str(s)] = main_rec["ms_per_step"] if s == args.seed else run(args.shard, n_per_gpu, s, max(3, args.steps // 2), 1)["ms_per_step"]
+        extra["seeds_ms_per_step"] = dict(seeds, min=min(seeds.values()), median=statistics.median(seeds.values()))
+        if world > 1:
+            # what north_star names literally: window buckets sharded over ALL N GPUs, every rank holding all N * 2^20 points
+            if args.shard != "windows":
+                w = run("windows", n_per_gpu, args.seed, args.steps, args.warmup)
+                extra["windows_only"] = {"ms_per_step": w["ms_per_step"], "value": w["value"], "per_rank_ms_per_step": w["per_rank_ms_per_step"],
+                                         "same_result_as_default_shard": bool(N.cg1_eq(w["result"], main_rec["result"])),
+                                         "predicted_ms_per_step_emulated": EMULATED_MS["windows"].get(world)}
+            # BASELINE config 4: ONE MSM of 2^22 terms in total over the N GPUs (strong scaling)
+            if (1 << 22) % world == 0:
+                sc = run(args.shard, (1 << 22) // world, args.seed, args.steps, args.warmup)
+                extra["strong_2_22_total"] = {"terms_total": 1 << 22, "ms_per_step": sc["ms_per_step"], "value": sc["value"],
+                                              "per_rank_ms_per_step": sc["per_rank_ms_per_step"], "scaling": "strong"}
 
     if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = n_total * args.steps / elapsed
-        acc_ms = phase_acc["accumulate"] / args.steps
+        r = main_rec
+        w_rank, w_groups, p_rank, p_groups = r["layout"]
+        acc_ms = r["phases_ms"]["accumulate"]
         # roofline of the dominant kernel (k_accumulate): ALGORITHMIC bytes = 128 B per (point, scalar) term
         # (96 B affine point + 32 B scalar, SURVEY.md 8(d)) x the terms one launch processes
-        terms_per_launch = n_local
-        achieved = 128.0 * terms_per_launch / (acc_ms * 1e-3) / 1e9
-        nwin = 255 // c + 1
-        local_windows = (nwin + w_groups - 1) // w_groups
-        mads = terms_per_launch * local_windows * 3542.0
-        traffic = None
+        achieved = 128.0 * r["n_local"] / (acc_ms * 1e-3) / 1e9
+        madds = r["counts"]["mixed_adds"]                   # bucket entries - chunks: a chunk's first entry is a copy
+        mads = madds * float(MADS_PER_MADD)
+        traffic = pmc = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.logn == 20:
             try:
-                traffic = json.load(open(tpath)).get("k_accumulate_hbm_bytes_per_launch")
+                pmc = json.load(open(tpath))
+                traffic = pmc.get("k_accumulate_hbm_bytes_per_launch")
             except Exception:
-                traffic = None
+                pmc = None
         out = {
             "metric": "BLS12-381 G1 scalar-muls/sec at MSM size 2^20",
-            "value": value,
+            "value": r["value"],
             "unit": "G1 scalar-muls/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": r["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u32",
-            "data": "synthetic: points k_i*G and scalars uniform in [1,r-1], splitmix64-seeded, generated on the GPU",
+            "data": "synthetic: points k_i*G and scalars uniform in [1,r-1], splitmix64-seeded (seed %d), generated on the GPU" % args.seed,
             "config": {"workload": f"single MSM of 2^{args.logn} x {world} BLS12-381 G1 terms, resident in HBM, "
                                    f"sharded over {world} GPU(s): {w_groups} window-bucket group(s) x {p_groups} point group(s)",
-                       "terms_total": n_total, "terms_per_gpu": n_per_gpu, "window_c": c, "shard": args.shard,
+                       "terms_total": n_per_gpu * world, "terms_per_gpu": n_per_gpu, "window_c": c, "shard": args.shard,
                        "parallelism": f"windows x{w_groups} . points x{p_groups}, one all-gather of {world} partial G1 sums",
                        "arithmetic": "381-bit Fp as 14 x 28-bit limbs in u32, Montgomery, 64-bit column accumulators (v_mad_u64_u32)",
                        "bit_exact_vs_oracle": "tests/test_msm_gpu.py"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_source": (pmc or {}).get("source", None) and ("NOT measured in this run: " + pmc["source"]),
                          "kernel": "k_accumulate", "kernel_ms": acc_ms,
-                         "note": "path is integer-multiply (v_mad_u64_u32) bound, not HBM-bound: see DESIGN.md"},
+                         "note": "path is integer-multiply (v_mad_u64_u32) bound, not HBM-bound: see roofline_int_mad and DESIGN.md"},
             # The bound that actually applies (DESIGN.md 3/5): 32x32+64 integer multiply-adds.  Algorithmic MADs of one
-            # k_accumulate launch = terms x windows x 3542 (XYZZ mixed add = 6 products x 392 + one fused double
-            # product x 588 + 2 squarings x 301 v_mad_u64_u32); peak = the chip-wide v_mad_u64_u32 rate measured by
-            # tools/ubench_valu.hip on MI355X (profiles/r01_ubench_valu_rates.txt, 2 waves/SIMD).
-            "roofline_int_mad": {"bound": "valu v_mad_u64_u32", "achieved": mads / (acc_ms * 1e-3) / 1e12, "peak": 30.3,
-                                 "unit": "T mad/s", "frac": mads / (acc_ms * 1e-3) / 30.3e12, "kernel": "k_accumulate"},
-            "phases_ms": {k: v / args.steps for k, v in phase_acc.items() if k != "window_c"},
+            # k_accumulate launch = the mixed additions it really performs (bucket entries minus one copy per chunk, both
+            # counted on the device in this run) x 3542; peak = the chip-wide v_mad_u64_u32 rate measured by tools/ubench_valu.hip.
+            "roofline_int_mad": {"bound": "valu v_mad_u64_u32", "achieved": mads / (acc_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T,
+                                 "unit": "T mad/s", "frac": mads / (acc_ms * 1e-3) / (MAD_PEAK_T * 1e12), "kernel": "k_accumulate",
+                                 "mixed_adds_per_launch": madds, "bucket_entries": r["counts"]["entries"], "chunks": r["counts"]["chunks"],
+                                 "mads_per_mixed_add": MADS_PER_MADD,
+                                 "valu_per_wave_mixed_add": (pmc or {}).get("k_accumulate_valu_per_wave_mixed_add"),
+                                 "valu_source": (pmc or {}).get("sq_source")},
+            "phases_ms": r["phases_ms"],
+            "per_rank_ms_per_step": r["per_rank_ms_per_step"],
         }
+        out.update(extra)
+        if world > 1:
+            out["collective"] = {"backend": dist.get_backend(), "world_seen": dist.get_world_size(),
+                                 "what": "all_gather of one 144-byte partial G1 sum per rank, then world-1 host additions on every rank",
+                                 "bytes_per_step": 144 * world, "ms_per_exchange": r["exchange_ms"]}
+            out["predicted_ms_per_step_emulated"] = EMULATED_MS.get(args.shard, {}).get(world)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(ctx, d_pts, d_sc, 1 << args.cpu_sample_logn)
+            wl = Workload(ctx, d_g, max(1 << 18, 1 << args.cpu_sample_logn), args.seed)
+            out["cpu_baseline"] = cpu_baseline(wl.d_pts, wl.d_sc, 1 << args.cpu_sample_logn)
+            wl.free()
+        if world == 1 and not args.no_secondary:
+            cores = int(N.cg1_shuffle_default_threads())
+            out["secondary"] = verify_measure(ctx, cores, args.verify_steps, 2, args.batch, args.verify_mode, cpu_leg=not args.no_cpu_baseline)
         print(json.dumps(out), flush=True)
 
     if world > 1:

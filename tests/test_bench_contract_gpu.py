@@ -22,7 +22,8 @@ def _last_json(out: str) -> dict:
 
 
 def test_single_gpu_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--logn", "16", "--cpu-sample-logn", "10"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--logn", "16", "--cpu-sample-logn", "10",
+                        "--verify-steps", "3", "--batch", "256"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     d = _last_json(r.stdout)
@@ -32,6 +33,15 @@ def test_single_gpu_line():
     assert d["roofline"]["bound"] in ("hbm", "mfma") and 0 < d["roofline"]["frac"] < 1
     assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] == 1
     assert "workload" in d["config"]
+    im = d["roofline_int_mad"]
+    assert im["mixed_adds_per_launch"] == im["bucket_entries"] - im["chunks"] > 0 and 0 < im["frac"] < 1
+    assert set(d["seeds_ms_per_step"]) >= {"1", "2", "3", "min", "median"}
+    assert [b["cores"] for b in d["cpu_baseline"]["stronger_non_reference_baselines"]][0] == 1
+    # the metric's second half, in the same line
+    sec = d["secondary"]
+    assert sec["unit"] == "proofs/s" and sec["value"] > 0 and sec["batch"] == 256 and sec["distinct_proofs"] >= 64
+    assert 0 < sec["roofline_int_mad"]["frac"] < 1 and sec["roofline_int_mad"]["kernel"].startswith("k_batch_decompress")
+    assert sec["cpu_baseline"]["kind"] == "port" and sec["cpu_baseline"]["cores"] == 1
 
 
 def test_two_rank_launch_prints_one_line():
@@ -50,3 +60,7 @@ def test_two_rank_launch_prints_one_line():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["terms_total"] == 2 * (1 << 16)
     assert d["config"]["parallelism"].startswith("windows x2 . points x1")
+    col = d["collective"]
+    assert col["world_seen"] == 2 and col["backend"] == "gloo" and col["bytes_per_step"] == 288 and col["ms_per_exchange"] > 0
+    assert d["per_rank_ms_per_step"]["min"] <= d["per_rank_ms_per_step"]["max"]
+    assert d["strong_2_22_total"]["terms_total"] == 1 << 22 and d["strong_2_22_total"]["value"] > 0
