@@ -972,7 +972,7 @@ int cg1_subgroup_flags_enqueue(cg1_ctx* ctx, const void* d_affine96, size_t stri
                                const uint32_t* offsets, size_t k, void* d_flags) {
   if (!ctx) return CG1_ERR_HIP;
   if (n_proofs == 0 || k == 0) return CG1_OK;
-  if (!offsets || k > 16 || n_proofs * k >= (1ull << 31)) return CG1_ERR_ARG;
+  if (!offsets || k > 16 || n_proofs * k >= (1ull << 29)) return CG1_ERR_ARG;
   for (size_t j = 0; j < k; ++j) if (offsets[j] >= stride_points) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->side_stream) {
@@ -984,7 +984,7 @@ int cg1_subgroup_flags_enqueue(cg1_ctx* ctx, const void* d_affine96, size_t stri
   cg1::SgOffsets so;
   for (size_t j = 0; j < 16; ++j) so.off[j] = j < k ? offsets[j] : 0u;
   so.k = (uint32_t)k;
-  const size_t lanes = n_proofs * k;
+  const size_t lanes = n_proofs * k * 4;           // one DPP quad per point
   hipLaunchKernelGGL(cg1::k_subgroup_flags, dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, ctx->side_stream,
                      (const uint32_t*)d_affine96, (uint32_t)stride_points, (uint32_t)n_proofs, so, (uint8_t*)d_flags);
   HIPCHK(hipGetLastError());

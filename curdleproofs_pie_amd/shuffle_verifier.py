@@ -151,7 +151,8 @@ class ShuffleBatchVerifier:
                 for k in ("wire", "pts", "pstat", "sgflags", "sc"):
                     b[k].free()
                 for h in b["host"].values():
-                    h.free()
+                    if isinstance(h, N.PinnedBuffer):          # (the staging dict also caches plain ctypes buffers)
+                        h.free()
                 self._slots[i] = None
         if self._ctx_msm is not None:
             self._ctx_msm.close()
@@ -304,9 +305,6 @@ class ShuffleBatchVerifier:
         ctx.check(N.cg1_copy_fence(ctx.handle))
         ctx.check(N.cg1_batch_decompress_enqueue(ctx.handle, b["wire"].ptr + lo * L * 48, b["pts"].ptr + lo * L * 96,
                                                  b["pstat"].ptr + lo * L, (hi - lo) * L, 0))
-        # beside the next kernels (side stream): are the points of the exactly-asserted same-scalar equalities in G1?
-        ctx.check(N.cg1_subgroup_flags_enqueue(ctx.handle, b["pts"].ptr + lo * L * 96, L, hi - lo, self._exact_offsets,
-                                               N_EXACT_POINTS, b["sgflags"].ptr + lo * N_EXACT_POINTS))
 
     def _decompress_collect(self, b: dict, lo: int, hi: int) -> None:
         """GPU thread: wait for the kernel, bring back the per-point verdicts and the 8-point window the front-end wants."""
@@ -352,6 +350,11 @@ class ShuffleBatchVerifier:
                         tk["weights"] = self.draw_weights(n, rng)
                     if i + 1 < len(bounds):
                         self._stage_in(b, instances, proofs, *bounds[i + 1])
+                    if i + 1 == len(bounds):
+                        # beside whatever runs next (side stream, one launch per batch): are the proof's points in the
+                        # exactly-asserted same-scalar equalities inside G1?
+                        self.ctx.check(N.cg1_subgroup_flags_enqueue(self.ctx.handle, b["pts"].ptr, L, n, self._exact_offsets,
+                                                                    N_EXACT_POINTS, b["sgflags"].ptr))
                     self._decompress_collect(b, lo, hi)
                     tk["decompress_s"] = time.perf_counter() - t_dec   # staging + H2D + kernel + D2H of the batch's sub-batches
                     tk["chunks"].put((lo, hi))

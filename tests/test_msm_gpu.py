@@ -177,31 +177,6 @@ def test_config4_full_size_2_22_window_shards(native_lib, ctx):
     assert compress_blob(N, sum_blobs(parts)) == want
 
 
-def test_split_pipeline_agrees(native_lib):
-    """split2 = 1: one MSM as two window halves on two streams sharing the prepared points (A/B switch, off by default)."""
-    N = native_lib
-    c1 = N.Context(0)
-    n = 1 << 18
-    dk, dg, dp, ds = c1.alloc(32 * n), c1.alloc(96), c1.alloc(96 * n), c1.alloc(32 * n)
-    c1.gen_scalars_device(dk, n, 51); c1.gen_scalars_device(ds, n, 52)
-    dg.upload(raw96(O.G1_GEN))
-    c1.batch_mul_device(dg, 1, dk, dp, n)
-    kb, sb = dk.download(), ds.download()
-    tot = sum(int.from_bytes(kb[32 * i: 32 * i + 32], "little") * int.from_bytes(sb[32 * i: 32 * i + 32], "little") for i in range(n)) % O.R
-    want = O.g1_compress(O.g1_mul(O.G1_GEN, tot))
-    assert compress_blob(N, c1.msm_device(dp, ds, n)) == want
-    c1.set_param("split2", 1)
-    for _ in range(3):
-        assert compress_blob(N, c1.msm_device(dp, ds, n)) == want
-    assert compress_blob(N, c1.msm_device(dp, ds, n, window_c=13)) == want
-    dbad = c1.alloc(32 * n)
-    dbad.upload(sb[:-32] + (1 << 255).to_bytes(32, "little"))
-    with pytest.raises(N.NativeError):
-        c1.msm_device(dp, dbad, n)                      # the error of either half surfaces; the context stays usable
-    assert compress_blob(N, c1.msm_device(dp, ds, n)) == want
-    c1.close()
-
-
 def test_batch_mul_variable_base(native_lib, ctx):
     rng = random.Random(9)
     n = 37
@@ -279,14 +254,14 @@ def test_pipeline_variants_agree(native_lib, golden):
         s32 = b"".join(rng.choice([rng.randint(0, O.R - 1), 7, O.R - 1]).to_bytes(32, "little") for _ in range(n))
         want = C.compress(C.compute_msm(p96, s32, n))
         for params in ({"partition_sort": 0}, {"chunk_len": 1}, {"chunk_len": 7}, {"chunk_len": 4096}, {"seg_m": 1},
-                       {"seg_m": 2}, {"seg_m": 16}, {"wave_agg": 0}, {"stage_sort": 0}, {"host_split": 0}, {"big_bins": 0}, {"split2": 1}, {"partition_sort": 0, "chunk_len": 3, "seg_m": 8},
+                       {"seg_m": 2}, {"seg_m": 16}, {"wave_agg": 0}, {"stage_sort": 0}, {"host_split": 0}, {"big_bins": 0}, {"partition_sort": 0, "chunk_len": 3, "seg_m": 8},
                        {"reduce_2d": 0}, {"reduce_2d": 0, "seg_m": 8}, {"quad": 0}):
             for k, v in params.items():
                 c2.set_param(k, v)
             for c in (0, 4, 5, 6, 9, 16):
                 assert gpu_msm(N, c2, p96, s32, n, window_c=c) == want, (params, c)
             for k in params:   # back to defaults
-                c2.set_param(k, {"partition_sort": 1, "chunk_len": 8, "seg_m": 4, "wave_agg": 1, "stage_sort": 1, "host_split": 1, "big_bins": 1, "split2": 0, "reduce_2d": 1, "quad": 1}[k])
+                c2.set_param(k, {"partition_sort": 1, "chunk_len": 8, "seg_m": 4, "wave_agg": 1, "stage_sort": 1, "host_split": 1, "big_bins": 1, "reduce_2d": 1, "quad": 1}[k])
     finally:
         c2.close()
 

@@ -24,14 +24,18 @@ def tors():
 
 
 class MultiplesOfThree:
-    """rng stand-in: every weight is divisible by 3 (and canonical), the adversary's best case."""
+    """rng stand-in, the adversary's best case: every weight w is = 1 (mod 3).  The proof's own points carry the scalar
+    -w = r - w (the equalities are moved to one side), and r = 1 (mod 3), so every such scalar is a MULTIPLE OF 3: an
+    order-3 defect in one of those points is invisible to the weighted check."""
 
     def __init__(self):
         self.k = 1
 
     def randint(self, lo, hi):
         self.k += 7
-        return 3 * (0x1234567 * self.k + (1 << 200))
+        w = 3 * (0x1234567 * self.k + (1 << 200)) + 1
+        assert (FR - w) % 3 == 0
+        return w
 
 
 def test_oracle_agrees_the_torsion_point_has_order_three(tors):
@@ -87,4 +91,8 @@ def test_shuffle_batch_with_torsion_points(native_lib, tors, mode):
     assert v.last_stats["exact_checks"] == 2                          # the two proofs with a point outside G1, nobody else
     assert v.verify_many(items * 16, mode=mode) == want * 16
     assert v.verify_many([items[0], items[2]] * 8, mode=mode, rng=MultiplesOfThree()) == [True] * 16 and v.last_stats["exact_checks"] == 0
+    # without the exact check the weighted equalities alone would have accepted the two torsion proofs under these weights
+    prep = v.prepare(*v.pack(items)[:2], len(items), rng=MultiplesOfThree())
+    from oracle.shuffle_check import oracle_verdicts
+    assert oracle_verdicts(v, prep) == [True] * 4
     v.close()
