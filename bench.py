@@ -276,7 +276,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logn", type=int, default=20, help="log2 of terms per GPU")
-    ap.add_argument("--window", type=int, default=16)
+    ap.add_argument("--window", type=int, default=0, help="0 = the library's plan for the size (c = 16 at 2^20); 4..16 uniform; -16..-4 balanced")
     ap.add_argument("--seed", type=int, default=1, help="input seed of the timed region (seeds 1, 2, 3 are also reported side by side)")
     ap.add_argument("--shard", choices=["hybrid", "windows", "points"], default="hybrid",
                     help="N>1: hybrid = 2 window-bucket groups x N/2 point groups (default); windows / points = pure splits")
@@ -382,6 +382,7 @@ def main():
         rec = {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "value": n_per_gpu * world * steps / elapsed,
                "per_rank_ms_per_step": {"min": min(per_rank) / steps * 1e3, "max": max(per_rank) / steps * 1e3},
                "phases_ms": {k: v / steps for k, v in phase_acc.items() if k != "window_c"}, "counts": counts,
+               "phases_ms_window_c": phase_acc.get("window_c", 0) / steps,
                "layout": (w_rank, w_groups, p_rank, p_groups), "n_local": wl.n,
                "exchange_ms": (ex["t"] / ex["n"] * 1e3) if ex["n"] else None, "result": results[-1]}
         wl.free()
@@ -442,7 +443,7 @@ def main():
             "data": "synthetic: points k_i*G and scalars uniform in [1,r-1], splitmix64-seeded (seed %d), generated on the GPU" % args.seed,
             "config": {"workload": f"single MSM of 2^{args.logn} x {world} BLS12-381 G1 terms, resident in HBM, "
                                    f"sharded over {world} GPU(s): {w_groups} window-bucket group(s) x {p_groups} point group(s)",
-                       "terms_total": n_per_gpu * world, "terms_per_gpu": n_per_gpu, "window_c": c, "shard": args.shard,
+                       "terms_total": n_per_gpu * world, "terms_per_gpu": n_per_gpu, "window_c": int(r["phases_ms_window_c"]), "shard": args.shard,
                        "parallelism": f"windows x{w_groups} . points x{p_groups}, one all-gather of {world} partial G1 sums",
                        "arithmetic": "381-bit Fp as 14 x 28-bit limbs in u32, Montgomery, 64-bit column accumulators (v_mad_u64_u32)",
                        "bit_exact_vs_oracle": "tests/test_msm_gpu.py"},

@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(256) k_heavy_combine(const uint32_t* __restric
 // so chunks are kept short for parallelism in k_accumulate) get their chunk sums added serially into the first
 // slot.  Buckets with more chunks were already handled by k_heavy_combine; single-chunk buckets are untouched.
 __global__ void __launch_bounds__(256) k_bucket_fold(const uint32_t* __restrict__ choff, PointSum* __restrict__ sums,
-                                                     uint8_t* __restrict__ combined, uint32_t nb_total) {
+                                                     uint8_t* __restrict__ combined, uint32_t nb_total, const uint32_t* __restrict__ any_multi = nullptr) {
+  if (any_multi && *any_multi == 0u) return;       // no bucket was cut into 2..16 chunks (uniform scalars on one GPU): nothing to fold
   uint32_t b = blockIdx.x * 256 + threadIdx.x;
   if (b >= nb_total) return;
   const uint32_t c0 = choff[b], c1 = choff[b + 1];

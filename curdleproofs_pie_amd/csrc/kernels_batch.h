@@ -119,22 +119,24 @@ __global__ void __launch_bounds__(64) k_subgroup_flags(const uint32_t* __restric
   constexpr uint64_t ZABS = 0xd201000000010000ull;
   constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
   fp beta; for (int k = 0; k < NL; ++k) beta.l[k] = bt[k];
-  const xyzz P = xyzz_from_affine(x, y);
-  xyzz a = P;                                       // [|z|] P
-#pragma unroll 1
-  for (int bit = 62; bit >= 0; --bit) {
-    a = quad_dbl(a, q);
-    if ((ZABS >> bit) & 1ull) a = quad_add(a, P, q);
-  }
-  const xyzz Q = a;                                 // [|z|] Q
-#pragma unroll 1
-  for (int bit = 62; bit >= 0; --bit) {
-    a = quad_dbl(a, q);
-    if ((ZABS >> bit) & 1ull) a = quad_add(a, Q, q);
-  }
+  // acc = [|z|] [|z|] P - P - phi(P) as ONE loop with one quad_dbl and one quad_add call site (instruction cache, registers):
+  // steps 0..62 and 63..125: double, then add the pass's base (P, then Q = [|z|] P) where |z| has a one; steps 126, 127: add -P, -phi(P).
   const fp yneg = fp_norm(fp_neg<3>(y));
-  a = quad_add(a, xyzz_from_affine(x, yneg), q);                   // - P
-  a = quad_add(a, xyzz_from_affine(fp_mul(x, beta), yneg), q);     // - phi(P)
+  const fp bx = fp_mul(x, beta);
+  xyzz a = xyzz_from_affine(x, y), base = a;
+#pragma unroll 1
+  for (int step = 0; step < 128; ++step) {
+    bool add = true;
+    if (step < 126) {
+      if (step == 63) base = a;                    // second pass: the base is Q
+      const int bit = 62 - (step < 63 ? step : step - 63);
+      a = quad_dbl(a, q);
+      add = (ZABS >> bit) & 1ull;
+    } else {
+      base = xyzz_from_affine(step == 126 ? x : bx, yneg);
+    }
+    if (add) a = quad_add(a, base, q);
+  }
   if (q == 0) flags[t] = a.inf ? 0 : 1;
 }
 

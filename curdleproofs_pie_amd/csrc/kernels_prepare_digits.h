@@ -6,8 +6,10 @@
 // 96-B affine record -> 128-B Montgomery record.  A block moves its 256 records through LDS so that both the reads
 // (24.6 KB) and the writes (32 KB) are whole contiguous lines; a lane-strided access touched 64 lines per instruction
 // (3.5 TB/s effective; this kernel runs over ALL N * 2^20 points on every rank of a window-sharded MSM).
+// (also clears the call's status words -- the input-validation flag k_digits may set -- so no memset launch is needed)
 __global__ void __launch_bounds__(256) k_prepare_points(const uint32_t* __restrict__ raw, PreparedPoint* __restrict__ out,
-                                                        uint8_t* __restrict__ inf_flag, uint32_t n) {
+                                                        uint8_t* __restrict__ inf_flag, uint32_t n, uint32_t* __restrict__ status_words = nullptr) {
+  if (status_words && blockIdx.x == 0 && threadIdx.x < 4) status_words[threadIdx.x] = 0;
   __shared__ uint4 stage[256 * 8];                       // 32 KB: input (6 uint4 per record), then output (8 per record)
   const uint32_t base = blockIdx.x * 256u, t = threadIdx.x;
   const uint32_t cnt = (n - base < 256u) ? n - base : 256u;
@@ -41,13 +43,19 @@ __global__ void __launch_bounds__(256) k_prepare_points(const uint32_t* __restri
 }
 
 // ------------------------------------------------------------------ signed digit recoding
-// digit w of scalar s (LE words), window width c: value in [-(2^(c-1)-1), 2^(c-1)]
+// The 256 bit positions of a scalar are cut into nwin windows of widths width[w] <= cmax starting at bit off[w]
+// (uniform: width = c, off = c w; balanced plans mix cmax and cmax - 1 so that EVERY window keeps >= cmax - 2 scalar bits:
+// a thin top window would pile all n terms into a handful of buckets).  Digit w: value in [-(2^(width-1)-1), 2^(width-1)].
+struct WinPlan {
+  int nwin, cmax, n_hi;                  // windows 0 .. n_hi-1 have width cmax, the others cmax - 1 (uniform: n_hi = nwin)
+  CG1_HD int width(int w) const { return w < n_hi ? cmax : cmax - 1; }
+  CG1_HD int off(int w) const { return w < n_hi ? w * cmax : n_hi * cmax + (w - n_hi) * (cmax - 1); }
+};
 struct DigitIter {
   uint32_t s[8];
   uint32_t carry;
-  int c;
-  __device__ __forceinline__ int next(int w) {         // must be called for w = 0,1,2,... in order
-    int bit = w * c;
+  __device__ __forceinline__ int next(const WinPlan& pl, int w) {         // must be called for w = 0,1,2,... in order
+    const int bit = pl.off(w), c = pl.width(w);
     uint32_t wi = bit >> 5, sh = bit & 31;
     uint64_t v = (wi < 8) ? s[wi] : 0u;
     if (wi + 1 < 8) v |= (uint64_t)s[wi + 1] << 32;
@@ -58,7 +66,6 @@ struct DigitIter {
     return (int)d;
   }
 };
-
 __device__ __forceinline__ void load_scalar(const uint32_t* scalars, uint32_t i, DigitIter& it) {
   const uint4* q = reinterpret_cast<const uint4*>(scalars + 8ull * i);
   uint4 a = q[0], b = q[1];
@@ -69,17 +76,17 @@ __device__ __forceinline__ void load_scalar(const uint32_t* scalars, uint32_t i,
 
 // counts per (local window, bucket); skips zero digits and identity points
 __global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
-                                              uint32_t* __restrict__ hist, uint32_t n, int c, int nwin, int rank, int world,
+                                              uint32_t* __restrict__ hist, uint32_t n, WinPlan pl, int rank, int world,
                                               uint32_t* __restrict__ bad_flag) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   if (inf_flag[i]) return;
-  DigitIter it; it.c = c;
+  DigitIter it;
   load_scalar(scalars, i, it);
   if (it.s[7] >> 31) *bad_flag = 1u;
-  const uint32_t NB = 1u << (c - 1);
-  for (int w = 0; w < nwin; ++w) {
-    int d = it.next(w);
+  const uint32_t NB = 1u << (pl.cmax - 1);
+  for (int w = 0; w < pl.nwin; ++w) {
+    int d = it.next(pl, w);
     if (d == 0 || (w % world) != rank) continue;
     uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
     atomicAdd(&hist[(uint32_t)(w / world) * NB + b], 1u);
@@ -88,15 +95,15 @@ __global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scala
 
 __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
                                                  uint32_t* __restrict__ cursor, const uint32_t* __restrict__ off,
-                                                 uint32_t* __restrict__ sorted, uint32_t n, int c, int nwin, int rank, int world) {
+                                                 uint32_t* __restrict__ sorted, uint32_t n, WinPlan pl, int rank, int world) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   if (inf_flag[i]) return;
-  DigitIter it; it.c = c;
+  DigitIter it;
   load_scalar(scalars, i, it);
-  const uint32_t NB = 1u << (c - 1);
-  for (int w = 0; w < nwin; ++w) {
-    int d = it.next(w);
+  const uint32_t NB = 1u << (pl.cmax - 1);
+  for (int w = 0; w < pl.nwin; ++w) {
+    int d = it.next(pl, w);
     if (d == 0 || (w % world) != rank) continue;
     uint32_t key = (uint32_t)(w / world) * NB + (uint32_t)(d < 0 ? -d : d) - 1u;
     uint32_t slot = atomicSub(&cursor[key], 1u) - 1u;      // cursor starts at the bucket's count

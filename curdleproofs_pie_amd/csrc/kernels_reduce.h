@@ -149,6 +149,62 @@ __global__ void __launch_bounds__(256, 2) k_rowcol(const uint32_t* __restrict__ 
   }
 }
 
+// Quad-lane k_bucket_fold for small bucket counts (same regime as k_rowcol_quad): one DPP quad per bucket adds the bucket's
+// 2..16 chunk sums into its first slot (balanced plans of mid-size inputs cut every bucket into a few short chunks so that
+// the madd chains of k_accumulate stay short; a lone lane needs ~26 us per addition, a quad ~10).
+__global__ void __launch_bounds__(256, 2) k_bucket_fold_quad(const uint32_t* __restrict__ choff, PointSum* __restrict__ sums,
+                                                             uint8_t* __restrict__ combined, uint32_t nb_total,
+                                                             const uint32_t* __restrict__ any_multi) {
+  if (*any_multi == 0u) return;
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x, b = t >> 2, q = t & 3u;
+  if (b >= nb_total) return;                               // whole quads leave together
+  const uint32_t c0 = choff[b], c1 = choff[b + 1];
+  if (c1 - c0 < 2u || c1 - c0 >= HEAVY_MIN_CHUNKS) return;
+  xyzz acc = load_sum(sums + c0);
+#pragma unroll 1
+  for (uint32_t k = c0 + 1; k < c1; ++k) acc = quad_add(acc, load_sum(sums + k), q);
+  if (q == 0) { store_sum(sums + c0, acc); combined[b] = 1; }
+}
+
+// Quad-lane variant of k_rowcol for SMALL bucket counts (balanced plans of mid-size inputs: <= 2^18 buckets), where the
+// reduction is bound by its chain of dependent EC additions (~26 us each in one lane of a lone wave), not by throughput:
+// ONE WAVE per row / column, its 16 DPP quads take the elements p, p + 16, ... (each addition shared by the 4 lanes of a
+// quad, g1_quad.h: ~2.6x shorter), then four quad-shuffle levels.  Same results as k_rowcol.
+__global__ void __launch_bounds__(256, 2) k_rowcol_quad(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+                                                        PointSum* __restrict__ rowsum, PointSum* __restrict__ colsum,
+                                                        uint32_t nlw, uint32_t hb, uint32_t lb) {
+  const uint32_t R = 1u << hb, Cn = 1u << lb;
+  const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u, q = lane & 3u, p = lane >> 2;
+  const uint32_t nrows = nlw * R, ncols = nlw * Cn;
+  if (gw >= nrows + ncols) return;                          // whole waves leave together
+  // element i of this row / column is bucket first + i * stride, i < len
+  uint32_t first, stride, len;
+  if (gw < nrows) { first = gw * Cn; stride = 1u; len = Cn; }
+  else { const uint32_t gc = gw - nrows, lw = gc / Cn, l = gc % Cn; first = lw * R * Cn + l; stride = Cn; len = R; }
+  const uint32_t nser = (len + 15u) >> 4;                   // serial elements per quad (wave-uniform)
+  xyzz acc = xyzz_identity();
+  // ONE quad_add call site for the serial steps and the four shuffle levels (the kernel must stay inside the instruction
+  // cache and under 256 registers).  k_bucket_fold / k_heavy_combine ran before: a non-empty bucket's sum is its first slot.
+#pragma unroll 1
+  for (uint32_t step = 0; step < nser + 4u; ++step) {
+    xyzz o;
+    bool go;
+    if (step < nser) {
+      const uint32_t i = p + 16u * step;
+      const uint32_t b = first + (i < len ? i : 0u) * stride;
+      const uint32_t c0 = choff[b];
+      go = i < len && choff[b + 1] > c0;
+      o = load_sum(sums + c0);                               // (a valid address even for an empty bucket: the next bucket's slot or the pad)
+    } else {
+      const uint32_t dq = 8u >> (step - nser);
+      o = shfl_down_xyzz(acc, (int)(4u * dq));
+      go = p < dq;
+    }
+    if (go) acc = quad_add(acc, o, q);
+  }
+  if (lane == 0) store_sum(gw < nrows ? rowsum + gw : colsum + (gw - nrows), acc);
+}
+
 // grid = (1 + hb + lb, nlw), 256 threads.  item 0: T0 = sum_h A_h; item 1+k (k < hb): sum of A_h with bit k of h set;
 // item 1+hb+k (k < lb): sum of C_l with bit k of l set.  Requires 2^hb, 2^lb <= 256.  Emits canonical words.
 __global__ void __launch_bounds__(256) k_small_tree(const PointSum* __restrict__ rowsum, const PointSum* __restrict__ colsum,

@@ -42,16 +42,16 @@ __device__ __forceinline__ uint32_t lds_ranked_inc(uint32_t* ctr, uint32_t key, 
 }
 
 __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ scalars, const uint8_t* __restrict__ inf_flag,
-                                                uint16_t* __restrict__ digits, uint32_t n, int c, int nwin, int rank, int world,
+                                                uint16_t* __restrict__ digits, uint32_t n, WinPlan pl, int rank, int world,
                                                 uint32_t* __restrict__ bad_flag) {
   uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const bool inf = inf_flag[i] != 0;
-  DigitIter it; it.c = c;
+  DigitIter it;
   load_scalar(scalars, i, it);
   if (it.s[7] >> 31) *bad_flag = 1u;              // >= 2^255: the signed-digit recoding would carry out of the top window
-  for (int w = 0; w < nwin; ++w) {
-    int d = it.next(w);
+  for (int w = 0; w < pl.nwin; ++w) {
+    int d = it.next(pl, w);
     if ((w % world) != rank) continue;
     digits[(size_t)(w / world) * n + i] = inf ? (uint16_t)0 : (uint16_t)(d & 0xFFFF);
   }
@@ -531,7 +531,7 @@ __device__ __forceinline__ uint32_t len_key(uint32_t len) { return len < LEN_BIN
 __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__ off, const uint32_t* __restrict__ choff,
                                                     uint2* __restrict__ desc, uint32_t* __restrict__ len_hist,
                                                     uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
-                                                    uint32_t heavy_cap, uint32_t nb_total, uint32_t L0) {
+                                                    uint32_t heavy_cap, uint32_t nb_total, uint32_t L0, uint32_t* __restrict__ any_multi = nullptr) {
   __shared__ uint32_t sh[LEN_BINS];
   sh[threadIdx.x] = 0;
   __syncthreads();
@@ -548,6 +548,8 @@ __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__
       if (nch >= HEAVY_MIN_CHUNKS) {
         uint32_t slot = atomicAdd(&heavy[0], 1u);
         if (slot < heavy_cap) heavy[1 + slot] = b;
+      } else if (nch >= 2u && any_multi) {
+        *any_multi = 1u;                 // k_bucket_fold has work (benign race: every writer stores 1)
       }
     }
   }

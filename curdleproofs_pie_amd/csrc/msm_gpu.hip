@@ -35,13 +35,18 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
-#include <future>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
 #include "g1_xyzz.h"
 #include "g1_quad.h"
 #include "host_g1.h"
 #include "../../include/curdle_g1.h"
 
 namespace cg1 {
+
+int pick_window(size_t n);
 
 #include "kernels_records.h"
 #include "kernels_prepare_digits.h"
@@ -54,8 +59,47 @@ namespace cg1 {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
   snprintf(ctx->err, sizeof ctx->err, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); return CG1_ERR_HIP; } } while (0)
 
+// One persistent helper thread per context for the second half of the host Horner tail (a std::async per call paid a
+// thread creation, ~40 us, on a ~150 us tail).
+struct Helper {
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::function<void()> job;
+  bool has = false, done = true, quit = false;
+  void run(std::function<void()> f) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (!th.joinable()) th = std::thread([this]() { loop(); });
+    job = std::move(f); has = true; done = false;
+    cv.notify_all();
+  }
+  void wait() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this]() { return done; });
+  }
+  void loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    for (;;) {
+      cv.wait(lk, [this]() { return has || quit; });
+      if (quit) return;
+      std::function<void()> f = std::move(job);
+      has = false;
+      lk.unlock();
+      f();
+      lk.lock();
+      done = true;
+      cv.notify_all();
+    }
+  }
+  ~Helper() {
+    { std::unique_lock<std::mutex> lk(mu); quit = true; cv.notify_all(); }
+    if (th.joinable()) th.join();
+  }
+};
+
 struct Ctx {
   int device = 0;
+  Helper helper;
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;    // H2D staging copies that overlap kernels on `stream` (cg1_h2d_async / cg1_copy_fence)
   hipEvent_t copy_ev = nullptr;
@@ -70,7 +114,10 @@ struct Ctx {
   uint8_t* d_flags = nullptr;
   uint32_t *d_hist = nullptr, *d_off = nullptr, *d_choff = nullptr, *d_sorted = nullptr;
   uint2 *d_blocktot = nullptr, *d_desc = nullptr;
-  uint32_t *d_order = nullptr, *d_lenhist = nullptr;      // [2*LEN_BINS]: histogram, cursor
+  uint32_t *d_order = nullptr, *d_lenhist = nullptr;      // [2*LEN_BINS]: histogram, cursor  (points into d_zblock)
+  // one block cleared by ONE memset per call: chunk-length histogram | any_multi flag | combined[] bytes | heavy count (+ ids)
+  uint32_t* d_zblock = nullptr; size_t cap_zblock = 0;
+  uint32_t* d_any_multi = nullptr;
   PointSum* d_partial = nullptr; size_t cap_partial = 0;
   uint16_t* d_digits = nullptr; uint32_t* d_part = nullptr; uint32_t* d_blockcnt = nullptr; uint32_t* d_ublocktot = nullptr;
   size_t cap_digits = 0, cap_part = 0, cap_blockcnt = 0;
@@ -80,9 +127,12 @@ struct Ctx {
   int use_partition_sort = 1;
   int stage_sort = 1;                   // LDS-staged, line-coalesced writes in k_part_scatter / k_bin_sort (A/B switch)
   int host_split = 1;                   // host Horner tail on two threads (A/B switch)
+  int rowcol_quad = 1;                  // k_rowcol_quad for small bucket counts (A/B switch)
+  int auto_plan = 1;                    // window_c = 0 picks balanced window plans for mid-size inputs (A/B switch)
   struct Pending {                      // what msm_finish needs from msm_enqueue
     bool active = false;
     int c = 0, rank = 0, world = 1, nlw = 0, nbits = 0;
+    WinPlan plan;
     uint32_t m = 1, lb2 = 0, hb2 = 0, nitems = 0;
     bool use2d = true;
     size_t nout_words = 0;
@@ -116,7 +166,8 @@ struct Ctx {
 static void free_bufs(Ctx* c) {
   auto F = [](auto*& p) { if (p) { (void)hipFree(p); p = nullptr; } };
   F(c->d_pts); F(c->d_flags); F(c->d_hist); F(c->d_off); F(c->d_choff); F(c->d_sorted); F(c->d_blocktot); F(c->d_desc);
-  F(c->d_sums); F(c->d_segrun); F(c->d_segtot); F(c->d_out); F(c->d_order); F(c->d_lenhist); F(c->d_partial);
+  F(c->d_sums); F(c->d_segrun); F(c->d_segtot); F(c->d_out); F(c->d_order); F(c->d_zblock); F(c->d_partial);
+  c->d_lenhist = c->d_heavy = c->d_any_multi = nullptr; c->d_combined = nullptr; c->cap_zblock = 0; c->cap_heavy = 0; c->cap_combined = 0;
   c->cap_partial = 0;
   F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot); F(c->d_boffs); F(c->d_gsum); F(c->d_bout);
   F(c->d_slice_base); F(c->d_slicehist); F(c->d_subbase); F(c->d_bigflag); c->cap_bigflag = 0; c->cap_slices = 0;
@@ -162,19 +213,23 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
     HIPCHK(hipMalloc(&ctx->d_sums, chunks * sizeof(PointSum)));
     ctx->cap_chunks = chunks;
   }
-  if (!ctx->d_lenhist) HIPCHK(hipMalloc(&ctx->d_lenhist, 2 * LEN_BINS * 4));
   {
+    // [lenhist 2*LEN_BINS words][any_multi][combined: nb_total bytes][heavy count][heavy ids]: the call clears everything up to
+    // and including the heavy count with one memset
     const size_t hcap = entries / ((size_t)L * (HEAVY_MIN_CHUNKS - 1)) + 2;     // a heavy bucket holds > (MIN-1)*L entries
-    if (hcap > ctx->cap_heavy) {
-      if (ctx->d_heavy) (void)hipFree(ctx->d_heavy);
-      HIPCHK(hipMalloc(&ctx->d_heavy, (hcap + 1) * 4));
-      ctx->cap_heavy = hcap;
+    const size_t z0 = 2 * LEN_BINS + 1, h0 = z0 + (nb_total + 3) / 4, words = h0 + 1 + hcap + 64;     // (+64: room for the 256-byte round-up of the per-call memset)
+    if (words > ctx->cap_zblock) {
+      if (ctx->d_zblock) (void)hipFree(ctx->d_zblock);
+      ctx->d_zblock = nullptr; ctx->cap_zblock = 0;
+      HIPCHK(hipMalloc(&ctx->d_zblock, words * 4));
+      ctx->cap_zblock = words;
     }
-    if (nb_total > ctx->cap_combined) {
-      if (ctx->d_combined) (void)hipFree(ctx->d_combined);
-      HIPCHK(hipMalloc(&ctx->d_combined, nb_total));
-      ctx->cap_combined = nb_total;
-    }
+    ctx->d_lenhist = ctx->d_zblock;
+    ctx->d_any_multi = ctx->d_zblock + 2 * LEN_BINS;
+    ctx->d_combined = reinterpret_cast<uint8_t*>(ctx->d_zblock + z0);
+    ctx->d_heavy = ctx->d_zblock + h0;
+    ctx->cap_heavy = hcap;
+    ctx->cap_combined = nb_total;
   }
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
     const size_t nslices = (n + PART_TILE - 1) / PART_TILE;
@@ -229,6 +284,15 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
   return CG1_OK;
 }
 
+// bytes of d_zblock the per-call memset clears: everything up to and including the heavy-bucket count, rounded up to 256 B
+// (one fill kernel instead of an aligned body + a tail; the heavy ids it may touch are written later by k_chunk_desc)
+static size_t zblock_clear_bytes(const Ctx* ctx) {
+  size_t bytes = (size_t)((ctx->d_heavy + 1) - ctx->d_zblock) * 4;
+  bytes = (bytes + 255) & ~(size_t)255;
+  const size_t cap = ctx->cap_zblock * 4;
+  return bytes < cap ? bytes : cap;
+}
+
 static cg1h::fe fe_from_words12(const uint32_t w[12]) {     // already canonical and in the host's Montgomery form
   cg1h::fe r;
   for (int i = 0; i < 6; ++i) r.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
@@ -237,6 +301,27 @@ static cg1h::fe fe_from_words12(const uint32_t w[12]) {     // already canonical
 static cg1h::jac jac_from_words(const PointWords& p) {
   if (p.inf) return cg1h::jac_identity();
   return cg1h::jac_from_xyzz(fe_from_words12(p.w[0]), fe_from_words12(p.w[1]), fe_from_words12(p.w[2]), fe_from_words12(p.w[3]));
+}
+
+// c > 0: uniform windows of width c (nwin = 255 / c + 1).  c < 0: a BALANCED plan with cmax = -c: the 256 bit positions
+// are cut into nwin = ceil(256 / cmax) windows of width cmax (the low ones) or cmax - 1, so the top window keeps
+// >= cmax - 2 scalar bits and the recoding carry never leaves it (scalars are < 2^255).
+static WinPlan make_plan(int c) {
+  WinPlan pl;
+  if (c > 0) { pl.cmax = c; pl.nwin = 255 / c + 1; pl.n_hi = pl.nwin; }
+  else { const int cm = -c, nw = (256 + cm - 1) / cm; pl.cmax = cm; pl.nwin = nw; pl.n_hi = 256 - nw * (cm - 1); }
+  return pl;
+}
+
+// window_c = 0: the plan per input size (tools/gpu_window_sweep.py on MI355X).  The 2-D bucket reduction costs two EC additions
+// per BUCKET, the accumulation one per (term, window): mid-size inputs want fewer, fuller buckets than c = 16 gives them.
+static int pick_plan_c(size_t n, int auto_plan) {
+  const int c = pick_window(n);
+  if (!auto_plan || c != 16) return c;
+  if (n <= (1u << 14)) return -12;
+  if (n <= (3u << 15)) return -13;
+  if (n <= (3u << 16)) return -15;
+  return 16;
 }
 
 int pick_window(size_t n) {
@@ -259,12 +344,12 @@ static int wait_stream(Ctx* ctx) {
   return CG1_OK;
 }
 
-// Enqueue the whole launch chain of this context's share of an MSM (windows w = rank mod world) up to the D2H of the
-// window sums; nothing waits.
-static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world) {
+// Enqueue the whole launch chain of this context's share of an MSM (windows w = rank mod world of the plan) up to the D2H of
+// the window sums; nothing waits.
+static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, const WinPlan& plan, int rank, int world) {
   ctx->pend.active = false;
   HIPCHK(hipSetDevice(ctx->device));
-  const int nwin = 255 / c + 1;
+  const int c = plan.cmax, nwin = plan.nwin;
   const int nlw = (nwin - rank + world - 1) / world;           // windows w = rank, rank+world, ...
   if (nlw <= 0) return CG1_OK;
   const uint32_t NB = 1u << (c - 1);
@@ -289,20 +374,18 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   auto h0 = std::chrono::steady_clock::now();
   const PreparedPoint* pts = ctx->d_pts;
   const uint8_t* flags = ctx->d_flags;
-  HIPCHK(hipEventRecord(ctx->ev[0], st));
-  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32);
-  HIPCHK(hipEventRecord(ctx->ev[1], st));
   const size_t nout_words = (size_t)nlw * nitems;
-  uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // set by the digit kernels: a scalar >= 2^255
-  HIPCHK(hipMemsetAsync(bad_flag, 0, 4, st));
+  uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // [0] set by the digit kernels: a scalar >= 2^255; [1], [2]: counts
+  HIPCHK(hipEventRecord(ctx->ev[0], st));
+  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32, bad_flag);
+  HIPCHK(hipEventRecord(ctx->ev[1], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
     // ---- two-level partition sort: no global atomics
-    const uint32_t bb = (uint32_t)c - 1u;                       // bucket bits
     const uint32_t sub_bits = bb < 8u ? bb : 8u, nbins = 1u << (bb - sub_bits);
     const uint32_t nslices = (n32 + PART_TILE - 1) / PART_TILE;
     const uint32_t nbc = (uint32_t)nlw * nbins * nslices;
-    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_digits, n32, c, nwin, rank, world, bad_flag);
+    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_digits, n32, plan, rank, world, bad_flag);
     hipLaunchKernelGGL(k_part_count, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, n32, nslices, nbins, sub_bits);
     const uint32_t ublk = (nbc + SCAN_ITEMS - 1) / SCAN_ITEMS;
     hipLaunchKernelGGL(k_uscan1, dim3(ublk), dim3(256), 0, st, ctx->d_blockcnt, ctx->d_ublocktot, nbc);
@@ -326,18 +409,17 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   } else {
     // ---- global-atomic counting sort (any n < 2^31)
     HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
-    hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, n32, c, nwin, rank, world, bad_flag);
+    hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, n32, plan, rank, world, bad_flag);
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     HIPCHK(hipEventRecord(ctx->ev[3], st));
-    hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, c, nwin, rank, world);
+    hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, plan, rank, world);
   }
-  HIPCHK(hipMemsetAsync(ctx->d_lenhist, 0, LEN_BINS * 4, st));
-  HIPCHK(hipMemsetAsync(ctx->d_heavy, 0, 4, st));
-  HIPCHK(hipMemsetAsync(ctx->d_combined, 0, nb_total, st));
-  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0);
+  // one memset: chunk-length histogram, the any_multi flag, combined[] and the heavy-bucket count (ensure() laid them out together)
+  HIPCHK(hipMemsetAsync(ctx->d_zblock, 0, zblock_clear_bytes(ctx), st));
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0, ctx->d_any_multi);
   const size_t max_chunks = nb_total + (n * (size_t)nlw) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
@@ -346,7 +428,11 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, pts, ctx->d_sums);
   HIPCHK(hipEventRecord(ctx->ev[5], st));
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
-  hipLaunchKernelGGL(k_bucket_fold, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total);
+  const bool small_quad = ctx->quad && ctx->rowcol_quad && nb_total <= (1u << 18);      // latency-bound regime: every addition by a quad
+  if (small_quad)
+    hipLaunchKernelGGL(k_bucket_fold_quad, dim3((uint32_t)((nb_total * 4 + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);
+  else
+    hipLaunchKernelGGL(k_bucket_fold, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);
   if (use2d) {
     const uint32_t R = 1u << hb2, Cn = 1u << lb2;
     const uint32_t lpr = Cn < 32u ? Cn : 32u, lpc = R < 16u ? R : 16u;
@@ -354,8 +440,12 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     const uint32_t ncol_blocks = ((uint32_t)nlw * Cn + (256u / lpc) - 1u) / (256u / lpc);
     PointSum* rowsum = ctx->d_segrun;                     // reuse the segment buffers (>= nb_total records each)
     PointSum* colsum = ctx->d_segtot;
-    hipLaunchKernelGGL(k_rowcol, dim3(nrow_blocks + ncol_blocks), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
-                       rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks, ctx->quad);
+    if (small_quad)
+      hipLaunchKernelGGL(k_rowcol_quad, dim3(((uint32_t)nlw * (R + Cn) + 3u) / 4u), dim3(256), 0, st, ctx->d_choff, ctx->d_sums,
+                         rowsum, colsum, (uint32_t)nlw, hb2, lb2);
+    else
+      hipLaunchKernelGGL(k_rowcol, dim3(nrow_blocks + ncol_blocks), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
+                         rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks, ctx->quad);
     HIPCHK(hipEventRecord(ctx->ev[6], st));
     if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(512), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
     else hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
@@ -371,7 +461,7 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
   Ctx::Pending& pd = ctx->pend;
-  pd.active = true; pd.c = c; pd.rank = rank; pd.world = world; pd.nlw = nlw; pd.nbits = nbits; pd.m = m; pd.lb2 = lb2; pd.hb2 = hb2;
+  pd.active = true; pd.c = c; pd.plan = plan; pd.rank = rank; pd.world = world; pd.nlw = nlw; pd.nbits = nbits; pd.m = m; pd.lb2 = lb2; pd.hb2 = hb2;
   pd.nitems = nitems; pd.use2d = use2d; pd.nout_words = nout_words; pd.h0 = h0; pd.h1 = h1;
   return CG1_OK;
 }
@@ -383,6 +473,7 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   const Ctx::Pending pd = ctx->pend;
   ctx->pend.active = false;
   const int c = pd.c, rank = pd.rank, world = pd.world, nlw = pd.nlw, nbits = pd.nbits;
+  (void)c;
   const uint32_t m = pd.m, lb2 = pd.lb2, hb2 = pd.hb2, nitems = pd.nitems;
   const bool use2d = pd.use2d;
   const size_t nout_words = pd.nout_words;
@@ -404,44 +495,62 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   ctx->last_c = c;
 
   // ---- host tail: ONE Horner over global bit positions.
-  //   result = sum_w 2^(c w) [ T_w + m * sum_b 2^b Y_{w,b} ] = sum over points P with weight 2^e(P),
-  //   e(T_w) = c w,  e(Y_{w,b}) = c w + log2(m) + b  (< c (w+1) since log2(m) + nbits = c - 1).
+  //   result = sum over the exported points P of 2^e(P) P, with (window w of the plan starts at bit off[w]):
+  //   2-D reduction:  e(T0_w) = off[w];  e(column bit k) = off[w] + k (k < lb);  e(row bit k) = off[w] + lb + k (k < hb)
+  //   1-D fallback:   e(T_w) = off[w];   e(Y_{w,b}) = off[w] + log2(m) + b
+  // (a window narrower than cmax leaves its top row bits empty: their points are the identity and are skipped)
   auto t0 = std::chrono::steady_clock::now();
   ctx->host_ms[0] = std::chrono::duration<float, std::milli>(h1 - h0).count();
   ctx->host_ms[1] = std::chrono::duration<float, std::milli>(h2 - h1).count();
   ctx->host_ms[2] = std::chrono::duration<float, std::milli>(t0 - h2).count();
   int lm = 0; while ((1u << lm) < m) ++lm;
-  const int top_w = rank + (nlw - 1) * world;
+  const WinPlan& plan = pd.plan;
+  constexpr int EMAX = 2 * 256 + 64;
+  std::vector<std::pair<int, const PointWords*>> items;          // (exponent, point), then grouped by exponent
+  items.reserve((size_t)nlw * nitems);
+  int e_top = 0;
+  for (int lw = 0; lw < nlw; ++lw) {
+    const int w = rank + lw * world, base = plan.off(w);
+    const PointWords* row = ctx->h_out + (size_t)lw * nitems;
+    auto put = [&](int e, const PointWords* p) { if (!p->inf) { items.emplace_back(e, p); if (e > e_top) e_top = e; } };
+    put(base, &row[0]);
+    if (use2d) {
+      for (uint32_t k = 0; k < hb2; ++k) put(base + (int)lb2 + (int)k, &row[1 + k]);
+      for (uint32_t k = 0; k < lb2; ++k) put(base + (int)k, &row[1 + hb2 + k]);
+    } else {
+      for (int b2 = 0; b2 < nbits; ++b2) put(base + lm + b2, &row[1 + b2]);
+    }
+  }
+  uint16_t first[EMAX + 1];                                       // counting sort by exponent
+  memset(first, 0, sizeof first);
+  for (const auto& it : items) ++first[it.first + 1];
+  for (int e = 0; e < EMAX; ++e) first[e + 1] = (uint16_t)(first[e + 1] + first[e]);
+  std::vector<const PointWords*> byexp(items.size());
+  {
+    uint16_t cur[EMAX];
+    memcpy(cur, first, sizeof cur);
+    for (const auto& it : items) byexp[cur[it.first]++] = it.second;
+  }
   // horner(lo, hi) = sum_{e in [lo, hi]} 2^(e - lo) * (points of weight 2^e)
   auto horner = [&](int lo, int hi) {
     cg1h::jac a = cg1h::jac_identity();
     for (int e = hi; e >= lo; --e) {
       a = cg1h::jac_dbl(a);
-      const int w = e / c, r = e % c;
-      if (w % world != rank) continue;
-      const PointWords* row = ctx->h_out + (size_t)(w / world) * nitems;
-      if (r == 0) a = cg1h::jac_add(a, jac_from_words(row[0]));
-      if (use2d) {
-        //   e(T0) = c w;  e(column bit k) = c w + k (k < lb);  e(row bit k) = c w + lb + k (k < hb)
-        if (r < (int)lb2) a = cg1h::jac_add(a, jac_from_words(row[1 + hb2 + r]));
-        else if (r - (int)lb2 < (int)hb2) a = cg1h::jac_add(a, jac_from_words(row[1 + (r - lb2)]));
-      } else {
-        //   e(T_w) = c w;  e(Y_{w,b}) = c w + log2(m) + b
-        if (r >= lm && r - lm < nbits) a = cg1h::jac_add(a, jac_from_words(row[1 + (r - lm)]));
-      }
+      for (uint16_t k = first[e]; k < first[e + 1]; ++k) a = cg1h::jac_add(a, jac_from_words(*byexp[k]));
     }
     return a;
   };
-  const int e_top = c * top_w + c - 2;
   cg1h::jac acc;
   if (ctx->host_split && e_top >= 96) {
-    // two host threads: the low half of the exponent range on a helper while this thread does the high half and
-    // then its e_mid doublings (255 doublings + 129 additions on the critical path instead of 255 + 256)
+    // two host threads: the low half of the exponent range on the context's helper thread while this thread does the high
+    // half and then its e_mid doublings (255 doublings + 129 additions on the critical path instead of 255 + 256)
     const int e_mid = (e_top + 1) / 2;
-    auto low = std::async(std::launch::async, horner, 0, e_mid - 1);
+    cg1h::jac low;
+    ctx->helper.run([&]() { low = horner(0, e_mid - 1); });
     acc = horner(e_mid, e_top);
     for (int k = 0; k < e_mid; ++k) acc = cg1h::jac_dbl(acc);
-    acc = cg1h::jac_add(acc, low.get());
+    ctx->helper.wait();
+    acc = cg1h::jac_add(acc, low);
   } else {
     acc = horner(0, e_top);
   }
@@ -452,16 +561,21 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
 }
 
 // One MSM: this context's share (windows w = rank mod world) of sum_i scalar_i * point_i.
+// c = 0: automatic plan; 4..16: uniform windows of that width; -16..-4: the balanced plan with cmax = -c.
 int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
   result = cg1h::jac_identity();
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "n too large"); return CG1_ERR_ARG; }
   if (world < 1 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
-  if (c <= 0) c = pick_window(n);
-  if (c < 4 || c > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
-  int rc = msm_enqueue(ctx, d_points96, d_scalars32, n, c, rank, world);
+  if (c == 0) c = pick_plan_c(n, ctx->auto_plan);
+  const int cabs = c < 0 ? -c : c;
+  if (cabs < 4 || cabs > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
+  const WinPlan plan = make_plan(c);
+  int rc = msm_enqueue(ctx, d_points96, d_scalars32, n, plan, rank, world);
   if (rc) return rc;
-  return msm_finish(ctx, result);
+  rc = msm_finish(ctx, result);
+  ctx->last_c = c;                                   // negative: a balanced plan (cg1_get_timings reports it)
+  return rc;
 }
 
 
@@ -528,11 +642,10 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   auto h0 = std::chrono::steady_clock::now();
   HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, st));
   HIPCHK(hipEventRecord(ctx->ev[0], st));
-  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, N32);
-  HIPCHK(hipEventRecord(ctx->ev[1], st));
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_bout + M);
-  HIPCHK(hipMemsetAsync(bad_flag, 0, 4, st));
-  hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, N32, c, (int)nwin, 0, 1, bad_flag);
+  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, N32, bad_flag);
+  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, N32, make_plan(c), 0, 1, bad_flag);
   hipLaunchKernelGGL(k_group_count, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_hist, N32, NB, nwin);
   HIPCHK(hipEventRecord(ctx->ev[2], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
@@ -541,10 +654,8 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
   hipLaunchKernelGGL(k_group_scatter, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_off, ctx->d_sorted, N32, NB, nwin);
   HIPCHK(hipEventRecord(ctx->ev[3], st));
-  HIPCHK(hipMemsetAsync(ctx->d_lenhist, 0, LEN_BINS * 4, st));
-  HIPCHK(hipMemsetAsync(ctx->d_heavy, 0, 4, st));
-  HIPCHK(hipMemsetAsync(ctx->d_combined, 0, nb_total, st));
-  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0);
+  HIPCHK(hipMemsetAsync(ctx->d_zblock, 0, zblock_clear_bytes(ctx), st));
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0, ctx->d_any_multi);
   const size_t max_chunks = nb_total + (N * (size_t)nwin) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
@@ -794,6 +905,8 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "blocking_sync")) { ctx->blocking_sync = value != 0; return CG1_OK; }
   if (!strcmp(name, "big_bins")) { ctx->big_bins = value != 0; return CG1_OK; }
   if (!strcmp(name, "host_split")) { ctx->host_split = value != 0; return CG1_OK; }
+  if (!strcmp(name, "auto_plan")) { ctx->auto_plan = value != 0; return CG1_OK; }
+  if (!strcmp(name, "rowcol_quad")) { ctx->rowcol_quad = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
     int v = value ? 1 : 0;
     HIPCHK(hipSetDevice(ctx->device));

@@ -90,7 +90,8 @@ int  cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value);   /* "chunk_l
 int cg1_msm(cg1_ctx* ctx, const uint8_t* points_affine96, const uint8_t* scalars32, size_t n,
             uint8_t out[CG1_POINT_BYTES]);
 /* Same with inputs already resident in device memory (hipMalloc / cg1_dev_malloc / a torch tensor's
- * data_ptr).  window_c: bucket window width 4..16, 0 = choose from n.
+ * data_ptr).  window_c: 4..16 = uniform signed-digit windows of that width; -16..-4 = the balanced plan with cmax = -window_c
+ * (ceil(256 / cmax) windows of width cmax or cmax - 1, so no window is thin); 0 = choose from n.
  * (shard_rank, shard_world): this call sums only windows w = shard_rank (mod shard_world) and returns
  * sum_w 2^(c w) S_w for those -- the per-GPU partial of a window-sharded MSM; (0,1) = the whole MSM.
  * window_c must then be the same on every rank. */

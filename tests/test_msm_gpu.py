@@ -43,7 +43,7 @@ def test_golden_vectors(native_lib, ctx, golden):
         n = len(pts)
         p96 = b"".join(raw96(p) for p in pts)
         s32 = b"".join(bytes.fromhex(h) for h in case["scalars"])
-        for c in (0, 5, 16):
+        for c in (0, 5, 16, -13, -7):         # automatic plan, uniform widths, balanced plans (cmax = 13 / 7)
             assert gpu_msm(native_lib, ctx, p96, s32, n, window_c=c).hex() == case["expected"], (case["name"], c)
         # host-pointer entry point (what compute_MSM uses)
         assert compress_blob(native_lib, ctx.msm_host(p96, s32, n)).hex() == case["expected"], case["name"]
@@ -53,7 +53,7 @@ def test_empty(native_lib, ctx):
     assert gpu_msm(native_lib, ctx, b"", b"", 0) == bytes([0xC0]) + bytes(47)
 
 
-@pytest.mark.parametrize("logn,c", [(10, 0), (10, 7), (12, 0), (12, 12), (12, 16)])
+@pytest.mark.parametrize("logn,c", [(10, 0), (10, 7), (12, 0), (12, 12), (12, 16), (12, -12), (12, -14), (10, -16), (10, -4)])
 def test_seeded_random_vs_naive_oracle(native_lib, ctx, logn, c):
     """Same seeded inputs through the reference algorithm (naive double-and-add loop, C oracle)."""
     rng = random.Random(1000 + logn)
@@ -83,7 +83,7 @@ def test_window_sharding_partials_sum_to_full(native_lib, ctx):
     want = C.compress(C.compute_msm(p96, s32, n))
     dp, ds = ctx.alloc(96 * n), ctx.alloc(32 * n)
     dp.upload(p96); ds.upload(s32)
-    for world, c in ((2, 8), (3, 9), (8, 16), (4, 0)):
+    for world, c in ((2, 8), (3, 9), (8, 16), (4, 0), (3, -13), (8, -12), (5, -15)):
         cc = c or 10
         acc = ctypes.create_string_buffer(N.POINT_BYTES)
         N.cg1_identity(acc)
@@ -255,13 +255,13 @@ def test_pipeline_variants_agree(native_lib, golden):
         want = C.compress(C.compute_msm(p96, s32, n))
         for params in ({"partition_sort": 0}, {"chunk_len": 1}, {"chunk_len": 7}, {"chunk_len": 4096}, {"seg_m": 1},
                        {"seg_m": 2}, {"seg_m": 16}, {"wave_agg": 0}, {"stage_sort": 0}, {"host_split": 0}, {"big_bins": 0}, {"partition_sort": 0, "chunk_len": 3, "seg_m": 8},
-                       {"reduce_2d": 0}, {"reduce_2d": 0, "seg_m": 8}, {"quad": 0}):
+                       {"reduce_2d": 0}, {"reduce_2d": 0, "seg_m": 8}, {"quad": 0}, {"rowcol_quad": 0}, {"auto_plan": 0}):
             for k, v in params.items():
                 c2.set_param(k, v)
-            for c in (0, 4, 5, 6, 9, 16):
+            for c in (0, 4, 5, 6, 9, 16, -10, -13):
                 assert gpu_msm(N, c2, p96, s32, n, window_c=c) == want, (params, c)
             for k in params:   # back to defaults
-                c2.set_param(k, {"partition_sort": 1, "chunk_len": 8, "seg_m": 4, "wave_agg": 1, "stage_sort": 1, "host_split": 1, "big_bins": 1, "reduce_2d": 1, "quad": 1}[k])
+                c2.set_param(k, {"partition_sort": 1, "chunk_len": 8, "seg_m": 4, "wave_agg": 1, "stage_sort": 1, "host_split": 1, "big_bins": 1, "reduce_2d": 1, "quad": 1, "rowcol_quad": 1, "auto_plan": 1}[k])
     finally:
         c2.close()
 
@@ -319,7 +319,7 @@ def test_argument_errors_are_reported(native_lib, ctx):
     N = native_lib
     dp, ds = ctx.alloc(96 * 4), ctx.alloc(32 * 4)
     dp.upload(raw96(O.G1_GEN) * 4); ds.upload((5).to_bytes(32, "little") * 4)
-    for kw in ({"window_c": 3}, {"window_c": 17}, {"shard_rank": 2, "shard_world": 2}, {"shard_rank": -1, "shard_world": 1},
+    for kw in ({"window_c": 3}, {"window_c": 17}, {"window_c": -3}, {"window_c": -17}, {"shard_rank": 2, "shard_world": 2}, {"shard_rank": -1, "shard_world": 1},
                {"shard_world": 0}):
         with pytest.raises(N.NativeError):
             ctx.msm_device(dp, ds, 4, **kw)
@@ -376,7 +376,7 @@ def test_randomised_differential(native_lib, ctx):
         p96 = b"".join(raws[i] for i in idx)
         s32 = b"".join(s.to_bytes(32, "little") for s in sc)
         want = C.compress(C.msm_bucket(p96, s32, n))
-        c = rng.choice([0, 0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16])
+        c = rng.choice([0, 0, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, -4, -6, -9, -11, -12, -13, -14, -15, -16])
         dp, ds = ctx.alloc(96 * n), ctx.alloc(32 * n)
         dp.upload(p96); ds.upload(s32)
         if rng.random() < 0.3:
