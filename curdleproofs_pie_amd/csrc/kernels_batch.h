@@ -140,6 +140,45 @@ __global__ void __launch_bounds__(64) k_subgroup_flags(const uint32_t* __restric
   if (q == 0) flags[t] = a.inf ? 0 : 1;
 }
 
+// y = a^((p+1)/4) by the FIXED addition chain of tools/sqrt_chain.py (bls_consts.h D_SQRT_CHAIN): sliding window of width 4
+// over the constant exponent, 376 squarings + 85 products (the run-time 3-bit window of fp_pow6 needed 378 + 109 and a
+// per-limb select chain for every product).  The eight odd powers a, a^3, ..., a^15 stay in registers; the chain steps come
+// from constant memory through scalar loads, so the step's table index is wave-uniform and picking the operand is a
+// scalar branch over plain register copies: the loop body has ONE squaring and ONE product call site (small code, no
+// divergence, no select chains).  (An LDS table -- 448 B per lane -- would halve the occupancy.)
+constexpr int SQRT_TAB = 8;
+__constant__ uint16_t g_sqrt_chain[D_SQRT_CHAIN_LEN] = CG1_SQRT_CHAIN_INIT;
+__device__ __forceinline__ fp sqrt_tab_pick(const fp (&T)[SQRT_TAB], uint32_t idx) {       // idx is wave-uniform
+  switch (idx) {
+    case 0: return T[0]; case 1: return T[1]; case 2: return T[2]; case 3: return T[3];
+    case 4: return T[4]; case 5: return T[5]; case 6: return T[6]; default: return T[7];
+  }
+}
+__device__ __forceinline__ fp fp_sqrt_chain(const fp& a) {
+  const fp a2 = fp_sqr(a);
+  fp T[SQRT_TAB];
+  T[0] = a;
+  fp cur = a;
+#pragma unroll 1
+  for (int i = 1; i < SQRT_TAB; ++i) {
+    cur = fp_mul(cur, a2);
+    switch (i) {                                     // uniform: a scalar branch around register copies
+      case 1: T[1] = cur; break; case 2: T[2] = cur; break; case 3: T[3] = cur; break; case 4: T[4] = cur; break;
+      case 5: T[5] = cur; break; case 6: T[6] = cur; break; default: T[7] = cur; break;
+    }
+  }
+  fp r = T[D_SQRT_CHAIN_FIRST];
+#pragma unroll 1
+  for (int k = 0; k < D_SQRT_CHAIN_LEN; ++k) {
+    const uint32_t op = g_sqrt_chain[k];
+#pragma unroll 1
+    for (uint32_t n = op >> 8; n; --n) r = fp_sqr(r);
+    const uint32_t idx = op & 0xffu;
+    if (idx != 0xffu) r = fp_mul(r, sqrt_tab_pick(T, idx));
+  }
+  return r;
+}
+
 // CHECK is a template parameter: the unchecked instantiation (the reference's default, util.py:35-36) must not carry the
 // register footprint of the subgroup test's scalar multiplication (256 VGPRs + spills, 1 wave/SIMD when it did).
 template <bool CHECK>
@@ -171,7 +210,7 @@ __global__ void __launch_bounds__(128) k_batch_decompress(const uint8_t* __restr
   const fp x = fp_to_mont(fp_from_words(w));
   fp four = fp_one(); four = fp_dbl(fp_dbl(four));
   const fp rhs = fp_norm(fp_add(fp_mul(fp_sqr(x), x), four));
-  fp y = fp_sqrt_candidate(rhs);
+  fp y = fp_sqrt_chain(rhs);
   if (!fp_is_zero_mod_p(fp_sub<3>(fp_sqr(y), fp_mul(rhs, fp_one())), 8)) { status[i] = CG1_ERR_NOT_ON_CURVE; return; }
   uint32_t yw[12];
   fp_to_words(y, yw);
