@@ -28,15 +28,10 @@ def main():
     t = time.perf_counter(); ctx.batch_mul_device(dg, 1, dk, dp, nmax); print(f"generated 2^23 points in {time.perf_counter()-t:.2f}s", flush=True)
     ctx.gen_scalars_device(ds, nmax, 2)
     print("## size sweep (uniform scalars, whole MSM on one GPU)")
-    for logn in (10, 12, 14, 16, 18, 20, 22, 23):
+    for logn in (10, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 23):
         n = 1 << logn
-        best = None
-        for c in ([0] if logn < 14 else sorted({0, 13, 14, 16})):
-            w = med(lambda: ctx.msm_device(dp, ds, n, window_c=c))
-            tm = ctx.timings()
-            if best is None or w < best[0]:
-                best = (w, tm)
-        w, tm = best
+        w = med(lambda: ctx.msm_device(dp, ds, n, window_c=0), reps=7)      # the library's own plan for the size
+        tm = ctx.timings()
         print(f"n=2^{logn} c={tm['window_c']}: {w:.3f} ms  {n/w/1e3:.1f} M scalar-mul/s | " + " ".join(f"{k}={v:.3f}" for k, v in tm.items() if k not in ('window_c', 'host_events')), flush=True)
     print("## structured scalars (bucket skew)")
     for agg in (0, 1, 0, 1):

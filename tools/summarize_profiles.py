@@ -23,6 +23,9 @@ def agg(pattern):
 
 shutil.copy(glob.glob(f"gpurun_out/{tag}_kt/*/*_kernel_stats.csv")[0], out + "_kernel_stats.csv")
 shutil.copy(f"gpurun_out/{tag}_bench.json", out + "_bench.json")
+import subprocess
+res = subprocess.run([sys.executable, "tools/asm_stats.py", "build/asm/dev_current.s"], capture_output=True, text=True).stdout
+open(out + "_kernel_resources.txt", "w").write("# per-kernel resource usage and instruction mix of the shipped device code (hipcc -S --offload-device-only; tools/asm_stats.py)\n" + res)
 f, w, q = agg(f"gpurun_out/{tag}_fetch/*/*_counter_collection.csv"), agg(f"gpurun_out/{tag}_write/*/*_counter_collection.csv"), agg(f"gpurun_out/{tag}_sq/*/*_counter_collection.csv")
 lines = ["# rocprofv3 --pmc summaries of `python3 bench.py` (one 2^20-term MSM per step, c=16), MI355X",
          "# separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE.  FETCH/WRITE in KiB per launch (average over launches).",
@@ -38,8 +41,18 @@ for (k, c), (v, n) in sorted(q.items()):
         lines.append(f"{k},{c},{v:.0f}")
 open(out + "_pmc_summary.csv", "w").write("\n".join(lines) + "\n")
 F, W = f[("cg1::k_accumulate", "FETCH_SIZE")][0], w[("cg1::k_accumulate", "WRITE_SIZE")][0]
+bench = json.loads([ln for ln in open(f"gpurun_out/{tag}_bench.json") if ln.startswith("{")][0])
+madds = bench["roofline_int_mad"]["mixed_adds_per_launch"]
+valu, waves = q[("cg1::k_accumulate", "SQ_INSTS_VALU")][0], q[("cg1::k_accumulate", "SQ_WAVES")][0]
+shutil.copy(glob.glob(f"gpurun_out/{tag}_vkt/*/*_kernel_stats.csv")[0], out + "_verify_kernel_stats.csv")
+shutil.copy(f"gpurun_out/{tag}_sweep.txt", out + "_sweep.txt")
+shutil.copy(f"gpurun_out/{tag}_vkt.txt", out + "_bench_verify.txt")
 json.dump({"source": out + "_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over python3 bench.py --steps 4 --warmup 1)",
+           "sq_source": out + "_pmc_summary.csv (rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU ..., its own pass); mixed adds counted on the device in "
+                        + out + "_bench.json; a wave-level mixed add = 64 lane-level ones (chunks are length-ordered: lanes of a wave finish together)",
            "workload": "single MSM of 2^20 terms, c=16, 1 GPU",
+           "k_accumulate_SQ_INSTS_VALU": valu, "k_accumulate_SQ_WAVES": waves, "k_accumulate_mixed_adds": madds,
+           "k_accumulate_valu_per_wave_mixed_add": valu / (madds / 64.0),
            "k_accumulate_FETCH_SIZE_KiB": F, "k_accumulate_WRITE_SIZE_KiB": W,
            "k_accumulate_hbm_bytes_per_launch": (2 * F + W) * 1024,
            "note": "FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md; these fabric-side counters include "
