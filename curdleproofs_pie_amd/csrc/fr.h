@@ -1,5 +1,8 @@
-// Host-side BLS12-381 scalar field Fr (r = 0x73eda753...00000001, 255 bits): 4 x 64-bit limbs, Montgomery
-// radix 2^256, header-only.  Backs the verifier-side scalar work of the shuffle argument (csrc/shuffle_verify.cpp):
+// BLS12-381 scalar field Fr (r = 0x73eda753...00000001, 255 bits): 4 x 64-bit limbs, Montgomery radix 2^256,
+// header-only, ONE source for the host (csrc/shuffle_verify.cpp) and the device (csrc/kernels_rows.h: the same functions
+// compiled __host__ __device__, so both sides produce the same bytes by construction; the device code is not tuned --
+// a verification needs a few thousand Fr products against ~10^5 Fp products).
+// Backs the verifier-side scalar work of the shuffle argument:
 // the reference does this with one Python `Scalar` object per operation over the Rust wheel
 // (py_arkworks_bls12381-stubs/__init__.pyi:32-54; ipa.py:164-186,216,227-229; same_msm.py:155-182,213;
 // grand_prod.py:139-170; same_perm.py:94-98), including one `inverse()` per vector element (util.py:51-54) --
@@ -11,26 +14,32 @@
 #include <vector>
 #include "bls_consts.h"
 
+#if defined(__HIPCC__)
+#define CG1FR_HD __host__ __device__ inline
+#else
+#define CG1FR_HD static inline
+#endif
+
 namespace cg1fr {
 
 typedef unsigned __int128 u128;
 
 struct fr { uint64_t l[4]; };       // Montgomery form, canonical (< r)
 
-static inline fr fr_zero() { return fr{{0, 0, 0, 0}}; }
-static inline fr fr_one() { return fr{{cg1::H_FR_R1[0], cg1::H_FR_R1[1], cg1::H_FR_R1[2], cg1::H_FR_R1[3]}}; }
-static inline bool fr_is_zero(const fr& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
-static inline bool fr_eq(const fr& a, const fr& b) {
+CG1FR_HD fr fr_zero() { return fr{{0, 0, 0, 0}}; }
+CG1FR_HD fr fr_one() { return fr{{cg1::H_FR_R1[0], cg1::H_FR_R1[1], cg1::H_FR_R1[2], cg1::H_FR_R1[3]}}; }
+CG1FR_HD bool fr_is_zero(const fr& a) { return (a.l[0] | a.l[1] | a.l[2] | a.l[3]) == 0; }
+CG1FR_HD bool fr_eq(const fr& a, const fr& b) {
   return ((a.l[0] ^ b.l[0]) | (a.l[1] ^ b.l[1]) | (a.l[2] ^ b.l[2]) | (a.l[3] ^ b.l[3])) == 0;
 }
 
-static inline bool geq_r(const uint64_t a[4]) {
+CG1FR_HD bool geq_r(const uint64_t a[4]) {
   for (int i = 3; i >= 0; --i) {
     if (a[i] != cg1::H_FR[i]) return a[i] > cg1::H_FR[i];
   }
   return true;
 }
-static inline void sub_r(uint64_t a[4]) {
+CG1FR_HD void sub_r(uint64_t a[4]) {
   u128 borrow = 0;
   for (int i = 0; i < 4; ++i) {
     u128 d = (u128)a[i] - cg1::H_FR[i] - borrow;
@@ -39,14 +48,14 @@ static inline void sub_r(uint64_t a[4]) {
   }
 }
 
-static inline fr fr_add(const fr& a, const fr& b) {
+CG1FR_HD fr fr_add(const fr& a, const fr& b) {
   fr r;
   u128 c = 0;
   for (int i = 0; i < 4; ++i) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
   if (geq_r(r.l)) sub_r(r.l);           // a + b < 2r < 2^256: no carry out
   return r;
 }
-static inline fr fr_neg(const fr& a) {
+CG1FR_HD fr fr_neg(const fr& a) {
   if (fr_is_zero(a)) return a;
   fr r;
   u128 borrow = 0;
@@ -57,10 +66,10 @@ static inline fr fr_neg(const fr& a) {
   }
   return r;
 }
-static inline fr fr_sub(const fr& a, const fr& b) { return fr_add(a, fr_neg(b)); }
+CG1FR_HD fr fr_sub(const fr& a, const fr& b) { return fr_add(a, fr_neg(b)); }
 
 // Montgomery product a * b / 2^256 mod r (CIOS)
-static inline fr fr_mul(const fr& a, const fr& b) {
+CG1FR_HD fr fr_mul(const fr& a, const fr& b) {
   uint64_t t[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 4; ++i) {
     u128 c = 0;
@@ -88,16 +97,16 @@ static inline fr fr_mul(const fr& a, const fr& b) {
   if (t[4] || geq_r(r.l)) sub_r(r.l);
   return r;
 }
-static inline fr fr_sqr(const fr& a) { return fr_mul(a, a); }
+CG1FR_HD fr fr_sqr(const fr& a) { return fr_mul(a, a); }
 
-static inline fr fr_from_u64(uint64_t v) {
+CG1FR_HD fr fr_from_u64(uint64_t v) {
   fr a{{v, 0, 0, 0}};
   fr r2{{cg1::H_FR_R2[0], cg1::H_FR_R2[1], cg1::H_FR_R2[2], cg1::H_FR_R2[3]}};
   return fr_mul(a, r2);
 }
 // 32 little-endian bytes, canonical (< r) required: false otherwise (Scalar.from_le_bytes raises ValueError,
 // test_curdleproofs.py:210-213)
-static inline bool fr_from_le32(const uint8_t* b, fr& out) {
+CG1FR_HD bool fr_from_le32(const uint8_t* b, fr& out) {
   fr a;
   memcpy(a.l, b, 32);
   if (geq_r(a.l)) return false;
@@ -106,7 +115,7 @@ static inline bool fr_from_le32(const uint8_t* b, fr& out) {
   return true;
 }
 // out of Montgomery form: four reduction rounds only (half the work of a multiplication by 1)
-static inline void fr_to_le32(const fr& a, uint8_t* b) {
+CG1FR_HD void fr_to_le32(const fr& a, uint8_t* b) {
   uint64_t t[4] = {a.l[0], a.l[1], a.l[2], a.l[3]};
   for (int i = 0; i < 4; ++i) {
     const uint64_t m = t[0] * cg1::H_FR_INV;
@@ -123,7 +132,7 @@ static inline void fr_to_le32(const fr& a, uint8_t* b) {
   memcpy(b, t, 32);
 }
 
-static inline fr fr_pow_u64(fr base, uint64_t e) {
+CG1FR_HD fr fr_pow_u64(fr base, uint64_t e) {
   fr acc = fr_one();
   while (e) {
     if (e & 1) acc = fr_mul(acc, base);
@@ -134,7 +143,7 @@ static inline fr fr_pow_u64(fr base, uint64_t e) {
 }
 
 // a^(r-2); 0 -> 0
-static inline fr fr_inv(const fr& a) {
+CG1FR_HD fr fr_inv(const fr& a) {
   fr acc = fr_one();
   for (int i = 254; i >= 0; --i) {
     acc = fr_sqr(acc);
@@ -143,7 +152,7 @@ static inline fr fr_inv(const fr& a) {
   return acc;
 }
 
-// in-place inversion of n NON-ZERO elements with one field inversion
+// in-place inversion of n NON-ZERO elements with one field inversion (host only)
 static inline void fr_batch_inv(fr* v, size_t n) {
   if (n == 0) return;
   std::vector<fr> pre(n);

@@ -54,6 +54,9 @@ int pick_window(size_t n);
 #include "kernels_accumulate.h"
 #include "kernels_reduce.h"
 #include "kernels_batch.h"
+}  // namespace cg1
+#include "kernels_rows.h"
+namespace cg1 {
 
 // ------------------------------------------------------------------ host-side context
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
@@ -1108,6 +1111,25 @@ int cg1_side_sync(cg1_ctx* ctx) {
   if (!ctx->side_stream) return CG1_OK;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->side_stream));
+  return CG1_OK;
+}
+// The scalar rows of a batch of shuffle statements, built on the device from the host front-end's input blocks
+// (cg1_shuffle_prepare_inputs), and the sum of the live proofs' CRS rows written behind the own-point scalars
+// (d_out_scalars: n_proofs x (4 ell + 19 + 10 lg) scalars, then ell + 9).  Asynchronous on the compute stream.
+int cg1_shuffle_rows_device(cg1_ctx* ctx, size_t ell, size_t lg, size_t n_proofs, const void* d_rowin, const void* d_host_status,
+                            const void* d_point_status, void* d_out_scalars, void* d_crs_rows, void* d_status_out) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n_proofs == 0) return CG1_OK;
+  if (!d_rowin || !d_host_status || !d_point_status || !d_out_scalars || !d_crs_rows || !d_status_out || lg >= 32 || ell + 4 != ((size_t)1 << lg))
+    return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t L = 4 * ell + 19 + 10 * lg, C = ell + 9;
+  hipLaunchKernelGGL(cg1rows::k_shuffle_rows, dim3((unsigned)n_proofs), dim3(128), 0, ctx->stream, (const uint8_t*)d_rowin,
+                     (const int32_t*)d_host_status, (const uint8_t*)d_point_status, (uint32_t)ell, (uint32_t)lg,
+                     (uint8_t*)d_out_scalars, (uint8_t*)d_crs_rows, (int32_t*)d_status_out);
+  hipLaunchKernelGGL(cg1rows::k_crs_row_sum, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)d_crs_rows,
+                     (const int32_t*)d_status_out, (uint32_t)n_proofs, (uint32_t)C, (uint8_t*)d_out_scalars + n_proofs * L * 32);
+  HIPCHK(hipGetLastError());
   return CG1_OK;
 }
 int cg1_batch_compress_device(cg1_ctx* ctx, const void* d_in_affine96, void* d_out48, size_t n) {

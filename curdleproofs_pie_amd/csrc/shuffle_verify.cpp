@@ -270,11 +270,31 @@ class Pool {
   size_t want_ = 0, pending_ = 0, generation_ = 0;
 };
 
+// The per-proof block the DEVICE row builder (csrc/kernels_rows.h, k_shuffle_rows) works from, instead of the rows themselves:
+// every challenge the transcript produced plus the handful of scalars derived from them on the host, 32-byte little-endian
+// canonical each.  Layout = cg1rows::RowIn:  alpha_p beta_p alpha_g beta_g alpha_i beta_i alpha_s alpha_m | gamma[lg] |
+// gamma_m[lg] | a[ell] | beta^-1 | inner_prod | gamma^-1[lg] | gamma_m^-1[lg] | c d z_k z_t z_u x | rho[12].
+size_t rowin_scalars(size_t ell, size_t lg) { return 28 + 4 * lg + ell; }
+void write_rowin(uint8_t* o, size_t ell, size_t lg, const fr head[8], const fr* gam, const fr* gm, const fr* a, const fr& beta_inv,
+                 const fr& inner_prod, const fr* gam_inv, const fr* gm_inv, const fr fields[6], const fr* rho) {
+  auto put = [&](const fr& v) { fr_to_le32(v, o); o += 32; };
+  for (int k = 0; k < 8; ++k) put(head[k]);
+  for (size_t j = 0; j < lg; ++j) put(gam[j]);
+  for (size_t j = 0; j < lg; ++j) put(gm[j]);
+  for (size_t i = 0; i < ell; ++i) put(a[i]);
+  put(beta_inv); put(inner_prod);
+  for (size_t j = 0; j < lg; ++j) put(gam_inv[j]);
+  for (size_t j = 0; j < lg; ++j) put(gm_inv[j]);
+  for (int k = 0; k < 6; ++k) put(fields[k]);
+  for (int k = 0; k < 12; ++k) put(rho[k]);
+}
+
 // One proof.  Returns 0 (prepared) or a CG1_SHUFFLE_* reject code.
 int prepare_one(const Crs& crs, const uint8_t* inst /* 4*ell*48 */, const uint8_t* proof, const uint8_t* weights /* 12*32 */,
                 const uint8_t* decoded /* own points 4*ell+1 .. 4*ell+8 (A T_1 T_2 U_1 U_2 R S B) as affine96, or NULL */,
                 uint8_t* out_points, uint8_t* out_scalars, uint8_t* out_crs_scalars, uint8_t* out_challenges,
-                fr* alpha_s_out = nullptr /* the same-scalar challenge (same_scalar.py:99) */) {
+                fr* alpha_s_out = nullptr /* the same-scalar challenge (same_scalar.py:99) */,
+                uint8_t* out_rowin = nullptr /* non-NULL: emit the device row builder's input block instead of the rows */) {
   const size_t ell = crs.ell, lg = crs.lg, n = ell + NB;
   const Layout L(ell, lg);
 
@@ -454,6 +474,12 @@ int prepare_one(const Crs& crs, const uint8_t* inst /* 4*ell*48 */, const uint8_
   }
   gm_inv = gm;
   fr_batch_inv(gm_inv.data(), lg);
+  if (out_rowin) {
+    const fr head[8] = {alpha_p, beta_p, alpha_g, beta_g, alpha_i, beta_i, alpha_s, alpha_m};
+    const fr fields[6] = {c_fin, d_fin, z_k, z_t, z_u, x_fin};
+    write_rowin(out_rowin, ell, lg, head, gam.data(), gm.data(), a.data(), beta_inv, inner_prod, gam_inv.data(), gm_inv.data(), fields, rho);
+    return 0;
+  }
   std::vector<fr> sm;
   fold_scalars(gm, sm);
   {
@@ -530,7 +556,8 @@ struct ProfTimer {
 
 void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const uint8_t* const* proof, const uint8_t* const* weights,
                    const uint8_t* const* decoded, uint8_t* const* out_points, uint8_t* const* out_scalars,
-                   uint8_t* const* out_crs_scalars, uint8_t* const* out_challenges, int32_t* const* status_out) {
+                   uint8_t* const* out_crs_scalars, uint8_t* const* out_challenges, int32_t* const* status_out,
+                   uint8_t* const* out_rowin = nullptr) {
   const size_t ell = crs.ell, lg = crs.lg, n = ell + NB;
   const Layout L(ell, lg);
   ProofWork w[cg1m::G];
@@ -713,6 +740,14 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
   for (int k = 0; k < cnt; ++k) {
     ProofWork& q = w[k];
     *status_out[k] = q.status;
+    if (out_rowin) {                                   // rows are built on the device from this block (k_shuffle_rows)
+      if (q.status) { memset(out_rowin[k], 0, rowin_scalars(ell, lg) * 32); continue; }
+      const fr head[8] = {q.alpha_p, q.beta_p, q.alpha_g, q.beta_g, q.alpha_i, q.beta_i, q.alpha_s, q.alpha_m};
+      const fr fields[6] = {q.c_fin, q.d_fin, q.z_k, q.z_t, q.z_u, q.x_fin};
+      write_rowin(out_rowin[k], ell, lg, head, q.gam.data(), q.gm.data(), q.a.data(), q.beta_inv, q.inner_prod, q.gam_inv.data(),
+                  q.gm_inv.data(), fields, q.rho);
+      continue;
+    }
     if (q.status) {
       memset(out_scalars[k], 0, L.count() * 32);
       memset(out_crs_scalars[k], 0, L.ncrs() * 32);
@@ -859,14 +894,19 @@ size_t cg1_shuffle_challenges_per_proof(const cg1_shuffle_crs* crs) {
 // CURDLE_G1_THREADS overrides)
 size_t cg1_shuffle_default_threads(void) { return Pool::get().size() + 1; }
 
-int cg1_shuffle_prepare(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
-                        const uint8_t* weights, const uint8_t* decoded96, size_t decoded_stride, uint8_t* out_points48, uint8_t* out_scalars32, uint8_t* out_crs_scalars32,
-                        int32_t* status, uint8_t* out_challenges32, int n_threads) {
-  if (!crs_ || (n_proofs && (!instances || !proofs || !weights || !out_points48 || !out_scalars32 || !out_crs_scalars32 || !status)))
+}  // extern "C"
+
+// out_rowin != NULL: emit the device row builder's input blocks (n x rowin_scalars x 32 B) instead of the rows themselves
+static int prepare_dispatch(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
+                            const uint8_t* weights, const uint8_t* decoded96, size_t decoded_stride, uint8_t* out_points48, uint8_t* out_scalars32, uint8_t* out_crs_scalars32,
+                            int32_t* status, uint8_t* out_challenges32, int n_threads, uint8_t* out_rowin) {
+  if (!crs_ || (n_proofs && (!instances || !proofs || !weights || !out_points48 || !status)))
     return CG1_ERR_ARG;
+  if (n_proofs && !out_rowin && (!out_scalars32 || !out_crs_scalars32)) return CG1_ERR_ARG;
   const Crs& crs = *reinterpret_cast<const Crs*>(crs_);
   const Layout L(crs.ell, crs.lg);
   const size_t inst_b = 4 * crs.ell * 48, proof_b = proof_wire_bytes(crs.lg), nch = 8 + 2 * crs.lg + crs.ell;
+  const size_t rin_b = rowin_scalars(crs.ell, crs.lg) * 32;
   std::atomic<size_t> next{0};
   const bool grouped = g_grouped.load() != 0;
   const size_t per_item = grouped ? (size_t)cg1m::G : 1, n_items = (n_proofs + per_item - 1) / per_item;
@@ -877,30 +917,32 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint
       if (grouped) {
         const size_t lo = item * per_item, cnt = std::min(per_item, n_proofs - lo);
         const uint8_t *in[cg1m::G], *pr[cg1m::G], *we[cg1m::G], *de[cg1m::G];
-        uint8_t *pts[cg1m::G], *scs[cg1m::G], *ccs[cg1m::G], *chs[cg1m::G];
+        uint8_t *pts[cg1m::G], *scs[cg1m::G], *ccs[cg1m::G], *chs[cg1m::G], *rin[cg1m::G];
         int32_t* sts[cg1m::G];
         for (size_t k = 0; k < cnt; ++k) {
           const size_t i = lo + k;
           in[k] = instances + i * inst_b; pr[k] = proofs + i * proof_b; we[k] = weights + i * 12 * 32;
           de[k] = decoded96 ? decoded96 + i * decoded_stride : nullptr;
-          pts[k] = out_points48 + i * L.count() * 48; scs[k] = out_scalars32 + i * L.count() * 32;
-          ccs[k] = out_crs_scalars32 + i * L.ncrs() * 32;
+          pts[k] = out_points48 + i * L.count() * 48;
+          scs[k] = out_rowin ? nullptr : out_scalars32 + i * L.count() * 32;
+          ccs[k] = out_rowin ? nullptr : out_crs_scalars32 + i * L.ncrs() * 32;
+          rin[k] = out_rowin ? out_rowin + i * rin_b : nullptr;
           chs[k] = out_challenges32 ? out_challenges32 + i * nch * 32 : nullptr;
           sts[k] = status + i;
         }
-        prepare_group(crs, (int)cnt, in, pr, we, de, pts, scs, ccs, chs, sts);
+        prepare_group(crs, (int)cnt, in, pr, we, de, pts, scs, ccs, chs, sts, out_rowin ? rin : nullptr);
         continue;
       }
       const size_t i = item;
       uint8_t* pts = out_points48 + i * L.count() * 48;
-      uint8_t* scs = out_scalars32 + i * L.count() * 32;
-      uint8_t* ccs = out_crs_scalars32 + i * L.ncrs() * 32;
+      uint8_t* scs = out_rowin ? nullptr : out_scalars32 + i * L.count() * 32;
+      uint8_t* ccs = out_rowin ? nullptr : out_crs_scalars32 + i * L.ncrs() * 32;
       int rc = prepare_one(crs, instances + i * inst_b, proofs + i * proof_b, weights + i * 12 * 32,
                            decoded96 ? decoded96 + i * decoded_stride : nullptr, pts, scs, ccs,
-                           out_challenges32 ? out_challenges32 + i * nch * 32 : nullptr);
+                           out_challenges32 ? out_challenges32 + i * nch * 32 : nullptr, nullptr, out_rowin ? out_rowin + i * rin_b : nullptr);
       if (rc) {                               // a rejected proof contributes nothing to a merged check
-        memset(scs, 0, L.count() * 32);
-        memset(ccs, 0, L.ncrs() * 32);
+        if (out_rowin) memset(out_rowin + i * rin_b, 0, rin_b);
+        else { memset(scs, 0, L.count() * 32); memset(ccs, 0, L.ncrs() * 32); }
       }
       status[i] = rc;
     }
@@ -914,6 +956,30 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint
     pool.run(work, nt);
   }
   return CG1_OK;
+}
+
+extern "C" {
+
+int cg1_shuffle_prepare(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
+                        const uint8_t* weights, const uint8_t* decoded96, size_t decoded_stride, uint8_t* out_points48, uint8_t* out_scalars32, uint8_t* out_crs_scalars32,
+                        int32_t* status, uint8_t* out_challenges32, int n_threads) {
+  return prepare_dispatch(crs_, n_proofs, instances, proofs, weights, decoded96, decoded_stride, out_points48, out_scalars32, out_crs_scalars32,
+                          status, out_challenges32, n_threads, nullptr);
+}
+
+// The same front-end, but instead of the scalar rows it emits, per proof, the input block of the DEVICE row builder
+// (cg1_shuffle_rows_device): cg1_shuffle_rowin_scalars(crs) 32-byte scalars (challenges, their inverses, inner_prod,
+// beta^-1, the proof's Fr fields, the weights).  A rejected proof gets a zero block and its code in status[].
+size_t cg1_shuffle_rowin_scalars(const cg1_shuffle_crs* crs) {
+  const Crs* c = reinterpret_cast<const Crs*>(crs);
+  return rowin_scalars(c->ell, c->lg);
+}
+int cg1_shuffle_prepare_inputs(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
+                               const uint8_t* weights, const uint8_t* decoded96, size_t decoded_stride, uint8_t* out_points48,
+                               uint8_t* out_rowin32, int32_t* status, int n_threads) {
+  if (n_proofs && !out_rowin32) return CG1_ERR_ARG;
+  return prepare_dispatch(crs_, n_proofs, instances, proofs, weights, decoded96, decoded_stride, out_points48, nullptr, nullptr,
+                          status, nullptr, n_threads, out_rowin32);
 }
 
 // ---- Whisk tracker-opening proofs (opening.py:21-79; IsValidWhiskOpeningProof, whisk_interface.py:147-169), batched the

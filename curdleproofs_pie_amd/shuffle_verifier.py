@@ -119,7 +119,7 @@ class Prepared:
 
 
 class ShuffleBatchVerifier:
-    def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256):
+    def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True):
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
@@ -128,6 +128,11 @@ class ShuffleBatchVerifier:
         self._gpu_jobs = [None, None]
         self._ctx_msm = None
         self.prefetch_big = True            # two large decompress launches for batches decoded a batch ahead (A/B switch)
+        # True: the host front-end emits only the challenges (+ a few derived scalars) per proof and the GPU expands them into
+        # the scalar rows (k_shuffle_rows: SURVEY 8(f) row 3) -- 5.7 KB instead of 23 KB per proof over PCIe, and a quarter
+        # of the front-end's arithmetic off the host.  False: rows on the host (A/B switch; what `prepare()` always does).
+        self.device_rows = device_rows
+        self._rowin_scalars = N.cg1_shuffle_rowin_scalars(self.crs.handle)
         self._slots = [None, None, None]
         self._next_slot = 0
         self.last_stats = {}
@@ -148,7 +153,7 @@ class ShuffleBatchVerifier:
             self._gpu_threads[lane] = self._gpu_jobs[lane] = None
         for i, b in enumerate(self._slots):
             if b is not None:
-                for k in ("wire", "pts", "pstat", "sgflags", "sc"):
+                for k in ("wire", "pts", "pstat", "sgflags", "sc", "rowin", "hstat", "csrows", "dstat"):
                     b[k].free()
                 for h in b["host"].values():
                     if isinstance(h, N.PinnedBuffer):          # (the staging dict also caches plain ctypes buffers)
@@ -261,9 +266,13 @@ class ShuffleBatchVerifier:
             "pstat": ctx.alloc(n * L),
             "sgflags": ctx.alloc(n * N_EXACT_POINTS),        # 1 = outside G1, for the points of the exactly-asserted equalities
             "sc": ctx.alloc((n * L + C) * 32),
+            "rowin": ctx.alloc(n * self._rowin_scalars * 32),   # device row builder: input blocks, host codes, CRS rows, final codes
+            "hstat": ctx.alloc(4 * n), "csrows": ctx.alloc(n * C * 32), "dstat": ctx.alloc(4 * n),
             "host": {                                        # page-locked staging
                 "wire": N.PinnedBuffer(ctx, n * L * 48),
                 "sc": N.PinnedBuffer(ctx, (n * L + C) * 32),
+                "rowin": N.PinnedBuffer(ctx, n * self._rowin_scalars * 32),
+                "hstat": N.PinnedBuffer(ctx, 4 * n),
                 "pstat": N.PinnedBuffer(ctx, n * L),
                 "decoded": N.PinnedBuffer(ctx, n * 768),
             },
@@ -366,16 +375,21 @@ class ShuffleBatchVerifier:
 
     def _front_end(self, tk: dict) -> None:
         """Stage 2 (caller's thread, all cores through the native pool): the front-end of each sub-batch as soon as the
-        GPU has decoded it; then point verdicts, early rejects, and the summed CRS row."""
+        GPU has decoded it.  device_rows: it emits the row builder's input blocks (challenges + derived scalars), which go
+        to the device with the host's reject codes; else the rows themselves, then point verdicts, early rejects and the
+        summed CRS row on the host."""
         import time
 
         crs = self.crs
-        L, C = crs.points_per_proof, crs.ncrs
+        L, C, K = crs.points_per_proof, crs.ncrs, self._rowin_scalars
         b, n = tk["slot"], tk["n"]
         host = b["host"]
         t0 = time.perf_counter()
-        prep = Prepared(crs, n, False, host)
+        dev = self.device_rows
+        tk["device_rows"] = dev
+        prep = None if dev else Prepared(crs, n, False, host)
         tk["prep"] = prep
+        hstat = (ctypes.c_int32 * n).from_address(host["hstat"].ptr)
         for _ in tk["bounds"]:
             r = tk["chunks"].get()
             if isinstance(r, BaseException):
@@ -383,14 +397,25 @@ class ShuffleBatchVerifier:
                 tk["done"].set()
                 raise r
             lo, hi = r
-            rc = N.cg1_shuffle_prepare(crs.handle, hi - lo, _addr(tk["instances"]) + lo * 4 * crs.ell * 48,
-                                       _addr(tk["proofs"]) + lo * crs.proof_bytes, _addr(tk["weights"]) + lo * N_WEIGHTS * 32,
-                                       host["decoded"].ptr + lo * 768, 768, host["wire"].ptr + lo * L * 48,
-                                       host["sc"].ptr + lo * L * 32, ctypes.addressof(prep.crs_scalars32) + lo * C * 32,
-                                       ctypes.addressof(prep.status) + lo * 4, None, self.threads)
+            args = (crs.handle, hi - lo, _addr(tk["instances"]) + lo * 4 * crs.ell * 48, _addr(tk["proofs"]) + lo * crs.proof_bytes,
+                    _addr(tk["weights"]) + lo * N_WEIGHTS * 32, host["decoded"].ptr + lo * 768, 768, host["wire"].ptr + lo * L * 48)
+            if dev:
+                rc = N.cg1_shuffle_prepare_inputs(*args, host["rowin"].ptr + lo * K * 32, host["hstat"].ptr + lo * 4, self.threads)
+            else:
+                rc = N.cg1_shuffle_prepare(*args, host["sc"].ptr + lo * L * 32, ctypes.addressof(prep.crs_scalars32) + lo * C * 32,
+                                           ctypes.addressof(prep.status) + lo * 4, None, self.threads)
             if rc:
                 tk["done"].set()
                 raise N.NativeError(f"cg1_shuffle_prepare failed ({rc})")
+        if dev:
+            for i, s in enumerate(tk["pre_status"] or ()):
+                if s:
+                    hstat[i] = s
+            # input blocks + host codes to the device on the MSM context's copy stream, from this thread
+            self.ctx_msm.check(N.cg1_h2d_async(self.ctx_msm.handle, b["rowin"].ptr, host["rowin"].ptr, n * K * 32))
+            self.ctx_msm.check(N.cg1_h2d_async(self.ctx_msm.handle, b["hstat"].ptr, host["hstat"].ptr, 4 * n))
+            tk["front_end_s"] = time.perf_counter() - t0
+            return
         self.ctx.check(N.cg1_shuffle_apply_point_status(prep.status, host["pstat"].buf, n, L, prep.scalars32, prep.crs_scalars32, C))
         for i, s in enumerate(tk["pre_status"] or ()):
             if s:
@@ -416,22 +441,33 @@ class ShuffleBatchVerifier:
         def gpu_stage():
             try:
                 t0 = time.perf_counter()
-                status = [int(prep.status[i]) for i in range(n)]
+                ctx.check(N.cg1_copy_fence(ctx.handle))          # the scalars / input blocks queued by _front_end
+                if tk["device_rows"]:
+                    # the rows are expanded on the device, the point verdicts folded in there, the CRS rows summed behind them
+                    ctx.check(N.cg1_shuffle_rows_device(ctx.handle, crs.ell, crs.lg, n, b["rowin"].ptr, b["hstat"].ptr, b["pstat"].ptr,
+                                                        b["sc"].ptr, b["csrows"].ptr, b["dstat"].ptr))
+                    ctx.check(N.cg1_stream_sync(ctx.handle))
+                    status = list((ctypes.c_int32 * n).from_buffer_copy(b["dstat"].download(4 * n)))
+                else:
+                    status = [int(prep.status[i]) for i in range(n)]
                 live = [i for i in range(n) if status[i] == 0]
                 merged_ok = None
-                ctx.check(N.cg1_copy_fence(ctx.handle))          # the scalars queued by _front_end
                 if live and tk["mode"] == "merged":
                     merged_ok = bool(N.cg1_is_identity(ctx.msm_device(b["pts"], b["sc"], n * L + C)))
                 t1 = time.perf_counter()
                 if live and not merged_ok:
                     # independent: P_i over the proof's own points, Q_i over the CRS points; valid iff P_i + Q_i = 0
                     own = ctx.msm_batched_device(b["pts"], b["sc"], [i * L for i in range(n + 1)])
-                    rep_pts, rep_sc = ctx.alloc(n * C * 96), ctx.alloc(n * C * 32)
+                    rep_pts = ctx.alloc(n * C * 96)
                     rep_pts.upload(crs.affine96 * n)
-                    ctx.check(N.cg1_h2d(ctx.handle, rep_sc.ptr, prep.crs_scalars32, n * C * 32))
-                    shared = ctx.msm_batched_device(rep_pts, rep_sc, [i * C for i in range(n + 1)])
+                    if tk["device_rows"]:
+                        shared = ctx.msm_batched_device(rep_pts, b["csrows"], [i * C for i in range(n + 1)])
+                    else:
+                        rep_sc = ctx.alloc(n * C * 32)
+                        ctx.check(N.cg1_h2d(ctx.handle, rep_sc.ptr, prep.crs_scalars32, n * C * 32))
+                        shared = ctx.msm_batched_device(rep_pts, rep_sc, [i * C for i in range(n + 1)])
+                        rep_sc.free()
                     rep_pts.free()
-                    rep_sc.free()
                     tmp = ctypes.create_string_buffer(N.POINT_BYTES)
                     for i in live:
                         N.cg1_add(tmp, own[i], shared[i])

@@ -223,6 +223,19 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8
 void cg1_shuffle_set_grouped(int on);
 /* threads used when n_threads = 0: usable CPUs (affinity mask capped by the cgroup CPU quota; env CURDLE_G1_THREADS overrides) */
 size_t cg1_shuffle_default_threads(void);
+/* Scalar rows on the device (ipa.py:155-186,216,227-229; same_msm.py:146-182,213; grand_prod.py:64-71;
+ * msm_accumulator.py:43-58).  cg1_shuffle_prepare_inputs is cg1_shuffle_prepare without the row expansion: per proof it emits
+ * cg1_shuffle_rowin_scalars(crs) 32-byte scalars (the transcript's challenges, their inverses, beta^-1, inner_prod, the
+ * proof's Fr fields, the weights).  cg1_shuffle_rows_device expands them on the GPU into the same rows, byte for byte:
+ * d_out_scalars receives n_proofs x points_per_proof own-point scalars followed by the crs_points sums over the live proofs;
+ * d_crs_rows the per-proof CRS rows; d_status_out the final per-proof codes (host code, or CG1_SHUFFLE_BAD_POINT when
+ * d_point_status -- the decompression verdicts of the proof's own points -- has a non-zero byte). */
+size_t cg1_shuffle_rowin_scalars(const cg1_shuffle_crs* crs);
+int cg1_shuffle_prepare_inputs(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
+                               const uint8_t* weights, const uint8_t* decoded_affine96, size_t decoded_stride, uint8_t* out_points48,
+                               uint8_t* out_rowin32, int32_t* status, int n_threads);
+int cg1_shuffle_rows_device(cg1_ctx* ctx, size_t ell, size_t lg, size_t n_proofs, const void* d_rowin, const void* d_host_status,
+                            const void* d_point_status, void* d_out_scalars, void* d_crs_rows, void* d_status_out);
 /* Exact (unweighted) evaluation on the host of the equalities the reference asserts directly, for proofs that carry a
  * point outside G1 (cg1_subgroup_flags_enqueue / CG1_ERR_NOT_IN_SUBGROUP): the four same-scalar equalities of one shuffle
  * proof (same_scalar.py:101-108; *ok = 1 iff all hold), and the two equalities of one tracker-opening proof

@@ -33,12 +33,13 @@ def _items(case, variants):
     return [apply_edits(case, x["edits"]) for x in variants]
 
 
+@pytest.mark.parametrize("device_rows", [True, False], ids=["rows_on_device", "rows_on_host"])
 @pytest.mark.parametrize("mode", ["merged", "independent"])
-def test_golden_verdicts(gold, ctx, mode):
+def test_golden_verdicts(gold, ctx, mode, device_rows):
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
 
     for case in gold["cases"]:
-        v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx)
+        v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), ctx, device_rows=device_rows)
         got = v.verify_many(_items(case, case["variants"]), mode=mode, rng=random.Random(case["seed"]))
         want = [x["accepts"] for x in case["variants"]]
         assert got == want, [(x["name"], g, w, s) for x, g, w, s in zip(case["variants"], got, want, v.last_status) if g != w]
