@@ -114,6 +114,16 @@ cg1_merlin_append_list = _proto("cg1_merlin_append_list", None, _buf, _u8p, c_si
 cg1_merlin_challenge = _proto("cg1_merlin_challenge", None, _buf, _u8p, c_size_t, _buf, c_size_t)
 cg1_merlin_challenge_scalar = _proto("cg1_merlin_challenge_scalar", None, _buf, _u8p, c_size_t, _buf)
 
+
+
+class MerlinOp(ctypes.Structure):
+    """cg1_merlin_op: one step of the batched device transcript (include/curdle_g1.h)."""
+    _fields_ = [("kind", ctypes.c_uint8), ("label_len", ctypes.c_uint8), ("pad", ctypes.c_uint16), ("len", ctypes.c_uint32),
+                ("data_off", ctypes.c_uint32), ("out_off", ctypes.c_uint32), ("label", ctypes.c_uint8 * 32)]
+
+
+cg1_merlin_batch_device = _proto("cg1_merlin_batch_device", c_int, c_void_p, c_void_p, POINTER(MerlinOp), c_size_t, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_size_t)
+
 # batch verifier front-end of the shuffle argument (host)
 cg1_shuffle_crs_create = _proto("cg1_shuffle_crs_create", c_void_p, _u8p, c_size_t, c_size_t)
 cg1_shuffle_crs_destroy = _proto("cg1_shuffle_crs_destroy", None, c_void_p)
@@ -139,7 +149,7 @@ EXPORTED_SYMBOLS = [
     "cg1_shuffle_crs_create", "cg1_shuffle_crs_destroy", "cg1_shuffle_proof_bytes", "cg1_shuffle_points_per_proof",
     "cg1_shuffle_crs_points", "cg1_shuffle_challenges_per_proof", "cg1_opening_prepare", "cg1_shuffle_prepare", "cg1_shuffle_set_grouped", "cg1_shuffle_default_threads", "cg1_shuffle_gather_points", "cg1_shuffle_rowin_scalars", "cg1_shuffle_prepare_inputs", "cg1_shuffle_rows_device", "cg1_shuffle_exact_same_scalar", "cg1_opening_exact", "cg1_subgroup_flags_enqueue", "cg1_side_sync", "cg1_shuffle_apply_point_status", "cg1_shuffle_sum_crs_scalars",
     "cg1_keccak_f1600", "cg1_keccak_f1600_x8", "cg1_keccak_f1600_x8_states", "cg1_strobe_new", "cg1_strobe_meta_ad", "cg1_strobe_ad", "cg1_strobe_prf", "cg1_strobe_key", "cg1_merlin_init",
-    "cg1_merlin_append", "cg1_merlin_append_list", "cg1_merlin_challenge", "cg1_merlin_challenge_scalar",
+    "cg1_merlin_append", "cg1_merlin_append_list", "cg1_merlin_challenge", "cg1_merlin_challenge_scalar", "cg1_merlin_batch_device",
     "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",

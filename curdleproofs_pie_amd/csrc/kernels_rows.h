@@ -46,18 +46,30 @@ struct Lay {
   __device__ size_t ncrs() const { return ell + 9; }
 };
 
-__device__ __forceinline__ fr ld(const uint8_t* blk, size_t idx) {
+// out-of-line Fr product for this kernel: ~60 call sites of an ~800-instruction body would make a 560 KB kernel
+__device__ __noinline__ fr mulx(const fr& a, const fr& b) { return cg1fr::fr_mul(a, b); }
+
+__device__ __noinline__ fr ld(const uint8_t* blk, size_t idx) {
   fr v;
   cg1fr::fr_from_le32(blk + 32 * idx, v);              // canonical by construction (written by the host front-end)
   return v;
 }
-__device__ __forceinline__ void st(uint8_t* dst, size_t idx, const fr& v) { cg1fr::fr_to_le32(v, dst + 32 * idx); }
+__device__ __noinline__ void st(uint8_t* dst, size_t idx, const fr& v) { cg1fr::fr_to_le32(v, dst + 32 * idx); }
+__device__ inline fr powx(fr base, uint64_t e) {        // fr_pow_u64 over the out-of-line product
+  fr acc = cg1fr::fr_one();
+  while (e) {
+    if (e & 1) acc = mulx(acc, base);
+    base = mulx(base, base);
+    e >>= 1;
+  }
+  return acc;
+}
 
 // prod over j of g_j^{bit j of i, MSB first}  (fold_scalars of the host front-end, element i)
 __device__ inline fr fold_elem(const uint8_t* blk, size_t first, size_t lg, uint32_t i) {
   fr acc = cg1fr::fr_one();
   for (size_t j = 0; j < lg; ++j)
-    if ((i >> (lg - 1 - j)) & 1u) acc = cg1fr::fr_mul(acc, ld(blk, first + j));
+    if ((i >> (lg - 1 - j)) & 1u) acc = mulx(acc, ld(blk, first + j));
   return acc;
 }
 
@@ -91,23 +103,23 @@ __global__ void __launch_bounds__(128) k_shuffle_rows(const uint8_t* __restrict_
            rho4 = ld(blk, R.rho() + 4), rho5 = ld(blk, R.rho() + 5);
   const fr c_fin = ld(blk, R.fields() + 0), d_fin = ld(blk, R.fields() + 1), x_fin = ld(blk, R.fields() + 5);
   const fr beta_inv = ld(blk, R.beta_inv());
-  const fr wc = fr_mul(rho1, c_fin), wd = fr_mul(rho2, d_fin);
-  const fr x4 = fr_mul(rho3, x_fin), x5 = fr_mul(rho4, x_fin), x6 = fr_mul(rho5, x_fin);
+  const fr wc = mulx(rho1, c_fin), wd = mulx(rho2, d_fin);
+  const fr x4 = mulx(rho3, x_fin), x5 = mulx(rho4, x_fin), x6 = mulx(rho5, x_fin);
   // ---- vector entries: thread i owns index i of the n-vectors
   for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
     const fr s = fold_elem(blk, R.gam(), lg, (uint32_t)i), s_inv = fold_elem(blk, R.gam_inv(), lg, (uint32_t)i);
     const fr sm = fold_elem(blk, R.gm(), lg, (uint32_t)i);
-    const fr u = fr_pow_u64(beta_inv, (i < ell ? i : ell) + 1);          // beta^-(i+1); beta^-(ell+1) for the blinder slots
-    fr g = fr_neg(fr_add(fr_mul(wc, s), fr_mul(wd, fr_mul(s_inv, u))));  // CRS slot i (vec_G | vec_H): E2 and E3
+    const fr u = powx(beta_inv, (i < ell ? i : ell) + 1);          // beta^-(i+1); beta^-(ell+1) for the blinder slots
+    fr g = fr_neg(fr_add(mulx(wc, s), mulx(wd, mulx(s_inv, u))));  // CRS slot i (vec_G | vec_H): E2 and E3
     if (i < ell) {
-      g = fr_sub(g, fr_add(fr_mul(rho0, ld(blk, R.head() + 1)), fr_mul(x4, sm)));     // E1: -rho0 beta_p;  same-MSM: -x4 sm_i
+      g = fr_sub(g, fr_add(mulx(rho0, ld(blk, R.head() + 1)), mulx(x4, sm)));     // E1: -rho0 beta_p;  same-MSM: -x4 sm_i
       const fr a = ld(blk, R.a() + i);
-      st(sc, i, fr_neg(fr_mul(ld(blk, R.rho() + 6), a)));                 // R_i
-      st(sc, ell + i, fr_neg(fr_mul(ld(blk, R.rho() + 7), a)));           // S_i
-      st(sc, 2 * ell + i, fr_neg(fr_mul(x5, sm)));                        // T_i
-      st(sc, 3 * ell + i, fr_neg(fr_mul(x6, sm)));                        // U_i
+      st(sc, i, fr_neg(mulx(ld(blk, R.rho() + 6), a)));                 // R_i
+      st(sc, ell + i, fr_neg(mulx(ld(blk, R.rho() + 7), a)));           // S_i
+      st(sc, 2 * ell + i, fr_neg(mulx(x5, sm)));                        // T_i
+      st(sc, 3 * ell + i, fr_neg(mulx(x6, sm)));                        // U_i
     } else if (i < ell + 2) {
-      g = fr_sub(g, fr_mul(x4, sm));                                      // vec_H[0], vec_H[1] stand in G'' (curdleproofs.py:206-224)
+      g = fr_sub(g, mulx(x4, sm));                                      // vec_H[0], vec_H[1] stand in G'' (curdleproofs.py:206-224)
     }
     st(cs, i, g);
   }
@@ -116,33 +128,33 @@ __global__ void __launch_bounds__(128) k_shuffle_rows(const uint8_t* __restrict_
   if (t < lg) {
     const fr g = ld(blk, R.gam() + t), gi = ld(blk, R.gam_inv() + t), m = ld(blk, R.gm() + t), mi = ld(blk, R.gm_inv() + t);
     const size_t b = L.base() + 12;
-    st(sc, b + t, fr_mul(rho1, g));                   // L_C[j]
-    st(sc, b + lg + t, fr_mul(rho1, gi));             // R_C[j]
-    st(sc, b + 2 * lg + t, fr_mul(rho2, g));          // L_D[j]
-    st(sc, b + 3 * lg + t, fr_mul(rho2, gi));         // R_D[j]
+    st(sc, b + t, mulx(rho1, g));                   // L_C[j]
+    st(sc, b + lg + t, mulx(rho1, gi));             // R_C[j]
+    st(sc, b + 2 * lg + t, mulx(rho2, g));          // L_D[j]
+    st(sc, b + 3 * lg + t, mulx(rho2, gi));         // R_D[j]
     const size_t q = L.cmA1() + 7;
-    st(sc, q + t, fr_mul(rho3, m));                   // L_A[j]
-    st(sc, q + lg + t, fr_mul(rho4, m));              // L_T[j]
-    st(sc, q + 2 * lg + t, fr_mul(rho5, m));          // L_U[j]
-    st(sc, q + 3 * lg + t, fr_mul(rho3, mi));         // R_A[j]
-    st(sc, q + 4 * lg + t, fr_mul(rho4, mi));         // R_T[j]
-    st(sc, q + 5 * lg + t, fr_mul(rho5, mi));         // R_U[j]
+    st(sc, q + t, mulx(rho3, m));                   // L_A[j]
+    st(sc, q + lg + t, mulx(rho4, m));              // L_T[j]
+    st(sc, q + 2 * lg + t, mulx(rho5, m));          // L_U[j]
+    st(sc, q + 3 * lg + t, mulx(rho3, mi));         // R_A[j]
+    st(sc, q + 4 * lg + t, mulx(rho4, mi));         // R_T[j]
+    st(sc, q + 5 * lg + t, mulx(rho5, mi));         // R_U[j]
   } else if (t == 32) {
     const fr alpha_p = ld(blk, 0), alpha_i = ld(blk, 4), alpha_s = ld(blk, 6), alpha_m = ld(blk, 7);
     const fr w1 = ld(blk, R.rho() + 8), w2 = ld(blk, R.rho() + 9), w3 = ld(blk, R.rho() + 10), w4 = ld(blk, R.rho() + 11);
     const fr z_k = ld(blk, R.fields() + 2);
-    const fr r3a = fr_mul(rho3, alpha_m);
+    const fr r3a = mulx(rho3, alpha_m);
     const size_t b = L.base();
-    st(sc, b + 0, fr_neg(fr_mul(rho0, alpha_p)));                                  // M
+    st(sc, b + 0, fr_neg(mulx(rho0, alpha_p)));                                  // M
     st(sc, b + 1, fr_sub(r3a, rho0));                                              // A
-    st(sc, b + 2, fr_sub(r3a, fr_mul(w1, alpha_s)));                               // T_1
-    st(sc, b + 3, fr_sub(fr_mul(rho4, alpha_m), fr_mul(w2, alpha_s)));             // T_2
-    st(sc, b + 4, fr_sub(r3a, fr_mul(w3, alpha_s)));                               // U_1
-    st(sc, b + 5, fr_sub(fr_mul(rho5, alpha_m), fr_mul(w4, alpha_s)));             // U_2
-    st(sc, b + 6, fr_add(fr_mul(w2, z_k), ld(blk, R.rho() + 6)));                  // R
-    st(sc, b + 7, fr_add(fr_mul(w4, z_k), ld(blk, R.rho() + 7)));                  // S
-    st(sc, b + 8, fr_add(rho0, fr_mul(rho2, alpha_i)));                            // B
-    st(sc, b + 9, fr_mul(rho1, alpha_i));                                          // C
+    st(sc, b + 2, fr_sub(r3a, mulx(w1, alpha_s)));                               // T_1
+    st(sc, b + 3, fr_sub(mulx(rho4, alpha_m), mulx(w2, alpha_s)));             // T_2
+    st(sc, b + 4, fr_sub(r3a, mulx(w3, alpha_s)));                               // U_1
+    st(sc, b + 5, fr_sub(mulx(rho5, alpha_m), mulx(w4, alpha_s)));             // U_2
+    st(sc, b + 6, fr_add(mulx(w2, z_k), ld(blk, R.rho() + 6)));                  // R
+    st(sc, b + 7, fr_add(mulx(w4, z_k), ld(blk, R.rho() + 7)));                  // S
+    st(sc, b + 8, fr_add(rho0, mulx(rho2, alpha_i)));                            // B
+    st(sc, b + 9, mulx(rho1, alpha_i));                                          // C
     st(sc, b + 10, rho1);                                                          // B_c
     st(sc, b + 11, rho2);                                                          // B_d
     st(sc, L.cmA1() + 0, fr_neg(w1)); st(sc, L.cmA1() + 1, fr_neg(w2));            // cm_A
@@ -153,16 +165,16 @@ __global__ void __launch_bounds__(128) k_shuffle_rows(const uint8_t* __restrict_
     const fr w1 = ld(blk, R.rho() + 8), w2 = ld(blk, R.rho() + 9), w3 = ld(blk, R.rho() + 10), w4 = ld(blk, R.rho() + 11);
     const fr z_t = ld(blk, R.fields() + 3), z_u = ld(blk, R.fields() + 4);
     const fr sm2 = fold_elem(blk, R.gm(), lg, (uint32_t)(ell + 2)), sm3 = fold_elem(blk, R.gm(), lg, (uint32_t)(ell + 3));
-    const fr hcoef = fr_mul(beta_i, fr_sub(fr_mul(fr_sqr(alpha_i), ld(blk, R.inner_prod())), fr_mul(c_fin, d_fin)));
-    const fr wa = fr_mul(rho2, alpha_i);
+    const fr hcoef = mulx(beta_i, fr_sub(mulx(mulx(alpha_i, alpha_i), ld(blk, R.inner_prod())), mulx(c_fin, d_fin)));
+    const fr wa = mulx(rho2, alpha_i);
     // H:  E2's H coefficient, z_t and z_u of the same-scalar argument, the T' / U' blinder slots of the same-MSM argument
-    fr h = fr_add(fr_mul(rho1, hcoef), fr_add(fr_mul(w2, z_t), fr_mul(w4, z_u)));
-    h = fr_sub(h, fr_add(fr_mul(x5, sm2), fr_mul(x6, sm3)));
+    fr h = fr_add(mulx(rho1, hcoef), fr_add(mulx(w2, z_t), mulx(w4, z_u)));
+    h = fr_sub(h, fr_add(mulx(x5, sm2), mulx(x6, sm3)));
     st(cs, ell + 4, h);
-    st(cs, ell + 5, fr_sub(fr_mul(w1, z_t), fr_mul(x4, sm2)));                     // G_t
-    st(cs, ell + 6, fr_sub(fr_mul(w3, z_u), fr_mul(x4, sm3)));                     // G_u
-    st(cs, ell + 7, fr_neg(fr_mul(wa, beta_inv)));                                 // G_sum
-    st(cs, ell + 8, fr_mul(wa, alpha_g));                                          // H_sum
+    st(cs, ell + 5, fr_sub(mulx(w1, z_t), mulx(x4, sm2)));                     // G_t
+    st(cs, ell + 6, fr_sub(mulx(w3, z_u), mulx(x4, sm3)));                     // G_u
+    st(cs, ell + 7, fr_neg(mulx(wa, beta_inv)));                                 // G_sum
+    st(cs, ell + 8, mulx(wa, alpha_g));                                          // H_sum
   }
 }
 

@@ -56,6 +56,7 @@ int pick_window(size_t n);
 #include "kernels_batch.h"
 }  // namespace cg1
 #include "kernels_rows.h"
+#include "kernels_merlin.h"
 namespace cg1 {
 
 // ------------------------------------------------------------------ host-side context
@@ -1111,6 +1112,32 @@ int cg1_side_sync(cg1_ctx* ctx) {
   if (!ctx->side_stream) return CG1_OK;
   HIPCHK(hipSetDevice(ctx->device));
   HIPCHK(hipStreamSynchronize(ctx->side_stream));
+  return CG1_OK;
+}
+// n Merlin transcripts on the device, one per lane, all running the same operation list on their own data rows
+// (k_merlin_batch).  init_state208: MerlinTranscript(label) as the host left it (cg1_merlin_init); ops: host array.
+int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg1_merlin_op* ops, size_t nops, const void* d_data,
+                            size_t data_stride, void* d_out, size_t out_stride, void* d_states_out, size_t n) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) return CG1_OK;
+  if (!init_state208 || (nops && !ops) || !d_out || n >= (1ull << 31)) return CG1_ERR_ARG;
+  static_assert(sizeof(cg1_merlin_op) == sizeof(cg1merlin::Op), "op record layout");
+  for (size_t k = 0; k < nops; ++k) {
+    const cg1_merlin_op& o = ops[k];
+    if (o.kind > 3 || o.label_len > 32) return CG1_ERR_ARG;
+    if (o.kind == 0 && (!d_data || (size_t)o.data_off + o.len > data_stride)) return CG1_ERR_ARG;
+    if (o.kind != 0 && (size_t)o.out_off + (o.kind == 2 ? 32 : o.len) > out_stride) return CG1_ERR_ARG;
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf dst, dops;
+  HIPCHK(dst.alloc(208)); HIPCHK(dops.alloc(nops * sizeof(cg1_merlin_op)));
+  HIPCHK(hipMemcpyAsync(dst.p, init_state208, 208, hipMemcpyHostToDevice, ctx->stream));
+  if (nops) HIPCHK(hipMemcpyAsync(dops.p, ops, nops * sizeof(cg1_merlin_op), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(cg1merlin::k_merlin_batch, dim3((unsigned)((n + cg1merlin::LANES - 1) / cg1merlin::LANES)), dim3(cg1merlin::LANES), 0, ctx->stream,
+                     (const uint8_t*)dst.p, (const cg1merlin::Op*)dops.p, (uint32_t)nops, (const uint8_t*)d_data, data_stride,
+                     (uint8_t*)d_out, out_stride, (uint8_t*)d_states_out, (uint32_t)n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
   return CG1_OK;
 }
 // The scalar rows of a batch of shuffle statements, built on the device from the host front-end's input blocks

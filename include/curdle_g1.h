@@ -223,6 +223,22 @@ int cg1_shuffle_prepare(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8
 void cg1_shuffle_set_grouped(int on);
 /* threads used when n_threads = 0: usable CPUs (affinity mask capped by the cgroup CPU quota; env CURDLE_G1_THREADS overrides) */
 size_t cg1_shuffle_default_threads(void);
+/* Batched Merlin transcripts on the device (HIP half): n transcripts, one per GPU lane, all starting from
+ * init_state208 (what cg1_merlin_init left on the host) and all running the same operation list on their own data rows:
+ *   kind 0  append_message(label, data_row[data_off .. data_off + len))                      merlin_transcript.py:11-15
+ *   kind 1  challenge_bytes(label, len) -> out_row[out_off ..]                                merlin_transcript.py:20-24
+ *   kind 2  get_and_append_challenge(label) -> 32 bytes at out_row[out_off ..]                curdleproofs_transcript.py:15-25
+ *   kind 3  append_message(label, out_row[out_off .. out_off + len))   (a value the transcript produced itself)
+ * d_states_out (optional): the n final 208-byte state blobs, interchangeable with the host functions above. */
+typedef struct cg1_merlin_op {
+  uint8_t kind, label_len;
+  uint16_t pad;
+  uint32_t len, data_off, out_off;
+  uint8_t label[32];
+} cg1_merlin_op;
+int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg1_merlin_op* ops, size_t nops, const void* d_data,
+                            size_t data_stride, void* d_out, size_t out_stride, void* d_states_out, size_t n);
+
 /* Scalar rows on the device (ipa.py:155-186,216,227-229; same_msm.py:146-182,213; grand_prod.py:64-71;
  * msm_accumulator.py:43-58).  cg1_shuffle_prepare_inputs is cg1_shuffle_prepare without the row expansion: per proof it emits
  * cg1_shuffle_rowin_scalars(crs) 32-byte scalars (the transcript's challenges, their inverses, beta^-1, inner_prod, the
