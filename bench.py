@@ -277,6 +277,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--logn", type=int, default=20, help="log2 of terms per GPU")
     ap.add_argument("--window", type=int, default=0, help="0 = the library's plan for the size (c = 16 at 2^20); 4..16 uniform; -16..-4 balanced")
+    ap.add_argument("--pipeline", type=int, default=1, choices=[1, 2],
+                    help="MSM calls in flight per GPU in the timed region: 1 (default) = strictly one call after the other, so ms_per_step is "
+                         "the latency of one call and the kernel times are those of kernels that own the chip; 2 = two contexts take the steps "
+                         "alternately (cg1_msm_device_begin / _end): a step's sort phases run under the previous step's bucket accumulation and "
+                         "its reduction tail under the next one's (always reported beside the headline as `two_calls_in_flight`)")
     ap.add_argument("--seed", type=int, default=1, help="input seed of the timed region (seeds 1, 2, 3 are also reported side by side)")
     ap.add_argument("--shard", choices=["hybrid", "windows", "points"], default="hybrid",
                     help="N>1: hybrid = 2 window-bucket groups x N/2 point groups (default); windows / points = pure splits")
@@ -324,6 +329,7 @@ def main():
         else:
             dist.init_process_group(backend="gloo")
     ctx = N.Context(dev_index)
+    ctx2 = N.Context(dev_index)                               # second pipeline of the same GPU (own stream and scratch buffers)
 
     from curdleproofs_pie_amd.distributed import all_reduce_g1, shard_layout
 
@@ -338,17 +344,20 @@ def main():
                 torch.cuda.synchronize()
         ctx.sync()
 
-    def run(shard, n_per_gpu, seed, steps, warmup):
-        """One timed measurement: ONE MSM of world * n_per_gpu terms per step, sharded `shard`-wise.  Returns a dict with the
-        max-over-ranks time and what the audit needs."""
+    def run(shard, n_per_gpu, seed, steps, warmup, depth=None):
+        """One timed measurement: ONE MSM of world * n_per_gpu terms per step, sharded `shard`-wise, `depth` calls in flight.
+        Returns a dict with the max-over-ranks time and what the audit needs."""
+        depth = depth or args.pipeline
+        ctxs = [ctx, ctx2][:depth]
         w_rank, w_groups, p_rank, p_groups = shard_layout(rank, world, shard)
         n_group = n_per_gpu * world // p_groups            # terms of one point group (= of this rank)
         wl = Workload(ctx, d_g, n_per_gpu, seed, groups=[p_rank * (world // p_groups) + j for j in range(world // p_groups)])
         assert wl.n == n_group
         ex = {"t": 0.0, "n": 0}
 
-        def step():
-            part = ctx.msm_device(wl.d_pts, wl.d_sc, wl.n, window_c=c, shard_rank=w_rank, shard_world=w_groups)
+        phase_acc = {}
+
+        def exchange(part):
             if world == 1:
                 return part
             t = time.perf_counter()
@@ -357,15 +366,34 @@ def main():
             ex["n"] += 1
             return out
 
-        results = [step() for _ in range(warmup)]
+        def finish(cx):
+            part = cx.msm_device_end()
+            for k, v in cx.timings().items():
+                phase_acc[k] = phase_acc.get(k, 0.0) + v
+            return exchange(part)
+
+        def stream(count):
+            """`count` complete steps; with depth 2 step k+1 is enqueued on the other context before step k is collected"""
+            out, pending = [], None
+            for k in range(count):
+                cx = ctxs[k % len(ctxs)]
+                cx.msm_device_begin(wl.d_pts, wl.d_sc, wl.n, window_c=c, shard_rank=w_rank, shard_world=w_groups)
+                if len(ctxs) == 1:
+                    out.append(finish(cx))
+                    continue
+                if pending is not None:
+                    out.append(finish(pending))
+                pending = cx
+            if pending is not None:
+                out.append(finish(pending))
+            return out
+
+        results = stream(warmup)
         ex["t"], ex["n"] = 0.0, 0
-        phase_acc, counts = {}, None
+        phase_acc.clear()
         barrier_sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            results.append(step())
-            for k, v in ctx.timings().items():
-                phase_acc[k] = phase_acc.get(k, 0.0) + v
+        results += stream(steps)                            # every step is begun AND collected inside the timed region
         barrier_sync()
         elapsed = mine = time.perf_counter() - t0
         counts = ctx.last_counts()
@@ -383,7 +411,7 @@ def main():
                "per_rank_ms_per_step": {"min": min(per_rank) / steps * 1e3, "max": max(per_rank) / steps * 1e3},
                "phases_ms": {k: v / steps for k, v in phase_acc.items() if k != "window_c"}, "counts": counts,
                "phases_ms_window_c": phase_acc.get("window_c", 0) / steps,
-               "layout": (w_rank, w_groups, p_rank, p_groups), "n_local": wl.n,
+               "layout": (w_rank, w_groups, p_rank, p_groups), "n_local": wl.n, "depth": len(ctxs),
                "exchange_ms": (ex["t"] / ex["n"] * 1e3) if ex["n"] else None, "result": results[-1]}
         wl.free()
         return rec
@@ -398,6 +426,12 @@ def main():
         for s in (1, 2, 3):
             seeds[str(s)] = main_rec["ms_per_step"] if s == args.seed else run(args.shard, n_per_gpu, s, max(3, args.steps // 2), 1)["ms_per_step"]
         extra["seeds_ms_per_step"] = dict(seeds, min=min(seeds.values()), median=statistics.median(seeds.values()))
+        other = run(args.shard, n_per_gpu, args.seed, args.steps, args.warmup, depth=3 - main_rec["depth"])
+        extra["two_calls_in_flight" if main_rec["depth"] == 1 else "single_call"] = {
+            "what": ("the same steps with TWO MSM calls in flight on the GPU (two contexts, cg1_msm_device_begin / _end): throughput of a stream of "
+                     "MSMs; kernel times stretch because kernels of both calls share the chip" if main_rec["depth"] == 1 else
+                     "the same steps strictly one after the other (one MSM call in flight): per-call latency"),
+            "ms_per_step": other["ms_per_step"], "value": other["value"], "phases_ms": other["phases_ms"]}
         if world > 1:
             # what north_star names literally: window buckets sharded over ALL N GPUs, every rank holding all N * 2^20 points
             if args.shard != "windows":
@@ -445,6 +479,7 @@ def main():
                                    f"sharded over {world} GPU(s): {w_groups} window-bucket group(s) x {p_groups} point group(s)",
                        "terms_total": n_per_gpu * world, "terms_per_gpu": n_per_gpu, "window_c": int(r["phases_ms_window_c"]), "shard": args.shard,
                        "parallelism": f"windows x{w_groups} . points x{p_groups}, one all-gather of {world} partial G1 sums",
+                       "calls_in_flight": r["depth"],
                        "arithmetic": "381-bit Fp as 14 x 28-bit limbs in u32, Montgomery, 64-bit column accumulators (v_mad_u64_u32)",
                        "bit_exact_vs_oracle": "tests/test_msm_gpu.py"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

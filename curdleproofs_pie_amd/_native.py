@@ -79,6 +79,8 @@ cg1_ctx_sync = _proto("cg1_ctx_sync", c_int, c_void_p)
 cg1_ctx_set_param = _proto("cg1_ctx_set_param", c_int, c_void_p, c_char_p, c_int)
 cg1_msm = _proto("cg1_msm", c_int, c_void_p, _u8p, _u8p, c_size_t, _buf)
 cg1_msm_device = _proto("cg1_msm_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, _buf)
+cg1_msm_device_begin = _proto("cg1_msm_device_begin", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int)
+cg1_msm_device_end = _proto("cg1_msm_device_end", c_int, c_void_p, _buf)
 cg1_msm_batched_device = _proto("cg1_msm_batched_device", c_int, c_void_p, c_void_p, c_void_p, POINTER(ctypes.c_uint32), c_size_t, c_int, _buf)
 cg1_msm_batched = _proto("cg1_msm_batched", c_int, c_void_p, _u8p, _u8p, POINTER(ctypes.c_uint32), c_size_t, _buf)
 cg1_get_timings = _proto("cg1_get_timings", c_int, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_int))
@@ -154,7 +156,7 @@ EXPORTED_SYMBOLS = [
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_h2d_async", "cg1_copy_fence", "cg1_stream_sync", "cg1_batch_decompress_enqueue", "cg1_host_alloc", "cg1_host_free", "cg1_ctx_sync", "cg1_ctx_set_param",
-    "cg1_msm", "cg1_msm_device", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_get_last_counts", "cg1_timer_begin", "cg1_timer_end", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
+    "cg1_msm", "cg1_msm_device", "cg1_msm_device_begin", "cg1_msm_device_end", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_get_last_counts", "cg1_timer_begin", "cg1_timer_end", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
 ]
 
 
@@ -253,6 +255,16 @@ class Context:
         s = d_scalars.ptr if isinstance(d_scalars, DeviceBuffer) else int(d_scalars)
         out = ctypes.create_string_buffer(POINT_BYTES)
         self.check(cg1_msm_device(self.handle, p, s, n, window_c, shard_rank, shard_world, out))
+        return out.raw
+
+    def msm_device_begin(self, d_points, d_scalars, n: int, window_c: int = 0, shard_rank: int = 0, shard_world: int = 1) -> None:
+        """Enqueue this context's whole MSM launch chain and return; msm_device_end() waits and delivers the point."""
+        g = lambda b: b.ptr if isinstance(b, DeviceBuffer) else int(b)
+        self.check(cg1_msm_device_begin(self.handle, g(d_points), g(d_scalars), n, window_c, shard_rank, shard_world))
+
+    def msm_device_end(self) -> bytes:
+        out = ctypes.create_string_buffer(POINT_BYTES)
+        self.check(cg1_msm_device_end(self.handle, out))
         return out.raw
 
     def msm_batched_device(self, d_points, d_scalars, offsets, window_c: int = 0) -> list:

@@ -162,7 +162,7 @@ struct Ctx {
   int profile = 1;                      // read the per-phase hipEvents after each call
   uint32_t last_chunks = 0, last_entries = 0;   // of the last MSM call: non-zero digits sorted into buckets; chunks k_accumulate ran
   hipEvent_t tm_ev[2] = {nullptr, nullptr};     // cg1_timer_begin / cg1_timer_end
-  int last_c = 0;
+  int last_c = 0, pend_c = 0;
   uint32_t L0 = 8;                      // MINIMUM chunk length; the per-call length grows with the entry count
   uint32_t seg_m = 4;
 };
@@ -566,8 +566,12 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
 
 // One MSM: this context's share (windows w = rank mod world) of sum_i scalar_i * point_i.
 // c = 0: automatic plan; 4..16: uniform windows of that width; -16..-4: the balanced plan with cmax = -c.
-int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
-  result = cg1h::jac_identity();
+// msm_begin enqueues the whole launch chain and returns; msm_end waits for it and runs the host tail.  Two contexts on one
+// GPU can thus keep two MSMs in flight: the sort phases of the next one run under this one's k_accumulate (they need few
+// registers and co-reside with its waves), and this one's reduction tree, D2H and host Horner run under the next one's.
+int msm_begin(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world) {
+  ctx->pend.active = false;
+  ctx->pend_c = 0;
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "n too large"); return CG1_ERR_ARG; }
   if (world < 1 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
@@ -575,11 +579,19 @@ int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t
   const int cabs = c < 0 ? -c : c;
   if (cabs < 4 || cabs > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
   const WinPlan plan = make_plan(c);
-  int rc = msm_enqueue(ctx, d_points96, d_scalars32, n, plan, rank, world);
-  if (rc) return rc;
-  rc = msm_finish(ctx, result);
-  ctx->last_c = c;                                   // negative: a balanced plan (cg1_get_timings reports it)
+  ctx->pend_c = c;
+  return msm_enqueue(ctx, d_points96, d_scalars32, n, plan, rank, world);
+}
+int msm_end(Ctx* ctx, cg1h::jac& result) {
+  int rc = msm_finish(ctx, result);
+  if (ctx->pend_c) ctx->last_c = ctx->pend_c;          // negative: a balanced plan (cg1_get_timings reports it)
   return rc;
+}
+int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
+  result = cg1h::jac_identity();
+  int rc = msm_begin(ctx, d_points96, d_scalars32, n, c, rank, world);
+  if (rc) return rc;
+  return msm_end(ctx, result);
 }
 
 
@@ -927,6 +939,20 @@ int cg1_msm_device(cg1_ctx* ctx, const void* d_points, const void* d_scalars, si
   if (!ctx) return CG1_ERR_HIP;
   cg1h::jac r;
   int rc = cg1::msm_device(ctx, d_points, d_scalars, n, window_c, shard_rank, shard_world, r);
+  if (rc == CG1_OK) blob_out(out, r);
+  return rc;
+}
+
+// The same call in two halves: _begin enqueues this context's whole launch chain and returns at once, _end waits for it,
+// runs the host tail and delivers the point.  With two contexts on one GPU, begin the next MSM before ending this one.
+int cg1_msm_device_begin(cg1_ctx* ctx, const void* d_points, const void* d_scalars, size_t n, int window_c, int shard_rank, int shard_world) {
+  if (!ctx) return CG1_ERR_HIP;
+  return cg1::msm_begin(ctx, d_points, d_scalars, n, window_c, shard_rank, shard_world);
+}
+int cg1_msm_device_end(cg1_ctx* ctx, uint8_t* out) {
+  if (!ctx) return CG1_ERR_HIP;
+  cg1h::jac r;
+  int rc = cg1::msm_end(ctx, r);
   if (rc == CG1_OK) blob_out(out, r);
   return rc;
 }

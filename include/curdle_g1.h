@@ -103,6 +103,12 @@ int cg1_msm_device(cg1_ctx* ctx, const void* d_points_affine96, const void* d_sc
  * n_msm+1 entries with offsets[0] == 0; out_blobs receives n_msm point blobs.  window_c 4..9, 0 = auto. */
 int cg1_msm_batched_device(cg1_ctx* ctx, const void* d_points_affine96, const void* d_scalars32,
                            const uint32_t* offsets, size_t n_msm, int window_c, uint8_t* out_blobs);
+/* cg1_msm_device in two halves: _begin enqueues the context's launch chain and returns, _end waits, runs the host tail and
+ * delivers the point (identity when n was 0).  Two contexts on one GPU keep two MSMs in flight: the next one's sort phases
+ * run under this one's bucket accumulation, this one's reduction tail under the next one's. */
+int cg1_msm_device_begin(cg1_ctx* ctx, const void* d_points_affine96, const void* d_scalars32, size_t n, int window_c,
+                         int shard_rank, int shard_world);
+int cg1_msm_device_end(cg1_ctx* ctx, uint8_t out[CG1_POINT_BYTES]);
 int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points_affine96, const uint8_t* scalars32,
                     const uint32_t* offsets, size_t n_msm, uint8_t* out_blobs);
 /* per-phase GPU times (hipEvents on the context's stream) and host Horner tail of the last MSM call */
