@@ -266,21 +266,18 @@ int g1_decompress(const uint8_t in[48], bool check_subgroup, jac& out) {
   uint8_t flags = in[0];
   bool compressed = flags & 0x80, infinity = flags & 0x40, largest = flags & 0x20;
   if (!compressed) return 1;
-  if (infinity && largest) return 1;
+  (void)largest;
+  // infinity flag: the identity, whatever the sign flag and the remaining bits say -- the wheel (ark-bls12-381 0.4 `read_g1_compressed`) returns the identity as soon as the infinity flag is set, whatever the sign flag and the other 381 bits say, and re-serialises it canonically (0xC0, 47 zero bytes) wherever the reference hashes or compares it; its source is not in /root/reference, so this leniency is restated from the published crate, not pinned by a reference vector
+  if (infinity) { out = jac_identity(); return 0; }
   uint8_t xb[48];
   memcpy(xb, in, 48);
   xb[0] &= 0x1F;
-  if (infinity) {
-    for (int i = 0; i < 48; ++i) if (xb[i]) return 1;
-    out = jac_identity();
-    return 0;
-  }
   fe x;
   if (!fe_from_be48(xb, x)) return 2;
   fe rhs = fe_add(fe_mul(fe_sqr(x), x), mk(cg1::H_B4));
   fe y;
   if (!fe_sqrt(rhs, y)) return 3;
-  if (fe_lex_largest(y) != largest) y = fe_neg(y);
+  if (fe_lex_largest(y) != ((flags & 0x20) != 0)) y = fe_neg(y);
   out = jac_from_affine(x, y);
   if (check_subgroup && !jac_in_subgroup(out)) return 4;
   return 0;

@@ -197,13 +197,8 @@ __global__ void __launch_bounds__(128) k_batch_decompress(const uint8_t* __restr
     uint32_t b0 = (j == 11) ? (uint32_t)(q[0] & 0x1F) : (uint32_t)q[0];
     w[j] = (b0 << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
   }
-  if (!compressed || (infinity && largest)) { status[i] = CG1_ERR_ENCODING; return; }
-  if (infinity) {
-    uint32_t any = 0;
-    for (int j = 0; j < 12; ++j) any |= w[j];
-    status[i] = any ? CG1_ERR_ENCODING : CG1_OK;
-    return;
-  }
+  if (!compressed) { status[i] = CG1_ERR_ENCODING; return; }
+  if (infinity) { status[i] = CG1_OK; return; }          // the identity whatever the other bits say (as the wheel decodes it; host_g1.cpp)
   bool lt = false, decided = false;             // x < p ?
   for (int j = 11; j >= 0 && !decided; --j) if (w[j] != W_P[j]) { lt = w[j] < W_P[j]; decided = true; }
   if (!lt) { status[i] = CG1_ERR_ENCODING; return; }

@@ -159,6 +159,16 @@ struct Layout {
 
 size_t proof_wire_bytes(size_t lg) { return 48 * (19 + 10 * lg) + 32 * 7; }
 
+// The wheel decodes ANY encoding with the infinity flag set as the identity (host_g1.cpp g1_decompress) and the reference hashes
+// points after re-serialising them (points_projective_to_bytes, util.py:27-32): what enters the transcript for such a point is
+// the canonical 0xC0 00 .. 00, not the wire bytes.  Applied to the gathered copy of the wire points before any hashing.
+inline void canonicalize_infinities(uint8_t* pts48, size_t count) {
+  for (size_t i = 0; i < count; ++i) {
+    uint8_t* b = pts48 + 48 * i;
+    if ((b[0] & 0xC0) == 0xC0) { memset(b, 0, 48); b[0] = 0xC0; }
+  }
+}
+
 struct Transcript {
   uint8_t st[CG1_MERLIN_STATE_BYTES];
   explicit Transcript(const char* label) { cg1_merlin_init(st, (const uint8_t*)label, strlen(label)); }
@@ -317,6 +327,7 @@ int prepare_one(const Crs& crs, const uint8_t* inst /* 4*ell*48 */, const uint8_
     sc(x_fin);
     if (!ok) return CG1_SHUFFLE_BAD_SCALAR;    // Scalar.from_le_bytes raises (util.py:151)
   }
+  canonicalize_infinities(out_points, L.count());
   auto P = [&](size_t idx) { return out_points + idx * 48; };
   if (P(L.T(0))[0] & 0x40) return CG1_SHUFFLE_T0_INFINITY;          // curdleproofs.py:173-174
 
@@ -580,6 +591,7 @@ void prepare_group(const Crs& crs, int cnt, const uint8_t* const* inst, const ui
     pts(2 + 4 * lg); sc(q.c_fin); sc(q.d_fin);
     pts(4); sc(q.z_k); sc(q.z_t); sc(q.z_u);
     pts(3 + 6 * lg); sc(q.x_fin);
+    canonicalize_infinities(q.pts, L.count());
     if (!ok) q.status = CG1_SHUFFLE_BAD_SCALAR;
     else if (q.pts[L.T(0) * 48] & 0x40) q.status = CG1_SHUFFLE_T0_INFINITY;
     for (int j = 0; j < 12; ++j)
@@ -998,6 +1010,7 @@ int cg1_opening_prepare(size_t n, const uint8_t* trackers, const uint8_t* k_comm
     const uint8_t *rG = trackers + 96 * i, *krG = rG + 48, *kG = k_commitments + 48 * i, *A = proofs + 128 * i, *B = A + 48;
     uint8_t* pts = out_points48 + 5 * 48 * i;
     memcpy(pts, kG, 48); memcpy(pts + 48, krG, 48); memcpy(pts + 96, rG, 48); memcpy(pts + 144, A, 48); memcpy(pts + 192, B, 48);
+    canonicalize_infinities(pts, 5);
     uint8_t* sc = out_scalars32 + 5 * 32 * i;
     uint8_t* gs = out_g_scalars32 + 32 * i;
     memset(sc, 0, 5 * 32);
@@ -1006,7 +1019,7 @@ int cg1_opening_prepare(size_t n, const uint8_t* trackers, const uint8_t* k_comm
     if (!fr_from_le32(A + 96, s_)) { status[i] = CG1_SHUFFLE_BAD_SCALAR; return; }
     if (!fr_from_le32(weights + 64 * i, r1) || !fr_from_le32(weights + 64 * i + 32, r2)) { status[i] = CG1_SHUFFLE_BAD_WEIGHT; return; }
     Transcript tr("whisk_opening_proof");
-    const uint8_t* order[6] = {kG, G48, krG, rG, A, B};
+    const uint8_t* order[6] = {pts, G48, pts + 48, pts + 96, pts + 144, pts + 192};          // k_G G k_r_G r_G A B, as re-serialised
     for (const uint8_t* p : order) tr.point("tracker_opening_proof", p);
     const fr c = tr.challenge("tracker_opening_proof_challenge");
     fr_to_le32(fr_mul(r1, c), sc);                 // k_G
@@ -1081,10 +1094,12 @@ int cg1_opening_exact(const uint8_t* tracker96, const uint8_t* k_commitment48, c
   if (cg1h::g1_decompress(rG, false, jrG) || cg1h::g1_decompress(krG, false, jkrG) || cg1h::g1_decompress(kG, false, jkG) ||
       cg1h::g1_decompress(A, false, jA) || cg1h::g1_decompress(B, false, jB))
     return CG1_OK;
-  uint8_t G48[48];
+  uint8_t G48[48], own[5 * 48];
   cg1h::g1_compress(cg1h::jac_generator(), G48);
+  memcpy(own, kG, 48); memcpy(own + 48, krG, 48); memcpy(own + 96, rG, 48); memcpy(own + 144, A, 48); memcpy(own + 192, B, 48);
+  canonicalize_infinities(own, 5);
   Transcript tr("whisk_opening_proof");
-  const uint8_t* order[6] = {kG, G48, krG, rG, A, B};
+  const uint8_t* order[6] = {own, G48, own + 48, own + 96, own + 144, own + 192};
   for (const uint8_t* p : order) tr.point("tracker_opening_proof", p);
   const fr c = tr.challenge("tracker_opening_proof_challenge");
   uint8_t c32[32], s32[32];

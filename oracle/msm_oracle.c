@@ -275,15 +275,10 @@ int orc_decompress(const uint8_t in48[48], int check_subgroup, uint8_t out96[96]
   memset(out96, 0, 96);
   const uint8_t flags = in48[0];
   if (!(flags & 0x80)) return 1;
-  if ((flags & 0x40) && (flags & 0x20)) return 1;
+  if (flags & 0x40) return 0;              /* the identity whatever the other bits say (oracle/bls12_381.py g1_decompress) */
   uint8_t xle[48];
   for (int i = 0; i < 48; ++i) xle[i] = in48[47 - i];
   xle[47] &= 0x1f;
-  if (flags & 0x40) {
-    int any = 0;
-    for (int i = 0; i < 48; ++i) any |= xle[i];
-    return any ? 1 : 0;
-  }
   uint64_t xw[6];
   for (int i = 0; i < 6; ++i) { uint64_t w = 0; for (int j = 7; j >= 0; --j) w = (w << 8) | xle[8 * i + j]; xw[i] = w; }
   if (ge_p(xw)) return 1;

@@ -10,7 +10,11 @@ oracle backend of tests/golden/_backend.py; the provers are driven with a torsio
   opening  "A + T3":      A := A + T3, s recomputed for the new challenge       -> reference REJECTS (A' != A by T3)
   opening  "k_G + T3":    k_commitment := k_G + T3 and A := A + c*T3 (ground)   -> reference ACCEPTS (the defects cancel)
   shuffle  "cm_A.T_1+T3": SameScalarProof.new sends cm_A.T_1 + T3               -> reference REJECTS
-plus the honest versions.  Data only -> tests/golden/torsion_vectors.json.
+plus the honest versions, and NON-CANONICAL INFINITY encodings: the wheel decodes any encoding with the infinity flag as the
+identity and the reference re-serialises points before hashing, so an opening proof over the identity tracker (r_G = k_r_G =
+B = identity: valid) stays valid when those identities are written as 0xC0 + junk or with the sign flag set.  (Restated from
+the published ark-bls12-381 0.4 decoder in oracle/bls12_381.py; the wheel cannot run here.)
+Data only -> tests/golden/torsion_vectors.json.
 
     python tests/golden/gen_torsion_golden.py [--backend oracle|product]
 """
@@ -111,6 +115,21 @@ def shuffle_case(name, ell, crs, torsion):
             "proof": bytes(proof).hex(), "accepts": accepts}
 
 
+def identity_tracker_case(name, enc_rG, enc_krG, enc_B, enc_A=None):
+    """Opening proof over r_G = identity: k_r_G = identity, B = identity; the three identities encoded as given."""
+    k, blinder = G.random_scalar(), G.random_scalar()
+    Z = G1Point.identity()
+    k_G, A = G.G1 * k, G.G1 * blinder
+    tr = CurdleproofsTranscript(b"whisk_opening_proof")
+    tr.append_list(b"tracker_opening_proof", points_projective_to_bytes([k_G, G.G1, Z, Z, A, Z]))
+    c = tr.get_and_append_challenge(b"tracker_opening_proof_challenge")
+    s = blinder - c * k
+    proof = (enc_A or pb(A)) + enc_B + bytes(s.to_le_bytes())
+    tracker = G.WhiskTracker(G.BLSPubkey(enc_rG), G.BLSPubkey(enc_krG))
+    accepts = bool(IsValidWhiskOpeningProof(tracker, G.BLSPubkey(pb(k_G)), proof))
+    return {"name": name, "r_G": enc_rG.hex(), "k_r_G": enc_krG.hex(), "k_commitment": pb(k_G).hex(), "proof": proof.hex(), "accepts": accepts}
+
+
 def main():
     random.seed(333)
     opening = []
@@ -120,6 +139,13 @@ def main():
         while case is None:
             case = opening_case(name, where)
         opening.append(case)
+    canon = bytes([0xC0]) + bytes(47)
+    junk = bytes([0xC0]) + bytes(range(1, 48))
+    signed = bytes([0xE0]) + bytes(47)
+    tail = bytes([0xC0]) + bytes(46) + b"\x01"
+    opening += [identity_tracker_case("identity tracker, canonical encodings", canon, canon, canon),
+                identity_tracker_case("identity tracker, non-canonical infinity encodings", junk, signed, tail),
+                identity_tracker_case("identity tracker, A := non-canonical infinity", canon, junk, canon, enc_A=signed)]
     ell = 12
     crs = G.CurdleproofsCrs.new(ell, G.N_BLINDERS)
     shuffle = {"ell": ell, "crs": bytes(crs.to_bytes()).hex(),

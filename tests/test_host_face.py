@@ -93,9 +93,17 @@ def test_against_oracle(B):
     assert B.points_to_compressed(pts) == [p.to_compressed_bytes() for p in pts]
 
 
+def test_infinity_flag_decodes_to_the_identity(B):
+    """any encoding with the infinity flag is the identity (as the oracle restates the wheel's decoder), re-encoded canonically"""
+    for enc in (bytes([0xC0]) + bytes(47), bytes([0xE0]) + bytes(47), bytes([0xC0]) + bytes(46) + b"\x01", bytes([0xFF]) * 48):
+        for f in (B.G1Point.from_compressed_bytes_unchecked, B.G1Point.from_compressed_bytes):
+            p = f(enc)
+            assert p == B.G1Point.identity() and bytes(p.to_compressed_bytes()) == O.g1_compress(O.g1_decompress(enc))
+
+
 def test_bad_encodings_raise_valueerror(B):
     G1Point = B.G1Point
-    for bad in (bytes(48), bytes([0xE0]) + bytes(47), bytes([0xC0]) + bytes(46) + b"\x01", bytes([0x9F]) + b"\xff" * 47, b"\x80" * 47):
+    for bad in (bytes(48), bytes([0x9F]) + b"\xff" * 47, b"\x80" * 47):
         with pytest.raises(ValueError):
             G1Point.from_compressed_bytes_unchecked(bad)
     x = 1

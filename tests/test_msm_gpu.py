@@ -177,6 +177,43 @@ def test_config4_full_size_2_22_window_shards(native_lib, ctx):
     assert compress_blob(N, sum_blobs(parts)) == want
 
 
+def test_two_calls_in_flight(native_lib):
+    """cg1_msm_device_begin / _end: two contexts on one GPU hold two MSMs in flight (the next one's sort phases run under this
+    one's accumulation); results equal the one-call path, in any interleaving, including n = 0 and a window-sharded call."""
+    N = native_lib
+    a, b = N.Context(0), N.Context(0)
+    try:
+        n = 1 << 15
+        dk, dg, dp, ds = a.alloc(32 * n), a.alloc(96), a.alloc(96 * n), a.alloc(32 * n)
+        a.gen_scalars_device(dk, n, 21); a.gen_scalars_device(ds, n, 22)
+        dg.upload(raw96(O.G1_GEN))
+        a.batch_mul_device(dg, 1, dk, dp, n)
+        sizes = [n, 1000, n // 2, 0, 7, n]
+        want = [a.msm_device(dp, ds, m) for m in sizes]
+        got, pending = [], None
+        for k, m in enumerate(sizes):
+            cx = (a, b)[k % 2]
+            cx.msm_device_begin(dp, ds, m)
+            if pending is not None:
+                got.append(pending.msm_device_end())
+            pending = cx
+        got.append(pending.msm_device_end())
+        assert all(N.cg1_eq(g, w) == 1 for g, w in zip(got, want)) and len(got) == len(want)
+        from curdleproofs_pie_amd.distributed import sum_blobs
+
+        parts, got4 = [], []
+        for rank in range(4):                                   # the four window shards of one MSM, two in flight at a time
+            cx = (a, b)[rank % 2]
+            cx.msm_device_begin(dp, ds, n, window_c=16, shard_rank=rank, shard_world=4)
+            parts.append(cx)
+            if len(parts) == 2:
+                got4 += [p.msm_device_end() for p in parts]
+                parts = []
+        assert compress_blob(N, sum_blobs(got4)) == compress_blob(N, want[0])
+    finally:
+        a.close(); b.close()
+
+
 def test_batch_mul_variable_base(native_lib, ctx):
     rng = random.Random(9)
     n = 37

@@ -18,7 +18,7 @@ FR = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 @pytest.fixture(scope="module")
 def tors():
     t = json.load(open(os.path.join(ROOT, "tests", "golden", "torsion_vectors.json")))
-    assert [c["accepts"] for c in t["opening"]] == [True, False, True, True, True, False]
+    assert [c["accepts"] for c in t["opening"]] == [True, False, True, True, True, False, True, True, False]
     assert [c["accepts"] for c in t["shuffle"]["cases"]] == [True, False, True, False]
     return t
 
