@@ -344,11 +344,13 @@ def main():
                 torch.cuda.synchronize()
         ctx.sync()
 
-    def run(shard, n_per_gpu, seed, steps, warmup, depth=None):
+    def run(shard, n_per_gpu, seed, steps, warmup, depth=None, detail=False):
         """One timed measurement: ONE MSM of world * n_per_gpu terms per step, sharded `shard`-wise, `depth` calls in flight.
         Returns a dict with the max-over-ranks time and what the audit needs."""
         depth = depth or args.pipeline
         ctxs = [ctx, ctx2][:depth]
+        for cx in ctxs:                                       # 1: hipEvents around k_accumulate only (the roofline kernel); 2: around every
+            cx.set_param("profile", 2 if detail else 1)       # phase -- 8 marker packets of ~5.5 us each, kept out of the timed region
         w_rank, w_groups, p_rank, p_groups = shard_layout(rank, world, shard)
         n_group = n_per_gpu * world // p_groups            # terms of one point group (= of this rank)
         wl = Workload(ctx, d_g, n_per_gpu, seed, groups=[p_rank * (world // p_groups) + j for j in range(world // p_groups)])
@@ -418,6 +420,8 @@ def main():
 
     n_per_gpu = 1 << args.logn
     main_rec = run(args.shard, n_per_gpu, args.seed, args.steps, args.warmup)
+    # the per-phase table: a few more steps with an event around every phase (not the timed region)
+    main_rec["phases_ms_detailed"] = run(args.shard, n_per_gpu, args.seed, max(3, args.steps // 4), 1, detail=True)["phases_ms"]
 
     extra = {}
     if not args.no_secondary:
@@ -496,7 +500,8 @@ def main():
                                  "mads_per_mixed_add": MADS_PER_MADD,
                                  "valu_per_wave_mixed_add": (pmc or {}).get("k_accumulate_valu_per_wave_mixed_add"),
                                  "valu_source": (pmc or {}).get("sq_source")},
-            "phases_ms": r["phases_ms"],
+            "phases_ms": dict(r["phases_ms_detailed"], note="from extra steps with a hipEvent around every phase; the timed region brackets only "
+                                                                 "k_accumulate (roofline.kernel_ms)"),
             "per_rank_ms_per_step": r["per_rank_ms_per_step"],
         }
         out.update(extra)

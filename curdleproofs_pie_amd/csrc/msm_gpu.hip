@@ -159,7 +159,7 @@ struct Ctx {
   float phase_ms[CG1_NPHASE] = {0};
   float host_tail_ms = 0;
   float host_ms[4] = {0, 0, 0, 0};      // enqueue, wait-for-GPU, event readout, Horner tail
-  int profile = 1;                      // read the per-phase hipEvents after each call
+  int profile = 1;                      // 0: no hipEvents; 1: around k_accumulate only; 2: around every phase (read_phase_events)
   uint32_t last_chunks = 0, last_entries = 0;   // of the last MSM call: non-zero digits sorted into buckets; chunks k_accumulate ran
   hipEvent_t tm_ev[2] = {nullptr, nullptr};     // cg1_timer_begin / cg1_timer_end
   int last_c = 0, pend_c = 0;
@@ -297,6 +297,18 @@ static size_t zblock_clear_bytes(const Ctx* ctx) {
   return bytes < cap ? bytes : cap;
 }
 
+// profile 2: every phase is bracketed by hipEvents; 1 (default): only k_accumulate (the roofline kernel) -- each event record
+// is a marker packet that costs the stream ~5.5 us, 8 of them were 4 % of a 2^16-term MSM; 0: none.
+static int read_phase_events(Ctx* ctx) {
+  for (int i = 0; i < CG1_NPHASE; ++i) ctx->phase_ms[i] = 0.f;
+  if (ctx->profile >= 2) {
+    for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  } else if (ctx->profile == 1) {
+    HIPCHK(hipEventElapsedTime(&ctx->phase_ms[4], ctx->ev[4], ctx->ev[5]));
+  }
+  return CG1_OK;
+}
+
 static cg1h::fe fe_from_words12(const uint32_t w[12]) {     // already canonical and in the host's Montgomery form
   cg1h::fe r;
   for (int i = 0; i < 6; ++i) r.l[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
@@ -380,9 +392,9 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   const uint8_t* flags = ctx->d_flags;
   const size_t nout_words = (size_t)nlw * nitems;
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // [0] set by the digit kernels: a scalar >= 2^255; [1], [2]: counts
-  HIPCHK(hipEventRecord(ctx->ev[0], st));
+  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[0], st));
   hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32, bad_flag);
-  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[1], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
     // ---- two-level partition sort: no global atomics
@@ -395,7 +407,7 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     hipLaunchKernelGGL(k_uscan1, dim3(ublk), dim3(256), 0, st, ctx->d_blockcnt, ctx->d_ublocktot, nbc);
     hipLaunchKernelGGL(k_uscan2, dim3(1), dim3(256), 0, st, ctx->d_ublocktot, ublk, ctx->d_blockcnt, nbc);
     hipLaunchKernelGGL(k_uscan3, dim3(ublk), dim3(256), 0, st, ctx->d_ublocktot, ctx->d_blockcnt, nbc);
-    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_part_scatter, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, ctx->d_part, n32, nslices, nbins, sub_bits, ctx->stage_sort);
     const uint32_t nbt = (uint32_t)nlw * nbins;
     hipLaunchKernelGGL(k_slice_plan, dim3(1), dim3(256), 0, st, ctx->d_blockcnt, nbt, nslices, ctx->d_slice_base, ctx->d_bigflag, ctx->big_bins);
@@ -406,7 +418,7 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
       hipLaunchKernelGGL(k_slice_prefix, dim3(nbt), dim3(256), 0, st, ctx->d_blockcnt, nslices, sub_bits, ctx->d_slice_base, ctx->d_bigflag, ctx->d_slicehist, ctx->d_subbase, ctx->d_hist);
       hipLaunchKernelGGL(k_slice_scatter, dim3(max_slices), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, nbt, nslices, ctx->d_slice_base, ctx->d_slicehist, ctx->d_subbase, ctx->d_sorted);
     }
-    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
     hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
@@ -414,11 +426,11 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     // ---- global-atomic counting sort (any n < 2^31)
     HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
     hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, n32, plan, rank, world, bad_flag);
-    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
-    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
     hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, plan, rank, world);
   }
   // one memset: chunk-length histogram, the any_multi flag, combined[] and the heavy-bucket count (ensure() laid them out together)
@@ -428,9 +440,9 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
   hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
-  HIPCHK(hipEventRecord(ctx->ev[4], st));
+  if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[4], st));
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, pts, ctx->d_sums);
-  HIPCHK(hipEventRecord(ctx->ev[5], st));
+  if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[5], st));
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
   const bool small_quad = ctx->quad && ctx->rowcol_quad && nb_total <= (1u << 18);      // latency-bound regime: every addition by a quad
   if (small_quad)
@@ -450,19 +462,19 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     else
       hipLaunchKernelGGL(k_rowcol, dim3(nrow_blocks + ncol_blocks), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
                          rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks, ctx->quad);
-    HIPCHK(hipEventRecord(ctx->ev[6], st));
+    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
     if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(512), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
     else hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
   } else {
     const uint32_t nseg_total = (uint32_t)(nb_total / m);
     hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
-    HIPCHK(hipEventRecord(ctx->ev[6], st));
+    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
     uint32_t S = (J + BT_ELEMS - 1) / BT_ELEMS; if (S < 1) S = 1; if (S > 64) S = 64;   // J <= 2^15 / seg_m
     hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw, S), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_partial, J);
     hipLaunchKernelGGL(k_bit_tree_final, dim3((uint32_t)(nitems * nlw)), dim3(64), 0, st, ctx->d_partial, ctx->d_out, S);
   }
   HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, ((size_t)nlw * nitems + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipEventRecord(ctx->ev[7], st));
+  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
   Ctx::Pending& pd = ctx->pend;
   pd.active = true; pd.c = c; pd.plan = plan; pd.rank = rank; pd.world = world; pd.nlw = nlw; pd.nbits = nbits; pd.m = m; pd.lb2 = lb2; pd.hb2 = hb2;
@@ -494,8 +506,7 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
     }
   }
   auto h2 = std::chrono::steady_clock::now();
-  if (ctx->profile)
-    for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  read_phase_events(ctx);
   ctx->last_c = c;
 
   // ---- host tail: ONE Horner over global bit positions.
@@ -657,37 +668,37 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   const uint32_t N32 = (uint32_t)N, gn = (N32 + 255) / 256;
   auto h0 = std::chrono::steady_clock::now();
   HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, st));
-  HIPCHK(hipEventRecord(ctx->ev[0], st));
+  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[0], st));
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_bout + M);
   hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, N32, bad_flag);
-  HIPCHK(hipEventRecord(ctx->ev[1], st));
+  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[1], st));
   hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, N32, make_plan(c), 0, 1, bad_flag);
   hipLaunchKernelGGL(k_group_count, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_hist, N32, NB, nwin);
-  HIPCHK(hipEventRecord(ctx->ev[2], st));
+  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[2], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
   hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
   hipLaunchKernelGGL(k_group_scatter, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_off, ctx->d_sorted, N32, NB, nwin);
-  HIPCHK(hipEventRecord(ctx->ev[3], st));
+  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
   HIPCHK(hipMemsetAsync(ctx->d_zblock, 0, zblock_clear_bytes(ctx), st));
   hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0, ctx->d_any_multi);
   const size_t max_chunks = nb_total + (N * (size_t)nwin) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
   hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
-  HIPCHK(hipEventRecord(ctx->ev[4], st));
+  if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[4], st));
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
-  HIPCHK(hipEventRecord(ctx->ev[5], st));
+  if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[5], st));
   const uint32_t nseg_total = (uint32_t)(nb_total / m);
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
   hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
   hipLaunchKernelGGL(k_group_reduce, dim3((uint32_t)((G + 255) / 256)), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_gsum, (uint32_t)G, J, log2m);
-  HIPCHK(hipEventRecord(ctx->ev[6], st));
+  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
   if (ctx->quad) hipLaunchKernelGGL(k_msm_horner_quad, dim3((uint32_t)((M * 4 + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
   else hipLaunchKernelGGL(k_msm_horner, dim3((uint32_t)((M + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
   HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, (M + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipEventRecord(ctx->ev[7], st));
+  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
   { int wrc = wait_stream(ctx); if (wrc) return wrc; }
   HIPCHK(hipGetLastError());
@@ -700,8 +711,7 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
     }
   }
   auto h2 = std::chrono::steady_clock::now();
-  if (ctx->profile)
-    for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
+  read_phase_events(ctx);
   ctx->last_c = c;
   for (size_t j = 0; j < M; ++j) results[j] = jac_from_words(ctx->h_bout[j]);
   auto h3 = std::chrono::steady_clock::now();
@@ -929,7 +939,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(cg1::g_wave_agg), &v, sizeof v));
     return CG1_OK;
   }
-  if (!strcmp(name, "profile")) { ctx->profile = value ? 1 : 0; return CG1_OK; }
+  if (!strcmp(name, "profile")) { if (value < 0 || value > 2) return CG1_ERR_ARG; ctx->profile = value; return CG1_OK; }
   if (!strcmp(name, "seg_m")) { if (value != 1 && value != 2 && value != 4 && value != 8 && value != 16) return CG1_ERR_ARG; ctx->seg_m = (uint32_t)value; return CG1_OK; }
   return CG1_ERR_ARG;
 }

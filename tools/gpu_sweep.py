@@ -21,6 +21,7 @@ def med(f, reps=5):
 
 def main():
     ctx = N.Context(0)
+    ctx.set_param("profile", 2)
     nmax = 1 << 23
     dk, dp, ds, dg = ctx.alloc(32 * nmax), ctx.alloc(96 * nmax), ctx.alloc(32 * nmax), ctx.alloc(96)
     dg.upload(GX.to_bytes(48, "little") + GY.to_bytes(48, "little"))
@@ -30,7 +31,10 @@ def main():
     print("## size sweep (uniform scalars, whole MSM on one GPU)")
     for logn in (10, 12, 13, 14, 15, 16, 17, 18, 19, 20, 22, 23):
         n = 1 << logn
+        ctx.set_param("profile", 1)                                          # wall time without the per-phase marker packets
         w = med(lambda: ctx.msm_device(dp, ds, n, window_c=0), reps=7)      # the library's own plan for the size
+        ctx.set_param("profile", 2)
+        ctx.msm_device(dp, ds, n, window_c=0)
         tm = ctx.timings()
         print(f"n=2^{logn} c={tm['window_c']}: {w:.3f} ms  {n/w/1e3:.1f} M scalar-mul/s | " + " ".join(f"{k}={v:.3f}" for k, v in tm.items() if k not in ('window_c', 'host_events')), flush=True)
     print("## structured scalars (bucket skew)")

@@ -10,6 +10,7 @@ from curdleproofs_pie_amd import _native as N  # noqa: E402
 GX = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
 GY = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
 ctx = N.Context(0)
+ctx.set_param("profile", 2)
 nmax = 1 << 20
 dk, dp, ds, dg = ctx.alloc(32 * nmax), ctx.alloc(96 * nmax), ctx.alloc(32 * nmax), ctx.alloc(96)
 dg.upload(GX.to_bytes(48, "little") + GY.to_bytes(48, "little"))
