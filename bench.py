@@ -485,6 +485,7 @@ def main():
                        "parallelism": f"windows x{w_groups} . points x{p_groups}, one all-gather of {world} partial G1 sums",
                        "calls_in_flight": r["depth"],
                        "arithmetic": "381-bit Fp as 14 x 28-bit limbs in u32, Montgomery, 64-bit column accumulators (v_mad_u64_u32)",
+                       "device_build": N.build_info().get("pipeline", "unknown"),
                        "bit_exact_vs_oracle": "tests/test_msm_gpu.py"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,

@@ -32,6 +32,18 @@ if not os.path.exists(LIB_PATH):
 
 lib = ctypes.CDLL(LIB_PATH)
 
+
+def build_info() -> dict:
+    """How the loaded library was built: {"pipeline": "staged" | "plain", "dropped_passes": [...]} (build.py)."""
+    import json
+
+    try:
+        with open(LIB_PATH + ".buildinfo") as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
 _u8p = c_char_p  # immutable byte buffers in
 _buf = c_void_p  # mutable buffers out (ctypes.create_string_buffer / addresses)
 

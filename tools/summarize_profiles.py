@@ -24,8 +24,16 @@ def agg(pattern):
 shutil.copy(glob.glob(f"gpurun_out/{tag}_kt/*/*_kernel_stats.csv")[0], out + "_kernel_stats.csv")
 shutil.copy(f"gpurun_out/{tag}_bench.json", out + "_bench.json")
 import subprocess
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from curdleproofs_pie_amd import build as _B
+os.makedirs("build/asm", exist_ok=True)
+if _B.build_info().get("pipeline") == "staged":
+    _B.emit_device_asm("build/asm/dev_current.s")
+else:
+    subprocess.check_call(["hipcc", "-S", "--offload-device-only", "--offload-arch=gfx950", "-O3", "-std=c++17", "curdleproofs_pie_amd/csrc/msm_gpu.hip", "-o", "build/asm/dev_current.s"])
 res = subprocess.run([sys.executable, "tools/asm_stats.py", "build/asm/dev_current.s"], capture_output=True, text=True).stdout
-open(out + "_kernel_resources.txt", "w").write("# per-kernel resource usage and instruction mix of the shipped device code (hipcc -S --offload-device-only; tools/asm_stats.py)\n" + res)
+open(out + "_kernel_resources.txt", "w").write("# per-kernel resource usage and instruction mix of the shipped device code (build.py emit_device_asm, the staged pipeline's own listing; tools/asm_stats.py)\n" + res)
 f, w, q = agg(f"gpurun_out/{tag}_fetch/*/*_counter_collection.csv"), agg(f"gpurun_out/{tag}_write/*/*_counter_collection.csv"), agg(f"gpurun_out/{tag}_sq/*/*_counter_collection.csv")
 lines = ["# rocprofv3 --pmc summaries of `python3 bench.py` (one 2^20-term MSM per step, c=16), MI355X",
          "# separate passes: FETCH_SIZE | WRITE_SIZE | SQ_* + GRBM_GUI_ACTIVE.  FETCH/WRITE in KiB per launch (average over launches).",
