@@ -130,12 +130,26 @@ def sharded_msm_batch(jobs_affine, rank: int, world: int, group=None, compute=No
         for i, b in zip(mine, my_blobs):
             out[i] = bytes(b)
         return out
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (mine, [bytes(b) for b in my_blobs]), group=group)
+    import torch
+
+    # fixed-size tensor gather: rank g owns jobs g, g + world, ... (known to every rank, so no indices travel), each rank
+    # sends ceil(jobs / world) slots of 144 bytes, unused slots zero
+    width = (len(jobs_affine) + world - 1) // world
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    local = torch.zeros(width * N.POINT_BYTES, dtype=torch.uint8)
+    if my_blobs:
+        for b in my_blobs:
+            assert len(b) == N.POINT_BYTES
+        local[: len(my_blobs) * N.POINT_BYTES] = torch.frombuffer(bytearray(b"".join(bytes(b) for b in my_blobs)), dtype=torch.uint8)
+    local = local.to(dev)
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local, group=group)
     out = [None] * len(jobs_affine)
-    for idxs, blobs in gathered:
-        for i, b in zip(idxs, blobs):
-            out[i] = b
+    for g, t in enumerate(gathered):
+        raw = t.cpu().numpy().tobytes()
+        for k, i in enumerate(range(g, len(jobs_affine), world)):
+            out[i] = raw[k * N.POINT_BYTES:(k + 1) * N.POINT_BYTES]
     return out
 
 
