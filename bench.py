@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 MAD_PEAK_T = 30.3          # chip-wide v_mad_u64_u32 rate, T lane-ops/s, measured on MI355X (profiles/r01_ubench_valu_rates.txt)
 MADS_PER_MADD = 3542       # XYZZ mixed add (g1_xyzz.h): 6 products x 392 + one fused double product x 588 + 2 squarings x 301
+MADS_PER_MMADD = 1974      # affine + affine (xyzz_mmadd, the first addition of a chunk): 2 x 392 + 588 + 2 x 301
 MADS_MUL, MADS_SQR = 392, 301
 # one rank's share of ONE MSM of N x 2^20 terms, emulated on one GPU in round 1 (profiles/r01_v13_shard_emulation.txt), ms
 EMULATED_MS = {"hybrid": {1: 3.3, 2: 3.35, 4: 3.37, 8: 3.34}, "windows": {1: 3.3, 2: 3.35, 4: 3.58, 8: 4.03}, "points": {1: 3.3, 2: 3.21, 4: 3.18, 8: 3.17}}
@@ -456,8 +457,11 @@ def main():
         # roofline of the dominant kernel (k_accumulate): ALGORITHMIC bytes = 128 B per (point, scalar) term
         # (96 B affine point + 32 B scalar) x the terms one launch processes
         achieved = 128.0 * r["n_local"] / (acc_ms * 1e-3) / 1e9
-        madds = r["counts"]["mixed_adds"]                   # bucket entries - chunks: a chunk's first entry is a copy
-        mads = madds * float(MADS_PER_MADD)
+        # additions k_accumulate really performs: a chunk's first entry is a copy and its first addition is the cheaper
+        # affine + affine form.  Every chunk is charged one of those (a one-entry chunk performs none, so this undercounts).
+        madds = r["counts"]["mixed_adds"]                   # bucket entries - chunks
+        pair_adds = min(r["counts"]["chunks"], madds)
+        mads = (madds - pair_adds) * float(MADS_PER_MADD) + pair_adds * float(MADS_PER_MMADD)
         traffic = pmc = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.logn == 20:
@@ -493,12 +497,13 @@ def main():
                          "kernel": "k_accumulate", "kernel_ms": acc_ms,
                          "note": "path is integer-multiply (v_mad_u64_u32) bound, not HBM-bound: see roofline_int_mad and DESIGN.md"},
             # The bound that actually applies: 32x32+64 integer multiply-adds.  Algorithmic MADs of one
-            # k_accumulate launch = the mixed additions it really performs (bucket entries minus one copy per chunk, both
-            # counted on the device in this run) x 3542; peak = the chip-wide v_mad_u64_u32 rate measured by tools/ubench_valu.hip.
+            # k_accumulate launch = the additions it really performs (bucket entries minus one copy per chunk, both counted on
+            # the device in this run): 3542 each, 1974 for the first one of a chunk; peak = the chip-wide v_mad_u64_u32 rate
+            # measured by tools/ubench_valu.hip.
             "roofline_int_mad": {"bound": "valu v_mad_u64_u32", "achieved": mads / (acc_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T,
                                  "unit": "T mad/s", "frac": mads / (acc_ms * 1e-3) / (MAD_PEAK_T * 1e12), "kernel": "k_accumulate",
                                  "mixed_adds_per_launch": madds, "bucket_entries": r["counts"]["entries"], "chunks": r["counts"]["chunks"],
-                                 "mads_per_mixed_add": MADS_PER_MADD,
+                                 "mads_per_mixed_add": MADS_PER_MADD, "first_additions_of_chunks": pair_adds, "mads_per_first_addition": MADS_PER_MMADD,
                                  "valu_per_wave_mixed_add": (pmc or {}).get("k_accumulate_valu_per_wave_mixed_add"),
                                  "valu_source": (pmc or {}).get("sq_source")},
             "phases_ms": dict(r["phases_ms_detailed"], note="from extra steps with a hipEvent around every phase; the timed region brackets only "

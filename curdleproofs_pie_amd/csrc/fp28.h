@@ -50,10 +50,9 @@ CG1_KP_TAB(12)
 CG1_KP_TAB(32)
 #undef CG1_KP_TAB
 
-// acc + a*b.  hipcc starts every column's MAD chain from zero and adds the shifted carry of the previous column with
-// one extra half-rate v_lshl_add_u64 (~6 % of a Montgomery product); it buys a shorter dependent chain.  Pinning the
-// chain with inline asm was measured in round 1 and is a loss on ROCm 7.2 (the hazard recogniser pads asm statements
-// with s_nop).
+// acc + a*b.  With LLVM's Reassociate pass in the pipeline every column's MAD chain starts from zero and the shifted
+// carry of the previous column is added with one extra v_lshl_add_u64 (~6 % of a Montgomery product); build.py leaves
+// that pass out of the device pipeline, so the chain starts from the carry as written here.
 CG1_HD uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
 #if defined(CG1_CHECK_BOUNDS) && !defined(__HIP_DEVICE_COMPILE__)
   unsigned __int128 w = (unsigned __int128)a * b + c;

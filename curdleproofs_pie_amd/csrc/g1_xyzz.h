@@ -1,5 +1,5 @@
 // G1 group law on y^2 = x^3 + 4 in extended Jacobian ("XYZZ") coordinates over fp28.h.
-//   x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2.   Mixed add 8M+2S, full add 12M+2S, double 6M+4S (a = 0).
+//   x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2.   Mixed add 8M+2S, affine+affine 4M+2S, full add 12M+2S, double 6M+4S (a = 0).
 // Formulas: the standard madd-2008-s / add-2008-s / dbl-2008-s-1 of the EFD, with every exceptional
 // case handled exactly (P+P, P+(-P), identity operands) -- the callers of compute_MSM really do pass
 // duplicate bases and Z1 (curdleproofs.py:124-136 in the reference), and results must be bit-exact.
@@ -63,6 +63,30 @@ CG1_HD xyzz xyzz_madd(const xyzz& a, const fp& x2, const fp& y2) {
   r.Y = fp_mul2(R, fp_sub<12>(Q, X3), PPP, fp_neg<6>(a.Y));   // R(Q-X3) - Y1*PPP in one reduction; N-form, < 1.1p
   r.ZZ = fp_mul(a.ZZ, PP);
   r.ZZZ = fp_mul(a.ZZZ, PPP);
+  r.inf = 0;
+  return r;
+}
+
+// (x1, y1) + (x2, y2), both finite affine points (mmadd-2007-bl shape: 2M + 2S + one fused pair instead of madd's
+// 6M + 2S + pair -- the first addition of every bucket chunk in k_accumulate has two affine operands).
+CG1_HD xyzz xyzz_mmadd(const fp& x1, const fp& y1_maybe_lazy, const fp& x2, const fp& y2_maybe_lazy) {
+  const fp y1 = fp_norm(y1_maybe_lazy), y2 = fp_norm(y2_maybe_lazy);    // N-limb form, value <= 3p
+  fp P = fp_sub<3>(x2, x1);                 // value < 5p
+  fp R = fp_sub<6>(y2, y1);                 // value < 9p
+  if (fp_is_zero_mod_p(P, 6)) {             // same x: doubling or cancellation (rare, divergent)
+    if (fp_is_zero_mod_p(R, 10)) return xyzz_dbl(xyzz_from_affine(x2, y2));
+    return xyzz_identity();
+  }
+  xyzz r;
+  fp PP = fp_sqr(P);
+  fp PPP = fp_mul(P, PP);
+  fp Q = fp_mul(x1, PP);
+  fp RR = fp_sqr(R);
+  fp X3 = fp_norm(fp_add(fp_add(RR, fp_neg<3>(PPP)), fp_dbl(fp_neg<3>(Q))));
+  r.X = X3;
+  r.Y = fp_mul2(R, fp_sub<12>(Q, X3), PPP, fp_neg<6>(y1));    // R(Q-X3) - y1*PPP in one reduction
+  r.ZZ = PP;
+  r.ZZZ = PPP;
   r.inf = 0;
   return r;
 }

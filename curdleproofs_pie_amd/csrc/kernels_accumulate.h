@@ -11,13 +11,31 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint2* __restrict__ de
   const uint32_t t = order[g];              // chunks in descending length: lanes of a wave finish together
   const uint2 d = desc[t];
   const uint32_t* ent = sorted + d.x;
-  xyzz acc = xyzz_identity();
+  if (d.y == 0u) { store_sum(sums + t, xyzz_identity()); return; }     // k_chunk_desc emits no empty chunks; kept for safety
   uint32_t e = ent[0];
   fp x, y; uint32_t flags;
   load_affine(pts + (e & 0x7fffffffu), x, y, flags);
-  for (uint32_t j = 0; j < d.y; ++j) {
+  xyzz acc;
+  uint32_t j = 1;
+  if (e >> 31) y = fp_neg<3>(y);
+  if (d.y >= 2u) {
+    // the first addition of a chunk has two affine operands: 4M+2S instead of 8M+2S
+    const uint32_t e1 = ent[1];
+    fp x1, y1;
+    load_affine(pts + (e1 & 0x7fffffffu), x1, y1, flags);
+    if (e1 >> 31) y1 = fp_neg<3>(y1);
+    e = ent[d.y > 2u ? 2 : 1];
+    fp xn, yn;
+    load_affine(pts + (e & 0x7fffffffu), xn, yn, flags);          // prefetch entry 2 while the pair is being added
+    acc = xyzz_mmadd(x, y, x1, y1);
+    x = xn; y = yn;
+    j = 2;
+  } else {
+    acc = xyzz_from_affine(x, y);
+  }
+  for (; j < d.y; ++j) {
     // prefetch the next entry's point while this one is being added
-    uint32_t en = ent[(j + 1 < d.y) ? j + 1 : j];
+    const uint32_t en = ent[(j + 1 < d.y) ? j + 1 : j];
     fp xn, yn;
     load_affine(pts + (en & 0x7fffffffu), xn, yn, flags);
     if (e >> 31) y = fp_neg<3>(y);

@@ -178,20 +178,27 @@ __global__ void __launch_bounds__(128) k_shuffle_rows(const uint8_t* __restrict_
   }
 }
 
-// out[j] = sum over the proofs with status == 0 of crs_rows[i][j]  (cg1_shuffle_sum_crs_scalars on the device); thread per slot.
-// Rows are canonical little-endian integers: they add mod r as they are.
-__global__ void __launch_bounds__(64) k_crs_row_sum(const uint8_t* __restrict__ crs_rows, const int32_t* __restrict__ status,
-                                                    uint32_t n_proofs, uint32_t ncrs, uint8_t* __restrict__ out) {
-  const uint32_t j = blockIdx.x * 64 + threadIdx.x;
-  if (j >= ncrs) return;
+// out[j] = sum over the proofs with status == 0 of crs_rows[i][j]  (cg1_shuffle_sum_crs_scalars on the device).
+// One block per slot j: its 256 threads take the proofs t, t + 256, ..., then fold through LDS.  Rows are canonical
+// little-endian integers: they add mod r as they are (and addition mod r of canonical values does not depend on the order).
+__global__ void __launch_bounds__(256) k_crs_row_sum(const uint8_t* __restrict__ crs_rows, const int32_t* __restrict__ status,
+                                                     uint32_t n_proofs, uint32_t ncrs, uint8_t* __restrict__ out) {
+  __shared__ fr part[256];
+  const uint32_t j = blockIdx.x, t = threadIdx.x;
   fr acc = cg1fr::fr_zero();
-  for (uint32_t i = 0; i < n_proofs; ++i) {
+  for (uint32_t i = t; i < n_proofs; i += 256) {
     if (status[i]) continue;
     fr v;
     memcpy(v.l, crs_rows + ((size_t)i * ncrs + j) * 32, 32);
     acc = cg1fr::fr_add(acc, v);
   }
-  memcpy(out + 32 * (size_t)j, acc.l, 32);
+  part[t] = acc;
+  __syncthreads();
+  for (uint32_t d = 128; d >= 1; d >>= 1) {
+    if (t < d) part[t] = cg1fr::fr_add(part[t], part[t + d]);
+    __syncthreads();
+  }
+  if (t == 0) memcpy(out + 32 * (size_t)j, part[0].l, 32);
 }
 
 }  // namespace cg1rows

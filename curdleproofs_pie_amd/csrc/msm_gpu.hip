@@ -1190,7 +1190,7 @@ int cg1_shuffle_rows_device(cg1_ctx* ctx, size_t ell, size_t lg, size_t n_proofs
   hipLaunchKernelGGL(cg1rows::k_shuffle_rows, dim3((unsigned)n_proofs), dim3(128), 0, ctx->stream, (const uint8_t*)d_rowin,
                      (const int32_t*)d_host_status, (const uint8_t*)d_point_status, (uint32_t)ell, (uint32_t)lg,
                      (uint8_t*)d_out_scalars, (uint8_t*)d_crs_rows, (int32_t*)d_status_out);
-  hipLaunchKernelGGL(cg1rows::k_crs_row_sum, dim3((unsigned)((C + 63) / 64)), dim3(64), 0, ctx->stream, (const uint8_t*)d_crs_rows,
+  hipLaunchKernelGGL(cg1rows::k_crs_row_sum, dim3((unsigned)C), dim3(256), 0, ctx->stream, (const uint8_t*)d_crs_rows,
                      (const int32_t*)d_status_out, (uint32_t)n_proofs, (uint32_t)C, (uint8_t*)d_out_scalars + n_proofs * L * 32);
   HIPCHK(hipGetLastError());
   return CG1_OK;

@@ -66,6 +66,27 @@ void t_madd_seq(const uint8_t* pts96, const uint8_t* neg, int n, uint8_t* out) {
   export_xyzz(acc, out);
 }
 
+// The same sum the way k_accumulate forms a chunk: the first two entries through the affine+affine addition, the rest
+// through the mixed add.
+void t_chunk_seq(const uint8_t* pts96, const uint8_t* neg, int n, uint8_t* out) {
+  xyzz acc = xyzz_identity();
+  auto ld = [&](int i, fp& x, fp& y) {
+    x = load_mont(pts96 + 96 * i); y = load_mont(pts96 + 96 * i + 48);
+    if (neg[i]) y = fp_neg<3>(y);
+  };
+  fp x, y;
+  if (n >= 2) {
+    fp x1, y1;
+    ld(0, x, y); ld(1, x1, y1);
+    acc = xyzz_mmadd(x, y, x1, y1);
+  } else if (n == 1) {
+    ld(0, x, y);
+    acc = xyzz_from_affine(x, y);
+  }
+  for (int i = 2; i < n; ++i) { ld(i, x, y); acc = xyzz_madd(acc, x, y); }
+  export_xyzz(acc, out);
+}
+
 // Sum the same sequence as a balanced tree of full adds (exercises xyzz_add, incl. P+P and P-P).
 void t_add_tree(const uint8_t* pts96, const uint8_t* neg, int n, uint8_t* out) {
   if (n == 0) { export_xyzz(xyzz_identity(), out); return; }

@@ -36,11 +36,11 @@ def test_staged_build_drops_the_reassociate_adds(tmp_path):
     assert info.get("dropped_passes") == ["reassociate"]
     ops = _disassemble(B.LIB, r"k_accumulate", tmp_path)
     mads = ops.get("v_mad_u64_u32", 0)
-    assert mads > 6000                                   # two mixed additions' worth of 14x14 limb products
+    assert mads > 6000                                   # mixed addition + affine pair addition + the cold doubling paths
     # Reassociate costs one v_lshl_add_u64 per Montgomery column (449 in this kernel with plain hipcc)
-    assert ops.get("v_lshl_add_u64", 0) <= 8, ops.get("v_lshl_add_u64")
+    assert ops.get("v_lshl_add_u64", 0) <= 16, ops.get("v_lshl_add_u64")      # address arithmetic only
     valu = sum(n for op, n in ops.items() if op.startswith("v_"))
-    assert valu / mads < 1.34, (valu, mads)              # 1.328 staged, 1.394 plain
+    assert valu / mads < 1.35, (valu, mads)              # 1.33 staged, 1.39 plain
 
 
 def test_pipeline_choice_is_part_of_the_source_hash(monkeypatch):

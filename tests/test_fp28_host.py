@@ -63,6 +63,7 @@ def test_group_law_with_exceptional_cases(fp28_harness):
         for p, s in zip(seq, negs):
             want = O.g1_add(want, O.g1_neg(p) if s else p)
         L.t_madd_seq(buf, bytes(negs), len(seq), o); assert parse_xyzz(o) == want
+        L.t_chunk_seq(buf, bytes(negs), len(seq), o); assert parse_xyzz(o) == want      # first pair affine+affine, as k_accumulate
         L.t_add_tree(buf, bytes(negs), len(seq), o); assert parse_xyzz(o) == want
 
     check(pts, [rng.randrange(2) for _ in pts])
@@ -70,6 +71,9 @@ def test_group_law_with_exceptional_cases(fp28_harness):
     check([pts[0]], [1])
     check([pts[0], pts[0]], [0, 0])                       # P + P through the mixed add
     check([pts[0], pts[0]], [0, 1])                       # P + (-P)
+    check([pts[0], pts[0]], [1, 1])                       # (-P) + (-P): both lazily negated
+    check([pts[0], pts[0], pts[3]], [1, 0, 1])            # identity from the first pair, then continue
+    check([pts[0], pts[1]], [1, 0])
     check([pts[0]] * 9, [0] * 9)
     check([pts[0], pts[0], pts[0], pts[1], pts[0]], [0, 1, 0, 0, 0])
     s01 = O.g1_add(pts[0], pts[1])
