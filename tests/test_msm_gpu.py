@@ -303,6 +303,23 @@ def test_pipeline_variants_agree(native_lib, golden):
         c2.close()
 
 
+def test_identity_terms_contribute_nothing(native_lib, ctx):
+    """Many identity bases ((0, 0) records) among few distinct scalars: whole buckets of identities, identities first,
+    second and last in a bucket."""
+    N = native_lib
+    rng = random.Random(4242)
+    base = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(6)]
+    for n, p_inf, few_scalars in ((64, 0.5, True), (700, 0.7, True), (5000, 0.3, False), (3000, 1.0, True)):
+        pts = [None if rng.random() < p_inf else base[rng.randrange(6)] for _ in range(n)]
+        pool = [rng.randint(1, O.R - 1) for _ in range(3)]          # few distinct scalars: long chunks with many identity entries
+        sc = [rng.choice(pool) if few_scalars else rng.randint(0, O.R - 1) for _ in range(n)]
+        p96 = b"".join(raw96(p) for p in pts)
+        s32 = b"".join(s.to_bytes(32, "little") for s in sc)
+        want = C.compress(C.msm_bucket(p96, s32, n))
+        for c in (0, 8, 13, -12, 16):
+            assert gpu_msm(N, ctx, p96, s32, n, window_c=c) == want, (n, p_inf, c)
+
+
 def test_two_contexts_concurrently(native_lib):
     """One context per stream: independent MSMs issued from two host threads on the same GPU."""
     import threading
