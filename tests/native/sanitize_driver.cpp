@@ -51,6 +51,9 @@ int main() {
   uint8_t bad[48];
   memset(bad, 0xff, sizeof bad);
   jac tmp;
+  // the infinity flag decides alone (the wheel's decoder, host_g1.cpp): all-ones is the identity, not an error
+  if (g1_decompress(bad, false, tmp) != 0 || !jac_is_identity(tmp)) { printf("infinity flag not honoured\n"); return 1; }
+  bad[0] = 0x9f;                       // compressed, finite, x = 2^381 - 1 >= p
   if (g1_decompress(bad, false, tmp) == 0) { printf("accepted garbage\n"); return 1; }
   if (!jac_in_subgroup(pts[3])) { printf("subgroup\n"); return 1; }
   // transcript

@@ -48,7 +48,19 @@ int main(int argc, char** argv) {
   if (st[0] != 0) { printf("golden proof rejected by the front-end (%d)\n", st[0]); return 1; }
   if (st != st2 || sc != sc2 || cs != cs2 || pts != pts2) { printf("thread counts disagree\n"); return 1; }
   std::vector<uint8_t> wire(n * L * 48);
-  if (cg1_shuffle_gather_points(crs, n, insts.data(), proofs.data(), wire.data()) || wire != pts) { printf("gather mismatch\n"); return 1; }
+  if (cg1_shuffle_gather_points(crs, n, insts.data(), proofs.data(), wire.data())) { printf("gather failed\n"); return 1; }
+  // the front-end's copy carries what is HASHED: an encoding with the infinity flag set is replaced by the canonical
+  // 0xC0 00 .. 00 (the reference hashes re-serialised points); everything else is the wire bytes
+  for (size_t i = 0; i < n * L; ++i) {
+    const uint8_t* w = wire.data() + 48 * i;
+    const uint8_t* q = pts.data() + 48 * i;
+    bool same = memcmp(w, q, 48) == 0;
+    if (!same && (w[0] & 0xC0) == 0xC0) {
+      same = q[0] == 0xC0;
+      for (int k = 1; k < 48; ++k) same = same && q[k] == 0;
+    }
+    if (!same) { printf("gather mismatch at point %zu\n", i); return 1; }
+  }
   std::vector<uint8_t> pstat(n * L, 0), sum(C * 32);
   pstat[3 * L + 5] = 3;
   if (cg1_shuffle_apply_point_status(st.data(), pstat.data(), n, L, sc.data(), cs.data(), C)) return 1;
