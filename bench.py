@@ -516,6 +516,20 @@ def main():
                                  "what": "all_gather of one 144-byte partial G1 sum per rank, then world-1 host additions on every rank",
                                  "bytes_per_step": 144 * world, "ms_per_exchange": r["exchange_ms"]}
             out["predicted_ms_per_step_emulated"] = EMULATED_MS.get(args.shard, {}).get(world)
+        if world == 1:
+            # the practical ceiling of the same arithmetic: chains of dependent mixed additions on register-resident operands
+            # (k_probe_madd: no sort, no gathers, every lane busy), as many lane-level additions as one k_accumulate launch
+            wl = Workload(ctx, d_g, 4096, args.seed)
+            lanes, iters = 1 << 19, 32
+            ctx.set_param("profile", 0)
+            pms = min(ctx.probe_madd(wl.d_pts, 4096, lanes, iters) for _ in range(3))
+            wl.free()
+            probe_rate = lanes * iters / (pms * 1e-3)
+            acc_rate = mads / float(MADS_PER_MADD) / (acc_ms * 1e-3)       # k_accumulate in mixed-add equivalents per second
+            out["roofline_int_mad"]["madd_probe"] = {
+                "what": "k_probe_madd: %d lanes x %d dependent mixed additions, operands in registers" % (lanes, iters),
+                "ms": pms, "lane_mixed_adds_per_s": probe_rate, "k_accumulate_mixed_add_equivalents_per_s": acc_rate,
+                "k_accumulate_vs_probe": acc_rate / probe_rate}
         if world == 1 and not args.no_cpu_baseline:
             wl = Workload(ctx, d_g, max(1 << 18, 1 << args.cpu_sample_logn), args.seed)
             out["cpu_baseline"] = cpu_baseline(wl.d_pts, wl.d_sc, 1 << args.cpu_sample_logn)
