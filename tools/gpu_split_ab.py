@@ -30,8 +30,12 @@ def single(n):
     return a.msm_device(dp, ds, n, window_c=16)
 
 
-def split(n, parts=2):
+def split(n, parts=2, delay_us=0.0):
     a.msm_device_begin(dp, ds, n, window_c=16, shard_rank=0, shard_world=parts)
+    if delay_us:                                   # stagger: the second shard's sort chain under the first one's accumulation
+        t = time.perf_counter()
+        while (time.perf_counter() - t) * 1e6 < delay_us:
+            pass
     b.msm_device_begin(dp, ds, n, window_c=16, shard_rank=1, shard_world=parts)
     ra = a.msm_device_end()
     rb = b.msm_device_end()
@@ -40,11 +44,13 @@ def split(n, parts=2):
     return out.raw
 
 
-for logn in (18, 19, 20, 21, 22):
+for logn in (18, 20, 22):
     n = 1 << logn
     assert N.cg1_eq(single(n), split(n))
     res = {"single": [], "split": []}
     for r in range(3):
         res["single"].append(med(lambda: single(n)))
         res["split"].append(med(lambda: split(n)))
-    print(f"2^{logn}: single {min(res['single']):.3f} ms   two window shards in flight {min(res['split']):.3f} ms   {res}", flush=True)
+    print(f"2^{logn}: single {min(res['single']):.3f} ms   two window shards in flight {min(res['split']):.3f} ms", flush=True)
+    for d in (150, 300, 450, 600, 900):
+        print(f"      second shard begun {d} us later: {med(lambda: split(n, delay_us=d)):.3f} ms", flush=True)
