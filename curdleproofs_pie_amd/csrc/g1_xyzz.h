@@ -67,6 +67,29 @@ CG1_HD xyzz xyzz_madd(const xyzz& a, const fp& x2, const fp& y2) {
   return r;
 }
 
+// The common case of xyzz_madd, updating `a` in place: false (and `a` untouched) when the addition is one of the exceptional
+// cases (a is the identity, or the operands share their x coordinate) -- the caller then takes xyzz_madd.  Keeping the
+// exceptional results out of the hot loop's control flow lets the accumulator stay in the same registers across iterations.
+CG1_HD bool xyzz_madd_fast(xyzz& a, const fp& x2, const fp& y2) {
+  if (a.inf) return false;
+  fp U2 = fp_mul(x2, a.ZZ);
+  fp S2 = fp_mul(y2, a.ZZZ);
+  fp P = fp_sub<12>(U2, a.X);
+  fp R = fp_sub<6>(S2, a.Y);
+  if (fp_is_zero_mod_p(P, 14)) return false;
+  fp PP = fp_sqr(P);
+  fp PPP = fp_mul(P, PP);
+  fp Q = fp_mul(a.X, PP);
+  fp RR = fp_sqr(R);
+  fp X3 = fp_norm(fp_add(fp_add(RR, fp_neg<3>(PPP)), fp_dbl(fp_neg<3>(Q))));
+  fp Y3 = fp_mul2(R, fp_sub<12>(Q, X3), PPP, fp_neg<6>(a.Y));
+  a.X = X3;
+  a.Y = Y3;
+  a.ZZ = fp_mul(a.ZZ, PP);
+  a.ZZZ = fp_mul(a.ZZZ, PPP);
+  return true;
+}
+
 // (x1, y1) + (x2, y2), both finite affine points (mmadd-2007-bl shape: 2M + 2S + one fused pair instead of madd's
 // 6M + 2S + pair -- the first addition of every bucket chunk in k_accumulate has two affine operands).
 CG1_HD xyzz xyzz_mmadd(const fp& x1, const fp& y1_maybe_lazy, const fp& x2, const fp& y2_maybe_lazy) {

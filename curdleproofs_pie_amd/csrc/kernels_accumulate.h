@@ -39,8 +39,16 @@ __global__ void __launch_bounds__(256) k_accumulate(const uint2* __restrict__ de
     fp xn, yn;
     load_affine(pts + (en & 0x7fffffffu), xn, yn, flags);
     if (e >> 31) y = fp_neg<3>(y);
-    acc = xyzz_madd(acc, x, y);
+    if (!xyzz_madd_fast(acc, x, y)) break;                  // doubling / cancellation / identity accumulator: below
     e = en; x = xn; y = yn;
+  }
+  for (; j < d.y; ++j) {                                    // the rest of a chunk that met an exceptional case (y already signed)
+    acc = xyzz_madd(acc, x, y);
+    if (j + 1 < d.y) {
+      e = ent[j + 1];
+      load_affine(pts + (e & 0x7fffffffu), x, y, flags);
+      if (e >> 31) y = fp_neg<3>(y);
+    }
   }
   store_sum(sums + t, acc);
 }

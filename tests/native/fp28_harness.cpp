@@ -67,7 +67,7 @@ void t_madd_seq(const uint8_t* pts96, const uint8_t* neg, int n, uint8_t* out) {
 }
 
 // The same sum the way k_accumulate forms a chunk: the first two entries through the affine+affine addition, the rest
-// through the mixed add.
+// through the mixed add (its in-place common case first, as the kernel's hot loop does).
 void t_chunk_seq(const uint8_t* pts96, const uint8_t* neg, int n, uint8_t* out) {
   xyzz acc = xyzz_identity();
   auto ld = [&](int i, fp& x, fp& y) {
@@ -83,7 +83,10 @@ void t_chunk_seq(const uint8_t* pts96, const uint8_t* neg, int n, uint8_t* out) 
     ld(0, x, y);
     acc = xyzz_from_affine(x, y);
   }
-  for (int i = 2; i < n; ++i) { ld(i, x, y); acc = xyzz_madd(acc, x, y); }
+  for (int i = 2; i < n; ++i) {
+    ld(i, x, y);
+    if (!xyzz_madd_fast(acc, x, y)) acc = xyzz_madd(acc, x, y);     // the kernel's hot loop, then its exceptional-case tail
+  }
   export_xyzz(acc, out);
 }
 
