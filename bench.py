@@ -37,7 +37,7 @@ MADS_PER_MADD = 3542       # XYZZ mixed add (g1_xyzz.h): 6 products x 392 + one 
 MADS_PER_MMADD = 1974      # affine + affine (xyzz_mmadd, the first addition of a chunk): 2 x 392 + 588 + 2 x 301
 MADS_MUL, MADS_SQR = 392, 301
 # one rank's share of ONE MSM of N x 2^20 terms, emulated on one GPU in round 1 (profiles/r01_v13_shard_emulation.txt), ms
-# rank 0's share of ONE MSM of N x 2^20 terms timed on one GPU (profiles/r02_v3_shard_emulation.txt; that box ran the plain
+# rank 0's share of ONE MSM of N x 2^20 terms timed on one GPU (profiles/r02_v4_shard_emulation.txt; that box ran the plain
 # single-GPU step in 2.96-3.25 ms): what an N-GPU run should show per step before the exchange
 EMULATED_MS = {"hybrid": {1: 3.0, 2: 3.36, 4: 3.26, 8: 3.28}, "windows": {1: 3.0, 2: 3.36, 4: 3.43, 8: 3.68}, "points": {1: 3.0, 2: 3.12, 4: 2.96, 8: 2.96}}
 
