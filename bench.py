@@ -2,8 +2,11 @@
 """bench.py -- BASELINE.json's metric on MI355X: "BLS12-381 G1 scalar-muls/sec at MSM size 2^20; shuffle proofs verified/sec".
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          # spawns its own N ranks (fresh child processes, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W               # or under a launcher that exports RANK / LOCAL_RANK / WORLD_SIZE
+No PyTorch is imported on any path: the N>1 exchange is the library's own (cg1_comm_*: RCCL all-gather of one 144-byte
+partial G1 sum per rank over xGMI, TCP control channel for rendezvous / barriers / the max-over-ranks clock).
 
 HEADLINE (`value`): G1 scalar-muls/s.  A "step" is one complete compute_MSM-equivalent call (msm_accumulator.py:6-12 of
 the reference) over one batch of synthetic input that is already resident in HBM: point preparation, signed-digit recode,
@@ -13,7 +16,7 @@ timed region.  Workload at N=1: BASELINE.json configs[1]'s shape at the metric's
 N*2^20 terms.  --shard hybrid (default): the signed-digit windows are sharded over 2 window-bucket groups and the points over
 N/2 point groups (rank = window group + 2 * point group); --shard windows: pure window sharding (every rank holds all
 points, what north_star names; also timed as `windows_only` in every N>1 line); --shard points: pure point sharding.  The
-partial G1 sums are all-gathered over RCCL and added on every rank.  value = total terms / max-over-ranks time.
+partial G1 sums are all-gathered over RCCL (cg1_comm_allreduce_g1) and added on every rank.  value = total terms / max-over-ranks time.
 
 SECONDARY (same JSON line, key `secondary`, N=1): the metric's second half -- Whisk shuffle proofs verified/s
 (IsValidWhiskShuffleProof, whisk_interface.py:72-109 -> curdleproofs.py:162-248; BASELINE configs[2]): batches of 1024
@@ -32,7 +35,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MAD_PEAK_T = 30.3          # chip-wide v_mad_u64_u32 rate, T lane-ops/s, measured on MI355X (profiles/r01_ubench_valu_rates.txt)
+MAD_PEAK_T = 30.3          # chip-wide v_mad_u64_u32 rate, T lane-ops/s, round 1 on another box (profiles/r01_ubench_valu_rates.txt): kept as a
+                           # reference only -- every run measures its own peak (mad_peak_same_run) and prices the roofline against that
+FR_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 MADS_PER_MADD = 3542       # XYZZ mixed add (g1_xyzz.h): 6 products x 392 + one fused double product x 588 + 2 squarings x 301
 MADS_PER_MMADD = 1974      # affine + affine (xyzz_mmadd, the first addition of a chunk): 2 x 392 + 588 + 2 x 301
 MADS_MUL, MADS_SQR = 392, 301
@@ -46,6 +51,16 @@ def raw96_gen():
     gx = 0x17F1D3A73197D7942695638C4FA9AC0FC3688C4F9774B905A14E3A3F171BAC586C55E83FF97A1AEFFB3AF00ADB22C6BB
     gy = 0x08B3F481E3AAA0F1A09E30ED741D8AE4FCF5E095D5D00AF600DB18CB2C04B3EDD03CC744A2888AE40CAA232946C5E7E1
     return gx.to_bytes(48, "little") + gy.to_bytes(48, "little")
+
+
+def mad_peak_same_run(ctx):
+    """Chip-wide v_mad_u64_u32 issue rate measured in THIS process on THIS box (k_probe_mad_rate, 2 waves per SIMD -- the
+    occupancy of k_accumulate): best of five ~20 ms bursts, and one ~200 ms run (the clock the chip holds under sustained load)."""
+    burst = max(ctx.probe_mad_rate(2, 40) for _ in range(5))
+    sustained = ctx.probe_mad_rate(2, 400)
+    return {"burst_T": burst / 1e12, "sustained_T": sustained / 1e12,
+            "what": "k_probe_mad_rate: 8 independent v_mad_u64_u32 chains per lane, 2 waves per SIMD, hipEvents on the context's stream; "
+                    "burst = best of five ~20 ms launches, sustained = one ~200 ms launch"}
 
 
 def cpu_baseline(d_points, d_scalars, sample_n):
@@ -102,11 +117,13 @@ def decompress_mads_per_point():
     return (nsqr + 2) * MADS_SQR + (nmul + 4.5) * MADS_MUL, nsqr, nmul
 
 
-def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu_leg=True):
+def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu_leg=True, peak_T=None):
     """Stream `steps` batches of `batch` distinct-proof slots through the GPU verifier; returns the `secondary` object."""
     from curdleproofs_pie_amd import _native as N
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
 
+    if peak_T is None:
+        peak_T = mad_peak_same_run(ctx)["burst_T"]
     fx = load_batch_fixture()
     v = ShuffleBatchVerifier(fx.crs, ctx, threads=threads)
     inst, proofs, want = fx.tiled(batch)
@@ -153,8 +170,8 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
                                "note": "the three stages of consecutive batches overlap; they do not add up to ms_per_step"},
         "roofline_int_mad": {"kernel": "k_batch_decompress<false>", "bound": "valu v_mad_u64_u32", "kernel_ms": dec_ms, "points_per_launch": points,
                              "mads_per_point": mads_pp, "sqrt_chain": {"squarings": nsqr, "products": nmul},
-                             "achieved": mads_pp * points / (dec_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T, "unit": "T mad/s",
-                             "frac": mads_pp * points / (dec_ms * 1e-3) / (MAD_PEAK_T * 1e12)},
+                             "achieved": mads_pp * points / (dec_ms * 1e-3) / 1e12, "peak": peak_T, "unit": "T mad/s",
+                             "frac": mads_pp * points / (dec_ms * 1e-3) / (peak_T * 1e12), "peak_source": "k_probe_mad_rate in this run (burst)"},
     }
     if cpu_leg:
         # CPU port beside it: the same statement builder on ONE core + the statement's MSM by the CPU oracle (bucket method)
@@ -177,41 +194,53 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
     return out
 
 
+def open_comm(args, rank, world, ctx):
+    """The rank's communicator (None at N = 1): TCP control channel + RCCL for the data exchange unless the ranks share one GPU."""
+    if world == 1:
+        return None
+    from curdleproofs_pie_amd.distributed import init_comm
+
+    comm = init_comm(rank, world, timeout_s=900.0)
+    if args.backend == "rccl":
+        comm.attach_rccl(ctx)
+    return comm
+
+
 def verify_mode(args, rank, local_rank, world):
     """BASELINE config 3 (N = 1) / config 5's structure (N > 1, proof-per-GPU): `--batch` proofs per GPU per step, from wire
     bytes in host memory to verdicts.  Ranks share the host's cores evenly.  No data-path collective."""
     from curdleproofs_pie_amd import _native as N
+    from curdleproofs_pie_amd.distributed import max_over_ranks
 
-    dist = torch = None
     dev_index = 0 if args.same_device else local_rank
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(dev_index)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend="gloo")
     ctx = N.Context(dev_index)
+    comm = open_comm(args, rank, world, ctx)
     cores = int(N.cg1_shuffle_default_threads())         # usable CPUs (affinity mask capped by the cgroup quota)
     threads = max(1, cores // world)
-    if world > 1:
-        dist.barrier()
+    if comm:
+        comm.barrier()
     out = verify_measure(ctx, threads, args.steps, args.warmup, args.batch, args.verify_mode, cpu_leg=(rank == 0 and not args.no_cpu_baseline))
     el = out["ms_per_step"] * args.steps / 1e3
-    if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
+    per_rank = max_over_ranks(el, comm)
+    # a core-starved run must be visible: every rank's front-end time and thread count travel to rank 0
+    fe_key = "front_end (host: transcript + Fr algebra, all threads)"
+    fe = max_over_ranks(out["phases_ms_per_step"][fe_key], comm)
+    el = max(per_rank)
     if rank == 0:
         out.update({"value": world * args.batch * args.steps / el, "ms_per_step": el / args.steps * 1e3, "n_gpus": world, "scaling": "weak",
                     "vs_baseline": None, "dtype": "u32",
+                    "per_rank": {"ms_per_step": [x / args.steps * 1e3 for x in per_rank], "front_end_ms_per_step": fe,
+                                 "host_threads": threads, "host_cores_usable": cores,
+                                 "note": "proofs/s is host-bound when front_end_ms_per_step approaches ms_per_step: each rank runs the "
+                                         "verifier front-end on cores // n_gpus threads"},
                     "config": {"workload": "whisk_shuffle_verify ell=124 batch=%d per GPU" % args.batch,
                                "parallelism": "proof-per-GPU x%d, no data-path collective" % world}})
+        if comm:
+            out["collective"] = {"backend": comm.transport, "world_seen": comm.world_seen, "what": "none on the data path; clocks over the control channel"}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm:
+        comm.barrier()
+        comm.close()
 
 
 def side_mode(args):
@@ -261,16 +290,76 @@ class Workload:
 
     def __init__(self, ctx, d_g, n_local, seed, groups=(0,)):
         self.n = n_local * len(groups)
-        d_k = ctx.alloc(32 * n_local)
+        self.d_k = ctx.alloc(32 * self.n)
         self.d_pts, self.d_sc = ctx.alloc(96 * self.n), ctx.alloc(32 * self.n)
         for j, g in enumerate(groups):          # point group g of the job; a window-only rank holds every group
-            ctx.gen_scalars_device(d_k, n_local, 0xC0FFEE + 7919 * seed + 1000 * g)
-            ctx.batch_mul_device(d_g, 1, d_k, self.d_pts.ptr + 96 * n_local * j, n_local)
+            ctx.gen_scalars_device(self.d_k.ptr + 32 * n_local * j, n_local, 0xC0FFEE + 7919 * seed + 1000 * g)
+            ctx.batch_mul_device(d_g, 1, self.d_k.ptr + 32 * n_local * j, self.d_pts.ptr + 96 * n_local * j, n_local)
             ctx.gen_scalars_device(self.d_sc.ptr + 32 * n_local * j, n_local, 0xBEEF + 7919 * seed + 1000 * g)
-        d_k.free()
+
+    def closed_form_scalar(self):
+        """sum_i k_i * s_i mod r over this rank's terms: the points are k_i * G, so the MSM of these terms is exactly that multiple of G"""
+        kb, sb = memoryview(self.d_k.download()), memoryview(self.d_sc.download())
+        f = int.from_bytes
+        return sum(f(kb[o: o + 32], "little") * f(sb[o: o + 32], "little") for o in range(0, 32 * self.n, 32)) % FR_ORDER
 
     def free(self):
-        self.d_pts.free(); self.d_sc.free()
+        self.d_pts.free(); self.d_sc.free(); self.d_k.free()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: this process touches no GPU -- it builds the library (hipcc, no HIP
+    call), then starts the N ranks as fresh child processes (one per GPU, LOCAL_RANK = device ordinal), relays rank 0's JSON line
+    and exits with the worst child status.  The ranks find each other through a rendezvous file (distributed.init_comm)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    from curdleproofs_pie_amd import build as B
+    B.build(verbose=False)
+    n = args.gpus
+    tmp = tempfile.mkdtemp(prefix="cg1_bench_rdzv_")
+    env = dict(os.environ, WORLD_SIZE=str(n), CG1_RDZV_FILE=os.path.join(tmp, "rdzv"), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    procs = []
+    try:
+        for r in range(n):
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                          stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+        import threading
+
+        lines = []
+        reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+        reader.start()
+        rcs = [None] * n
+        while any(rc is None for rc in rcs):
+            for i, pr in enumerate(procs):
+                if rcs[i] is None:
+                    rcs[i] = pr.poll()
+            if any(rc not in (None, 0) for rc in rcs):          # one rank failed: the others would wait for it until their timeout
+                for i, pr in enumerate(procs):
+                    if rcs[i] is None:
+                        pr.terminate()
+                for i, pr in enumerate(procs):
+                    if rcs[i] is None:
+                        try:
+                            rcs[i] = pr.wait(timeout=20)
+                        except subprocess.TimeoutExpired:
+                            pr.kill()
+                            rcs[i] = pr.wait()
+                break
+            time.sleep(0.05)
+        reader.join(timeout=10)
+        sys.stdout.write("".join(lines))
+        sys.stdout.flush()
+        bad = [rc for rc in rcs if rc]
+        if bad:
+            sys.exit("bench.py: rank exit codes %s" % rcs)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -298,17 +387,22 @@ def main():
                     help="msm: the driver's line (headline MSM + secondary proofs/s). batched: BASELINE config 3's MSM content (1024 independent "
                          "627-term accumulator MSMs per step, regime B). verify: BASELINE config 3 end to end alone (and config 5's structure at "
                          "N>1). pcie: the headline MSM with inputs in HOST memory")
-    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
-                    help="transport of the N>1 partial-sum exchange (nccl == RCCL; gloo only to rehearse on one GPU)")
-    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (needs --backend gloo)")
+    ap.add_argument("--backend", choices=["rccl", "socket", "nccl", "gloo"], default="rccl",
+                    help="transport of the N>1 partial-sum exchange: rccl (ncclAllGather over xGMI, one GPU per rank) or socket (the TCP "
+                         "control channel alone: ranks rehearsing on one GPU); nccl / gloo are accepted as aliases")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (implies --backend socket)")
     args = ap.parse_args()
 
+    if args.backend in ("nccl", "gloo"):                      # the names torch gives the same two transports
+        args.backend = {"nccl": "rccl", "gloo": "socket"}[args.backend]
+    if args.same_device:
+        args.backend = "socket"                               # RCCL refuses two ranks on one device
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)                             # no launcher around us: spawn the ranks ourselves
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched through torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     # build BEFORE the library is first loaded: a stale .so must not stay mapped under a fresh one
@@ -316,38 +410,27 @@ def main():
     B.build(verbose=False)
     from curdleproofs_pie_amd import _native as N
 
-    dist = None
-    torch = None
     if args.mode == "verify":
         return verify_mode(args, rank, local_rank, world)
     if args.mode != "msm":
         return side_mode(args)
     dev_index = 0 if args.same_device else local_rank
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(dev_index)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group(backend="gloo")
     ctx = N.Context(dev_index)
     ctx2 = N.Context(dev_index)                               # second pipeline of the same GPU (own stream and scratch buffers)
+    comm = open_comm(args, rank, world, ctx)
 
-    from curdleproofs_pie_amd.distributed import all_reduce_g1, shard_layout
+    from curdleproofs_pie_amd.distributed import all_reduce_g1, max_over_ranks, shard_layout
 
     c = args.window
     d_g = ctx.alloc(96)
     d_g.upload(raw96_gen())
 
     def barrier_sync():
-        if world > 1:
-            dist.barrier()
-            if args.backend == "nccl":
-                torch.cuda.synchronize()
-        ctx.sync()
+        ctx.sync()                                            # hipDeviceSynchronize: this rank's GPU is idle ...
+        if comm:
+            comm.barrier()                                    # ... and so is every other rank's
 
-    def run(shard, n_per_gpu, seed, steps, warmup, depth=None, detail=False):
+    def run(shard, n_per_gpu, seed, steps, warmup, depth=None, detail=False, check=False):
         """One timed measurement: ONE MSM of world * n_per_gpu terms per step, sharded `shard`-wise, `depth` calls in flight.
         Returns a dict with the max-over-ranks time and what the audit needs."""
         depth = depth or args.pipeline
@@ -366,7 +449,7 @@ def main():
             if world == 1:
                 return part
             t = time.perf_counter()
-            out = all_reduce_g1(part)
+            out = all_reduce_g1(part, comm)
             ex["t"] += time.perf_counter() - t
             ex["n"] += 1
             return out
@@ -404,25 +487,33 @@ def main():
         counts = ctx.last_counts()
         if not all(N.cg1_eq(r, results[0]) for r in results[1:]):
             sys.exit("bench.py: MSM results differ between steps")
-        per_rank = [mine]
-        if world > 1:
-            dev = "cuda" if args.backend == "nccl" else "cpu"
-            t = torch.tensor([mine], dtype=torch.float64, device=dev)
-            g = [torch.empty_like(t) for _ in range(world)]
-            dist.all_gather(g, t)
-            per_rank = [float(x.item()) for x in g]
-            elapsed = max(per_rank)
+        closed = None
+        if check:
+            # the timed MSM against its closed form: every point group's sum_i k_i s_i (taken from the ranks of window group 0 --
+            # the other window groups hold the same points), added up, times G by the host operator (double-and-add, host_g1.cpp)
+            import ctypes
+            mine_sum = wl.closed_form_scalar() if w_rank == 0 else 0
+            parts = comm.allgather(mine_sum.to_bytes(32, "little"), host_only=True) if comm else [mine_sum.to_bytes(32, "little")]
+            tot = sum(int.from_bytes(b, "little") for b in parts) % FR_ORDER
+            g, want = ctypes.create_string_buffer(N.POINT_BYTES), ctypes.create_string_buffer(N.POINT_BYTES)
+            N.cg1_generator(g)
+            N.cg1_mul(want, g.raw, tot.to_bytes(32, "little"))
+            closed = bool(N.cg1_eq(results[-1], want.raw))
+            if not closed:
+                sys.exit("bench.py: the timed MSM's result differs from its closed form (sum k_i s_i) * G")
+        per_rank = max_over_ranks(mine, comm)
+        elapsed = max(per_rank)
         rec = {"elapsed": elapsed, "ms_per_step": elapsed / steps * 1e3, "value": n_per_gpu * world * steps / elapsed,
                "per_rank_ms_per_step": {"min": min(per_rank) / steps * 1e3, "max": max(per_rank) / steps * 1e3},
                "phases_ms": {k: v / steps for k, v in phase_acc.items() if k != "window_c"}, "counts": counts,
                "phases_ms_window_c": phase_acc.get("window_c", 0) / steps,
                "layout": (w_rank, w_groups, p_rank, p_groups), "n_local": wl.n, "depth": len(ctxs),
-               "exchange_ms": (ex["t"] / ex["n"] * 1e3) if ex["n"] else None, "result": results[-1]}
+               "exchange_ms": (ex["t"] / ex["n"] * 1e3) if ex["n"] else None, "result": results[-1], "closed_form_ok": closed}
         wl.free()
         return rec
 
     n_per_gpu = 1 << args.logn
-    main_rec = run(args.shard, n_per_gpu, args.seed, args.steps, args.warmup)
+    main_rec = run(args.shard, n_per_gpu, args.seed, args.steps, args.warmup, check=True)
     # the per-phase table: a few more steps with an event around every phase (not the timed region)
     main_rec["phases_ms_detailed"] = run(args.shard, n_per_gpu, args.seed, max(3, args.steps // 4), 1, detail=True)["phases_ms"]
 
@@ -464,14 +555,15 @@ def main():
         madds = r["counts"]["mixed_adds"]                   # bucket entries - chunks
         pair_adds = min(r["counts"]["chunks"], madds)
         mads = (madds - pair_adds) * float(MADS_PER_MADD) + pair_adds * float(MADS_PER_MMADD)
-        traffic = pmc = None
+        pmc = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and world == 1 and args.logn == 20:
             try:
                 pmc = json.load(open(tpath))
-                traffic = pmc.get("k_accumulate_hbm_bytes_per_launch")
             except Exception:
                 pmc = None
+        ctx.set_param("profile", 0)
+        peak = mad_peak_same_run(ctx)
         out = {
             "metric": "BLS12-381 G1 scalar-muls/sec at MSM size 2^20",
             "value": r["value"],
@@ -492,18 +584,22 @@ def main():
                        "calls_in_flight": r["depth"],
                        "arithmetic": "381-bit Fp as 14 x 28-bit limbs in u32, Montgomery, 64-bit column accumulators (v_mad_u64_u32)",
                        "device_build": N.build_info().get("pipeline", "unknown"),
+                       "result_equals_closed_form": r["closed_form_ok"],
                        "bit_exact_vs_oracle": "tests/test_msm_gpu.py"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "traffic_source": (pmc or {}).get("source", None) and ("NOT measured in this run: " + pmc["source"]),
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "traffic_note": "PMC counters cannot be read inside this run; the per-launch HBM bytes of k_accumulate from separate "
+                                         "rocprofv3 --pmc passes are kept in profiles/pmc_traffic.json",
                          "kernel": "k_accumulate", "kernel_ms": acc_ms,
                          "note": "path is integer-multiply (v_mad_u64_u32) bound, not HBM-bound: see roofline_int_mad and DESIGN.md"},
             # The bound that actually applies: 32x32+64 integer multiply-adds.  Algorithmic MADs of one
             # k_accumulate launch = the additions it really performs (bucket entries minus one copy per chunk, both counted on
             # the device in this run): 3542 each, 1974 for the first one of a chunk; peak = the chip-wide v_mad_u64_u32 rate
             # measured by tools/ubench_valu.hip.
-            "roofline_int_mad": {"bound": "valu v_mad_u64_u32", "achieved": mads / (acc_ms * 1e-3) / 1e12, "peak": MAD_PEAK_T,
-                                 "unit": "T mad/s", "frac": mads / (acc_ms * 1e-3) / (MAD_PEAK_T * 1e12), "kernel": "k_accumulate",
+            "roofline_int_mad": {"bound": "valu v_mad_u64_u32", "achieved": mads / (acc_ms * 1e-3) / 1e12, "peak": peak["burst_T"],
+                                 "unit": "T mad/s", "frac": mads / (acc_ms * 1e-3) / (peak["burst_T"] * 1e12), "kernel": "k_accumulate",
+                                 "kernel_ms": acc_ms, "peak_same_run": peak, "frac_vs_sustained_peak": mads / (acc_ms * 1e-3) / (peak["sustained_T"] * 1e12),
+                                 "peak_round1_other_box": MAD_PEAK_T,
                                  "mixed_adds_per_launch": madds, "bucket_entries": r["counts"]["entries"], "chunks": r["counts"]["chunks"],
                                  "mads_per_mixed_add": MADS_PER_MADD, "first_additions_of_chunks": pair_adds, "mads_per_first_addition": MADS_PER_MMADD,
                                  "valu_per_wave_mixed_add": (pmc or {}).get("k_accumulate_valu_per_wave_mixed_add"),
@@ -514,8 +610,10 @@ def main():
         }
         out.update(extra)
         if world > 1:
-            out["collective"] = {"backend": dist.get_backend(), "world_seen": dist.get_world_size(),
-                                 "what": "all_gather of one 144-byte partial G1 sum per rank, then world-1 host additions on every rank",
+            out["collective"] = {"backend": comm.transport, "world_seen": comm.world_seen,
+                                 "world_seen_source": "ncclCommCount" if comm.transport == "rccl" else "ranks connected to the TCP hub",
+                                 "what": "cg1_comm_allreduce_g1: all-gather of one 144-byte partial G1 sum per rank (ncclAllGather on the context's "
+                                         "stream when the backend is rccl), then world-1 host additions on every rank",
                                  "bytes_per_step": 144 * world, "ms_per_exchange": r["exchange_ms"]}
             out["predicted_ms_per_step_emulated"] = EMULATED_MS.get(args.shard, {}).get(world)
         if world == 1:
@@ -538,12 +636,12 @@ def main():
             wl.free()
         if world == 1 and not args.no_secondary:
             cores = int(N.cg1_shuffle_default_threads())
-            out["secondary"] = verify_measure(ctx, cores, args.verify_steps, 2, args.batch, args.verify_mode, cpu_leg=not args.no_cpu_baseline)
+            out["secondary"] = verify_measure(ctx, cores, args.verify_steps, 2, args.batch, args.verify_mode, cpu_leg=not args.no_cpu_baseline, peak_T=peak["burst_T"])
         print(json.dumps(out), flush=True)
 
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if comm:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

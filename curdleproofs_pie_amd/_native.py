@@ -17,7 +17,7 @@ POINT_BYTES = 144
 NPHASE = 7
 PHASE_NAMES = ("prepare", "sort_count", "sort_scatter", "chunks", "accumulate", "seg_reduce", "bit_tree")
 
-OK, ERR_ARG, ERR_HIP, ERR_ENCODING, ERR_NOT_ON_CURVE, ERR_NOT_IN_SUBGROUP = range(6)
+OK, ERR_ARG, ERR_HIP, ERR_ENCODING, ERR_NOT_ON_CURVE, ERR_NOT_IN_SUBGROUP, ERR_COMM = range(7)
 
 
 class NativeError(RuntimeError):
@@ -89,6 +89,24 @@ cg1_stream_sync = _proto("cg1_stream_sync", c_int, c_void_p)
 cg1_d2h_2d = _proto("cg1_d2h_2d", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_size_t, c_size_t)
 cg1_ctx_sync = _proto("cg1_ctx_sync", c_int, c_void_p)
 cg1_ctx_set_param = _proto("cg1_ctx_set_param", c_int, c_void_p, c_char_p, c_int)
+cg1_ctx_device = _proto("cg1_ctx_device", c_int, c_void_p)
+cg1_ctx_stream = _proto("cg1_ctx_stream", c_void_p, c_void_p)
+# multi-GPU: one process over a device list, and the per-rank communicator (TCP control channel + RCCL)
+cg1_msm_multi_device = _proto("cg1_msm_multi_device", c_int, POINTER(c_void_p), c_size_t, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_size_t), c_int, _buf)
+cg1_comm_create = _proto("cg1_comm_create", c_void_p, c_int, c_int)
+cg1_comm_port = _proto("cg1_comm_port", c_int, c_void_p)
+cg1_comm_rank = _proto("cg1_comm_rank", c_int, c_void_p)
+cg1_comm_connect = _proto("cg1_comm_connect", c_int, c_void_p, c_char_p, c_int, c_uint64, c_int)
+cg1_comm_set_timeout = _proto("cg1_comm_set_timeout", c_int, c_void_p, c_int)
+cg1_comm_attach_rccl = _proto("cg1_comm_attach_rccl", c_int, c_void_p, c_void_p)
+cg1_comm_transport = _proto("cg1_comm_transport", c_char_p, c_void_p)
+cg1_comm_world_seen = _proto("cg1_comm_world_seen", c_int, c_void_p)
+cg1_comm_error = _proto("cg1_comm_error", c_char_p, c_void_p)
+cg1_comm_allgather = _proto("cg1_comm_allgather", c_int, c_void_p, c_void_p, c_size_t, c_void_p)
+cg1_comm_allgather_host = _proto("cg1_comm_allgather_host", c_int, c_void_p, c_void_p, c_size_t, c_void_p)
+cg1_comm_barrier = _proto("cg1_comm_barrier", c_int, c_void_p)
+cg1_comm_allreduce_g1 = _proto("cg1_comm_allreduce_g1", c_int, c_void_p, _u8p, _buf, c_void_p)
+cg1_comm_destroy = _proto("cg1_comm_destroy", None, c_void_p)
 cg1_msm = _proto("cg1_msm", c_int, c_void_p, _u8p, _u8p, c_size_t, _buf)
 cg1_msm_device = _proto("cg1_msm_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, _buf)
 cg1_msm_device_begin = _proto("cg1_msm_device_begin", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int)
@@ -111,6 +129,9 @@ cg1_batch_compress_device = _proto("cg1_batch_compress_device", c_int, c_void_p,
 cg1_batch_decompress_gpu = _proto("cg1_batch_decompress_gpu", c_int, c_void_p, _u8p, _buf, c_size_t, c_int, POINTER(c_size_t))
 cg1_gen_scalars_device = _proto("cg1_gen_scalars_device", c_int, c_void_p, c_void_p, c_size_t, c_uint64)
 cg1_probe_madd = _proto("cg1_probe_madd", c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_int, POINTER(c_float))
+cg1_probe_mad_rate = _proto("cg1_probe_mad_rate", c_int, c_void_p, c_int, c_int, POINTER(ctypes.c_double))
+cg1_batch_sum_device = _proto("cg1_batch_sum_device", c_int, c_void_p, c_void_p, POINTER(ctypes.c_uint32), c_size_t, c_void_p)
+cg1_batch_sum = _proto("cg1_batch_sum", c_int, c_void_p, _u8p, POINTER(ctypes.c_uint32), c_size_t, _buf)
 
 # native Merlin transcript (host)
 MERLIN_STATE_BYTES = 208
@@ -169,6 +190,9 @@ EXPORTED_SYMBOLS = [
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_h2d_async", "cg1_copy_fence", "cg1_stream_sync", "cg1_batch_decompress_enqueue", "cg1_host_alloc", "cg1_host_free", "cg1_ctx_sync", "cg1_ctx_set_param",
     "cg1_msm", "cg1_msm_device", "cg1_msm_device_begin", "cg1_msm_device_end", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_get_last_counts", "cg1_timer_begin", "cg1_timer_end", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
+    "cg1_probe_mad_rate", "cg1_batch_sum_device", "cg1_batch_sum", "cg1_ctx_device", "cg1_ctx_stream", "cg1_msm_multi_device",
+    "cg1_comm_create", "cg1_comm_port", "cg1_comm_rank", "cg1_comm_connect", "cg1_comm_set_timeout", "cg1_comm_attach_rccl", "cg1_comm_transport",
+    "cg1_comm_world_seen", "cg1_comm_error", "cg1_comm_allgather", "cg1_comm_allgather_host", "cg1_comm_barrier", "cg1_comm_allreduce_g1", "cg1_comm_destroy",
 ]
 
 
@@ -350,6 +374,20 @@ class Context:
         p = d_out.ptr if isinstance(d_out, DeviceBuffer) else int(d_out)
         self.check(cg1_gen_scalars_device(self.handle, p, n, seed & 0xFFFFFFFFFFFFFFFF))
 
+    def probe_mad_rate(self, waves_per_simd: int = 2, iters: int = 2000) -> float:
+        """Chip-wide v_mad_u64_u32 rate in lane-operations per second (k_probe_mad_rate)."""
+        v = ctypes.c_double()
+        self.check(cg1_probe_mad_rate(self.handle, waves_per_simd, iters, ctypes.byref(v)))
+        return float(v.value)
+
+    def batch_sum_host(self, points_affine96: bytes, offsets) -> bytes:
+        """Segmented point sum (crs.py:64-65): one affine96 record per group [offsets[j], offsets[j+1])."""
+        m = len(offsets) - 1
+        arr = (ctypes.c_uint32 * (m + 1))(*offsets)
+        out = ctypes.create_string_buffer(96 * max(m, 1))
+        self.check(cg1_batch_sum(self.handle, points_affine96, arr, m, out))
+        return out.raw[: 96 * m]
+
     def probe_madd(self, d_points, npts: int, lanes: int, iters: int) -> float:
         p = d_points.ptr if isinstance(d_points, DeviceBuffer) else int(d_points)
         ms = c_float()
@@ -359,6 +397,88 @@ class Context:
     def close(self) -> None:
         if self.handle:
             cg1_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def msm_multi_device(ctxs, d_points, d_scalars, ns, window_c: int = 0) -> bytes:
+    """One MSM over several GPUs of this process (cg1_msm_multi_device): ctxs[i] owns point shard i on its own device."""
+    k = len(ctxs)
+    assert k and len(d_points) == len(d_scalars) == len(ns) == k
+    g = lambda b: b.ptr if isinstance(b, DeviceBuffer) else int(b)
+    hs = (c_void_p * k)(*[c.handle for c in ctxs])
+    ps = (c_void_p * k)(*[g(b) for b in d_points])
+    ss = (c_void_p * k)(*[g(b) for b in d_scalars])
+    nn = (c_size_t * k)(*[int(n) for n in ns])
+    out = ctypes.create_string_buffer(POINT_BYTES)
+    rc = cg1_msm_multi_device(hs, k, ps, ss, nn, window_c, out)
+    if rc != OK:
+        msgs = "; ".join((cg1_ctx_error(c.handle) or b"").decode() for c in ctxs)
+        raise NativeError(f"libcurdle_g1 error {rc}: {msgs}")
+    return out.raw
+
+
+class Comm:
+    """One rank's end of the N>1 exchange (cg1_comm_*): a TCP control channel on the loopback interface, plus RCCL once
+    `attach_rccl(ctx)` has run on every rank.  See curdleproofs_pie_amd/distributed.py for the rendezvous."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world = int(rank), int(world)
+        self.handle = cg1_comm_create(self.rank, self.world)
+        if not self.handle:
+            raise NativeError(f"cg1_comm_create({rank}, {world}) failed")
+
+    def check(self, rc: int) -> None:
+        if rc != OK:
+            msg = cg1_comm_error(self.handle)
+            raise NativeError(f"libcurdle_g1 comm error {rc}: {msg.decode() if msg else ''}")
+
+    @property
+    def port(self) -> int:
+        return int(cg1_comm_port(self.handle))
+
+    @property
+    def transport(self) -> str:
+        return cg1_comm_transport(self.handle).decode()
+
+    @property
+    def world_seen(self) -> int:
+        return int(cg1_comm_world_seen(self.handle))
+
+    def connect(self, host: str, port: int, nonce: int, timeout_ms: int) -> int:
+        return int(cg1_comm_connect(self.handle, host.encode() if host else None, int(port), int(nonce) & (2 ** 64 - 1), int(timeout_ms)))
+
+    def set_timeout(self, timeout_ms: int) -> None:
+        self.check(cg1_comm_set_timeout(self.handle, int(timeout_ms)))
+
+    def attach_rccl(self, ctx: "Context") -> None:
+        self.check(cg1_comm_attach_rccl(self.handle, ctx.handle))
+
+    def allgather(self, data: bytes, host_only: bool = False) -> list:
+        """Every rank passes the same number of bytes; returns the `world` byte strings in rank order."""
+        n = len(data)
+        out = ctypes.create_string_buffer(max(1, n * self.world))
+        fn = cg1_comm_allgather_host if host_only else cg1_comm_allgather
+        self.check(fn(self.handle, bytes(data), n, out))
+        raw = out.raw
+        return [raw[i * n:(i + 1) * n] for i in range(self.world)]
+
+    def barrier(self) -> None:
+        self.check(cg1_comm_barrier(self.handle))
+
+    def allreduce_g1(self, partial_blob: bytes) -> bytes:
+        out = ctypes.create_string_buffer(POINT_BYTES)
+        self.check(cg1_comm_allreduce_g1(self.handle, bytes(partial_blob), out, None))
+        return out.raw
+
+    def close(self) -> None:
+        if self.handle:
+            cg1_comm_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

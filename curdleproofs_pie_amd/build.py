@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcurdle_g1.so")
-SOURCES = [os.path.join(CSRC, "msm_gpu.hip"), os.path.join(CSRC, "host_g1.cpp"), os.path.join(CSRC, "merlin.cpp"), os.path.join(CSRC, "shuffle_verify.cpp")]
+SOURCES = [os.path.join(CSRC, "msm_gpu.hip"), os.path.join(CSRC, "host_g1.cpp"), os.path.join(CSRC, "merlin.cpp"), os.path.join(CSRC, "shuffle_verify.cpp"), os.path.join(CSRC, "comm.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("fp28.h", "g1_xyzz.h", "g1_quad.h", "host_g1.h", "fr.h", "merlin_group.h", "bls_consts.h", "kernels_records.h", "kernels_prepare_digits.h",
                                                     "kernels_sort.h", "kernels_accumulate.h", "kernels_reduce.h", "kernels_batch.h", "kernels_rows.h", "kernels_merlin.h")] + [
     os.path.join(HERE, "..", "include", "curdle_g1.h")
@@ -38,6 +38,24 @@ def _source_hash() -> str:
 
 
 HASH_FILE = LIB + ".srchash"
+HOST_ONLY = ("host_g1.cpp", "merlin.cpp", "shuffle_verify.cpp", "comm.cpp", "merlin_group.h")
+
+
+def _hip_unit_hash(extra_flags=()) -> str:
+    """Content hash of what the .hip translation unit is compiled from (every dependency that is not host-only)."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        if os.path.basename(d) in HOST_ONLY or not os.path.exists(d):
+            continue
+        h.update(os.path.basename(d).encode())
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(repr(tuple(extra_flags)).encode())
+    with open(os.path.abspath(__file__), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()[:24]
 
 
 def needs_build() -> bool:
@@ -132,6 +150,14 @@ def _build_staged(out_path: str, extra_flags, verbose: bool) -> None:
     assert len(hip_src) == 1
     common = ["-O3", "-std=c++17", "-fPIC", *extra_flags]
     tgt = ["-mtriple=amdgcn-amd-amdhsa", "-mcpu=gfx950"]
+    # the .hip translation unit (device pipeline + its host half) is by far the slow part: keep its object keyed by the content
+    # of everything it is built from, so a change to a host-only .cpp source relinks in seconds
+    cache_dir = os.path.join(HERE, "..", "build", "hip_obj_cache")
+    key = _hip_unit_hash(extra_flags)
+    cached = os.path.join(cache_dir, f"hip_host_{key}.o")
+    if os.path.exists(cached):
+        _run([hipcc, *common, "-shared", cached, *cpp_src, "-ldl", "-o", out_path], verbose)
+        return
     with tempfile.TemporaryDirectory(prefix="curdle_g1_build_") as td:
         j = lambda f: os.path.join(td, f)
         _device_opt_bc(hip_src[0], td, common, verbose)
@@ -141,12 +167,20 @@ def _build_staged(out_path: str, extra_flags, verbose: bool) -> None:
               "-input=/dev/null", f"-input={j('dev.hsaco')}", f"-output={j('dev.hipfb')}"], verbose)
         _run([tool("clang++"), "-x", "hip", "--offload-host-only", "--offload-arch=gfx950", *common, "-cuid=curdleg1", "-Xclang", "-fcuda-include-gpubinary", "-Xclang",
               j("dev.hipfb"), "-c", hip_src[0], "-o", j("hip_host.o")], verbose)
-        _run([hipcc, *common, "-shared", j("hip_host.o"), *cpp_src, "-o", out_path], verbose)
+        _run([hipcc, *common, "-shared", j("hip_host.o"), *cpp_src, "-ldl", "-o", out_path], verbose)
+        try:
+            os.makedirs(cache_dir, exist_ok=True)
+            for old in os.listdir(cache_dir):
+                os.unlink(os.path.join(cache_dir, old))
+            shutil.copyfile(j("hip_host.o"), cached + ".tmp")
+            os.replace(cached + ".tmp", cached)
+        except OSError:
+            pass
 
 
 def _build_plain(out_path: str, extra_flags, verbose: bool) -> None:
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    _run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", *extra_flags, *SOURCES, "-o", out_path], verbose)
+    _run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", *extra_flags, *SOURCES, "-ldl", "-o", out_path], verbose)
 
 
 def _write_info(lib_path: str, pipeline: str, note: str = "") -> None:

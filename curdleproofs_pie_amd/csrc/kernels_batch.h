@@ -47,6 +47,57 @@ __global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ 
   fp_to_words(fp_mul(acc.Y, izzz), o); for (int k = 0; k < 12; ++k) dst[12 + k] = o[k];
 }
 
+// ------------------------------------------------------------------ segmented point sum (fourth pattern)
+// G_sum = reduce(lambda a, b: a + b, vec_G, Z1), H_sum likewise (crs.py:64-65): group j is the sum of the points
+// [offs[j], offs[j+1]) of the input.  One wave per group: the lanes stride over the group's points with mixed additions
+// (every exceptional case exact: equal points, opposite points, identities), a shuffle tree joins the 64 lane sums, lane 0
+// normalises with one inversion.  Affine std words in and out (identity = zeros).
+__global__ void __launch_bounds__(64) k_batch_sum(const uint32_t* __restrict__ base_raw, const uint32_t* __restrict__ offs,
+                                                  uint32_t* __restrict__ out_raw) {
+  const uint32_t g = blockIdx.x, lo = offs[g], hi = offs[g + 1];
+  xyzz acc = xyzz_identity();
+  for (uint32_t i = lo + threadIdx.x; i < hi; i += 64) {
+    const uint32_t* src = base_raw + 24ull * i;
+    uint32_t w[24], any = 0;
+    for (int k = 0; k < 24; ++k) { w[k] = src[k]; any |= w[k]; }
+    if (any) acc = xyzz_madd(acc, fp_to_mont(fp_from_words(w)), fp_to_mont(fp_from_words(w + 12)));
+  }
+  for (int delta = 32; delta >= 1; delta >>= 1) {
+    xyzz o = shfl_down_xyzz(acc, delta);
+    if (threadIdx.x < (uint32_t)delta) acc = xyzz_add(acc, o);
+  }
+  if (threadIdx.x) return;
+  uint32_t* dst = out_raw + 24ull * g;
+  if (acc.inf) { for (int k = 0; k < 24; ++k) dst[k] = 0; return; }
+  fp t = fp_inv(fp_mul(acc.ZZ, acc.ZZZ));
+  fp izz = fp_mul(t, acc.ZZZ), izzz = fp_mul(t, acc.ZZ);
+  uint32_t o[12];
+  fp_to_words(fp_mul(acc.X, izz), o);  for (int k = 0; k < 12; ++k) dst[k] = o[k];
+  fp_to_words(fp_mul(acc.Y, izzz), o); for (int k = 0; k < 12; ++k) dst[12 + k] = o[k];
+}
+
+// ------------------------------------------------------------------ v_mad_u64_u32 issue-rate probe (bench.py, same-run peak)
+// Eight independent 64-bit accumulator chains per lane, nothing but the multiply-add the field arithmetic is made of: the
+// chip-wide rate this sustains at 2 waves per SIMD is the `peak` of roofline_int_mad, measured on the box and at the clock
+// the benchmark itself runs at (tools/ubench_valu.hip is the stand-alone form with the other instructions beside it).
+__global__ void __launch_bounds__(256) k_probe_mad_rate(uint32_t* __restrict__ out, int iters, uint32_t seed) {
+  uint32_t a = seed * (threadIdx.x + 1) | 1u, b = seed ^ (0x9e3779b9u * (blockIdx.x + 1));
+  uint64_t acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = (uint64_t)a * (c + 3) + b;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[c]) : "v"(a), "v"(b) : "vcc");
+    }
+  }
+  uint64_t r = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) r ^= acc[c];
+  if (r == 0x123456789abcdefull) out[0] = (uint32_t)r;      // keeps the chains alive; practically never taken
+}
+
 // ------------------------------------------------------------------ batched 48-byte G1 decompression
 // One lane per point: parse the ZCash-format encoding (util.py:35-36 -> G1Point.from_compressed_bytes[_unchecked]),
 // y = sqrt(x^3 + 4) by exponentiation, sign select, optional subgroup test  [z^2]P == phi(P) + P.

@@ -139,6 +139,7 @@ struct Ctx {
     WinPlan plan;
     uint32_t m = 1, lb2 = 0, hb2 = 0, nitems = 0;
     bool use2d = true;
+    int profile = 0;                    // the level the events of THIS call were recorded under (may change before msm_finish)
     size_t nout_words = 0;
     std::chrono::steady_clock::time_point h0, h1;
   } pend;
@@ -299,11 +300,11 @@ static size_t zblock_clear_bytes(const Ctx* ctx) {
 
 // profile 2: every phase is bracketed by hipEvents; 1 (default): only k_accumulate (the roofline kernel) -- each event record
 // is a marker packet that costs the stream ~5.5 us, 8 of them were 4 % of a 2^16-term MSM; 0: none.
-static int read_phase_events(Ctx* ctx) {
+static int read_phase_events(Ctx* ctx, int profile) {
   for (int i = 0; i < CG1_NPHASE; ++i) ctx->phase_ms[i] = 0.f;
-  if (ctx->profile >= 2) {
+  if (profile >= 2) {
     for (int i = 0; i < CG1_NPHASE; ++i) HIPCHK(hipEventElapsedTime(&ctx->phase_ms[i], ctx->ev[i], ctx->ev[i + 1]));
-  } else if (ctx->profile == 1) {
+  } else if (profile == 1) {
     HIPCHK(hipEventElapsedTime(&ctx->phase_ms[4], ctx->ev[4], ctx->ev[5]));
   }
   return CG1_OK;
@@ -387,14 +388,15 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipStream_t st = ctx->stream;
   const uint32_t n32 = (uint32_t)n;
   const uint32_t gn = (n32 + 255) / 256;
+  const int profile = ctx->profile;
   auto h0 = std::chrono::steady_clock::now();
   const PreparedPoint* pts = ctx->d_pts;
   const uint8_t* flags = ctx->d_flags;
   const size_t nout_words = (size_t)nlw * nitems;
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // [0] set by the digit kernels: a scalar >= 2^255; [1], [2]: counts
-  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[0], st));
+  if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[0], st));
   hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32, bad_flag);
-  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[1], st));
+  if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[1], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
     // ---- two-level partition sort: no global atomics
@@ -407,7 +409,7 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     hipLaunchKernelGGL(k_uscan1, dim3(ublk), dim3(256), 0, st, ctx->d_blockcnt, ctx->d_ublocktot, nbc);
     hipLaunchKernelGGL(k_uscan2, dim3(1), dim3(256), 0, st, ctx->d_ublocktot, ublk, ctx->d_blockcnt, nbc);
     hipLaunchKernelGGL(k_uscan3, dim3(ublk), dim3(256), 0, st, ctx->d_ublocktot, ctx->d_blockcnt, nbc);
-    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[2], st));
+    if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_part_scatter, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, ctx->d_part, n32, nslices, nbins, sub_bits, ctx->stage_sort);
     const uint32_t nbt = (uint32_t)nlw * nbins;
     hipLaunchKernelGGL(k_slice_plan, dim3(1), dim3(256), 0, st, ctx->d_blockcnt, nbt, nslices, ctx->d_slice_base, ctx->d_bigflag, ctx->big_bins);
@@ -418,7 +420,7 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
       hipLaunchKernelGGL(k_slice_prefix, dim3(nbt), dim3(256), 0, st, ctx->d_blockcnt, nslices, sub_bits, ctx->d_slice_base, ctx->d_bigflag, ctx->d_slicehist, ctx->d_subbase, ctx->d_hist);
       hipLaunchKernelGGL(k_slice_scatter, dim3(max_slices), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, nbt, nslices, ctx->d_slice_base, ctx->d_slicehist, ctx->d_subbase, ctx->d_sorted);
     }
-    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
+    if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
     hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
@@ -426,11 +428,11 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     // ---- global-atomic counting sort (any n < 2^31)
     HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
     hipLaunchKernelGGL(k_hist, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, n32, plan, rank, world, bad_flag);
-    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[2], st));
+    if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
     hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
     hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
-    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
+    if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
     hipLaunchKernelGGL(k_scatter, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_hist, ctx->d_off, ctx->d_sorted, n32, plan, rank, world);
   }
   // one memset: chunk-length histogram, the any_multi flag, combined[] and the heavy-bucket count (ensure() laid them out together)
@@ -440,9 +442,9 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
   hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
-  if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[4], st));
+  if (profile >= 1) HIPCHK(hipEventRecord(ctx->ev[4], st));
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, pts, ctx->d_sums);
-  if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[5], st));
+  if (profile >= 1) HIPCHK(hipEventRecord(ctx->ev[5], st));
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
   const bool small_quad = ctx->quad && ctx->rowcol_quad && nb_total <= (1u << 18);      // latency-bound regime: every addition by a quad
   if (small_quad)
@@ -462,23 +464,23 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     else
       hipLaunchKernelGGL(k_rowcol, dim3(nrow_blocks + ncol_blocks), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
                          rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks, ctx->quad);
-    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
+    if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
     if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(512), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
     else hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
   } else {
     const uint32_t nseg_total = (uint32_t)(nb_total / m);
     hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
-    if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
+    if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
     uint32_t S = (J + BT_ELEMS - 1) / BT_ELEMS; if (S < 1) S = 1; if (S > 64) S = 64;   // J <= 2^15 / seg_m
     hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw, S), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_partial, J);
     hipLaunchKernelGGL(k_bit_tree_final, dim3((uint32_t)(nitems * nlw)), dim3(64), 0, st, ctx->d_partial, ctx->d_out, S);
   }
   HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, ((size_t)nlw * nitems + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
-  if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[7], st));
+  if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
   Ctx::Pending& pd = ctx->pend;
   pd.active = true; pd.c = c; pd.plan = plan; pd.rank = rank; pd.world = world; pd.nlw = nlw; pd.nbits = nbits; pd.m = m; pd.lb2 = lb2; pd.hb2 = hb2;
-  pd.nitems = nitems; pd.use2d = use2d; pd.nout_words = nout_words; pd.h0 = h0; pd.h1 = h1;
+  pd.nitems = nitems; pd.use2d = use2d; pd.profile = profile; pd.nout_words = nout_words; pd.h0 = h0; pd.h1 = h1;
   return CG1_OK;
 }
 
@@ -506,7 +508,7 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
     }
   }
   auto h2 = std::chrono::steady_clock::now();
-  read_phase_events(ctx);
+  { int erc = read_phase_events(ctx, pd.profile); if (erc) return erc; }
   ctx->last_c = c;
 
   // ---- host tail: ONE Horner over global bit positions.
@@ -711,7 +713,7 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
     }
   }
   auto h2 = std::chrono::steady_clock::now();
-  read_phase_events(ctx);
+  { int erc = read_phase_events(ctx, ctx->profile); if (erc) return erc; }
   ctx->last_c = c;
   for (size_t j = 0; j < M; ++j) results[j] = jac_from_words(ctx->h_bout[j]);
   auto h3 = std::chrono::steady_clock::now();
@@ -921,6 +923,8 @@ int cg1_ctx_sync(cg1_ctx* ctx) {
   HIPCHK(hipDeviceSynchronize());
   return CG1_OK;
 }
+int cg1_ctx_device(const cg1_ctx* ctx) { return ctx ? ctx->device : -1; }
+void* cg1_ctx_stream(cg1_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return CG1_ERR_ARG;
   if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
@@ -964,6 +968,30 @@ int cg1_msm_device_end(cg1_ctx* ctx, uint8_t* out) {
   cg1h::jac r;
   int rc = cg1::msm_end(ctx, r);
   if (rc == CG1_OK) blob_out(out, r);
+  return rc;
+}
+
+// One MSM over several GPUs of THIS process: context i owns point shard i on its own device.  Every launch chain is enqueued
+// before any is waited for, so the devices work concurrently; the partials are added in context order.
+int cg1_msm_multi_device(cg1_ctx* const* ctxs, size_t n_ctx, const void* const* d_points, const void* const* d_scalars, const size_t* n,
+                         int window_c, uint8_t* out) {
+  if (!ctxs || !n_ctx || !d_points || !d_scalars || !n || !out) return CG1_ERR_ARG;
+  for (size_t i = 0; i < n_ctx; ++i) {
+    if (!ctxs[i]) return CG1_ERR_HIP;
+    for (size_t j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return CG1_ERR_ARG;        // a context takes one call at a time
+  }
+  int rc = CG1_OK;
+  size_t begun = 0;
+  for (; begun < n_ctx && rc == CG1_OK; ++begun)
+    rc = cg1::msm_begin(ctxs[begun], d_points[begun], d_scalars[begun], n[begun], window_c, 0, 1);
+  cg1h::jac acc = cg1h::jac_identity();
+  for (size_t i = 0; i < begun; ++i) {                     // drain every context that was begun, also after a failure
+    cg1h::jac part;
+    int r2 = cg1::msm_end(ctxs[i], part);
+    if (rc == CG1_OK) rc = r2;
+    if (r2 == CG1_OK) acc = cg1h::jac_add(acc, part);
+  }
+  if (rc == CG1_OK) blob_out(out, acc);
   return rc;
 }
 
@@ -1232,6 +1260,59 @@ int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
   HIPCHK(hipGetLastError());
   return CG1_OK;
 }
+// chip-wide v_mad_u64_u32 rate (lane-operations per second) at `waves_per_simd` resident waves, hipEvents on the context's stream
+int cg1_probe_mad_rate(cg1_ctx* ctx, int waves_per_simd, int iters, double* lane_ops_per_s) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (waves_per_simd < 1 || waves_per_simd > 8 || iters < 1 || !lane_ops_per_s) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+  const unsigned blocks = (unsigned)prop.multiProcessorCount * (unsigned)waves_per_simd;       // 256 threads = 4 waves = one per SIMD of a CU
+  DevBuf out;
+  HIPCHK(out.alloc(256));
+  hipLaunchKernelGGL(cg1::k_probe_mad_rate, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t*)out.p, 8, 12345u);      // warm-up
+  HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+  hipLaunchKernelGGL(cg1::k_probe_mad_rate, dim3(blocks), dim3(256), 0, ctx->stream, (uint32_t*)out.p, iters, 12345u);
+  HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  float ms = 0;
+  HIPCHK(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+  *lane_ops_per_s = (double)blocks * 256.0 * (double)iters * 128.0 / ((double)ms * 1e-3);
+  return CG1_OK;
+}
+
+// out[j] = sum of points [offsets[j], offsets[j+1]) (affine96 in and out; offsets: HOST array of n_groups + 1 entries)
+int cg1_batch_sum_device(cg1_ctx* ctx, const void* d_points, const uint32_t* offsets, size_t n_groups, void* d_out) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n_groups == 0) return CG1_OK;
+  if (!d_points || !offsets || !d_out || offsets[0] != 0 || n_groups >= (1u << 30)) return CG1_ERR_ARG;
+  for (size_t j = 0; j < n_groups; ++j) if (offsets[j + 1] < offsets[j]) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf offs;
+  HIPCHK(offs.alloc((n_groups + 1) * 4));
+  HIPCHK(hipMemcpyAsync(offs.p, offsets, (n_groups + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(cg1::k_batch_sum, dim3((unsigned)n_groups), dim3(64), 0, ctx->stream, (const uint32_t*)d_points, (const uint32_t*)offs.p, (uint32_t*)d_out);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
+int cg1_batch_sum(cg1_ctx* ctx, const uint8_t* points, const uint32_t* offsets, size_t n_groups, uint8_t* out) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n_groups == 0) return CG1_OK;
+  if (!points || !offsets || !out) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t n = offsets[n_groups];
+  DevBuf in, res;
+  HIPCHK(in.alloc(96 * (n ? n : 1)));
+  HIPCHK(res.alloc(96 * n_groups));
+  if (n) HIPCHK(hipMemcpy(in.p, points, 96 * n, hipMemcpyHostToDevice));
+  int rc = cg1_batch_sum_device(ctx, in.p, offsets, n_groups, res.p);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(out, res.p, 96 * n_groups, hipMemcpyDeviceToHost));
+  return CG1_OK;
+}
+
 int cg1_probe_madd(cg1_ctx* ctx, const void* d_points, size_t npts, size_t lanes, int iters, float* ms) {
   if (!ctx) return CG1_ERR_HIP;
   if (npts == 0 || lanes == 0 || lanes % 256) return CG1_ERR_ARG;

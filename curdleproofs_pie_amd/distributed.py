@@ -1,27 +1,39 @@
-"""Multi-GPU MSM: one process per GPU, one tiny exchange step.
+"""Multi-GPU MSM: one process per GPU, one tiny exchange step.  No PyTorch: the exchange lives behind the
+C ABI (cg1_comm_*, csrc/comm.cpp) -- an RCCL all-gather over xGMI on a GPU node, a TCP star on the loopback interface when
+several ranks rehearse on one GPU or on a CPU-only box.
 
 A single large MSM is partitioned across the ranks of one node either
   * by WINDOW  ("windows", what BASELINE.json's north_star names): rank g owns the signed-digit windows
     w = g (mod world); every rank holds all n points/scalars and returns  sum_{w in g} 2^(c w) S_w ; or
-  * by POINT   ("points"): rank g owns points [g*n/world, (g+1)*n/world) with all windows.
+  * by POINT   ("points"): rank g owns points [g*n/world, (g+1)*n/world) with all windows; or
+  * by both    ("hybrid", `shard_layout`).
 Either way the partials are ONE G1 point per rank.  RCCL has no elliptic-curve reduction operator, so the
-"all-reduce of partial G1 sums" is an all-gather of `world` 144-byte blobs (over xGMI, latency-bound: ~1 KB)
-followed by world-1 host G1 additions on every rank -- every rank ends with the same, bit-exact result
-(G1 addition is commutative/associative and the final encoding is canonical).
+"all-reduce of partial G1 sums" is an all-gather of `world` 144-byte blobs (latency-bound: ~1 KB) followed by world-1 host
+G1 additions on every rank -- every rank ends with the same, bit-exact result (G1 addition is commutative/associative and
+the final encoding is canonical).
 
-torch.distributed is used only as the transport (backend "nccl" == RCCL on ROCm; "gloo" in CPU tests);
-the MSM itself never touches torch.
+Rendezvous (one node): rank 0 listens on an ephemeral loopback port and publishes "port nonce" in a small file; the other
+ranks poll the file and connect.  The file's path comes from CG1_RDZV_FILE (bench.py's own launcher sets it) or is derived
+from what every rank of one launch shares: the launcher's pid (all ranks are its children) and MASTER_PORT (torchrun sets it).
 """
 from __future__ import annotations
 
-import ctypes
+import os
+import secrets
+import struct
+import tempfile
+import time
 from typing import List, Optional
 
 from . import _native as N
 
+Comm = N.Comm
+
 
 def sum_blobs(blobs: List[bytes]) -> bytes:
     """Host G1 sum of point blobs (the reduction operator of the 'all-reduce')."""
+    import ctypes
+
     acc = ctypes.create_string_buffer(N.POINT_BYTES)
     N.cg1_identity(acc)
     for b in blobs:
@@ -29,36 +41,76 @@ def sum_blobs(blobs: List[bytes]) -> bytes:
     return acc.raw
 
 
-_bufs = {}
+def default_rendezvous_file() -> str:
+    explicit = os.environ.get("CG1_RDZV_FILE")
+    if explicit:
+        return explicit
+    return os.path.join(tempfile.gettempdir(), "cg1_rdzv_%d_%d_%s" % (os.getuid(), os.getppid(), os.environ.get("MASTER_PORT", "0")))
 
 
-def all_reduce_g1(partial_blob: bytes, group=None, device: Optional[str] = None) -> bytes:
-    """All-gather every rank's partial G1 point and add them; returns the same blob on all ranks.
+def init_comm(rank: int, world: int, rendezvous_file: Optional[str] = None, timeout_s: float = 600.0) -> "N.Comm":
+    """Connect the control channel of this rank (collective: every rank of the job calls it)."""
+    comm = N.Comm(rank, world)
+    if world == 1:
+        return comm
+    path = rendezvous_file or default_rendezvous_file()
+    deadline = time.monotonic() + timeout_s
+    if rank == 0:
+        nonce = secrets.randbits(63)
+        tmp = "%s.%d.tmp" % (path, os.getpid())
+        with open(tmp, "w") as f:
+            f.write("%d %d\n" % (comm.port, nonce))
+        os.replace(tmp, path)                       # atomic: a reader sees the old file, no file, or the whole new one
+        try:
+            comm.check(comm.connect("", 0, nonce, int(timeout_s * 1000)))
+        finally:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return comm
+    while True:
+        try:
+            with open(path) as f:
+                port, nonce = (int(x) for x in f.read().split())
+        except (OSError, ValueError):
+            port = None
+        if port:
+            left_ms = max(1000, int((deadline - time.monotonic()) * 1000))
+            rc = comm.connect("127.0.0.1", port, nonce, left_ms)
+            if rc == N.OK:
+                return comm
+        if time.monotonic() > deadline:
+            comm.check(N.ERR_COMM if not port else rc)
+            raise N.NativeError("rendezvous timed out: %s never appeared" % path)
+        time.sleep(0.05)                            # no file yet, a stale file of an earlier launch, or not the hub: look again
 
-    One collective per call: a single all-gather of 144 bytes per rank into a cached device buffer, one D2H copy,
-    world-1 host additions."""
-    import torch
-    import torch.distributed as dist
 
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+def init_from_env(ctx: Optional["N.Context"] = None, transport: str = "auto", timeout_s: float = 600.0) -> "N.Comm":
+    """RANK / WORLD_SIZE (as torch.distributed.run and bench.py's own launcher export them) -> a connected communicator.
+    transport: "rccl" attaches RCCL on ctx's device (needs one GPU per rank), "socket" keeps the TCP star, "auto" = rccl when a
+    context is given."""
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    comm = init_comm(rank, world, timeout_s=timeout_s)
+    if transport == "rccl" or (transport == "auto" and ctx is not None):
+        if ctx is None:
+            raise ValueError("the RCCL transport needs the rank's Context")
+        comm.attach_rccl(ctx)
+    return comm
+
+
+def all_reduce_g1(partial_blob: bytes, comm: Optional["N.Comm"] = None) -> bytes:
+    """All-gather every rank's partial G1 point and add them; returns the same blob on all ranks (one collective)."""
+    if comm is None or comm.world == 1:
         return bytes(partial_blob)
-    world = dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    dev = device or ("cuda" if backend == "nccl" else "cpu")
-    key = (dev, world)
-    if key not in _bufs:
-        _bufs[key] = (torch.empty(N.POINT_BYTES, dtype=torch.uint8, device=dev),
-                      torch.empty(world * N.POINT_BYTES, dtype=torch.uint8, device=dev))
-    mine, gathered = _bufs[key]
-    mine.copy_(torch.frombuffer(bytearray(partial_blob), dtype=torch.uint8))
-    try:
-        dist.all_gather_into_tensor(gathered, mine, group=group)
-        raw = gathered.cpu().numpy().tobytes()
-    except (RuntimeError, NotImplementedError):      # transports without the flat form
-        lst = [torch.empty(N.POINT_BYTES, dtype=torch.uint8, device=dev) for _ in range(world)]
-        dist.all_gather(lst, mine, group=group)
-        raw = b"".join(t.cpu().numpy().tobytes() for t in lst)
-    return sum_blobs([raw[i * N.POINT_BYTES:(i + 1) * N.POINT_BYTES] for i in range(world)])
+    return comm.allreduce_g1(partial_blob)
+
+
+def max_over_ranks(value: float, comm: Optional["N.Comm"]) -> List[float]:
+    """Every rank's value (control channel); bench.py takes the max of the per-rank clocks."""
+    if comm is None or comm.world == 1:
+        return [float(value)]
+    return [struct.unpack("<d", b)[0] for b in comm.allgather(struct.pack("<d", float(value)), host_only=True)]
 
 
 def shard_layout(rank: int, world: int, mode: str = "hybrid", window_groups: int = 2):
@@ -81,7 +133,7 @@ def shard_layout(rank: int, world: int, mode: str = "hybrid", window_groups: int
 
 
 def sharded_msm(ctx: "N.Context", d_points, d_scalars, n: int, rank: int, world: int, window_c: int = 16,
-                mode: str = "windows", group=None) -> bytes:
+                mode: str = "windows", comm: Optional["N.Comm"] = None) -> bytes:
     """This rank's share of one MSM, then the G1 all-reduce.
 
     mode "windows": d_points/d_scalars hold ALL n terms on every rank.
@@ -97,10 +149,10 @@ def sharded_msm(ctx: "N.Context", d_points, d_scalars, n: int, rank: int, world:
         part = ctx.msm_device(d_points, d_scalars, n, window_c=window_c, shard_rank=wr, shard_world=W)
     else:
         raise ValueError(f"unknown shard mode {mode!r}")
-    return all_reduce_g1(part, group=group)
+    return all_reduce_g1(part, comm)
 
 
-def sharded_msm_batch(jobs_affine, rank: int, world: int, group=None, compute=None) -> List[bytes]:
+def sharded_msm_batch(jobs_affine, rank: int, world: int, comm: Optional["N.Comm"] = None, compute=None) -> List[bytes]:
     """Many INDEPENDENT MSMs (e.g. one final accumulator MSM per proof; BASELINE config 5: 16384 proofs over
     8 GPUs) sharded job-per-GPU: rank g computes jobs g, g+world, ... with the regime-B batched kernels, then the
     per-job result blobs are all-gathered so every rank holds all results.  Embarrassingly parallel: the only
@@ -108,7 +160,7 @@ def sharded_msm_batch(jobs_affine, rank: int, world: int, group=None, compute=No
 
     jobs_affine: list of (points_affine96: bytes, scalars32: bytes, n: int).
     compute: callable(list_of_jobs) -> list of blobs for this rank's share; defaults to the GPU batched path
-             (curdleproofs_pie_amd has no CPU path; the parameter exists so the gloo tests can exercise the
+             (curdleproofs_pie_amd has no CPU path; the parameter exists so the CPU tests can exercise the
              sharding/gather logic on a CPU-only box with the host operators).
     """
     mine = list(range(rank, len(jobs_affine), world))
@@ -123,45 +175,32 @@ def sharded_msm_batch(jobs_affine, rank: int, world: int, group=None, compute=No
             return N.default_context().msm_batched_host(b"".join(p for p, _, _ in js), b"".join(s for _, s, _ in js), offs)
     my_blobs = compute(my_jobs)
     assert len(my_blobs) == len(my_jobs)
-    import torch.distributed as dist
-
-    if world == 1 or not dist.is_initialized():
-        out = [None] * len(jobs_affine)
+    out = [None] * len(jobs_affine)
+    if world == 1 or comm is None:
         for i, b in zip(mine, my_blobs):
             out[i] = bytes(b)
         return out
-    import torch
-
-    # fixed-size tensor gather: rank g owns jobs g, g + world, ... (known to every rank, so no indices travel), each rank
+    # fixed-size gather: rank g owns jobs g, g + world, ... (known to every rank, so no indices travel), each rank
     # sends ceil(jobs / world) slots of 144 bytes, unused slots zero
     width = (len(jobs_affine) + world - 1) // world
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    local = torch.zeros(width * N.POINT_BYTES, dtype=torch.uint8)
-    if my_blobs:
-        for b in my_blobs:
-            assert len(b) == N.POINT_BYTES
-        local[: len(my_blobs) * N.POINT_BYTES] = torch.frombuffer(bytearray(b"".join(bytes(b) for b in my_blobs)), dtype=torch.uint8)
-    local = local.to(dev)
-    gathered = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(gathered, local, group=group)
-    out = [None] * len(jobs_affine)
-    for g, t in enumerate(gathered):
-        raw = t.cpu().numpy().tobytes()
+    for b in my_blobs:
+        assert len(b) == N.POINT_BYTES
+    local = b"".join(bytes(b) for b in my_blobs).ljust(width * N.POINT_BYTES, b"\0")
+    for g, raw in enumerate(comm.allgather(local)):
         for k, i in enumerate(range(g, len(jobs_affine), world)):
             out[i] = raw[k * N.POINT_BYTES:(k + 1) * N.POINT_BYTES]
     return out
 
 
-def sharded_verify(verifier, instances: bytes, proofs: bytes, n: int, rank: int, world: int, group=None, mode: str = "merged",
-                   verify=None) -> List[int]:
+def sharded_verify(verifier, instances: bytes, proofs: bytes, n: int, rank: int, world: int, comm: Optional["N.Comm"] = None,
+                   mode: str = "merged", verify=None) -> List[int]:
     """BASELINE config 5 (16 384 Whisk shuffle verifications over 8 GPUs): proof-per-GPU sharding.  Rank g verifies the
     contiguous slice [g*n/world, (g+1)*n/world) of the packed batch with its own `ShuffleBatchVerifier` (one merged MSM
     per rank); the per-proof status codes (0 = valid) are all-gathered so every rank returns the full list.
-    No data-path collective: the only exchange is that gather of one small integer per proof.
+    No data-path collective: the only exchange is that gather of one small integer per proof (control channel).
 
     verify: callable(instances_slice, proofs_slice, m) -> list of m status ints; defaults to verifier.verify_packed
-            (the parameter exists so the gloo tests can exercise the slicing / gather logic on a CPU-only box).
+            (the parameter exists so the CPU tests can exercise the slicing / gather logic on a CPU-only box).
     """
     crs = verifier.crs
     inst_b, proof_b = 4 * crs.ell * 48, crs.proof_bytes
@@ -170,23 +209,13 @@ def sharded_verify(verifier, instances: bytes, proofs: bytes, n: int, rank: int,
         verify = lambda a, b, m: verifier.verify_packed(a, b, m, mode=mode)
     mine = list(verify(instances[lo * inst_b: hi * inst_b], proofs[lo * proof_b: hi * proof_b], hi - lo)) if hi > lo else []
     assert len(mine) == hi - lo
-    import torch.distributed as dist
-
-    if world == 1 or not dist.is_initialized():
+    if world == 1 or comm is None:
         return mine
-    import torch
-
-    # fixed-size tensor gather (n/world differs by at most one between ranks: pad to the maximum)
+    # fixed-size gather (n/world differs by at most one between ranks: pad to the maximum)
     width = (n + world - 1) // world
-    backend = dist.get_backend(group)
-    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    local = torch.full((width,), -1, dtype=torch.int32, device=dev)
-    if mine:
-        local[: len(mine)] = torch.tensor(mine, dtype=torch.int32, device=dev)
-    gathered = [torch.empty_like(local) for _ in range(world)]
-    dist.all_gather(gathered, local, group=group)
+    local = struct.pack("<%di" % width, *(list(mine) + [-1] * (width - len(mine))))
     out: List[int] = []
-    for g, t in enumerate(gathered):
+    for g, raw in enumerate(comm.allgather(local, host_only=True)):
         cnt = (n * (g + 1)) // world - (n * g) // world
-        out.extend(int(x) for x in t[:cnt].cpu().tolist())
+        out.extend(struct.unpack("<%di" % width, raw)[:cnt])
     return out

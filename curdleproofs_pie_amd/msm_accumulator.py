@@ -98,6 +98,20 @@ def batch_fold(left: Iterable[G1Point], right: Iterable[G1Point], scalar: Scalar
     return _blobs_from_affine96(raw, n)
 
 
+def batch_sum(groups: Iterable[Iterable[G1Point]]) -> List[G1Point]:
+    """[reduce(lambda a, b: a + b, g, Z1) for g in groups] on the GPU -- the linear point sums G_sum / H_sum of the CRS
+    (crs.py:64-65: over vec_G and vec_H), one wave per group (k_batch_sum)."""
+    groups = [list(g) for g in groups]
+    if not groups:
+        return []
+    offsets = [0]
+    for g in groups:
+        offsets.append(offsets[-1] + len(g))
+    flat = [p for g in groups for p in g]
+    raw = N.default_context().batch_sum_host(points_to_affine96(flat) if flat else b"", offsets)
+    return _blobs_from_affine96(raw, len(groups))
+
+
 def batch_from_compressed(encodings: Iterable[bytes], checked: bool = False) -> List[G1Point]:
     """[G1Point.from_compressed_bytes[_unchecked](e) for e in encodings] with the square roots (and subgroup
     checks) on the GPU -- e.g. the 4*ell tracker points + every proof element of IsValidWhiskShuffleProof

@@ -340,7 +340,7 @@ class ShuffleBatchVerifier:
         b = self._slot(n)
         tk = {"slot": b, "n": n, "instances": instances, "proofs": proofs, "weights": weights, "mode": mode,
               "pre_status": batch[3] if len(batch) > 3 else None, "chunks": queue.Queue(), "done": threading.Event(),
-              "error": None, "t0": time.perf_counter()}
+              "error": None, "t0": time.perf_counter(), "flags_done": threading.Event(), "sgflags": None}
         step = max(self.chunk, (n + 1) // 2) if (prefetched and self.prefetch_big) else self.chunk
         tk["bounds"] = [(lo, min(lo + step, n)) for lo in range(0, n, step)]
         b["busy"] = tk["done"]
@@ -367,8 +367,14 @@ class ShuffleBatchVerifier:
                     self._decompress_collect(b, lo, hi)
                     tk["decompress_s"] = time.perf_counter() - t_dec   # staging + H2D + kernel + D2H of the batch's sub-batches
                     tk["chunks"].put((lo, hi))
+                # the subgroup flags come back on THIS thread (a context takes one call at a time; the MSM stage runs on the other
+                # lane): the front-end is already released, so only this lane's next batch waits for the side stream
+                self.ctx.check(N.cg1_side_sync(self.ctx.handle))
+                tk["sgflags"] = b["sgflags"].download(n * N_EXACT_POINTS)
             except BaseException as e:                          # surfaced in the consumer
                 tk["chunks"].put(e)
+            finally:
+                tk["flags_done"].set()
 
         self._gpu_submit(gpu_stage)
         return tk
@@ -429,6 +435,40 @@ class ShuffleBatchVerifier:
         self.ctx_msm.check(N.cg1_h2d_async(self.ctx_msm.handle, b["sc"].ptr, host["sc"].ptr, (n * L + C) * 32))
         tk["front_end_s"] = time.perf_counter() - t0
 
+    def _decide_flagged(self, tk: dict, i: int) -> bool:
+        """MSM lane: proof i of the batch (it carries a point outside G1 in the same-scalar argument) on its own -- the weighted
+        statement without the four same-scalar equalities (w1..w4 = 0) over its decoded points, which are still on the device,
+        plus those four equalities exactly (cg1_shuffle_exact_same_scalar)."""
+        crs, ctx = self.crs, self.ctx_msm
+        L, C = crs.points_per_proof, crs.ncrs
+        b, n = tk["slot"], tk["n"]
+        ib, pb = 4 * crs.ell * 48, crs.proof_bytes
+        inst, proof = _addr(tk["instances"]) + i * ib, _addr(tk["proofs"]) + i * pb
+        ok = ctypes.c_int(0)
+        ctx.check(N.cg1_shuffle_exact_same_scalar(crs.handle, inst, proof, ctypes.byref(ok)))
+        if not ok.value:
+            return False
+        w = bytearray(tk["weights"][i * N_WEIGHTS * 32: (i + 1) * N_WEIGHTS * 32])
+        w[8 * 32: 12 * 32] = bytes(4 * 32)
+        host = b["host"]
+        sc, csc, st = ctypes.create_string_buffer(L * 32), ctypes.create_string_buffer(C * 32), (ctypes.c_int32 * 1)()
+        rc = N.cg1_shuffle_prepare(crs.handle, 1, inst, proof, bytes(w), host["decoded"].ptr + i * 768, 768, host["wire"].ptr + i * L * 48,
+                                   sc, csc, st, None, 1)
+        if rc:
+            raise N.NativeError(f"cg1_shuffle_prepare failed ({rc})")
+        if st[0]:
+            return False
+        d_sc, d_csc = ctx.alloc(L * 32), ctx.alloc(C * 32)
+        try:
+            d_sc.upload(sc.raw); d_csc.upload(csc.raw)
+            own = ctx.msm_device(b["pts"].ptr + i * L * 96, d_sc, L)
+            shared = ctx.msm_device(b["pts"].ptr + n * L * 96, d_csc, C)
+        finally:
+            d_sc.free(); d_csc.free()
+        tmp = ctypes.create_string_buffer(N.POINT_BYTES)
+        N.cg1_add(tmp, own, shared)
+        return bool(N.cg1_is_identity(tmp.raw))
+
     def _enqueue_msm(self, tk: dict) -> None:
         """Stage 3 (asynchronous, GPU thread): scalars H2D, the merged MSM, and -- if it is not the identity, or in mode
         "independent" -- the per-proof MSMs that name the invalid proofs."""
@@ -473,22 +513,24 @@ class ShuffleBatchVerifier:
                         N.cg1_add(tmp, own[i], shared[i])
                         if not N.cg1_is_identity(tmp.raw):
                             status[i] = REJECT_EQUATION
-                # Proofs carrying a point outside G1 in the same-scalar equalities: the reference asserts those exactly
-                # (same_scalar.py:108) and random weights are blind to a torsion defect with probability 1/3, so they
-                # are re-checked on the host without weights.  (None in honest traffic: one D2H of 10 bytes per proof.)
-                self.ctx.check(N.cg1_side_sync(self.ctx.handle))
-                flags = b["sgflags"].download(n * N_EXACT_POINTS)
+                # Proofs carrying a point outside G1 in the same-scalar equalities.  The reference asserts those four equalities
+                # EXACTLY (same_scalar.py:101-108), with its scalars as integers in [0, r): a random weight reduced mod r is blind
+                # to a torsion defect with probability 1/3, and -- the other direction -- torsion components that cancel in the
+                # exact equalities (the reference accepts) do NOT cancel once T_1, U_1, cm_A, cm_B carry different weights.  So a
+                # flagged proof is decided apart from the batch, whatever the weighted passes above said about it: its statement
+                # again with the same-scalar weights w1..w4 (rho[8..11]) set to ZERO -- every check the reference itself runs
+                # through its randomised MSMAccumulator, where A' = A + T_1 + U_1 is formed from the decoded points as the
+                # reference forms it -- AND the four equalities evaluated without weights on the host.
+                # (None in honest traffic.  The flags were brought back by the decompression lane: tk["sgflags"].)
+                tk["flags_done"].wait()
+                flags = tk["sgflags"]
                 n_exact = 0
-                if any(flags):
-                    ib, pb = 4 * crs.ell * 48, crs.proof_bytes
-                    ok = ctypes.c_int(0)
-                    for i in live:
-                        if status[i] == 0 and any(flags[i * N_EXACT_POINTS: (i + 1) * N_EXACT_POINTS]):
+                if flags is not None and any(flags):
+                    was_live = set(live)
+                    for i in range(n):
+                        if i in was_live and any(flags[i * N_EXACT_POINTS: (i + 1) * N_EXACT_POINTS]):
                             n_exact += 1
-                            self.ctx.check(N.cg1_shuffle_exact_same_scalar(crs.handle, _addr(tk["instances"]) + i * ib,
-                                                                           _addr(tk["proofs"]) + i * pb, ctypes.byref(ok)))
-                            if not ok.value:
-                                status[i] = REJECT_EQUATION
+                            status[i] = 0 if self._decide_flagged(tk, i) else REJECT_EQUATION
                 tk["status"] = status
                 tk["stats"] = {"merged_msm_s": t1 - t0, "exact_checks": n_exact, "independent_s": time.perf_counter() - t1, "merged_ok": merged_ok,
                                "front_end_s": tk.get("front_end_s", 0.0), "decompress_s": tk.get("decompress_s", 0.0), "n": n, "points": n * L + C, "pipelined": len(tk["bounds"]) > 1}

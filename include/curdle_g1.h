@@ -35,6 +35,7 @@ extern "C" {
 #define CG1_ERR_ENCODING  3   /* malformed compressed48 / affine96 / scalar32 -> Python ValueError */
 #define CG1_ERR_NOT_ON_CURVE 4
 #define CG1_ERR_NOT_IN_SUBGROUP 5
+#define CG1_ERR_COMM      6   /* multi-GPU exchange failed (rendezvous, socket, RCCL); message via cg1_comm_error */
 
 #define CG1_POINT_BYTES 144
 #define CG1_NPHASE 7          /* prepare, sort_count, sort_scatter, chunks, accumulate, seg_reduce, bit_tree(+D2H) */
@@ -83,6 +84,8 @@ void cg1_host_free(cg1_ctx* ctx, void* p);
 /* strided gather: `rows` records of `width` bytes lying `src_pitch` apart on the device -> `dst_pitch` apart on the host */
 int  cg1_d2h_2d(cg1_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t width, size_t rows);
 int  cg1_ctx_sync(cg1_ctx* ctx);                                     /* hipDeviceSynchronize on the context's GPU */
+int  cg1_ctx_device(const cg1_ctx* ctx);                             /* the HIP device ordinal the context was created on */
+void* cg1_ctx_stream(cg1_ctx* ctx);                                  /* the context's compute stream (a hipStream_t), for callers ordering their own work */
 int  cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value);   /* "chunk_len" (L0), "seg_m", "profile" */
 
 /* ---------------- the hot path: compute_MSM  (msm_accumulator.py:6-12) ------------------------- */
@@ -123,6 +126,51 @@ int cg1_timer_end(cg1_ctx* ctx, float* ms);
 
 /* host-side wall times of the last MSM call: enqueue, wait-for-GPU, event readout, Horner tail (ms) */
 int cg1_get_host_timings(const cg1_ctx* ctx, float host_ms[4]);
+
+/* Segmented point sum -- the linear point sum of crs.py:64-65 (G_sum = reduce(a + b, vec_G, Z1), H_sum): out[j] = sum of the
+ * points [offsets[j], offsets[j+1]); affine96 in and out; offsets is a HOST array of n_groups + 1 entries, offsets[0] == 0.
+ * One wave per group. */
+int cg1_batch_sum_device(cg1_ctx* ctx, const void* d_points_affine96, const uint32_t* offsets, size_t n_groups, void* d_out_affine96);
+int cg1_batch_sum(cg1_ctx* ctx, const uint8_t* points_affine96, const uint32_t* offsets, size_t n_groups, uint8_t* out_affine96);
+/* chip-wide v_mad_u64_u32 issue rate (lane-operations/s) with `waves_per_simd` resident waves: the peak roofline_int_mad is
+ * priced against, measured in the same run as the benchmark (bench.py). */
+int cg1_probe_mad_rate(cg1_ctx* ctx, int waves_per_simd, int iters, double* lane_ops_per_s);
+
+/* ---------------- multi-GPU (SURVEY.md 8(b) "multi-GPU variants taking a device list", 8(e)) ---- */
+/* The reference has no multi-device code; the contract is BASELINE.json's north_star: window buckets sharded over
+ * the GPUs of one node, "final RCCL all-reduce of partial G1 sums".  RCCL has no elliptic-curve reduction, so the all-reduce is an
+ * all-gather of ONE 144-byte point blob per rank + world-1 host additions on every rank (bit-identical on all ranks).
+ *
+ * (1) One process, several GPUs: ctxs[i] owns point shard i, resident on ITS device.  All launch chains are enqueued before
+ *     any is waited for; out = the sum of the partials = compute_MSM (msm_accumulator.py:6-12) over the concatenation. */
+int cg1_msm_multi_device(cg1_ctx* const* ctxs, size_t n_ctx, const void* const* d_points_affine96, const void* const* d_scalars32,
+                         const size_t* n, int window_c, uint8_t out[CG1_POINT_BYTES]);
+/* (2) One process per GPU (bench.py --gpus N, distributed.py).  A communicator is a TCP control channel on the loopback
+ *     interface (rank 0 = hub: rendezvous, barriers, clocks, verdict gathers; alone it is the whole exchange when ranks rehearse on
+ *     one GPU or on a CPU-only box) to which RCCL is attached for the data exchange on a GPU node.  No PyTorch anywhere.
+ *       rank 0:  c = cg1_comm_create(0, world); publish cg1_comm_port(c) (file / env); cg1_comm_connect(c, NULL, 0, nonce, ms)
+ *       others:  c = cg1_comm_create(r, world); cg1_comm_connect(c, "127.0.0.1", port, nonce, ms)   (CG1_ERR_COMM = wrong or
+ *                not-yet-there listener: re-read the rendezvous and call again)
+ *       all:     cg1_comm_attach_rccl(c, ctx)   -- ncclGetUniqueId on rank 0, id broadcast over the control channel,
+ *                ncclCommInitRank on ctx's device; librccl.so is dlopen'ed here, on first use. */
+typedef struct cg1_comm cg1_comm;
+cg1_comm* cg1_comm_create(int rank, int world);                        /* NULL: bad arguments / cannot listen */
+int  cg1_comm_port(const cg1_comm* c);                                 /* rank 0: the loopback port it listens on */
+int  cg1_comm_rank(const cg1_comm* c);
+int  cg1_comm_connect(cg1_comm* c, const char* host_ipv4, int port, uint64_t nonce, int timeout_ms);
+int  cg1_comm_set_timeout(cg1_comm* c, int timeout_ms);                /* per collective; default 120 s */
+int  cg1_comm_attach_rccl(cg1_comm* c, cg1_ctx* ctx);                  /* collective over all ranks */
+const char* cg1_comm_transport(const cg1_comm* c);                     /* "rccl" once attached, else "socket" */
+int  cg1_comm_world_seen(const cg1_comm* c);                           /* RCCL attached: ncclCommCount; else connected ranks */
+const char* cg1_comm_error(const cg1_comm* c);
+/* every rank contributes `bytes` host bytes, every rank receives world * bytes in rank order.  RCCL attached: one
+ * ncclAllGather(uint8) on ctx's compute stream (payload staged through pinned memory); else the TCP star. */
+int  cg1_comm_allgather(cg1_comm* c, const void* send, size_t bytes, void* recv);
+int  cg1_comm_allgather_host(cg1_comm* c, const void* send, size_t bytes, void* recv);   /* always the control channel */
+int  cg1_comm_barrier(cg1_comm* c);                                    /* control channel; pair with cg1_ctx_sync */
+/* the "all-reduce of partial G1 sums": sum = partial_0 + ... + partial_{world-1}; all_blobs (may be NULL) gets the world blobs */
+int  cg1_comm_allreduce_g1(cg1_comm* c, const uint8_t partial[CG1_POINT_BYTES], uint8_t sum[CG1_POINT_BYTES], uint8_t* all_blobs);
+void cg1_comm_destroy(cg1_comm* c);
 
 /* ---------------- batched scalar multiplication (`G1Point * Scalar`, vectorised) --------------- */
 /* out[i] = scalars[i] * bases[i % nbase]; all device pointers; affine96 in and out.

@@ -10,6 +10,9 @@ oracle backend of tests/golden/_backend.py; the provers are driven with a torsio
   opening  "A + T3":      A := A + T3, s recomputed for the new challenge       -> reference REJECTS (A' != A by T3)
   opening  "k_G + T3":    k_commitment := k_G + T3 and A := A + c*T3 (ground)   -> reference ACCEPTS (the defects cancel)
   shuffle  "cm_A.T_1+T3": SameScalarProof.new sends cm_A.T_1 + T3               -> reference REJECTS
+  shuffle  "cancelling":  cm_T.T_1 + T3, cm_U.T_1 - T3, cm_A.T_1 - a*T3, cm_B.T_1 + a*T3 with a = alpha mod 3
+                          (the same-scalar equalities hold exactly, A' = A + T_1 + U_1 has no torsion part)
+                                                                                -> reference ACCEPTS, every time
 plus the honest versions, and NON-CANONICAL INFINITY encodings: the wheel decodes any encoding with the infinity flag as the
 identity and the reference re-serialises points before hashing, so an opening proof over the identity tracker (r_G = k_r_G =
 B = identity: valid) stays valid when those identities are written as 0xC0 + junk or with the sign flag set.  (Restated from
@@ -101,6 +104,82 @@ def _ss_new(cls, *a, **kw):
 same_scalar.SameScalarProof.new = classmethod(_ss_new)
 
 
+# ---- cancelling torsion (the reference accepts): cm_T.T_1 += T3 and cm_U.T_1 -= T3 where the shuffle prover makes them
+# (curdleproofs.py:102-107), and inside the same-scalar prover cm_A.T_1 -= a*T3, cm_B.T_1 += a*T3 with a = alpha mod 3 -- alpha
+# is drawn AFTER cm_A / cm_B are absorbed, so all three guesses of a are tried on copies of the transcript.
+CANCEL = {"on": False, "calls": 0, "guess": 0}
+import curdleproofs.curdleproofs as cp_mod  # noqa: E402
+
+_orig_cp_new = cp_mod.CurdleProofsProof.new.__func__
+
+
+class NoGuessFits(Exception):
+    pass
+
+
+def _gc_new_cancel(cls, crs_G, crs_H, T, r):
+    cm = _orig_gc_new(cls, crs_G, crs_H, T, r)
+    if not CANCEL["on"]:                          # the verifier's own GroupCommitment.new calls (same_scalar.py:101-106)
+        return cm
+    CANCEL["calls"] += 1
+    n, T3 = CANCEL["calls"], t3()
+    if n == 1:
+        cm.T_1 = cm.T_1 + T3                      # cm_T
+    elif n == 2:
+        cm.T_1 = cm.T_1 - T3                      # cm_U
+    elif n % 2 == 1:                              # cm_A of a same-scalar attempt
+        for _ in range(CANCEL["guess"]):
+            cm.T_1 = cm.T_1 - T3
+    else:                                         # cm_B
+        for _ in range(CANCEL["guess"]):
+            cm.T_1 = cm.T_1 + T3
+    return cm
+
+
+def _ss_new_cancel(cls, crs_G_t, crs_G_u, crs_H, R, S, cm_T, cm_U, k, r_t, r_u, transcript):
+    import copy
+
+    t0 = copy.deepcopy(transcript)
+    for guess in range(3):
+        CANCEL["guess"] = guess
+        tr = copy.deepcopy(t0)
+        proof = _orig_ss_new(cls, crs_G_t=crs_G_t, crs_G_u=crs_G_u, crs_H=crs_H, R=R, S=S, cm_T=cm_T, cm_U=cm_U, k=k, r_t=r_t, r_u=r_u, transcript=tr)
+        CANCEL["on"] = False
+        try:
+            proof.verify(crs_G_t, crs_G_u, crs_H, R, S, cm_T, cm_U, copy.deepcopy(t0))      # same_scalar.py:71-108, exact equalities
+        except AssertionError:
+            continue
+        finally:
+            CANCEL["on"] = True
+        transcript.__dict__.update(tr.__dict__)   # the caller's transcript continues from the accepted attempt
+        return proof
+    raise NoGuessFits()
+
+
+def cancelling_shuffle_case(name, ell, crs, want_nonzero=False):
+    pre = G.make_trackers(ell)
+    while True:
+        CANCEL.update(on=True, calls=0, guess=0)
+        same_scalar.GroupCommitment.new = classmethod(_gc_new_cancel)
+        same_scalar.SameScalarProof.new = classmethod(_ss_new_cancel)
+        try:
+            post, proof = G.GenerateWhiskShuffleProof(crs, pre)
+            if want_nonzero and CANCEL["guess"] == 0:
+                continue                              # this case shall carry torsion on cm_A / cm_B too
+            break
+        except NoGuessFits:
+            continue
+        finally:
+            same_scalar.GroupCommitment.new = classmethod(_orig_gc_new)
+            same_scalar.SameScalarProof.new = classmethod(_ss_new)
+            CANCEL["on"] = False
+    pre_r, pre_k = G.cat(pre)
+    post_r, post_k = G.cat(post)
+    accepts = bool(G.IsValidWhiskShuffleProof(crs, pre, post, proof))
+    return {"name": name, "pre_r": pre_r.hex(), "pre_k": pre_k.hex(), "post_r": post_r.hex(), "post_k": post_k.hex(),
+            "proof": bytes(proof).hex(), "accepts": accepts, "alpha_mod_3": CANCEL["guess"]}
+
+
 def shuffle_case(name, ell, crs, torsion):
     pre = G.make_trackers(ell)
     ARMED[0] = torsion
@@ -150,7 +229,9 @@ def main():
     crs = G.CurdleproofsCrs.new(ell, G.N_BLINDERS)
     shuffle = {"ell": ell, "crs": bytes(crs.to_bytes()).hex(),
                "cases": [shuffle_case("honest", ell, crs, False), shuffle_case("cm_A.T_1 + T3", ell, crs, True),
-                         shuffle_case("honest 2", ell, crs, False), shuffle_case("cm_A.T_1 + T3 (2)", ell, crs, True)]}
+                         shuffle_case("honest 2", ell, crs, False), shuffle_case("cm_A.T_1 + T3 (2)", ell, crs, True),
+                         cancelling_shuffle_case("cancelling T3 on cm_T / cm_U / cm_A / cm_B", ell, crs),
+                         cancelling_shuffle_case("cancelling T3 on cm_T / cm_U / cm_A / cm_B (2)", ell, crs, want_nonzero=True)]}
     out = {"generator": "tests/golden/gen_torsion_golden.py (reference classes; G1Point/Scalar = %s)" % G.BACKEND_MODULE,
            "backend": G.BACKEND_MODULE, "t3": T3_BYTES.hex(), "opening": opening, "shuffle": shuffle}
     path = G._backend.out_path("torsion_vectors.json")

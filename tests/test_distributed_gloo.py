@@ -1,7 +1,7 @@
-"""The N>1 combine step on CPU: world_size-2 `gloo` ranks each hold one partial G1 sum (a share of the
-terms of one MSM, computed here with the host operators), all-gather the 144-byte blobs and add them --
-exactly what curdleproofs_pie_amd.distributed does over RCCL on the GPU box.  Every rank must end with the
-same group element as the single-process oracle."""
+"""The same sharding / gather logic over a `gloo` process group (world_size 2, CPU): the functions of
+curdleproofs_pie_amd.distributed only need an object with `.world`, `.allgather(bytes)` and `.allreduce_g1(blob)`, so a
+test-side adapter over torch.distributed stands in for the product's communicator (cg1_comm_*, which is what runs in
+production and in tests/test_distributed_socket.py -- the product itself never imports torch)."""
 import os
 import socket
 import sys
@@ -19,19 +19,54 @@ def _free_port():
     return p
 
 
+class GlooComm:
+    """torch.distributed (gloo) behind the interface of curdleproofs_pie_amd._native.Comm -- test infrastructure only."""
+
+    def __init__(self, rank, world):
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        self.rank, self.world, self.transport = rank, world, "gloo"
+
+    def allgather(self, data, host_only=False):
+        import torch
+        import torch.distributed as dist
+
+        mine = torch.frombuffer(bytearray(data), dtype=torch.uint8)
+        out = [torch.empty_like(mine) for _ in range(self.world)]
+        dist.all_gather(out, mine)
+        return [t.numpy().tobytes() for t in out]
+
+    def allreduce_g1(self, blob):
+        from curdleproofs_pie_amd.distributed import sum_blobs
+
+        return sum_blobs(self.allgather(blob))
+
+    def barrier(self):
+        import torch.distributed as dist
+
+        dist.barrier()
+
+    def close(self):
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, mode, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import ctypes
     import random
 
-    import torch.distributed as dist
-
     from curdleproofs_pie_amd import _native as N
     from curdleproofs_pie_amd.distributed import all_reduce_g1
     from curdleproofs_pie_amd.py_arkworks_bls12381 import G1Point, Scalar
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_distributed_gloo import GlooComm
+
+    comm = GlooComm(rank, world)
     rng = random.Random(2024)          # same inputs on every rank
     n = 24
     bases = [G1Point() * Scalar(rng.randint(1, 2 ** 200)) for _ in range(n)]
@@ -52,12 +87,12 @@ def _worker(rank, world, port, mode, q):
         for b, s in zip(bases, scalars):
             mine = sum(((s >> (16 * w)) & 0xFFFF) << (16 * w) for w in range(16) if w % world == rank)
             part = part + b * Scalar(mine)
-    total = all_reduce_g1(part._b)
+    total = all_reduce_g1(part._b, comm)
     out = ctypes.create_string_buffer(48)
     N.cg1_compress(out, total)
     q.put((rank, out.raw.hex()))
-    dist.barrier()
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 @pytest.mark.parametrize("mode", ["windows", "points"])
@@ -86,113 +121,20 @@ def test_two_rank_g1_all_reduce(native_lib, mode):
     assert got[0] == got[1] == want
 
 
-def test_four_rank_hybrid_all_reduce(native_lib):
-    """2 window groups x 2 point groups over 4 gloo ranks: every rank ends with the single-process result."""
-    import random
-
-    import torch.multiprocessing as mp
-
-    from curdleproofs_pie_amd.distributed import shard_layout
-    from oracle import bls12_381 as O
-
-    assert [shard_layout(r, 8, "hybrid") for r in range(8)] == [(r % 2, 2, r // 2, 4) for r in range(8)]
-    assert shard_layout(3, 8, "windows") == (3, 8, 0, 1) and shard_layout(3, 8, "points") == (0, 1, 3, 8)
-    assert shard_layout(2, 3, "hybrid") == (2, 3, 0, 1)                  # odd world: pure window sharding
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 4, port, "hybrid", q)) for r in range(4)]
-    for p in procs:
-        p.start()
-    got = dict(q.get(timeout=240) for _ in range(4))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    rng = random.Random(2024)
-    n = 24
-    ks = [rng.randint(1, 2 ** 200) for _ in range(n)]
-    scalars = [rng.randint(0, 2 ** 255 - 20) for _ in range(n)]
-    want = O.g1_compress(O.g1_mul(O.G1_GEN, sum(k * (s % O.R) for k, s in zip(ks, scalars)) % O.R)).hex()
-    assert got[0] == got[1] == got[2] == got[3] == want
-
-
-def _worker_batch(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import ctypes
-    import random
-
-    import torch.distributed as dist
-
-    from curdleproofs_pie_amd import _native as N
-    from curdleproofs_pie_amd.distributed import sharded_msm_batch
-    from curdleproofs_pie_amd.py_arkworks_bls12381 import G1Point, Scalar, points_to_affine96
-
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = random.Random(77)
-    jobs, truth = [], []
-    for n in (3, 1, 0, 5, 2):          # 5 independent "proofs"
-        ks = [rng.randint(1, 2 ** 100) for _ in range(n)]
-        ss = [rng.randint(0, 2 ** 250) for _ in range(n)]
-        pts = [G1Point() * Scalar(k) for k in ks]
-        jobs.append((points_to_affine96(pts), b"".join(s.to_bytes(32, "little") for s in ss), n))
-        truth.append(sum(k * s for k, s in zip(ks, ss)))
-
-    def host_compute(js):              # CPU stand-in for the GPU batched kernels (test only)
-        out = []
-        for p96, s32, n in js:
-            acc = G1Point.identity()
-            for i in range(n):
-                b = ctypes.create_string_buffer(N.POINT_BYTES)
-                assert N.cg1_from_affine96(b, p96[96 * i: 96 * i + 96], 1) == 0
-                acc = acc + G1Point._from_blob(b.raw) * Scalar(int.from_bytes(s32[32 * i: 32 * i + 32], "little"))
-            out.append(acc._b)
-        return out
-
-    blobs = sharded_msm_batch(jobs, rank, world, compute=host_compute)
-    res = []
-    for b in blobs:
-        o = ctypes.create_string_buffer(48)
-        N.cg1_compress(o, b)
-        res.append(o.raw.hex())
-    q.put((rank, res, truth))
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-def test_two_rank_job_sharding(native_lib):
-    import torch.multiprocessing as mp
-
-    from oracle import bls12_381 as O
-
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker_batch, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = [q.get(timeout=180) for _ in range(2)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    (_, r0, truth), (_, r1, _) = got
-    assert r0 == r1
-    assert r0 == [O.g1_compress(O.g1_mul(O.G1_GEN, t % O.R)).hex() for t in truth]
-
-
 def _worker_verify(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import json
     import random
 
-    import torch.distributed as dist
-
     from curdleproofs_pie_amd.distributed import sharded_verify
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
     from oracle.shuffle_check import oracle_verdicts
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_distributed_gloo import GlooComm
+
+    comm = GlooComm(rank, world)
     with open(os.path.join(ROOT, "tests", "golden", "shuffle_vectors.json")) as f:
         case = json.load(f)["cases"][1]
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -206,10 +148,10 @@ def _worker_verify(rank, world, port, q):
         prep = v.prepare(a, b, m, rng=random.Random(5 + rank))
         return [0 if ok else 6 for ok in oracle_verdicts(v, prep)]
 
-    status = sharded_verify(v, inst, proofs, len(variants), rank, world, verify=host_verify)
+    status = sharded_verify(v, inst, proofs, len(variants), rank, world, comm=comm, verify=host_verify)
     q.put((rank, status, [x["accepts"] for x in variants]))
-    dist.barrier()
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 def test_two_rank_proof_sharding(native_lib):

@@ -164,3 +164,56 @@ def test_batch_from_compressed(api):
     assert batch_from_compressed([bytes(e)]) == [A.G1Point.from_compressed_bytes_unchecked(bytes(e))]
     with pytest.raises(ValueError):
         batch_from_compressed(enc[:2] + [bytes(e)], checked=True)
+
+
+def test_batch_sum_is_the_crs_point_sum(api):
+    """crs.py:64-65: G_sum = reduce(a + b, vec_G, Z1), H_sum likewise -- against the oracle's group law, including groups
+    that hit every exceptional case of the addition (equal points, opposite points, identities, an empty group)."""
+    A, U = api
+    from curdleproofs_pie_amd.msm_accumulator import batch_sum
+
+    random.seed(11)
+    vec_G = [U.get_random_point() for _ in range(124)]          # Whisk: ell = 124, n_blinders = 4
+    vec_H = [U.get_random_point() for _ in range(4)]
+    P = vec_G[0]
+    groups = [vec_G, vec_H, [], [P], [P, P], [P, -P], [U.Z1, P, U.Z1], [P] * 70 + [-P] * 69, vec_G[:65], [U.Z1] * 3]
+    got = batch_sum(groups)
+    assert len(got) == len(groups)
+    for g, r in zip(groups, got):
+        want = None
+        for p in g:
+            want = O.g1_add(want, O.g1_decompress(bytes(p.to_compressed_bytes())))
+        assert bytes(r.to_compressed_bytes()) == O.g1_compress(want)
+    assert got[7] == P and got[5] == U.Z1 and got[2] == U.Z1
+    assert batch_sum([]) == []
+
+
+def test_msm_over_a_device_list(native_lib):
+    """cg1_msm_multi_device (SURVEY 8(b) "multi-GPU variants taking a device list"): one MSM whose point shards live on several
+    contexts -- here both on this GPU -- equals the single-context MSM and the oracle."""
+    import ctypes
+
+    from oracle import c_oracle as C
+
+    N = native_lib
+    c0, c1 = N.Context(0), N.Context(0)
+    rng = random.Random(12)
+    n0, n1 = 3000, 1777
+    base = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(16)]
+    raw = lambda p: p[0].to_bytes(48, "little") + p[1].to_bytes(48, "little")
+    p96 = b"".join(raw(base[rng.randrange(16)]) for _ in range(n0 + n1))
+    s32 = b"".join(rng.randint(0, O.R - 1).to_bytes(32, "little") for _ in range(n0 + n1))
+    bufs = []
+    for cx, lo, hi in ((c0, 0, n0), (c1, n0, n0 + n1)):
+        dp, ds = cx.alloc(96 * (hi - lo)), cx.alloc(32 * (hi - lo))
+        dp.upload(p96[96 * lo: 96 * hi]); ds.upload(s32[32 * lo: 32 * hi])
+        bufs.append((dp, ds))
+    blob = N.msm_multi_device([c0, c1], [b[0] for b in bufs], [b[1] for b in bufs], [n0, n1])
+    out = ctypes.create_string_buffer(48)
+    N.cg1_compress(out, blob)
+    assert out.raw == C.compress(C.msm_bucket(p96, s32, n0 + n1))
+    assert N.cg1_eq(blob, c0.msm_host(p96, s32, n0 + n1))
+    with pytest.raises(N.NativeError):                       # one context twice: a context takes one call at a time
+        N.msm_multi_device([c0, c0], [bufs[0][0]] * 2, [bufs[0][1]] * 2, [n0, n0])
+    # an empty shard contributes the identity
+    assert N.cg1_eq(N.msm_multi_device([c0, c1], [bufs[0][0], bufs[1][0]], [bufs[0][1], bufs[1][1]], [n0, 0]), c0.msm_host(p96, s32, n0))

@@ -6,6 +6,7 @@ as the reference decided."""
 import ctypes
 import json
 import os
+import random
 import sys
 
 import pytest
@@ -19,7 +20,8 @@ FR = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 def tors():
     t = json.load(open(os.path.join(ROOT, "tests", "golden", "torsion_vectors.json")))
     assert [c["accepts"] for c in t["opening"]] == [True, False, True, True, True, False, True, True, False]
-    assert [c["accepts"] for c in t["shuffle"]["cases"]] == [True, False, True, False]
+    assert [c["accepts"] for c in t["shuffle"]["cases"]] == [True, False, True, False, True, True]
+    assert [c.get("alpha_mod_3") for c in t["shuffle"]["cases"]][4:] == [1, 1]       # torsion on cm_A / cm_B too, not only on cm_T / cm_U
     return t
 
 
@@ -28,14 +30,22 @@ class MultiplesOfThree:
     -w = r - w (the equalities are moved to one side), and r = 1 (mod 3), so every such scalar is a MULTIPLE OF 3: an
     order-3 defect in one of those points is invisible to the weighted check."""
 
+    residue = 1
+
     def __init__(self):
         self.k = 1
 
     def randint(self, lo, hi):
         self.k += 7
-        w = 3 * (0x1234567 * self.k + (1 << 200)) + 1
-        assert (FR - w) % 3 == 0
+        w = 3 * (0x1234567 * self.k + (1 << 200)) + self.residue
+        assert (FR - w) % 3 == (1 - self.residue) % 3
         return w
+
+
+class NeverMultiplesOfThree(MultiplesOfThree):
+    """every weight w = 0 (mod 3), so every own-point scalar r - w = 1 (mod 3): torsion components are fully visible to the
+    weighted check, each under its own weight -- components that cancel in the reference's exact equalities do not cancel here."""
+    residue = 0
 
 
 def test_oracle_agrees_the_torsion_point_has_order_three(tors):
@@ -87,12 +97,28 @@ def test_shuffle_batch_with_torsion_points(native_lib, tors, mode):
     items = [(tr(bytes.fromhex(c["pre_r"]), bytes.fromhex(c["pre_k"])), tr(bytes.fromhex(c["post_r"]), bytes.fromhex(c["post_k"])),
               bytes.fromhex(c["proof"])) for c in sh["cases"]]
     want = [c["accepts"] for c in sh["cases"]]
-    assert v.verify_many(items, mode=mode, rng=MultiplesOfThree()) == want
-    assert v.last_stats["exact_checks"] == 2                          # the two proofs with a point outside G1, nobody else
-    assert v.verify_many(items * 16, mode=mode) == want * 16
-    assert v.verify_many([items[0], items[2]] * 8, mode=mode, rng=MultiplesOfThree()) == [True] * 16 and v.last_stats["exact_checks"] == 0
-    # without the exact check the weighted equalities alone would have accepted the two torsion proofs under these weights
-    prep = v.prepare(*v.pack(items)[:2], len(items), rng=MultiplesOfThree())
     from oracle.shuffle_check import oracle_verdicts
-    assert oracle_verdicts(v, prep) == [True] * 4
+
+    assert v.verify_many(items, mode=mode, rng=MultiplesOfThree()) == want
+    assert v.last_stats["exact_checks"] == 4                          # the four proofs with a point outside G1, nobody else
+    # the reference ACCEPTS the proofs whose torsion components cancel, every time: so must we, whatever the weights are
+    assert v.verify_many(items, mode=mode, rng=NeverMultiplesOfThree()) == want
+    for seed in range(3):
+        assert v.verify_many(items, mode=mode, rng=random.Random(seed)) == want
+    assert v.verify_many(items * 16, mode=mode) == want * 16
+    assert v.verify_many(items[4:] * 3, mode=mode) == [True] * 6 and v.last_stats["exact_checks"] == 6
+    assert v.verify_many([items[0], items[2]] * 8, mode=mode, rng=MultiplesOfThree()) == [True] * 16 and v.last_stats["exact_checks"] == 0
+    # why flagged proofs are decided apart from the batch -- the weighted statement ALONE (CPU oracle over the same rows)
+    # disagrees with the reference in BOTH directions, and differently from one draw of weights to the next:
+    #   weights = 1 (mod 3): accepts the two proofs the reference rejects, rejects one the reference accepts;
+    #   weights = 0 (mod 3): rejects a cancelling proof the reference accepts;
+    #   same-scalar weights w1..w4 zeroed (what _decide_flagged feeds the MSM): all six pass -- the exact host check then
+    #   decides the four equalities, as the reference does.
+    packed = v.pack(items)[:2]
+    assert oracle_verdicts(v, v.prepare(*packed, len(items), rng=MultiplesOfThree())) == [True, True, True, True, False, True]
+    assert oracle_verdicts(v, v.prepare(*packed, len(items), rng=NeverMultiplesOfThree())) == [True, False, True, False, False, True]
+    w = bytearray(v.draw_weights(len(items), random.Random(1)))
+    for i in range(len(items)):
+        w[(12 * i + 8) * 32: (12 * i + 12) * 32] = bytes(128)
+    assert oracle_verdicts(v, v.prepare(*packed, len(items), weights=bytes(w))) == [True] * 6
     v.close()
