@@ -1,5 +1,7 @@
 """Loader for tests/golden/shuffle_batch_ell124.{bin,json} (made by gen_shuffle_batch.py with the reference prover):
-distinct ell = 124 Whisk shuffle proofs over one CRS + tampered variants with the reference verifier's verdicts.  Data only."""
+distinct ell = 124 Whisk shuffle proofs over one CRS + tampered variants with the reference verifier's verdicts, and the
+extension shuffle_batch_ell124_more.{bin,json} (proofs 64 .. 1023 of the same seeded sequence: 1024 distinct proofs in all).
+Data only."""
 import hashlib
 import json
 import os
@@ -23,6 +25,19 @@ class ShuffleBatch:
             rec = blob[m["crs_bytes"] + i * rb: m["crs_bytes"] + (i + 1) * rb]
             self.instances.append(rec[: 4 * tb])                 # pre_r | pre_k | post_r | post_k  = vec_R | vec_S | vec_T | vec_U
             self.proofs.append(rec[4 * tb:])
+        more = os.path.join(HERE, "shuffle_batch_ell124_more.json")
+        self.backends = {m["backend"]: self.count}
+        if os.path.exists(more):
+            mm = json.load(open(more))
+            blob2 = open(os.path.join(HERE, "shuffle_batch_ell124_more.bin"), "rb").read()
+            assert hashlib.sha256(blob2).hexdigest() == mm["sha256"] and mm["first"] == self.count and mm["record_bytes"] == rb
+            assert mm["ell"] == self.ell and mm["crs_seed"] == m["crs_seed"] and mm["proof_seed_base"] == m["proof_seed_base"]
+            for i in range(mm["count"]):
+                rec = blob2[i * rb: (i + 1) * rb]
+                self.instances.append(rec[: 4 * tb])
+                self.proofs.append(rec[4 * tb:])
+            self.count += mm["count"]
+            self.backends[mm["backend"]] = self.backends.get(mm["backend"], 0) + mm["count"]
         self.tampered = []
         for t in m["tampered"]:
             bufs = dict(zip(KEYS, self._split(t["base"])))

@@ -15,6 +15,13 @@ bench.py tiles these to a batch of 1024 (fresh random weights per slot); tests/t
 batch with tampered proofs at known slots through the GPU verifier.
 
     python tests/golden/gen_shuffle_batch.py [--backend oracle|product] [--count 64] [--workers 8] [--out DIR]
+
+EXTENSION to 1024 distinct proofs ("1 024 / 16 384 distinct proofs"):
+    python tests/golden/gen_shuffle_batch.py --backend product --first 64 --count 960
+writes shuffle_batch_ell124_more.{bin,json}: proofs 64 .. 1023 of the SAME seeded sequence (seed 9100 + i, same CRS), records
+only.  Pure-Python arithmetic would need ~20 core-hours for them, so these are made by the reference prover over the product's
+host backend -- the backend tests/test_golden_backends.py shows to reproduce proofs 0 .. 63 (and every other fixture) byte for
+byte; the .json says so ("backend").  Every proof is accepted by the reference verifier before it is written.
 """
 import hashlib
 import json
@@ -68,11 +75,30 @@ def judge(args):
     return bool(G.IsValidWhiskShuffleProof(crs, G.split(b["pre_r"], b["pre_k"]), G.split(b["post_r"], b["post_k"]), b["proof"]))
 
 
+def extend(first, count, workers, out_dir, crs_bytes):
+    with ProcessPoolExecutor(workers) as ex:
+        proofs = sorted(ex.map(make_proof, [(i, crs_bytes) for i in range(first, first + count)], chunksize=4))
+    blob = b"".join(b"".join(p[1:]) for p in proofs)
+    with open(os.path.join(out_dir, "shuffle_batch_ell124_more.bin"), "wb") as f:
+        f.write(blob)
+    meta = {"generator": "tests/golden/gen_shuffle_batch.py --first %d (reference whisk_interface; G1Point/Scalar = %s)" % (first, _backend.inject()),
+            "backend": _backend.inject(), "ell": ELL, "n_blinders": N_BLINDERS, "first": first, "count": count,
+            "record_bytes": len(blob) // count, "crs_seed": CRS_SEED, "proof_seed_base": PROOF_SEED, "sha256": hashlib.sha256(blob).hexdigest(),
+            "note": "proofs first .. first+count-1 of the seeded sequence of shuffle_batch_ell124.bin, same CRS; every one accepted by the "
+                    "reference's IsValidWhiskShuffleProof when it was made"}
+    with open(os.path.join(out_dir, "shuffle_batch_ell124_more.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    print("wrote", len(blob), "bytes:", count, "more distinct proofs")
+
+
 def main():
     count = int(_backend._arg("--count", "64"))
     workers = int(_backend._arg("--workers", "8"))
     out_dir = _backend.OUT or os.path.dirname(os.path.abspath(__file__))
     crs_bytes = make_crs()
+    first = int(_backend._arg("--first", "0"))
+    if first:
+        return extend(first, count, workers, out_dir, crs_bytes)
     with ProcessPoolExecutor(workers) as ex:
         proofs = sorted(ex.map(make_proof, [(i, crs_bytes) for i in range(count)]))
         G = _setup()

@@ -24,7 +24,7 @@ def _last_json(out: str) -> dict:
 
 def im_peak_ok(im):
     pk = im["peak_same_run"]
-    return 10 < pk["sustained_T"] <= pk["burst_T"] * 1.05 < 80 and im["peak"] == pk["burst_T"]
+    return 10 < pk["peak_T"] < 80 and im["peak"] == pk["peak_T"] == max(pk["runs_T"])
 
 
 def test_single_gpu_line():

@@ -1,5 +1,5 @@
-"""BASELINE config 3 at its own size: a batch of 1024 Whisk shuffle verifications (ell = 124 + 4 blinders) made of the 64
-DISTINCT proofs of tests/golden/shuffle_batch_ell124.bin (reference prover, tests/golden/gen_shuffle_batch.py) with
+"""BASELINE config 3 at its own size: a batch of 1024 Whisk shuffle verifications (ell = 124 + 4 blinders) made of the 1024
+DISTINCT proofs of tests/golden/shuffle_batch_ell124{,_more}.bin (reference prover, tests/golden/gen_shuffle_batch.py) with
 tampered proofs at known slots; verdicts must equal the ones the reference's IsValidWhiskShuffleProof
 (whisk_interface.py:72-87 -> curdleproofs.py:162-248) returned when the fixture was made.
 
@@ -20,7 +20,7 @@ from batch_fixture import ShuffleBatch  # noqa: E402
 @pytest.fixture(scope="module")
 def fx():
     f = ShuffleBatch()
-    assert f.count >= 64 and f.ell == 124 and len({p for p in f.proofs}) == f.count      # all distinct
+    assert f.count == 1024 and f.ell == 124 and len(set(f.proofs)) == len(set(f.instances)) == f.count      # all distinct
     assert [t["accepts"] for t in f.tampered].count(False) >= 10
     return f
 
@@ -69,4 +69,67 @@ def test_stream_of_1024_batches(native_lib, fx):
     bad = fx.tiled(1024, SLOTS_1024)
     got = list(v.verify_stream([(clean[0], clean[1], 1024), (bad[0], bad[1], 1024), (clean[0], clean[1], 1024)]))
     assert [[s == 0 for s in st] for st in got] == [clean[2], bad[2], clean[2]]
+    v.close()
+
+
+@pytest.mark.gpu
+def test_config5_16384_proofs_sharded_proof_per_gpu(native_lib, fx):
+    """BASELINE config 5 at its size: 16 384 ell = 124 verifications sharded proof-per-GPU over 8 ranks
+    (whisk_interface.py:72-87 per proof; distributed.sharded_verify per rank) -- the 8 rank slices of 2048 proofs run one after
+    another on this GPU, each through its own streamed verifier calls, tampered proofs in EVERY slice (at slice-dependent slots);
+    the gathered verdicts must equal the fixture's (the reference verifier's).  Every distinct proof of the fixture is used."""
+    from curdleproofs_pie_amd.distributed import sharded_verify
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    n, world = 16384, 8
+    slots = {}
+    for g in range(world):                                              # 5 tampered proofs per slice, the variants rotating
+        for j in range(5):
+            slots[g * (n // world) + (131 * j + 17 * g) % (n // world)] = (5 * g + j) % len(fx.tampered)
+    inst, proofs, want = fx.tiled(n, slots)
+    assert want.count(False) >= 30 and all(want[g * 2048: (g + 1) * 2048].count(False) >= 3 for g in range(world))
+    v = ShuffleBatchVerifier(fx.crs, native_lib.Context(0))
+
+    def verify(a, b, m):                                                # one rank's slice as a stream of 1024-proof batches
+        ib, pb = fx.inst_bytes, fx.proof_bytes
+        batches = [(a[lo * ib: (lo + 1024) * ib], b[lo * pb: (lo + 1024) * pb], min(1024, m - lo)) for lo in range(0, m, 1024)]
+        out = []
+        for st in v.verify_stream(batches):
+            out.extend(st)
+        return out
+
+    # eight ranks as eight threads of this process, each with its own communicator (the library's TCP control channel, world 8);
+    # the GPU is taken in turns (one verifier), the slicing and the verdict gather are sharded_verify's own
+    import tempfile
+    import threading
+
+    from curdleproofs_pie_amd.distributed import init_comm
+
+    path = os.path.join(tempfile.mkdtemp(prefix="cg1_cfg5_"), "rdzv")
+    turn = threading.Lock()
+
+    def locked_verify(a, b, m):
+        with turn:
+            return verify(a, b, m)
+
+    results, errors = {}, []
+
+    def rank_main(rank):
+        try:
+            comm = init_comm(rank, world, rendezvous_file=path, timeout_s=300)
+            comm.set_timeout(900000)
+            results[rank] = sharded_verify(v, inst, proofs, n, rank, world, comm=comm, verify=locked_verify)
+            comm.barrier()
+            comm.close()
+        except BaseException as e:
+            errors.append((rank, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=1500)
+    assert not errors, errors
+    for rank in range(world):
+        assert [s == 0 for s in results[rank]] == want, rank
     v.close()
