@@ -98,6 +98,18 @@ def batch_fold(left: Iterable[G1Point], right: Iterable[G1Point], scalar: Scalar
     return _blobs_from_affine96(raw, n)
 
 
+def batch_fold_scalars(left: Iterable[G1Point], right: Iterable[G1Point], scalars: Iterable[Scalar]) -> List[G1Point]:
+    """[l + r * s for l, r, s in zip(left, right, scalars)] as one launch: the folds of several provers' rounds (each with its
+    own challenge) side by side."""
+    trip = list(zip(left, right, scalars))
+    n = len(trip)
+    if n == 0:
+        return []
+    raw = N.default_context().batch_mul_add_host(points_to_affine96([r for _, r, _ in trip]), n, b"".join(s._v.to_bytes(32, "little") for _, _, s in trip), n,
+                                                 points_to_affine96([l for l, _, _ in trip]), n)
+    return _blobs_from_affine96(raw, n)
+
+
 def batch_sum(groups: Iterable[Iterable[G1Point]]) -> List[G1Point]:
     """[reduce(lambda a, b: a + b, g, Z1) for g in groups] on the GPU -- the linear point sums G_sum / H_sum of the CRS
     (crs.py:64-65: over vec_G and vec_H), one wave per group (k_batch_sum)."""

@@ -86,3 +86,31 @@ def test_grand_product_bases(pv):
     g = pv["grand_product_bases"]
     Gp, Hp = grand_product_bases([P(h) for h in g["vec_G"]], [P(h) for h in g["vec_H"]], S(g["beta_inv"]))
     assert enc(Gp + Hp) == g["G_prime_H_prime"]
+
+
+def test_cross_proof_batched_rounds_equal_single_prover_rounds(pv):
+    """ipa_rounds_many / same_msm_rounds_many: three provers in step (the reference-recorded inputs, and the same inputs with the
+    vectors of prover 2 and 3 rotated so the three differ) -- prover 0's outputs must still be the reference's bytes, and every
+    prover's outputs must equal what it gets alone."""
+    from curdleproofs_pie_amd.prover_kernels import ipa_rounds, ipa_rounds_many, same_msm_rounds, same_msm_rounds_many
+
+    r = pv["ipa"]
+    rot = lambda v, k: v[k:] + v[:k]
+    base = ([P(h) for h in r["crs_G_vec"]], [P(h) for h in r["crs_G_prime_vec"]], P(r["H"]), [S(h) for h in r["vec_c"]], [S(h) for h in r["vec_d"]])
+    provers = [base] + [(base[0], base[1], base[2], rot(base[3], k), rot(base[4], 2 * k)) for k in (1, 2)]
+    mk = lambda: (lambda gs: (lambda *pts: gs.pop(0)))([S(g) for g in r["gammas"]])
+    many = ipa_rounds_many(provers, [mk() for _ in provers])
+    assert (enc(many[0][0]), enc(many[0][1]), enc(many[0][2]), enc(many[0][3])) == (r["vec_L_C"], r["vec_R_C"], r["vec_L_D"], r["vec_R_D"])
+    for pr, got in zip(provers, many):
+        alone = ipa_rounds(*pr, mk())
+        assert [enc(x) for x in got[:4]] == [enc(x) for x in alone[:4]] and got[4] == alone[4] and got[5] == alone[5]
+    r = pv["same_msm"]
+    base = ([P(h) for h in r["crs_G_vec"]], [P(h) for h in r["vec_T"]], [P(h) for h in r["vec_U"]], [S(h) for h in r["vec_x"]])
+    provers = [base] + [(base[0], rot(base[1], k), base[2], rot(base[3], k)) for k in (3, 5)]
+    mk = lambda: (lambda gs: (lambda *pts: gs.pop(0)))([S(g) for g in r["gammas"]])
+    many = same_msm_rounds_many(provers, [mk() for _ in provers])
+    for got, key in zip(many[0][:6], ("vec_L_A", "vec_L_T", "vec_L_U", "vec_R_A", "vec_R_T", "vec_R_U")):
+        assert enc(got) == r[key], key
+    for pr, got in zip(provers, many):
+        alone = same_msm_rounds(*pr, mk())
+        assert [enc(x) for x in got[:6]] == [enc(x) for x in alone[:6]] and got[6] == alone[6]
