@@ -240,42 +240,59 @@ __global__ void __launch_bounds__(256) k_small_tree(const PointSum* __restrict__
 }
 
 
+// The last kernel of an MSM call: the exported window sums (+ the status words behind them) from device memory into MAPPED HOST
+// memory, 16 bytes per store, then -- after a system-scope fence -- the call's sequence number into the flag word the host polls.
+// One block: 66 KB at most.
+__global__ void __launch_bounds__(1024) k_export_host(const uint4* __restrict__ src, uint4* __restrict__ dst_host, uint32_t nvec,
+                                                      uint32_t* __restrict__ flag_host, uint32_t seq) {
+  for (uint32_t i = threadIdx.x; i < nvec; i += 1024) dst_host[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 // ------------------------------------------------------------------ quad-lane variants (g1_quad.h)
 // Same results as k_small_tree / k_msm_horner; every EC operation is shared by the 4 lanes of a DPP quad, which
 // shortens each dependent step ~2.5x.  These kernels are purely latency-bound (a few hundred waves at most).
 
-// grid = (1 + hb + lb, nlw), 512 threads = 128 quads: each quad takes elements Q and Q + 128 of its item.
+// grid = (1 + hb + lb, nlw); blockDim = 64 .. 512 threads = NQ quads (the host sizes it to the longer of the two sums): each quad
+// takes elements Q, Q + NQ, ... of its item, then a quad tree inside each wave and one across the block's waves.
 __global__ void __launch_bounds__(512) k_small_tree_quad(const PointSum* __restrict__ rowsum, const PointSum* __restrict__ colsum,
                                                          PointWords* __restrict__ out, uint32_t hb, uint32_t lb) {
   __shared__ PointSum sh[8];
   const uint32_t item = blockIdx.x, lw = blockIdx.y;
   const uint32_t q = threadIdx.x & 3u, Q = threadIdx.x >> 2, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t NQ = blockDim.x >> 2, NW = blockDim.x >> 6;
   const bool on_rows = item <= hb;
   const uint32_t J = on_rows ? (1u << hb) : (1u << lb);
   const PointSum* src = on_rows ? rowsum + (size_t)lw * J : colsum + (size_t)lw * J;
   const uint32_t bit = on_rows ? item - 1u : item - 1u - hb;
   xyzz acc = xyzz_identity();
-  for (uint32_t e = Q; e < J; e += 128u)
+  for (uint32_t e = Q; e < J; e += NQ)
     if (item == 0 || ((e >> bit) & 1u)) acc = quad_add(acc, load_sum(src + e), q);
   for (uint32_t dq = 8; dq >= 1; dq >>= 1) {               // 16 quads per wave
     xyzz o = shfl_down_xyzz(acc, (int)(4u * dq));
     if ((lane >> 2) < dq) acc = quad_add(acc, o, q);
   }
-  if (lane == 0) store_sum(&sh[wave], acc);
-  __syncthreads();
-  if (wave == 0) {
-    acc = (Q < 8u) ? load_sum(&sh[Q]) : xyzz_identity();
-    for (uint32_t dq = 4; dq >= 1; dq >>= 1) {
-      xyzz o = shfl_down_xyzz(acc, (int)(4u * dq));
-      if (Q < dq) acc = quad_add(acc, o, q);
+  if (NW > 1) {
+    if (lane == 0) store_sum(&sh[wave], acc);
+    __syncthreads();
+    if (wave == 0) {
+      acc = (Q < NW) ? load_sum(&sh[Q]) : xyzz_identity();
+      for (uint32_t dq = NW >> 1; dq >= 1; dq >>= 1) {
+        xyzz o = shfl_down_xyzz(acc, (int)(4u * dq));
+        if (Q < dq) acc = quad_add(acc, o, q);
+      }
     }
-    if (threadIdx.x == 0) {
-      xyzz_words o;
-      xyzz_export(acc, o);
-      PointWords* dst = out + (size_t)lw * gridDim.x + item;
-      for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
-      dst->inf = o.inf;
-    }
+  }
+  if (threadIdx.x == 0) {
+    xyzz_words o;
+    xyzz_export(acc, o);
+    PointWords* dst = out + (size_t)lw * gridDim.x + item;
+    for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
+    dst->inf = o.inf;
   }
 }
 

@@ -34,6 +34,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <functional>
@@ -103,7 +104,7 @@ struct Helper {
 
 struct Ctx {
   int device = 0;
-  Helper helper;
+  Helper helper[3];                     // the host Horner tail runs on up to four threads (this one + three helpers)
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;    // H2D staging copies that overlap kernels on `stream` (cg1_h2d_async / cg1_copy_fence)
   hipEvent_t copy_ev = nullptr;
@@ -132,6 +133,10 @@ struct Ctx {
   int stage_sort = 1;                   // LDS-staged, line-coalesced writes in k_part_scatter / k_bin_sort (A/B switch)
   int host_split = 1;                   // host Horner tail on two threads (A/B switch)
   int rowcol_quad = 1;                  // k_rowcol_quad for small bucket counts (A/B switch)
+  int rowcol_quad_max = 1 << 18;        // ... up to this many buckets ("rowcol_quad_max")
+  int tree_half = 1;                    // k_small_tree_quad: 2 lanes per element (a quad takes two elements) instead of 4 (A/B switch)
+  int fold_pass = 1;                    // k_bucket_fold in front of k_rowcol / k_seg_reduce; 0 leaves multi-chunk buckets to their bucket_sum loops
+                                        // (measured WORSE: 372 instead of 235 us at 2^16 -- divergent trip counts inside the row / column lanes)
   int auto_plan = 1;                    // window_c = 0 picks balanced window plans for mid-size inputs (A/B switch)
   struct Pending {                      // what msm_finish needs from msm_enqueue
     bool active = false;
@@ -140,6 +145,7 @@ struct Ctx {
     uint32_t m = 1, lb2 = 0, hb2 = 0, nitems = 0;
     bool use2d = true;
     int profile = 0;                    // the level the events of THIS call were recorded under (may change before msm_finish)
+    bool zero_copy = false; uint32_t seq = 0;
     size_t nout_words = 0;
     std::chrono::steady_clock::time_point h0, h1;
   } pend;
@@ -152,7 +158,13 @@ struct Ctx {
   PointWords* d_bout = nullptr; PointWords* h_bout = nullptr; size_t cap_bout = 0;
   PointSum *d_sums = nullptr, *d_segrun = nullptr, *d_segtot = nullptr;
   PointWords* d_out = nullptr;
-  PointWords* h_out = nullptr;          // pinned
+  PointWords* h_out = nullptr;          // pinned, and mapped into the device: k_export_host writes the window sums straight into it
+  PointWords* h_out_dev = nullptr;      // the device's address of h_out
+  uint32_t* h_flag = nullptr;           // pinned + mapped: k_export_host stores the call's sequence number here when h_out is complete
+  uint32_t* h_flag_dev = nullptr;
+  uint32_t seq = 0;
+  int zero_copy = 1;                    // 1: export kernel + flag polling instead of a D2H copy + stream wait (A/B switch)
+  int horner_threads = 4;               // host threads of the Horner tail: 1, 2 or 4 (A/B switch; host_split = 0 forces 1)
   // staging for host-pointer entry points
   void* d_stage_pts = nullptr; void* d_stage_sc = nullptr; size_t cap_stage = 0;
   // timing
@@ -284,6 +296,7 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     HIPCHK(hipMalloc(&ctx->d_out, (nout + 1) * sizeof(PointWords)));      // + one record: the input-validation flag word
     HIPCHK(hipHostMalloc(&ctx->h_out, (nout + 1) * sizeof(PointWords)));
+    HIPCHK(hipHostGetDevicePointer((void**)&ctx->h_out_dev, ctx->h_out, 0));
     ctx->cap_out = nout;
   }
   return CG1_OK;
@@ -446,10 +459,14 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, pts, ctx->d_sums);
   if (profile >= 1) HIPCHK(hipEventRecord(ctx->ev[5], st));
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
-  const bool small_quad = ctx->quad && ctx->rowcol_quad && nb_total <= (1u << 18);      // latency-bound regime: every addition by a quad
+  // k_rowcol_quad (every addition by a DPP quad) only where the reduction is a pure latency chain: a few thousand buckets
+  const bool small_quad = ctx->quad && ctx->rowcol_quad && nb_total <= (size_t)ctx->rowcol_quad_max;
+  // Buckets cut into 2..16 chunks are folded into their first slot before the row / column sums (k_rowcol_quad requires it;
+  // k_rowcol / k_seg_reduce could add the chunk sums themselves -- bucket_sum -- but the divergent trip counts inside their lanes
+  // cost more than the separate pass: profiles/r03_rowcol_ab.txt).
   if (small_quad)
     hipLaunchKernelGGL(k_bucket_fold_quad, dim3((uint32_t)((nb_total * 4 + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);
-  else
+  else if (ctx->fold_pass)
     hipLaunchKernelGGL(k_bucket_fold, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);
   if (use2d) {
     const uint32_t R = 1u << hb2, Cn = 1u << lb2;
@@ -465,7 +482,9 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
       hipLaunchKernelGGL(k_rowcol, dim3(nrow_blocks + ncol_blocks), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
                          rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks, ctx->quad);
     if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
-    if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(512), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
+    // 4 lanes per element of the longer of the two sums (2^hb rows, 2^lb columns), at most 512 threads: no idle quads in the block
+    const uint32_t tree_threads = std::min<uint32_t>(512u, std::max<uint32_t>(64u, 4u << std::max(hb2, lb2)) >> (ctx->tree_half ? 1 : 0));
+    if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(std::max<uint32_t>(64u, tree_threads)), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
     else hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
   } else {
     const uint32_t nseg_total = (uint32_t)(nb_total / m);
@@ -475,10 +494,21 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     hipLaunchKernelGGL(k_bit_tree, dim3(nitems, nlw, S), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_partial, J);
     hipLaunchKernelGGL(k_bit_tree_final, dim3((uint32_t)(nitems * nlw)), dim3(64), 0, st, ctx->d_partial, ctx->d_out, S);
   }
-  HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, ((size_t)nlw * nitems + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
+  const bool zc = ctx->zero_copy != 0;
+  if (zc) {
+    // the window sums + status words go straight into mapped host memory, then the call's sequence number into the flag word the
+    // host polls: no DMA copy to set up, no stream wait to wake from (~25 us per call, all of it on the critical path of a small MSM)
+    ++ctx->seq;
+    const uint32_t nvec = (uint32_t)((((size_t)nlw * nitems + 1) * sizeof(PointWords)) / 16);
+    hipLaunchKernelGGL(k_export_host, dim3(1), dim3(1024), 0, st, reinterpret_cast<const uint4*>(ctx->d_out), reinterpret_cast<uint4*>(ctx->h_out_dev), nvec,
+                       ctx->h_flag_dev, ctx->seq);
+  } else {
+    HIPCHK(hipMemcpyAsync(ctx->h_out, ctx->d_out, ((size_t)nlw * nitems + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
+  }
   if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
   Ctx::Pending& pd = ctx->pend;
+  pd.zero_copy = zc; pd.seq = ctx->seq;
   pd.active = true; pd.c = c; pd.plan = plan; pd.rank = rank; pd.world = world; pd.nlw = nlw; pd.nbits = nbits; pd.m = m; pd.lb2 = lb2; pd.hb2 = hb2;
   pd.nitems = nitems; pd.use2d = use2d; pd.profile = profile; pd.nout_words = nout_words; pd.h0 = h0; pd.h1 = h1;
   return CG1_OK;
@@ -497,7 +527,21 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   const size_t nout_words = pd.nout_words;
   const auto h0 = pd.h0, h1 = pd.h1;
   HIPCHK(hipSetDevice(ctx->device));
-  { int wrc = wait_stream(ctx); if (wrc) return wrc; }
+  if (pd.zero_copy && !ctx->blocking_sync && pd.profile < 2) {
+    // poll the flag word k_export_host writes last; look at the stream now and then so that a failed launch cannot hang us
+    volatile uint32_t* flag = ctx->h_flag;
+    for (uint32_t spins = 0; *flag != pd.seq; ++spins) {
+      if ((spins & 0x3fffu) == 0x3fffu) {
+        hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) { if (*flag != pd.seq) { snprintf(ctx->err, sizeof ctx->err, "the stream drained without the export flag"); return CG1_ERR_HIP; } break; }
+        if (q != hipErrorNotReady) { snprintf(ctx->err, sizeof ctx->err, "stream failed: %s", hipGetErrorString(q)); return CG1_ERR_HIP; }
+      }
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    int wrc = wait_stream(ctx); if (wrc) return wrc;
+  }
   HIPCHK(hipGetLastError());
   {
     const uint32_t* st_words = reinterpret_cast<const uint32_t*>(ctx->h_out + nout_words);    // [0] bad scalar, [1] entries, [2] chunks
@@ -558,16 +602,23 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
     return a;
   };
   cg1h::jac acc;
-  if (ctx->host_split && e_top >= 96) {
-    // two host threads: the low half of the exponent range on the context's helper thread while this thread does the high
-    // half and then its e_mid doublings (255 doublings + 129 additions on the critical path instead of 255 + 256)
-    const int e_mid = (e_top + 1) / 2;
-    cg1h::jac low;
-    ctx->helper.run([&]() { low = horner(0, e_mid - 1); });
-    acc = horner(e_mid, e_top);
-    for (int k = 0; k < e_mid; ++k) acc = cg1h::jac_dbl(acc);
-    ctx->helper.wait();
-    acc = cg1h::jac_add(acc, low);
+  const int nth = (!ctx->host_split || e_top < 96) ? 1 : (ctx->horner_threads >= 4 && e_top >= 192 ? 4 : 2);
+  if (nth > 1) {
+    // the exponent range cut into nth parts: part j (on its own thread) forms horner(lo_j, hi_j) and then doubles it lo_j times, so
+    // every part ends with its full weight and the parts are simply added.  The critical path is the top part: e_top doublings,
+    // but only 1/nth of the additions (255 doublings + ~80 additions with four threads instead of 255 + ~320 on one).
+    cg1h::jac part[4];
+    int lo[5];
+    for (int j = 0; j <= nth; ++j) lo[j] = (int)(((long)(e_top + 1) * j) / nth);
+    auto run_part = [&](int j) {
+      cg1h::jac a = horner(lo[j], lo[j + 1] - 1);
+      for (int k = 0; k < lo[j]; ++k) a = cg1h::jac_dbl(a);
+      part[j] = a;
+    };
+    for (int j = 0; j + 1 < nth; ++j) ctx->helper[j].run([&, j]() { run_part(j); });
+    run_part(nth - 1);
+    acc = part[nth - 1];
+    for (int j = 0; j + 1 < nth; ++j) { ctx->helper[j].wait(); acc = cg1h::jac_add(acc, part[j]); }
   } else {
     acc = horner(0, e_top);
   }
@@ -832,6 +883,8 @@ cg1_ctx* cg1_ctx_create(int device) {
       hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { delete ctx; return nullptr; }
   for (int i = 0; i <= CG1_NPHASE; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return nullptr; }
+  if (hipHostMalloc((void**)&ctx->h_flag, 64) != hipSuccess || hipHostGetDevicePointer((void**)&ctx->h_flag_dev, ctx->h_flag, 0) != hipSuccess) { delete ctx; return nullptr; }
+  *ctx->h_flag = 0;
   return ctx;
 }
 void cg1_ctx_destroy(cg1_ctx* ctx) {
@@ -840,6 +893,7 @@ void cg1_ctx_destroy(cg1_ctx* ctx) {
   cg1::free_bufs(ctx);
   if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
   if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
+  if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
   for (int i = 0; i <= CG1_NPHASE; ++i) (void)hipEventDestroy(ctx->ev[i]);
   (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
@@ -935,8 +989,13 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "blocking_sync")) { ctx->blocking_sync = value != 0; return CG1_OK; }
   if (!strcmp(name, "big_bins")) { ctx->big_bins = value != 0; return CG1_OK; }
   if (!strcmp(name, "host_split")) { ctx->host_split = value != 0; return CG1_OK; }
+  if (!strcmp(name, "horner_threads")) { if (value != 1 && value != 2 && value != 4) return CG1_ERR_ARG; ctx->horner_threads = value; return CG1_OK; }
+  if (!strcmp(name, "zero_copy")) { ctx->zero_copy = value != 0; return CG1_OK; }
   if (!strcmp(name, "auto_plan")) { ctx->auto_plan = value != 0; return CG1_OK; }
   if (!strcmp(name, "rowcol_quad")) { ctx->rowcol_quad = value != 0; return CG1_OK; }
+  if (!strcmp(name, "rowcol_quad_max")) { if (value < 0) return CG1_ERR_ARG; ctx->rowcol_quad_max = value; return CG1_OK; }
+  if (!strcmp(name, "fold_pass")) { ctx->fold_pass = value != 0; return CG1_OK; }
+  if (!strcmp(name, "tree_half")) { ctx->tree_half = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
     int v = value ? 1 : 0;
     HIPCHK(hipSetDevice(ctx->device));

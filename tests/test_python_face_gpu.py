@@ -217,3 +217,27 @@ def test_msm_over_a_device_list(native_lib):
         N.msm_multi_device([c0, c0], [bufs[0][0]] * 2, [bufs[0][1]] * 2, [n0, n0])
     # an empty shard contributes the identity
     assert N.cg1_eq(N.msm_multi_device([c0, c1], [bufs[0][0], bufs[1][0]], [bufs[0][1], bufs[1][1]], [n0, 0]), c0.msm_host(p96, s32, n0))
+
+
+def test_compute_msm_python_face_at_config2_size(api):
+    """BASELINE config 2 through the reference's own signature: compute_MSM(bases, scalars) over 2^16 G1Point / Scalar OBJECTS
+    (msm_accumulator.py:6-12; the objects are marshalled by one batched normalisation).  The bases are k_i * G, so the result
+    must be exactly (sum k_i s_i) * G; a slice of the inputs is also summed by the oracle's naive loop."""
+    A, U = api
+    from curdleproofs_pie_amd.msm_accumulator import batch_mul
+    from oracle import c_oracle as C
+
+    rng = random.Random(16)
+    n = 1 << 16
+    ks = [A.Scalar(rng.randint(1, O.R - 1)) for _ in range(n)]
+    bases = batch_mul([A.G1Point()] * n, ks)                 # get_random_point() = G * random_scalar() (util.py:67-68), vectorised
+    scalars = [A.Scalar(rng.randint(0, O.R - 1)) for _ in range(n)]
+    got = A.compute_MSM(bases, scalars)
+    tot = sum(int(k) * int(s) for k, s in zip(ks, scalars)) % O.R
+    assert bytes(got.to_compressed_bytes()) == O.g1_compress(O.g1_mul(O.G1_GEN, tot))
+    # generators allowed, truncation to the shorter (msm_accumulator.py:10)
+    assert A.compute_MSM(iter(bases), (s for s in scalars[: n - 5])) == got - A.compute_MSM(bases[n - 5:], scalars[n - 5:])
+    m = 300
+    from curdleproofs_pie_amd.py_arkworks_bls12381 import points_to_affine96
+    want = C.compress(C.compute_msm(points_to_affine96(bases[:m]), b"".join(int(s).to_bytes(32, "little") for s in scalars[:m]), m))
+    assert bytes(A.compute_MSM(bases[:m], scalars[:m]).to_compressed_bytes()) == want

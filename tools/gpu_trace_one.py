@@ -10,6 +10,9 @@ if len(sys.argv) > 2:
     kw = {"window_c": 16, "shard_rank": 0, "shard_world": int(sys.argv[2])}
 ctx = N.Context(0)
 ctx.set_param("profile", 0)
+for kv in filter(None, os.environ.get("PARAMS", "").split(",")):          # e.g. PARAMS=rowcol_quad=0,chunk_len=8
+    k, v = kv.split("=")
+    ctx.set_param(k, int(v))
 n = 1 << logn
 dk, dp, ds, dg = ctx.alloc(32 * n), ctx.alloc(96 * n), ctx.alloc(32 * n), ctx.alloc(96)
 dg.upload(GX.to_bytes(48, "little") + GY.to_bytes(48, "little"))
