@@ -197,14 +197,31 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
 
 
 def open_comm(args, rank, world, ctx):
-    """The rank's communicator (None at N = 1): TCP control channel + RCCL for the data exchange unless the ranks share one GPU."""
+    """The rank's communicator (None at N = 1): TCP control channel + RCCL for the data exchange unless the ranks share one GPU.
+    If RCCL cannot be attached on some rank (library missing, ncclCommInitRank error) EVERY rank keeps the socket transport and the
+    line says so in `collective.backend_note` -- the exchange is 144 bytes per rank either way."""
     if world == 1:
         return None
+    from curdleproofs_pie_amd import _native as N
     from curdleproofs_pie_amd.distributed import init_comm
 
     comm = init_comm(rank, world, timeout_s=900.0)
+    comm.note = None
     if args.backend == "rccl":
-        comm.attach_rccl(ctx)
+        try:
+            comm.attach_rccl(ctx)
+            err = b""
+        except N.NativeError as e:
+            err = str(e).encode()[:200]
+        errs = [x.rstrip(b"\0") for x in comm.allgather(err.ljust(200, b"\0"), host_only=True)]
+        if any(errs):
+            bad = [(r, x.decode(errors="replace")) for r, x in enumerate(errs) if x]
+            comm.barrier()
+            comm.close()                                       # some ranks may hold a half-made RCCL communicator: every rank starts over
+            comm = init_comm(rank, world, timeout_s=900.0)     # (rank 0 removed the rendezvous file after the first connect and writes it anew)
+            comm.note = "RCCL not attached (rank %d: %s): socket transport" % bad[0]
+            if rank == 0:
+                print("bench.py: " + comm.note, file=sys.stderr, flush=True)
     return comm
 
 
@@ -397,8 +414,8 @@ def main():
 
     if args.backend in ("nccl", "gloo"):                      # the names torch gives the same two transports
         args.backend = {"nccl": "rccl", "gloo": "socket"}[args.backend]
-    if args.same_device:
-        args.backend = "socket"                               # RCCL refuses two ranks on one device
+    if args.same_device and not os.environ.get("CG1_BENCH_TRY_RCCL_ON_ONE_DEVICE"):
+        args.backend = "socket"                               # RCCL refuses two ranks on one device (the env switch lets a test see that refusal handled)
     if args.gpus > 1 and "RANK" not in os.environ:
         return launch_ranks(args)                             # no launcher around us: spawn the ranks ourselves
     rank = int(os.environ.get("RANK", "0"))
@@ -612,7 +629,7 @@ def main():
         }
         out.update(extra)
         if world > 1:
-            out["collective"] = {"backend": comm.transport, "world_seen": comm.world_seen,
+            out["collective"] = {"backend": comm.transport, "backend_note": getattr(comm, "note", None), "world_seen": comm.world_seen,
                                  "world_seen_source": "ncclCommCount" if comm.transport == "rccl" else "ranks connected to the TCP hub",
                                  "what": "cg1_comm_allreduce_g1: all-gather of one 144-byte partial G1 sum per rank (ncclAllGather on the context's "
                                          "stream when the backend is rccl), then world-1 host additions on every rank",

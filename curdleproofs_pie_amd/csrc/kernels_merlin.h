@@ -163,4 +163,287 @@ __global__ void __launch_bounds__(LANES) k_merlin_batch(const uint8_t* __restric
   }
 }
 
+// ------------------------------------------------------------------ permutation-synchronous interpreter (round 3)
+// k_merlin_batch above lets every lane call Keccak-f where ITS transcript needs it: after the first rejected challenge draw
+// (probability 0.55 per draw) the lanes of a wave need their permutations at different moments and the wave executes the
+// union -- ~1650 masked passes for a shuffle-shaped program whose transcripts need ~750 each -- and it reads its messages a
+// byte at a time from global memory with ONE wave per SIMD: every byte load is an exposed ~0.7 us round trip (64 ms per wave).
+// Here
+//   * a lane's STROBE work is a RESUMABLE byte-level state machine (op index, phase, byte index: registers): every lane advances
+//     until its sponge is full (or a PRF forces the permutation, or its program ends) and stops; then all lanes that stopped
+//     permute TOGETHER -- one pass of the Keccak code per permutation of the slowest lane (~800 passes) -- and resume;
+//   * messages are fetched in bursts of up to 48 bytes (a whole point: three independent 16-byte loads, one exposed latency),
+//     absorbed four bytes at a time; the labels live in an LDS table, the operations are 16-byte records (one load each);
+//     a drawn challenge stays in LDS for its range check and its re-absorption;
+//   * Keccak-f is inlined at its single call site (LDS address space instead of flat accesses) with its 64-bit rotations written
+//     as v_alignbit pairs (5.2 K instead of 6.9 K instructions, none of them a 64-bit shift).
+// Same LDS sponge layout, same 208-byte state blob, same results as the host transcript (tests/test_merlin_gpu.py).
+struct COp {                                 // 16 bytes: the kernel's own operation record (built by cg1_merlin_batch_device)
+  uint32_t kind_label;                       // kind | label index << 8 | label length << 16
+  uint32_t len, data_off, out_off;
+};
+constexpr int MAX_LABELS = 48;
+
+__device__ __forceinline__ void rotl64p(uint32_t lo, uint32_t hi, int n, uint32_t& olo, uint32_t& ohi) {     // compile-time n in [0, 63]
+  if (n == 0) { olo = lo; ohi = hi; }
+  else if (n < 32) { ohi = __builtin_amdgcn_alignbit(hi, lo, 32 - n); olo = __builtin_amdgcn_alignbit(lo, hi, 32 - n); }
+  else if (n == 32) { olo = hi; ohi = lo; }
+  else { ohi = __builtin_amdgcn_alignbit(lo, hi, 64 - n); olo = __builtin_amdgcn_alignbit(hi, lo, 64 - n); }
+}
+struct U64 { uint32_t lo, hi; };
+__device__ __forceinline__ U64 x2(U64 a, U64 b) { return U64{a.lo ^ b.lo, a.hi ^ b.hi}; }
+__device__ __forceinline__ U64 chi(U64 a, U64 b, U64 c) { return U64{a.lo ^ (~b.lo & c.lo), a.hi ^ (~b.hi & c.hi)}; }
+__device__ __forceinline__ U64 rot(U64 a, int n) { U64 r; rotl64p(a.lo, a.hi, n, r.lo, r.hi); return r; }
+
+// keccak.py:16-66 on the sponge words of one lane: w[i * LANES], i < 50
+__device__ __forceinline__ void keccak_words(uint32_t* w) {
+  static constexpr uint64_t RC[24] = {
+      0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull, 0x000000000000808bull,
+      0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008aull, 0x0000000000000088ull,
+      0x0000000080008009ull, 0x000000008000000aull, 0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull,
+      0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+      0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+  U64 a[25], e[25];
+#pragma unroll
+  for (int i = 0; i < 25; ++i) { a[i].lo = w[(2 * i) * LANES]; a[i].hi = w[(2 * i + 1) * LANES]; }
+#define CG1_KR2(A, E, rc)                                                                                                     \
+  {                                                                                                                           \
+    const U64 c0 = x2(x2(x2(A[0], A[5]), x2(A[10], A[15])), A[20]), c1 = x2(x2(x2(A[1], A[6]), x2(A[11], A[16])), A[21]),     \
+              c2 = x2(x2(x2(A[2], A[7]), x2(A[12], A[17])), A[22]), c3 = x2(x2(x2(A[3], A[8]), x2(A[13], A[18])), A[23]),     \
+              c4 = x2(x2(x2(A[4], A[9]), x2(A[14], A[19])), A[24]);                                                           \
+    const U64 d0 = x2(c4, rot(c1, 1)), d1 = x2(c0, rot(c2, 1)), d2 = x2(c1, rot(c3, 1)), d3 = x2(c2, rot(c4, 1)), d4 = x2(c3, rot(c0, 1)); \
+    U64 b0, b1, b2, b3, b4;                                                                                                   \
+    b0 = x2(A[0], d0); b1 = rot(x2(A[6], d1), 44); b2 = rot(x2(A[12], d2), 43); b3 = rot(x2(A[18], d3), 21); b4 = rot(x2(A[24], d4), 14); \
+    E[0] = chi(b0, b1, b2); E[0].lo ^= (uint32_t)(rc); E[0].hi ^= (uint32_t)((rc) >> 32);                                     \
+    E[1] = chi(b1, b2, b3); E[2] = chi(b2, b3, b4); E[3] = chi(b3, b4, b0); E[4] = chi(b4, b0, b1);                           \
+    b0 = rot(x2(A[3], d3), 28); b1 = rot(x2(A[9], d4), 20); b2 = rot(x2(A[10], d0), 3); b3 = rot(x2(A[16], d1), 45); b4 = rot(x2(A[22], d2), 61); \
+    E[5] = chi(b0, b1, b2); E[6] = chi(b1, b2, b3); E[7] = chi(b2, b3, b4); E[8] = chi(b3, b4, b0); E[9] = chi(b4, b0, b1);   \
+    b0 = rot(x2(A[1], d1), 1); b1 = rot(x2(A[7], d2), 6); b2 = rot(x2(A[13], d3), 25); b3 = rot(x2(A[19], d4), 8); b4 = rot(x2(A[20], d0), 18); \
+    E[10] = chi(b0, b1, b2); E[11] = chi(b1, b2, b3); E[12] = chi(b2, b3, b4); E[13] = chi(b3, b4, b0); E[14] = chi(b4, b0, b1); \
+    b0 = rot(x2(A[4], d4), 27); b1 = rot(x2(A[5], d0), 36); b2 = rot(x2(A[11], d1), 10); b3 = rot(x2(A[17], d2), 15); b4 = rot(x2(A[23], d3), 56); \
+    E[15] = chi(b0, b1, b2); E[16] = chi(b1, b2, b3); E[17] = chi(b2, b3, b4); E[18] = chi(b3, b4, b0); E[19] = chi(b4, b0, b1); \
+    b0 = rot(x2(A[2], d2), 62); b1 = rot(x2(A[8], d3), 55); b2 = rot(x2(A[14], d4), 39); b3 = rot(x2(A[15], d0), 41); b4 = rot(x2(A[21], d1), 2); \
+    E[20] = chi(b0, b1, b2); E[21] = chi(b1, b2, b3); E[22] = chi(b2, b3, b4); E[23] = chi(b3, b4, b0); E[24] = chi(b4, b0, b1); \
+  }
+#pragma unroll
+  for (int round = 0; round < 24; round += 2) {
+    CG1_KR2(a, e, RC[round]);
+    CG1_KR2(e, a, RC[round + 1]);
+  }
+#undef CG1_KR2
+#pragma unroll
+  for (int i = 0; i < 25; ++i) { w[(2 * i) * LANES] = a[i].lo; w[(2 * i + 1) * LANES] = a[i].hi; }
+}
+
+struct Machine {
+  uint32_t* w;                               // &lds[lane]; sponge word i at w[i * LANES]
+  uint32_t* drawn;                           // &lds_drawn[lane]; word j of the challenge being drawn at drawn[j * LANES]
+  const uint32_t* labels;                    // LDS label table: label L word j at labels[L * 8 + j]
+  uint32_t pos, pos_begin, cur_flags;
+  uint32_t k, ph, i, hdr, stage;             // op index, phase within the op, byte index within the phase, the two begin_op bytes, 0/1: challenge / append half of OP_CHALLENGE_SCALAR
+  uint4 rec;                                 // the operation record of op `k_loaded`
+  uint32_t k_loaded;
+
+  __device__ __forceinline__ void xor_byte(uint32_t p, uint32_t v) { w[(p >> 2) * LANES] ^= v << ((p & 3u) * 8u); }
+  __device__ __forceinline__ void xor_u32(uint32_t p, uint32_t v) {          // four bytes at byte position p (p + 4 <= 200)
+    const uint32_t sh = (p & 3u) * 8u;
+    w[(p >> 2) * LANES] ^= v << sh;
+    if (sh) w[((p >> 2) + 1u) * LANES] ^= v >> (32u - sh);
+  }
+  __device__ __forceinline__ uint32_t take_byte(uint32_t p) {                 // PRF: read the byte, leave zero (strobe.py:81-84)
+    const uint32_t sh = (p & 3u) * 8u;
+    uint32_t& x = w[(p >> 2) * LANES];
+    const uint32_t b = (x >> sh) & 0xffu;
+    x &= ~(0xffu << sh);
+    return b;
+  }
+  __device__ __forceinline__ void mark_f() {                                  // strobe.py:55-59, everything of run_f but the permutation
+    xor_byte(pos, pos_begin);
+    xor_byte(pos + 1, 0x04);
+    xor_byte(STROBE_R + 1, 0x80);
+  }
+  // Absorb src[i .. n) from GLOBAL memory.  true = the sponge is full: permutation pending (mark_f done); resume with the same phase.
+  __device__ __forceinline__ bool absorb_global(const uint8_t* __restrict__ src, uint32_t n) {
+    while (i < n) {
+      const uint32_t room = (uint32_t)STROBE_R - pos, left = n - i;
+      const bool al = ((reinterpret_cast<uintptr_t>(src) + i) & 3u) == 0u;
+      if (al && left >= 48u && room >= 48u) {                                 // a whole point: twelve independent loads, one exposed latency
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(src + i);
+        uint32_t v[12];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) v[j] = q[j];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) xor_u32(pos + 4u * j, v[j]);
+        pos += 48u; i += 48u;
+      } else if (al && left >= 16u && room >= 16u) {
+        const uint32_t* q = reinterpret_cast<const uint32_t*>(src + i);
+        uint32_t v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = q[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xor_u32(pos + 4u * j, v[j]);
+        pos += 16u; i += 16u;
+      } else if (left >= 4u && room >= 4u) {
+        const uint32_t v = (uint32_t)src[i] | ((uint32_t)src[i + 1] << 8) | ((uint32_t)src[i + 2] << 16) | ((uint32_t)src[i + 3] << 24);
+        xor_u32(pos, v);
+        pos += 4u; i += 4u;
+      } else {
+        xor_byte(pos, src[i]);
+        ++pos; ++i;
+      }
+      if (pos == (uint32_t)STROBE_R) { mark_f(); return true; }
+    }
+    return false;
+  }
+  // Absorb bytes i .. n of a little-endian word array in LDS (word j at words[j * stride])
+  __device__ __forceinline__ bool absorb_lds(const uint32_t* words, uint32_t stride, uint32_t n) {
+    while (i < n) {
+      if ((i & 3u) == 0u && n - i >= 4u && (uint32_t)STROBE_R - pos >= 4u) {
+        xor_u32(pos, words[(i >> 2) * stride]);
+        pos += 4u; i += 4u;
+      } else {
+        xor_byte(pos, (words[(i >> 2) * stride] >> ((i & 3u) * 8u)) & 0xffu);
+        ++pos; ++i;
+      }
+      if (pos == (uint32_t)STROBE_R) { mark_f(); return true; }
+    }
+    return false;
+  }
+  __device__ __forceinline__ bool absorb_word(uint32_t v, uint32_t n) {       // the low n <= 4 bytes of v, from byte i on
+    if (i == 0u && (uint32_t)STROBE_R - pos > n) {                            // the whole unit fits with room to spare: one or two word updates
+      xor_u32(pos, n == 4u ? v : (v & ((1u << (8u * n)) - 1u)));
+      pos += n; i = n;
+      return false;
+    }
+    while (i < n) {
+      xor_byte(pos, (v >> (8u * i)) & 0xffu);
+      ++pos; ++i;
+      if (pos == (uint32_t)STROBE_R) { mark_f(); return true; }
+    }
+    return false;
+  }
+  __device__ __forceinline__ void begin(uint32_t flags) {                      // strobe.py:89-107 up to the absorb of [old_begin, flags]
+    hdr = pos_begin | (flags << 8);
+    pos_begin = pos + 1u;
+    cur_flags = flags;
+  }
+
+  // Run this lane's program until a permutation is due (returns true; the caller permutes, then sets pos = pos_begin = 0) or the
+  // program ends (returns false with done = true).
+  __device__ __forceinline__ bool advance(const COp* __restrict__ ops, uint32_t nops, const uint8_t* __restrict__ row, uint8_t* __restrict__ orow, bool& done) {
+    for (;;) {
+      if (k >= nops) { done = true; return false; }
+      if (k != k_loaded) { rec = *reinterpret_cast<const uint4*>(ops + k); k_loaded = k; }      // one 16-byte load per operation
+      const uint32_t kind = rec.x & 0xffu, lab = (rec.x >> 8) & 0xffu, llen = rec.x >> 16;
+      const bool as_append = kind == OP_APPEND || kind == OP_APPEND_OUT || (kind == OP_CHALLENGE_SCALAR && stage == 1u);
+      const uint32_t len = kind == OP_CHALLENGE_SCALAR ? 32u : rec.y;
+      switch (ph) {
+        case 0: begin(FLAG_M | FLAG_A); i = 0; ph = 1; [[fallthrough]];       // frame: meta_ad(label), merlin_transcript.py:11-15 / :20-24
+        case 1: if (absorb_word(hdr, 2)) return true; i = 0; ph = 2; [[fallthrough]];
+        case 2: if (absorb_lds(labels + lab * 8u, 1u, llen)) return true; i = 0; ph = 3; [[fallthrough]];
+        case 3: if (absorb_word(len, 4)) return true; i = 0; ph = 4; [[fallthrough]];      // meta_ad(len as LE32, more = True)
+        case 4: begin(as_append ? (uint32_t)FLAG_A : (uint32_t)(FLAG_I | FLAG_A | FLAG_C)); i = 0; ph = 5; [[fallthrough]];
+        case 5: if (absorb_word(hdr, 2)) return true; i = 0; ph = as_append ? 6u : 7u; break;
+        case 6: {                                                             // ad(message)
+          bool full;
+          if (kind == OP_CHALLENGE_SCALAR) full = absorb_lds(drawn, LANES, 32u);       // the accepted draw, still in LDS
+          else full = absorb_global(kind == OP_APPEND ? row + rec.z : orow + rec.w, len);
+          if (full) return true;
+          ++k; ph = 0; i = 0; stage = 0;
+          break;
+        }
+        case 7:                                                               // PRF: the C flag forces a permutation unless the sponge was just permuted
+          ph = 8; i = 0;
+          if (pos != 0u) { mark_f(); return true; }
+          break;
+        case 8: {                                                             // squeeze `len` bytes (strobe.py:77-87)
+          uint8_t* o = orow + rec.w;
+          // (a PRF always starts on a freshly permuted sponge -- the C flag forced it -- so pos is 0 here and whole words can be taken)
+          while (i < len) {
+            if (((pos | i) & 3u) == 0u && len - i >= 4u && (uint32_t)STROBE_R - pos >= 4u && (reinterpret_cast<uintptr_t>(o) & 3u) == 0u) {
+              uint32_t& x = w[(pos >> 2) * LANES];
+              const uint32_t v = x;
+              x = 0u;
+              *reinterpret_cast<uint32_t*>(o + i) = v;
+              if (kind == OP_CHALLENGE_SCALAR) drawn[(i >> 2) * LANES] = v;
+              pos += 4u; i += 4u;
+            } else {
+              const uint32_t b = take_byte(pos);
+              o[i] = (uint8_t)b;
+              if (kind == OP_CHALLENGE_SCALAR) {
+                uint32_t& d = drawn[(i >> 2) * LANES];
+                d = (i & 3u) ? (d | (b << ((i & 3u) * 8u))) : b;
+              }
+              ++pos; ++i;
+            }
+            if (pos == (uint32_t)STROBE_R) { mark_f(); return true; }
+          }
+          if (kind == OP_CHALLENGE_SCALAR) {                                  // curdleproofs_transcript.py:15-25: accept a canonical non-zero draw and
+            uint64_t wv[4], any = 0;                                          // append it under the same label, else draw again
+            for (int j = 0; j < 4; ++j) { wv[j] = (uint64_t)drawn[(2 * j) * LANES] | ((uint64_t)drawn[(2 * j + 1) * LANES] << 32); any |= wv[j]; }
+            bool ok = any != 0;
+            if (ok) { ok = false; for (int j = 3; j >= 0; --j) if (wv[j] != cg1::H_FR[j]) { ok = wv[j] < cg1::H_FR[j]; break; } }
+            stage = ok ? 1u : 0u;
+            ph = 0; i = 0;
+          } else {
+            ++k; ph = 0; i = 0;
+          }
+          break;
+        }
+      }
+    }
+  }
+};
+
+__global__ void __launch_bounds__(LANES) k_merlin_batch_sync(const uint8_t* __restrict__ init_state, const COp* __restrict__ ops, uint32_t nops,
+                                                             const uint32_t* __restrict__ label_table, uint32_t nlabels,
+                                                             const uint8_t* __restrict__ data, size_t data_stride, uint8_t* __restrict__ out,
+                                                             size_t out_stride, uint8_t* __restrict__ states_out, uint32_t n, uint32_t* __restrict__ passes_out,
+                                                             uint32_t lanes_used) {
+  // lanes_used <= LANES transcripts per wave: the lanes of a wave drift apart by whole rejected draws, and the wave pays for the UNION
+  // of the code paths its lanes are on -- with few lanes per wave (the chip has 1024 SIMDs, a batch of 1024 transcripts fills 16 waves)
+  // a pass is cheaper and the batch simply spreads over more SIMDs
+  __shared__ uint32_t lds[52 * LANES];
+  __shared__ uint32_t lds_drawn[8 * LANES];
+  __shared__ uint32_t lds_labels[MAX_LABELS * 8];
+  const uint32_t t = blockIdx.x * lanes_used + threadIdx.x;
+  const bool live = threadIdx.x < lanes_used && t < n;
+  for (uint32_t j = threadIdx.x; j < nlabels * 8u; j += LANES) lds_labels[j] = label_table[j];
+  Machine m;
+  m.w = lds + threadIdx.x;
+  m.drawn = lds_drawn + threadIdx.x;
+  m.labels = lds_labels;
+  for (int i = 0; i < 50; ++i) m.w[i * LANES] = reinterpret_cast<const uint32_t*>(init_state)[i];
+  m.pos = init_state[200]; m.pos_begin = init_state[201]; m.cur_flags = init_state[202];
+  m.k = 0; m.ph = 0; m.i = 0; m.hdr = 0; m.stage = 0; m.k_loaded = 0xffffffffu; m.rec = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  const uint8_t* row = data + (size_t)(live ? t : 0) * data_stride;
+  uint8_t* orow = out + (size_t)(live ? t : 0) * out_stride;
+  bool done = !live;
+  uint32_t passes = 0;
+  unsigned long long t_adv = 0, t_kec = 0;           // shader clock spent in the two halves of a pass (reported per block)
+  for (;;) {
+    bool needf = false;
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+    if (!done) needf = m.advance(ops, nops, row, orow, done);
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+    if (__ballot(needf) == 0ull) break;              // a lane only stops for a permutation or at its end: nobody waits -> everyone is done
+    if (needf) { keccak_words(m.w); m.pos = 0; m.pos_begin = 0; }
+    const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+    t_adv += c1 - c0; t_kec += c2 - c1;
+    ++passes;
+  }
+  if (passes_out && threadIdx.x == 0) {
+    passes_out[4 * blockIdx.x] = passes;
+    passes_out[4 * blockIdx.x + 1] = (uint32_t)(t_adv >> 8);
+    passes_out[4 * blockIdx.x + 2] = (uint32_t)(t_kec >> 8);
+  }
+  if (states_out && live) {
+    uint8_t* so = states_out + (size_t)t * 208;
+    for (int i = 0; i < 50; ++i) reinterpret_cast<uint32_t*>(so)[i] = m.w[i * LANES];
+    so[200] = (uint8_t)m.pos; so[201] = (uint8_t)m.pos_begin; so[202] = (uint8_t)m.cur_flags;
+    for (int i = 203; i < 208; ++i) so[i] = 0;
+  }
+}
+
 }  // namespace cg1merlin

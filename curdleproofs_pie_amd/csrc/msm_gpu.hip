@@ -135,6 +135,10 @@ struct Ctx {
   int rowcol_quad = 1;                  // k_rowcol_quad for small bucket counts (A/B switch)
   int rowcol_quad_max = 1 << 18;        // ... up to this many buckets ("rowcol_quad_max")
   int tree_half = 1;                    // k_small_tree_quad: 2 lanes per element (a quad takes two elements) instead of 4 (A/B switch)
+  int merlin_sync = 1;                  // k_merlin_batch_sync (lanes permute together) instead of k_merlin_batch (A/B switch)
+  uint32_t merlin_clk[2] = {0, 0};
+  int merlin_lanes = 64;                // transcripts per wave of k_merlin_batch_sync ("merlin_lanes": 1 .. 64)
+  uint32_t merlin_passes = 0;           // of the last cg1_merlin_batch_device call: Keccak passes of the slowest wave
   int fold_pass = 1;                    // k_bucket_fold in front of k_rowcol / k_seg_reduce; 0 leaves multi-chunk buckets to their bucket_sum loops
                                         // (measured WORSE: 372 instead of 235 us at 2^16 -- divergent trip counts inside the row / column lanes)
   int auto_plan = 1;                    // window_c = 0 picks balanced window plans for mid-size inputs (A/B switch)
@@ -977,6 +981,7 @@ int cg1_ctx_sync(cg1_ctx* ctx) {
   HIPCHK(hipDeviceSynchronize());
   return CG1_OK;
 }
+int cg1_merlin_last_passes(const cg1_ctx* ctx) { return ctx ? (int)ctx->merlin_passes : -1; }
 int cg1_ctx_device(const cg1_ctx* ctx) { return ctx ? ctx->device : -1; }
 void* cg1_ctx_stream(cg1_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
@@ -995,6 +1000,8 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "rowcol_quad")) { ctx->rowcol_quad = value != 0; return CG1_OK; }
   if (!strcmp(name, "rowcol_quad_max")) { if (value < 0) return CG1_ERR_ARG; ctx->rowcol_quad_max = value; return CG1_OK; }
   if (!strcmp(name, "fold_pass")) { ctx->fold_pass = value != 0; return CG1_OK; }
+  if (!strcmp(name, "merlin_sync")) { ctx->merlin_sync = value != 0; return CG1_OK; }
+  if (!strcmp(name, "merlin_lanes")) { if (value < 1 || value > 64) return CG1_ERR_ARG; ctx->merlin_lanes = value; return CG1_OK; }
   if (!strcmp(name, "tree_half")) { ctx->tree_half = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
     int v = value ? 1 : 0;
@@ -1256,7 +1263,54 @@ int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg
   HIPCHK(dst.alloc(208)); HIPCHK(dops.alloc(nops * sizeof(cg1_merlin_op)));
   HIPCHK(hipMemcpyAsync(dst.p, init_state208, 208, hipMemcpyHostToDevice, ctx->stream));
   if (nops) HIPCHK(hipMemcpyAsync(dops.p, ops, nops * sizeof(cg1_merlin_op), hipMemcpyHostToDevice, ctx->stream));
-  hipLaunchKernelGGL(cg1merlin::k_merlin_batch, dim3((unsigned)((n + cg1merlin::LANES - 1) / cg1merlin::LANES)), dim3(cg1merlin::LANES), 0, ctx->stream,
+  const unsigned nblk = (unsigned)((n + cg1merlin::LANES - 1) / cg1merlin::LANES);
+  if (ctx->merlin_sync) {
+    // the kernel's own records: 16 bytes per operation, the distinct labels in a table (it keeps them in LDS)
+    std::vector<cg1merlin::COp> cops(nops);
+    std::vector<uint32_t> table;
+    std::vector<std::pair<std::vector<uint8_t>, uint32_t>> seen;
+    bool fits = true;
+    for (size_t k = 0; k < nops && fits; ++k) {
+      const cg1_merlin_op& o = ops[k];
+      std::vector<uint8_t> lb(o.label, o.label + o.label_len);
+      uint32_t idx = (uint32_t)seen.size();
+      for (const auto& e : seen) if (e.first == lb) { idx = e.second; break; }
+      if (idx == seen.size()) {
+        if (seen.size() >= (size_t)cg1merlin::MAX_LABELS) { fits = false; break; }
+        seen.emplace_back(lb, idx);
+        uint8_t padded[32] = {0};
+        memcpy(padded, o.label, o.label_len);
+        for (int j = 0; j < 8; ++j) { uint32_t v; memcpy(&v, padded + 4 * j, 4); table.push_back(v); }
+      }
+      cops[k] = cg1merlin::COp{(uint32_t)o.kind | (idx << 8) | ((uint32_t)o.label_len << 16), o.len, o.data_off, o.out_off};
+    }
+    if (fits) {
+      DevBuf dpass, dcops, dtab;
+      const unsigned lanes_used = (unsigned)ctx->merlin_lanes;
+      const unsigned nblk = (unsigned)((n + lanes_used - 1) / lanes_used);
+      HIPCHK(dpass.alloc(16 * (size_t)nblk));
+      HIPCHK(dcops.alloc(sizeof(cg1merlin::COp) * (nops ? nops : 1)));
+      HIPCHK(dtab.alloc(4 * (table.size() ? table.size() : 8)));
+      if (nops) HIPCHK(hipMemcpyAsync(dcops.p, cops.data(), sizeof(cg1merlin::COp) * nops, hipMemcpyHostToDevice, ctx->stream));
+      if (!table.empty()) HIPCHK(hipMemcpyAsync(dtab.p, table.data(), 4 * table.size(), hipMemcpyHostToDevice, ctx->stream));
+      hipLaunchKernelGGL(cg1merlin::k_merlin_batch_sync, dim3(nblk), dim3(cg1merlin::LANES), 0, ctx->stream,
+                         (const uint8_t*)dst.p, (const cg1merlin::COp*)dcops.p, (uint32_t)nops, (const uint32_t*)dtab.p, (uint32_t)seen.size(),
+                         (const uint8_t*)d_data, data_stride, (uint8_t*)d_out, out_stride, (uint8_t*)d_states_out, (uint32_t)n, (uint32_t*)dpass.p, lanes_used);
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipGetLastError());
+      std::vector<uint32_t> hp(4 * (size_t)nblk);
+      HIPCHK(hipMemcpy(hp.data(), dpass.p, 16 * (size_t)nblk, hipMemcpyDeviceToHost));
+      ctx->merlin_passes = 0;
+      for (unsigned b = 0; b < nblk; ++b)
+        if (hp[4 * b] >= ctx->merlin_passes) { ctx->merlin_passes = hp[4 * b]; ctx->merlin_clk[0] = hp[4 * b + 1]; ctx->merlin_clk[1] = hp[4 * b + 2]; }
+      if (getenv("CG1_MERLIN_TRACE"))
+        fprintf(stderr, "k_merlin_batch_sync: %u passes; s_memtime ticks / 256 in advance %u, in Keccak %u (slowest wave)\n", ctx->merlin_passes, ctx->merlin_clk[0], ctx->merlin_clk[1]);
+      return CG1_OK;
+    }
+    // more than MAX_LABELS distinct labels: the round-2 kernel takes the program as it is
+  }
+  ctx->merlin_passes = 0;
+  hipLaunchKernelGGL(cg1merlin::k_merlin_batch, dim3(nblk), dim3(cg1merlin::LANES), 0, ctx->stream,
                      (const uint8_t*)dst.p, (const cg1merlin::Op*)dops.p, (uint32_t)nops, (const uint8_t*)d_data, data_stride,
                      (uint8_t*)d_out, out_stride, (uint8_t*)d_states_out, (uint32_t)n);
   HIPCHK(hipStreamSynchronize(ctx->stream));

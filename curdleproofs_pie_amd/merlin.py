@@ -147,8 +147,13 @@ class TranscriptProgram:
         d_st = ctx.alloc(n * N.MERLIN_STATE_BYTES) if want_states else None
         d_data.upload(b"".join(r.ljust(stride, b"\0") for r in rows))
         ops = (N.MerlinOp * max(1, len(self._ops)))(*self._ops)
+        import time
+
+        t0 = time.perf_counter()
         ctx.check(N.cg1_merlin_batch_device(ctx.handle, self._init, ops, len(self._ops), d_data.ptr, stride, d_out.ptr, ostride,
                                             d_st.ptr if d_st else None, n))
+        self.last_call_ms = (time.perf_counter() - t0) * 1e3          # the device call alone (inputs already resident)
+        self.last_passes = int(N.cg1_merlin_last_passes(ctx.handle))  # Keccak passes of the slowest wave (k_merlin_batch_sync)
         out = d_out.download(n * ostride)
         outs = [out[i * ostride: (i + 1) * ostride] for i in range(n)]
         states = None

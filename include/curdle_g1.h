@@ -290,6 +290,9 @@ typedef struct cg1_merlin_op {
   uint32_t len, data_off, out_off;
   uint8_t label[32];
 } cg1_merlin_op;
+/* Keccak passes the slowest wave of the last cg1_merlin_batch_device call executed (the lanes of a wave permute together;
+ * a shuffle-shaped program needs ~750 permutations per transcript). */
+int cg1_merlin_last_passes(const cg1_ctx* ctx);
 int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg1_merlin_op* ops, size_t nops, const void* d_data,
                             size_t data_stride, void* d_out, size_t out_stride, void* d_states_out, size_t n);
 

@@ -17,11 +17,11 @@ batch with tampered proofs at known slots through the GPU verifier.
     python tests/golden/gen_shuffle_batch.py [--backend oracle|product] [--count 64] [--workers 8] [--out DIR]
 
 EXTENSION to 1024 distinct proofs ("1 024 / 16 384 distinct proofs"):
-    python tests/golden/gen_shuffle_batch.py --backend product --first 64 --count 960
+    python tests/golden/gen_shuffle_batch.py --first 64 --count 960 --workers 5
 writes shuffle_batch_ell124_more.{bin,json}: proofs 64 .. 1023 of the SAME seeded sequence (seed 9100 + i, same CRS), records
-only.  Pure-Python arithmetic would need ~20 core-hours for them, so these are made by the reference prover over the product's
-host backend -- the backend tests/test_golden_backends.py shows to reproduce proofs 0 .. 63 (and every other fixture) byte for
-byte; the .json says so ("backend").  Every proof is accepted by the reference verifier before it is written.
+only, made like the first 64 by the reference prover over the oracle backend (35 minutes on five cores; `--backend product`
+writes the very same 27 MB in 5 minutes -- tests/test_golden_backends.py re-makes records of it over both backends).  Every proof
+is accepted by the reference verifier before it is written.
 """
 import hashlib
 import json

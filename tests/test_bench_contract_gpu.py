@@ -109,3 +109,19 @@ def test_rccl_through_the_c_abi_single_rank():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_nccl_selftest.py")], capture_output=True, text=True, timeout=600, cwd=ROOT,
                        env={**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
     assert r.returncode == 0 and "rccl selftest ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
+
+
+def test_rccl_refusal_falls_back_to_the_socket_transport():
+    """Two ranks on ONE device with the RCCL backend forced: ncclCommInitRank refuses (duplicate GPU).  Every rank must notice,
+    start over on the socket transport and say so in the line -- not hang, not die."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env["CG1_BENCH_TRY_RCCL_ON_ONE_DEVICE"] = "1"
+    env["NCCL_DEBUG"] = "WARN"
+    r = subprocess.run(["timeout", "-k", "10", "400", sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--logn", "14",
+                        "--same-device", "--backend", "rccl", "--no-cpu-baseline", "--no-secondary"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    col = d["collective"]
+    assert col["backend"] == "socket" and "RCCL not attached" in col["backend_note"] and col["world_seen"] == 2
+    assert d["config"]["result_equals_closed_form"] is True
