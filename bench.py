@@ -495,6 +495,9 @@ def main():
                 out.append(finish(pending))
             return out
 
+        # bring the chip to the clock it holds under load before anything is timed: after the idle spell of input generation the first
+        # ~50 ms of work run at a ramping clock (the same kernels measure 28 T mad/s there and 33 once warm: profiles/r03_v2_bench.json)
+        ctx.probe_mad_rate(2, 200)
         results = stream(warmup)
         ex["t"], ex["n"] = 0.0, 0
         phase_acc.clear()

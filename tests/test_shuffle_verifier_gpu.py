@@ -130,36 +130,30 @@ def test_single_proof_wrapper_and_bad_shapes(gold, ctx):
 def _rank_sharded_verify(rank, world, port, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import torch.distributed as dist
-
     from curdleproofs_pie_amd import _native as N
-    from curdleproofs_pie_amd.distributed import sharded_verify
+    from curdleproofs_pie_amd.distributed import init_comm, sharded_verify
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
     from test_shuffle_verifier import apply_edits
 
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = init_comm(rank, world, rendezvous_file=port, timeout_s=300)      # the library's own exchange (socket transport: both ranks on one GPU)
     with open(os.path.join(ROOT, "tests", "golden", "shuffle_vectors.json")) as f:
         case = json.load(f)["cases"][2]
     v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), N.Context(0), threads=4)
     variants = case["variants"]
     inst, proofs, _ = v.pack([apply_edits(case, x["edits"]) for x in variants])
-    status = sharded_verify(v, inst, proofs, len(variants), rank, world)
+    status = sharded_verify(v, inst, proofs, len(variants), rank, world, comm=comm)
     q.put((rank, status, [x["accepts"] for x in variants]))
-    dist.barrier()
-    dist.destroy_process_group()
+    comm.barrier()
+    comm.close()
 
 
 def test_two_ranks_share_a_batch_on_the_gpu(gold):
-    """BASELINE config 5's structure with the real GPU path: two ranks (both on this GPU, gloo transport) verify disjoint
-    slices of one batch and all-gather the verdicts; every rank ends with the reference's verdict for every proof."""
-    import socket
+    """BASELINE config 5's structure with the real GPU path: two ranks (both on this GPU, cg1_comm_* socket transport) verify
+    disjoint slices of one batch and all-gather the verdicts; every rank ends with the reference's verdict for every proof."""
+    import multiprocessing as mp
+    import tempfile
 
-    import torch.multiprocessing as mp
-
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    port = os.path.join(tempfile.mkdtemp(prefix="cg1_rdzv_test_"), "rdzv")
     mpctx = mp.get_context("spawn")
     q = mpctx.Queue()
     procs = [mpctx.Process(target=_rank_sharded_verify, args=(r, 2, port, q)) for r in range(2)]
