@@ -72,3 +72,23 @@ def test_shuffle_front_end_under_asan_ubsan(tmp_path):
                        env={**os.environ, "ASAN_OPTIONS": "detect_leaks=0", "UBSAN_OPTIONS": "print_stacktrace=1"})
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "sanitize ok" in r.stdout
+
+
+import pytest
+
+
+@pytest.mark.parametrize("flags", [["-fsanitize=address,undefined", "-fno-sanitize-recover=all"], ["-fsanitize=thread"]], ids=["asan_ubsan", "tsan"])
+def test_comm_socket_transport_under_sanitizers(flags):
+    """csrc/comm.cpp: four ranks as threads over the TCP control channel (rendezvous with a stranger on the port, all-gathers,
+    the G1 all-reduce, a mismatched collective) under ASan + UBSan and under ThreadSanitizer."""
+    out_dir = os.path.join(ROOT, "tests", "native", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    exe = os.path.join(out_dir, "sanitize_comm_" + ("tsan" if "thread" in flags[0] else "asan"))
+    csrc = os.path.join(ROOT, "curdleproofs_pie_amd", "csrc")
+    src = [os.path.join(ROOT, "tests", "native", "sanitize_comm.cpp"), os.path.join(csrc, "comm.cpp"), os.path.join(csrc, "host_g1.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", *flags, "-fno-omit-frame-pointer", "-Wno-psabi", "-I/opt/rocm/include",
+                           *src, "-ldl", "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                       env={**os.environ, "ASAN_OPTIONS": "detect_leaks=1", "UBSAN_OPTIONS": "print_stacktrace=1", "TSAN_OPTIONS": "halt_on_error=1"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "sanitize ok" in r.stdout
