@@ -47,6 +47,60 @@ __global__ void __launch_bounds__(128) k_batch_mul(const uint32_t* __restrict__ 
   fp_to_words(fp_mul(acc.Y, izzz), o); for (int k = 0; k < 12; ++k) dst[12 + k] = o[k];
 }
 
+// The same map for SMALL n (the prover's fold launches: <= a few hundred outputs each, prover_kernels.py): the launch is a pure
+// latency chain, so one DPP QUAD per output (g1_quad.h: doubling 3.5 instead of 8 multiply-times, addition 4.5 instead of 14.5)
+// and two scalar bits per step over the table {P, 2P, 3P}: 128 x (2 doublings + 1 addition) instead of 255 x (doubling + mixed
+// addition whenever any lane of the wave has the bit set).  Same outputs, bit for bit (tests/test_prover_kernels_gpu.py).
+__global__ void __launch_bounds__(64) k_batch_mul_quad(const uint32_t* __restrict__ base_raw, uint32_t nbase,
+                                                       const uint32_t* __restrict__ scalars, uint32_t nscalars,
+                                                       const uint32_t* __restrict__ addend_raw, uint32_t* __restrict__ out_raw, uint32_t n) {
+  const uint32_t t = blockIdx.x * 64 + threadIdx.x, i = t >> 2, q = t & 3u;
+  if (i >= n) return;                                   // whole quads leave together
+  uint32_t w[24];
+  const uint32_t* src = base_raw + 24ull * (i % nbase);
+  uint32_t any = 0;
+  for (int k = 0; k < 24; ++k) { w[k] = src[k]; any |= w[k]; }
+  uint32_t s[8];
+  for (int k = 0; k < 8; ++k) s[k] = scalars[8ull * (i % nscalars) + k];
+  xyzz acc = xyzz_identity();
+  if (any) {
+    const xyzz P1 = xyzz_from_affine(fp_to_mont(fp_from_words(w)), fp_to_mont(fp_from_words(w + 12)));
+    const xyzz P2 = quad_dbl(P1, q);
+    const xyzz P3 = quad_add(P2, P1, q);
+#pragma unroll 1
+    for (int pair = 127; pair >= 0; --pair) {
+      acc = quad_dbl(quad_dbl(acc, q), q);
+      const uint32_t d = (s[pair >> 4] >> ((pair & 15) * 2)) & 3u;
+      if (d) {                                            // uniform inside the quad (its 4 lanes hold the same scalar)
+        xyzz T;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+          T.X.l[k] = d == 1u ? P1.X.l[k] : (d == 2u ? P2.X.l[k] : P3.X.l[k]);
+          T.Y.l[k] = d == 1u ? P1.Y.l[k] : (d == 2u ? P2.Y.l[k] : P3.Y.l[k]);
+          T.ZZ.l[k] = d == 1u ? P1.ZZ.l[k] : (d == 2u ? P2.ZZ.l[k] : P3.ZZ.l[k]);
+          T.ZZZ.l[k] = d == 1u ? P1.ZZZ.l[k] : (d == 2u ? P2.ZZZ.l[k] : P3.ZZZ.l[k]);
+        }
+        T.inf = 0;
+        acc = quad_add(acc, T, q);
+      }
+    }
+  }
+  if (addend_raw) {
+    const uint32_t* a = addend_raw + 24ull * i;
+    uint32_t aw[24], aany = 0;
+    for (int k = 0; k < 24; ++k) { aw[k] = a[k]; aany |= aw[k]; }
+    if (aany) acc = quad_add(acc, xyzz_from_affine(fp_to_mont(fp_from_words(aw)), fp_to_mont(fp_from_words(aw + 12))), q);
+  }
+  if (q) return;
+  uint32_t* dst = out_raw + 24ull * i;
+  if (acc.inf) { for (int k = 0; k < 24; ++k) dst[k] = 0; return; }
+  fp tinv = fp_inv(fp_mul(acc.ZZ, acc.ZZZ));
+  fp izz = fp_mul(tinv, acc.ZZZ), izzz = fp_mul(tinv, acc.ZZ);
+  uint32_t o[12];
+  fp_to_words(fp_mul(acc.X, izz), o);  for (int k = 0; k < 12; ++k) dst[k] = o[k];
+  fp_to_words(fp_mul(acc.Y, izzz), o); for (int k = 0; k < 12; ++k) dst[12 + k] = o[k];
+}
+
 // ------------------------------------------------------------------ segmented point sum (fourth pattern)
 // G_sum = reduce(lambda a, b: a + b, vec_G, Z1), H_sum likewise (crs.py:64-65): group j is the sum of the points
 // [offs[j], offs[j+1]) of the input.  One wave per group: the lanes stride over the group's points with mixed additions

@@ -240,6 +240,17 @@ __global__ void __launch_bounds__(256) k_small_tree(const PointSum* __restrict__
 }
 
 
+// XYZZ partial sums -> canonical words in the host's Montgomery form (regime B with few MSMs: their Horner runs on the host)
+__global__ void __launch_bounds__(64) k_export_sums(const PointSum* __restrict__ src, PointWords* __restrict__ out, uint32_t n) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  xyzz_words o;
+  xyzz_export(load_sum(src + i), o);
+  PointWords* dst = out + i;
+  for (int cidx = 0; cidx < 4; ++cidx) for (int k = 0; k < 12; ++k) dst->w[cidx][k] = o.w[cidx][k];
+  dst->inf = o.inf;
+}
+
 // The last kernel of an MSM call: the exported window sums (+ the status words behind them) from device memory into MAPPED HOST
 // memory, 16 bytes per store, then -- after a system-scope fence -- the call's sequence number into the flag word the host polls.
 // One block: 66 KB at most.

@@ -370,6 +370,27 @@ __global__ void __launch_bounds__(256) k_uscan3(const uint32_t* __restrict__ blo
   for (int k = 0; k < 4; ++k) if (base + k < n) a[base + k] += p;
 }
 
+// The same exclusive scan as ONE launch of one 1024-thread block, for n <= USCAN1_MAX items: each thread scans a contiguous run
+// (three launches of ~4.7 us each are all latency at the sizes of a mid-size MSM's sort: 5 K block counts at 2^16 terms).
+constexpr uint32_t USCAN1_MAX = 1u << 15;
+__global__ void __launch_bounds__(1024) k_uscan_one(uint32_t* __restrict__ a, uint32_t n) {
+  __shared__ uint32_t sh[1024];
+  const uint32_t per = (n + 1023u) / 1024u, lo = threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  uint32_t local = 0;
+  for (uint32_t i = lo; i < hi; ++i) local += a[i];
+  sh[threadIdx.x] = local;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint32_t u = ((int)threadIdx.x >= d) ? sh[threadIdx.x - d] : 0u;
+    __syncthreads();
+    sh[threadIdx.x] += u;
+    __syncthreads();
+  }
+  uint32_t excl = sh[threadIdx.x] - local;
+  for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = a[i]; a[i] = excl; excl += v; }
+  if (threadIdx.x == 1023) a[n] = sh[1023];
+}
+
 // ------------------------------------------------------------------ regime B: many independent small MSMs
 // A batch of M MSMs (MSM j = terms [offs[j], offs[j+1]) of one concatenated input) -- e.g. the 5*ell+7-term
 // final MSMs of 1024 MSMAccumulator.verify() calls (msm_accumulator.py:60-68).  Bucket space is indexed by
@@ -527,6 +548,32 @@ __global__ void __launch_bounds__(256) k_scan3(const uint2* __restrict__ block_t
 
 constexpr uint32_t LEN_BINS = 256;      // chunk-length keys: min(len, 255)
 __device__ __forceinline__ uint32_t len_key(uint32_t len) { return len < LEN_BINS - 1 ? len : LEN_BINS - 1; }
+
+// k_scan1 + k_scan2 + k_scan3 as one launch of one 1024-thread block, for nb_total <= SCAN1_MAX buckets
+constexpr uint32_t SCAN1_MAX = 1u << 13;        // beyond a few thousand buckets the serial runs of one block cost more than three launches (170 us at 82 K buckets)
+__global__ void __launch_bounds__(1024) k_scan_one(const uint32_t* __restrict__ hist, uint32_t* __restrict__ off, uint32_t* __restrict__ choff,
+                                                    uint32_t nb_total, uint32_t L0) {
+  __shared__ uint2 sh[1024];
+  const uint32_t per = (nb_total + 1023u) / 1024u, lo = threadIdx.x * per, hi = (lo + per < nb_total) ? lo + per : nb_total;
+  uint2 local = make_uint2(0, 0);
+  for (uint32_t i = lo; i < hi; ++i) { const uint32_t c = hist[i]; local.x += c; local.y += chunk_count(c, L0); }
+  sh[threadIdx.x] = local;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    uint2 v = make_uint2(0, 0);
+    if ((int)threadIdx.x >= d) v = sh[threadIdx.x - d];
+    __syncthreads();
+    sh[threadIdx.x].x += v.x; sh[threadIdx.x].y += v.y;
+    __syncthreads();
+  }
+  uint2 excl = make_uint2(sh[threadIdx.x].x - local.x, sh[threadIdx.x].y - local.y);
+  for (uint32_t i = lo; i < hi; ++i) {
+    const uint32_t c = hist[i];
+    off[i] = excl.x; choff[i] = excl.y;
+    excl.x += c; excl.y += chunk_count(c, L0);
+  }
+  if (threadIdx.x == 1023) { off[nb_total] = sh[1023].x; choff[nb_total] = sh[1023].y; }
+}
 
 __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__ off, const uint32_t* __restrict__ choff,
                                                     uint2* __restrict__ desc, uint32_t* __restrict__ len_hist,

@@ -139,6 +139,8 @@ struct Ctx {
   uint32_t merlin_clk[2] = {0, 0};
   int merlin_lanes = 64;                // transcripts per wave of k_merlin_batch_sync ("merlin_lanes": 1 .. 64)
   uint32_t merlin_passes = 0;           // of the last cg1_merlin_batch_device call: Keccak passes of the slowest wave
+  int batch_mul_quad_max = 8192;        // k_batch_mul_quad up to this many outputs ("batch_mul_quad_max"; 0 = always one lane per output)
+  int scan_one = 1;                     // the sort's two scans as one single-block launch each when they are small (A/B switch)
   int fold_pass = 1;                    // k_bucket_fold in front of k_rowcol / k_seg_reduce; 0 leaves multi-chunk buckets to their bucket_sum loops
                                         // (measured WORSE: 372 instead of 235 us at 2^16 -- divergent trip counts inside the row / column lanes)
   int auto_plan = 1;                    // window_c = 0 picks balanced window plans for mid-size inputs (A/B switch)
@@ -160,6 +162,8 @@ struct Ctx {
   uint32_t* d_boffs = nullptr; size_t cap_boffs = 0;          // regime B: MSM offsets, group sums, per-MSM results
   PointSum* d_gsum = nullptr; size_t cap_gsum = 0;
   PointWords* d_bout = nullptr; PointWords* h_bout = nullptr; size_t cap_bout = 0;
+  PointWords* d_gout = nullptr; PointWords* h_gout = nullptr; size_t cap_gout = 0;       // regime B, few MSMs: window sums exported for the host Horner
+  int batched_host_horner_max = 24;     // regime B calls with at most this many MSMs run their Horner on the host ("batched_host_horner_max")
   PointSum *d_sums = nullptr, *d_segrun = nullptr, *d_segtot = nullptr;
   PointWords* d_out = nullptr;
   PointWords* h_out = nullptr;          // pinned, and mapped into the device: k_export_host writes the window sums straight into it
@@ -193,6 +197,9 @@ static void free_bufs(Ctx* c) {
   F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot); F(c->d_boffs); F(c->d_gsum); F(c->d_bout);
   F(c->d_slice_base); F(c->d_slicehist); F(c->d_subbase); F(c->d_bigflag); c->cap_bigflag = 0; c->cap_slices = 0;
   if (c->h_bout) { (void)hipHostFree(c->h_bout); c->h_bout = nullptr; }
+  if (c->d_gout) { (void)hipFree(c->d_gout); c->d_gout = nullptr; }
+  if (c->h_gout) { (void)hipHostFree(c->h_gout); c->h_gout = nullptr; }
+  c->cap_gout = 0;
   c->cap_boffs = c->cap_gsum = c->cap_bout = 0;
   c->cap_digits = c->cap_part = c->cap_blockcnt = 0;
   if (c->h_out) { (void)hipHostFree(c->h_out); c->h_out = nullptr; }
@@ -423,9 +430,13 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
     hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_digits, n32, plan, rank, world, bad_flag);
     hipLaunchKernelGGL(k_part_count, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, n32, nslices, nbins, sub_bits);
     const uint32_t ublk = (nbc + SCAN_ITEMS - 1) / SCAN_ITEMS;
-    hipLaunchKernelGGL(k_uscan1, dim3(ublk), dim3(256), 0, st, ctx->d_blockcnt, ctx->d_ublocktot, nbc);
-    hipLaunchKernelGGL(k_uscan2, dim3(1), dim3(256), 0, st, ctx->d_ublocktot, ublk, ctx->d_blockcnt, nbc);
-    hipLaunchKernelGGL(k_uscan3, dim3(ublk), dim3(256), 0, st, ctx->d_ublocktot, ctx->d_blockcnt, nbc);
+    if (ctx->scan_one && nbc <= USCAN1_MAX) {
+      hipLaunchKernelGGL(k_uscan_one, dim3(1), dim3(1024), 0, st, ctx->d_blockcnt, nbc);
+    } else {
+      hipLaunchKernelGGL(k_uscan1, dim3(ublk), dim3(256), 0, st, ctx->d_blockcnt, ctx->d_ublocktot, nbc);
+      hipLaunchKernelGGL(k_uscan2, dim3(1), dim3(256), 0, st, ctx->d_ublocktot, ublk, ctx->d_blockcnt, nbc);
+      hipLaunchKernelGGL(k_uscan3, dim3(ublk), dim3(256), 0, st, ctx->d_ublocktot, ctx->d_blockcnt, nbc);
+    }
     if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[2], st));
     hipLaunchKernelGGL(k_part_scatter, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, ctx->d_part, n32, nslices, nbins, sub_bits, ctx->stage_sort);
     const uint32_t nbt = (uint32_t)nlw * nbins;
@@ -438,9 +449,13 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
       hipLaunchKernelGGL(k_slice_scatter, dim3(max_slices), dim3(256), 0, st, ctx->d_part, ctx->d_blockcnt, nbt, nslices, ctx->d_slice_base, ctx->d_slicehist, ctx->d_subbase, ctx->d_sorted);
     }
     if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
-    hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
-    hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
-    hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+    if (ctx->scan_one && nb_total <= SCAN1_MAX) {
+      hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(1024), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, (uint32_t)nb_total, L0);
+    } else {
+      hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
+      hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+      hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
+    }
   } else {
     // ---- global-atomic counting sort (any n < 2^31)
     HIPCHK(hipMemsetAsync(ctx->d_hist, 0, nb_total * 4, st));
@@ -752,9 +767,27 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
   hipLaunchKernelGGL(k_group_reduce, dim3((uint32_t)((G + 255) / 256)), dim3(256), 0, st, ctx->d_segrun, ctx->d_segtot, ctx->d_gsum, (uint32_t)G, J, log2m);
   if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
-  if (ctx->quad) hipLaunchKernelGGL(k_msm_horner_quad, dim3((uint32_t)((M * 4 + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
-  else hipLaunchKernelGGL(k_msm_horner, dim3((uint32_t)((M + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
-  HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, (M + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
+  // The Horner over an MSM's window sums is 255 DEPENDENT doublings: ~1.0 ms for a DPP quad, ~65 us for a host core.  A handful of
+  // MSMs (the prover's halving rounds: 4-6 per call) therefore finish on the host, on the context's four threads; hundreds of them
+  // (a batch of accumulator MSMs) keep the device's one-quad-per-MSM kernel, which does them all in the same millisecond.
+  const bool host_horner = M <= (size_t)ctx->batched_host_horner_max;
+  if (host_horner) {
+    if (G > ctx->cap_gout) {
+      if (ctx->d_gout) (void)hipFree(ctx->d_gout);
+      if (ctx->h_gout) (void)hipHostFree(ctx->h_gout);
+      ctx->d_gout = nullptr; ctx->h_gout = nullptr; ctx->cap_gout = 0;
+      HIPCHK(hipMalloc(&ctx->d_gout, G * sizeof(PointWords)));
+      HIPCHK(hipHostMalloc(&ctx->h_gout, G * sizeof(PointWords)));
+      ctx->cap_gout = G;
+    }
+    hipLaunchKernelGGL(k_export_sums, dim3((uint32_t)((G + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_gout, (uint32_t)G);
+    HIPCHK(hipMemcpyAsync(ctx->h_gout, ctx->d_gout, G * sizeof(PointWords), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ctx->h_bout + M, ctx->d_bout + M, sizeof(PointWords), hipMemcpyDeviceToHost, st));      // the status words
+  } else {
+    if (ctx->quad) hipLaunchKernelGGL(k_msm_horner_quad, dim3((uint32_t)((M * 4 + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
+    else hipLaunchKernelGGL(k_msm_horner, dim3((uint32_t)((M + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
+    HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, (M + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
+  }
   if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
   { int wrc = wait_stream(ctx); if (wrc) return wrc; }
@@ -770,7 +803,22 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   auto h2 = std::chrono::steady_clock::now();
   { int erc = read_phase_events(ctx, ctx->profile); if (erc) return erc; }
   ctx->last_c = c;
-  for (size_t j = 0; j < M; ++j) results[j] = jac_from_words(ctx->h_bout[j]);
+  if (host_horner) {
+    auto one = [&](size_t j) {
+      cg1h::jac a = cg1h::jac_identity();
+      for (int w = (int)nwin - 1; w >= 0; --w) {
+        for (int k = 0; k < c; ++k) a = cg1h::jac_dbl(a);
+        a = cg1h::jac_add(a, jac_from_words(ctx->h_gout[j * nwin + (size_t)w]));
+      }
+      results[j] = a;
+    };
+    const size_t nth = std::min<size_t>(4, M);
+    for (size_t t = 1; t < nth; ++t) ctx->helper[t - 1].run([&, t]() { for (size_t j = t; j < M; j += nth) one(j); });
+    for (size_t j = 0; j < M; j += nth) one(j);
+    for (size_t t = 1; t < nth; ++t) ctx->helper[t - 1].wait();
+  } else {
+    for (size_t j = 0; j < M; ++j) results[j] = jac_from_words(ctx->h_bout[j]);
+  }
   auto h3 = std::chrono::steady_clock::now();
   ctx->host_ms[0] = std::chrono::duration<float, std::milli>(h1 - h0).count();
   ctx->host_ms[1] = std::chrono::duration<float, std::milli>(h2 - h1).count();
@@ -1000,6 +1048,9 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "rowcol_quad")) { ctx->rowcol_quad = value != 0; return CG1_OK; }
   if (!strcmp(name, "rowcol_quad_max")) { if (value < 0) return CG1_ERR_ARG; ctx->rowcol_quad_max = value; return CG1_OK; }
   if (!strcmp(name, "fold_pass")) { ctx->fold_pass = value != 0; return CG1_OK; }
+  if (!strcmp(name, "scan_one")) { ctx->scan_one = value != 0; return CG1_OK; }
+  if (!strcmp(name, "batched_host_horner_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batched_host_horner_max = value; return CG1_OK; }
+  if (!strcmp(name, "batch_mul_quad_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batch_mul_quad_max = value; return CG1_OK; }
   if (!strcmp(name, "merlin_sync")) { ctx->merlin_sync = value != 0; return CG1_OK; }
   if (!strcmp(name, "merlin_lanes")) { if (value < 1 || value > 64) return CG1_ERR_ARG; ctx->merlin_lanes = value; return CG1_OK; }
   if (!strcmp(name, "tree_half")) { ctx->tree_half = value != 0; return CG1_OK; }
@@ -1154,9 +1205,14 @@ int cg1_batch_mul_add_device(cg1_ctx* ctx, const void* d_bases, size_t nbase, co
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(cg1::k_batch_mul, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                     (const uint32_t*)d_bases, (uint32_t)nbase, (const uint32_t*)d_scalars, (uint32_t)nscalars,
-                     (const uint32_t*)d_addend, (uint32_t*)d_out, (uint32_t)n);
+  if (ctx->quad && n <= (size_t)ctx->batch_mul_quad_max)       // latency-bound launches: one DPP quad per output
+    hipLaunchKernelGGL(cg1::k_batch_mul_quad, dim3((unsigned)((n * 4 + 63) / 64)), dim3(64), 0, ctx->stream,
+                       (const uint32_t*)d_bases, (uint32_t)nbase, (const uint32_t*)d_scalars, (uint32_t)nscalars,
+                       (const uint32_t*)d_addend, (uint32_t*)d_out, (uint32_t)n);
+  else
+    hipLaunchKernelGGL(cg1::k_batch_mul, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
+                       (const uint32_t*)d_bases, (uint32_t)nbase, (const uint32_t*)d_scalars, (uint32_t)nscalars,
+                       (const uint32_t*)d_addend, (uint32_t*)d_out, (uint32_t)n);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   return CG1_OK;
