@@ -21,6 +21,7 @@ verifier must not be predictable, so weights come from `secrets` unless the call
 from __future__ import annotations
 
 import ctypes
+import os
 import secrets
 from typing import List, Optional, Sequence, Tuple
 
@@ -119,10 +120,16 @@ class Prepared:
 
 
 class ShuffleBatchVerifier:
-    def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True):
+    def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True,
+                 blocking_sync: Optional[bool] = None):
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
+        # blocking_sync: the two GPU-lane threads wait for the device asleep (hipEventBlockingSync) instead of spinning.  Measured
+        # neutral on a 16-thread box (profiles/r03_verify_thread_sweep.txt: the front-end is bound by its 8 physical cores either
+        # way), so the default stays the lower-latency spinning wait; CURDLE_G1_BLOCKING_SYNC=1 turns it on.
+        env = os.environ.get("CURDLE_G1_BLOCKING_SYNC")
+        self.blocking_sync = (env == "1") if env is not None else bool(blocking_sync)
         self.chunk = chunk                  # sub-batch of the decompress / front-end pipeline
         self._gpu_threads = [None, None]
         self._gpu_jobs = [None, None]
@@ -162,6 +169,9 @@ class ShuffleBatchVerifier:
         if self._ctx_msm is not None:
             self._ctx_msm.close()
             self._ctx_msm = None
+        if getattr(self, "_ctx_blocking", False) and self._ctx is not None and self._ctx.handle:
+            self._ctx.set_param("blocking_sync", 0)
+            self._ctx_blocking = False
 
     def __del__(self):
         try:
@@ -226,6 +236,9 @@ class ShuffleBatchVerifier:
     def ctx(self) -> "N.Context":
         if self._ctx is None:
             self._ctx = N.default_context()
+        if self.blocking_sync and not getattr(self, "_ctx_blocking", False):
+            self._ctx.set_param("blocking_sync", 1)        # (a shared context: close() sets it back)
+            self._ctx_blocking = True
         return self._ctx
 
     @property
@@ -234,6 +247,7 @@ class ShuffleBatchVerifier:
         kernels then overlap the decompression of the next batch (which runs on `ctx` from another thread)."""
         if self._ctx_msm is None:
             self._ctx_msm = N.Context(self.ctx.device)
+            self._ctx_msm.set_param("blocking_sync", 1 if self.blocking_sync else 0)
         return self._ctx_msm
 
     def _gpu_submit(self, fn, lane: int = 0) -> None:
@@ -648,6 +662,9 @@ class OpeningBatchVerifier:
     def ctx(self) -> "N.Context":
         if self._ctx is None:
             self._ctx = N.default_context()
+        if self.blocking_sync and not getattr(self, "_ctx_blocking", False):
+            self._ctx.set_param("blocking_sync", 1)        # (a shared context: close() sets it back)
+            self._ctx_blocking = True
         return self._ctx
 
     def prepare(self, items, rng=None):

@@ -12,9 +12,10 @@ ctx = N.Context(0)
 n = 1024
 inst, proofs, want = fx.tiled(n)
 print("default threads:", N.cg1_shuffle_default_threads(), "os.cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)), flush=True)
-for rep in range(2):
-    for threads in (8, 12, 14, 16, 18, 20, 24, 32):
-        v = ShuffleBatchVerifier(fx.crs, ctx, threads=threads)
+for rep, blocking in ((0, False), (1, True), (2, False), (3, True)):
+    print("GPU lanes wait", "asleep (blocking sync)" if blocking else "spinning", flush=True)
+    for threads in (8, 12, 14, 16, 18, 20):
+        v = ShuffleBatchVerifier(fx.crs, ctx, threads=threads, blocking_sync=blocking)
         list(v.verify_stream([(inst, proofs, n)] * 2))
         K = 16
         acc = {}
