@@ -312,12 +312,20 @@ int cg1_comm_attach_rccl(cg1_comm* c, cg1_ctx* ctx) {
   int rc = socket_allgather(c, &mine, 1, all.data());
   if (rc) return rc;
   for (int r = 0; r < c->world; ++r) if (!all[r]) { if (mine) snprintf(c->err, sizeof c->err, "rank %d could not load librccl.so", r); return CG1_ERR_COMM; }
-  ncclUniqueId id;
-  memset(&id, 0, sizeof id);
-  if (c->rank == 0) COMM_NCCL(g_rccl.GetUniqueId(&id));
-  std::vector<uint8_t> ids(sizeof id * (size_t)c->world);
-  if ((rc = socket_allgather(c, &id, sizeof id, ids.data()))) return rc;
-  memcpy(&id, ids.data(), sizeof id);                                  // rank 0's
+  // rank 0's unique id travels over the control channel with a validity byte, so a failed ncclGetUniqueId is an error on every
+  // rank at once (nobody is left waiting inside ncclCommInitRank for a rank that never comes)
+  struct IdMsg { uint8_t ok; uint8_t pad[7]; ncclUniqueId id; } msg;
+  memset(&msg, 0, sizeof msg);
+  if (c->rank == 0) {
+    ncclResult_t r = g_rccl.GetUniqueId(&msg.id);
+    msg.ok = r == ncclSuccess ? 1 : 0;
+    if (!msg.ok) snprintf(c->err, sizeof c->err, "ncclGetUniqueId failed: %s", g_rccl.GetErrorString(r));
+  }
+  std::vector<uint8_t> ids(sizeof msg * (size_t)c->world);
+  if ((rc = socket_allgather(c, &msg, sizeof msg, ids.data()))) return rc;
+  memcpy(&msg, ids.data(), sizeof msg);                                // rank 0's
+  if (!msg.ok) { if (c->rank != 0) snprintf(c->err, sizeof c->err, "rank 0 could not create the RCCL unique id"); return CG1_ERR_COMM; }
+  ncclUniqueId id = msg.id;
   c->ctx = ctx;
   c->device = cg1_ctx_device(ctx);
   c->stream = static_cast<hipStream_t>(cg1_ctx_stream(ctx));
