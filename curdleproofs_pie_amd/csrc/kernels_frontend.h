@@ -1,0 +1,232 @@
+// The shuffle verifier's FRONT-END on the device (SURVEY 8(f) rows 1 + 3): everything csrc/shuffle_verify.cpp's
+// prepare_one does per proof between the wire bytes and the row builder's input block -- the Fiat-Shamir transcript
+// (curdleproofs_transcript.py:15-25 over merlin_transcripts/{merlin_transcript,strobe,keccak}.py), the grand-product scalar
+// (same_perm.py:98-101), D = B - beta^-1 G_sum + alpha H_sum (grand_prod.py:157) and A' = A + T_1 + U_1 (curdleproofs.py:210)
+// with their 48-byte encodings, inner_prod (grand_prod.py:164-166) and the challenge inverses (ipa.py:178, same_msm.py:175) --
+// one proof per lane, on the wire points the decompression stage already put into HBM.  Part of the single translation unit
+// csrc/msm_gpu.hip.
+//
+// The transcript is cg1merlin::Machine (kernels_merlin.h): a resumable byte-level STROBE state machine per lane, the lanes of a
+// wave permuting together.  The program is the verifier's own operation sequence (built on the host by fe_build_program in
+// msm_gpu.hip, the mirror of prepare_one); challenges are squeezed straight into their slots of the lane's row-input block
+// (cg1rows::RowIn layout, so k_shuffle_rows reads what this kernel wrote).  Three operations are BARRIERS: a lane that reaches
+// one waits until every lane of its wave has, then all take the step together -- the field / group arithmetic of a step is
+// thousands of instructions and must not run once per straggler:
+//   X_GPROD   prod_i (a_i + i alpha + beta)                                          -> scratch (absorbed next)
+//   X_DA      beta^-1, inner_prod; D (64 table additions: 8-bit fixed-base tables of G_sum and H_sum, + B), A'; one shared
+//             inversion; both compressed                                             -> row-input block + scratch
+//   X_FINAL   inverses of the 2 lg round challenges (Montgomery's trick); the finished block is copied to the caller's buffer
+// Output = exactly what cg1_shuffle_prepare_inputs writes on the host: the row-input block and the front-end status per proof
+// (tests/test_shuffle_frontend_gpu.py compares them byte for byte on every golden proof and tampered variant).
+#pragma once
+#include "fr.h"
+
+namespace cg1fe {
+using cg1fr::fr;
+using cg1merlin::COp;
+using cg1merlin::LANES;
+using cg1merlin::Machine;
+
+enum : uint8_t { X_GPROD = 16, X_DA = 17, X_FINAL = 18 };
+
+struct Params {
+  uint32_t ell, lg, L, K;                 // own points per proof, scalars of a row-input block
+  uint32_t out_stride;                    // bytes of a lane's private out row: (K + 6) * 32  [block | gprod | r_p | D48 (64 B) | A'48 (64 B)]
+  uint32_t idx_A, idx_T1, idx_U1, idx_B, idx_T0;   // own-point indices (csrc/shuffle_verify.cpp Layout)
+};
+
+__device__ __noinline__ fr fmul(const fr& a, const fr& b) { return cg1fr::fr_mul(a, b); }
+__device__ __noinline__ fr fld(const uint8_t* base, uint32_t slot) { fr v; cg1fr::fr_from_le32(base + 32u * slot, v); return v; }
+__device__ __noinline__ void fst(uint8_t* base, uint32_t slot, const fr& v) { cg1fr::fr_to_le32(v, base + 32u * slot); }
+__device__ inline fr fpow(fr base, uint64_t e) {
+  fr acc = cg1fr::fr_one();
+  while (e) { if (e & 1) acc = fmul(acc, base); base = fmul(base, base); e >>= 1; }
+  return acc;
+}
+__device__ __noinline__ fr finv(const fr& a) {                  // a^(r-2)
+  fr acc = cg1fr::fr_one();
+  for (int i = 254; i >= 0; --i) {
+    acc = fmul(acc, acc);
+    if ((cg1::H_FR_MINUS_2[i >> 6] >> (i & 63)) & 1) acc = fmul(acc, a);
+  }
+  return acc;
+}
+
+// affine standard words -> 48-byte ZCash encoding (the same rule as k_batch_compress)
+__device__ inline void compress48(const uint32_t w[24], bool inf, uint8_t* o) {
+  if (inf) { o[0] = 0xC0; for (int k = 1; k < 48; ++k) o[k] = 0; return; }
+  bool is_large = false, decided = false;
+  for (int j = 11; j >= 0 && !decided; --j) if (w[12 + j] != cg1::W_P_MINUS_1_HALF[j]) { is_large = w[12 + j] > cg1::W_P_MINUS_1_HALF[j]; decided = true; }
+  for (int j = 0; j < 12; ++j) {
+    const uint32_t v = w[11 - j];
+    o[4 * j] = (uint8_t)(v >> 24); o[4 * j + 1] = (uint8_t)(v >> 16); o[4 * j + 2] = (uint8_t)(v >> 8); o[4 * j + 3] = (uint8_t)v;
+  }
+  o[0] |= (uint8_t)(0x80 | (is_large ? 0x20 : 0));
+}
+
+// The four decoded points a proof's front-end needs as group elements (A, cm_T.T_1, cm_U.T_1, B: affine96 standard form as
+// k_batch_decompress wrote them; zeros = identity / failed decode) -> 128-byte Montgomery records, so that X_DA's additions read
+// every operand -- table entry or proof point -- the same way.
+__global__ void __launch_bounds__(256) k_fe_gather4(const uint32_t* __restrict__ aff, Params pr, uint32_t n, cg1::PreparedPoint* __restrict__ out) {
+  const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 4u * n) return;
+  const uint32_t proof = t >> 2, j = t & 3u;
+  const uint32_t idx = j == 0 ? pr.idx_A : (j == 1 ? pr.idx_T1 : (j == 2 ? pr.idx_U1 : pr.idx_B));
+  const uint32_t* src = aff + 24ull * ((size_t)proof * pr.L + idx);
+  uint32_t w[24], any = 0;
+  for (int k = 0; k < 24; ++k) { w[k] = src[k]; any |= w[k]; }
+  cg1::PreparedPoint rec;
+  const cg1::fp x = cg1::fp_to_mont(cg1::fp_from_words(w)), y = cg1::fp_to_mont(cg1::fp_from_words(w + 12));
+  for (int k = 0; k < cg1::NL; ++k) { rec.x[k] = x.l[k]; rec.y[k] = y.l[k]; }
+  rec.flags = any ? 0u : 1u;
+  rec.pad[0] = rec.pad[1] = rec.pad[2] = 0;
+  out[t] = rec;
+}
+
+// ---- the barrier steps (all lanes of the wave that are live take them together)
+__device__ __noinline__ void step_gprod(uint8_t* orow, const Params& pr) {
+  const cg1rows::RowIn R{pr.ell, pr.lg};
+  const fr alpha = fld(orow, (uint32_t)R.head()), beta = fld(orow, (uint32_t)R.head() + 1u);
+  fr t = beta, g = cg1fr::fr_one();                          // i * alpha + beta, built by repeated addition (same_perm.py:98-101)
+  for (uint32_t i = 0; i < pr.ell; ++i) {
+    g = fmul(g, cg1fr::fr_add(fld(orow, (uint32_t)R.a() + i), t));
+    t = cg1fr::fr_add(t, alpha);
+  }
+  fst(orow, pr.K, g);
+}
+
+__device__ __noinline__ void step_da(uint8_t* orow, const Params& pr, const cg1::PreparedPoint* __restrict__ tabG, const cg1::PreparedPoint* __restrict__ tabH,
+                                     const cg1::PreparedPoint* __restrict__ four) {
+  using namespace cg1;
+  const cg1rows::RowIn R{pr.ell, pr.lg};
+  const fr alpha_g = fld(orow, (uint32_t)R.head() + 2u), beta_g = fld(orow, (uint32_t)R.head() + 3u);
+  const fr beta_inv = finv(beta_g);
+  fst(orow, (uint32_t)R.beta_inv(), beta_inv);
+  {
+    const fr r_p = fld(orow, pr.K + 1u), gprod = fld(orow, pr.K);
+    const fr beta_ell = fpow(beta_g, pr.ell);
+    const fr ip = cg1fr::fr_sub(cg1fr::fr_add(fmul(r_p, fmul(beta_ell, beta_g)), fmul(gprod, beta_ell)), cg1fr::fr_one());   // grand_prod.py:164-166
+    fst(orow, (uint32_t)R.inner_prod(), ip);
+  }
+  // D = B - beta^-1 G_sum + alpha_g H_sum: one table entry per scalar byte; then A' = A + T_1 + U_1.  ONE addition call site: operand j
+  // of 68 is picked by address (tables, then the proof's four points), the accumulator is parked after B and restarted for A'.
+  uint8_t s1[32], s2[32];
+  cg1fr::fr_to_le32(cg1fr::fr_neg(beta_inv), s1);
+  cg1fr::fr_to_le32(alpha_g, s2);
+  xyzz acc = xyzz_identity(), Dp = xyzz_identity();
+#pragma unroll 1
+  for (uint32_t j = 0; j < 68u; ++j) {
+    const PreparedPoint* op;
+    bool skip = false;
+    if (j < 32u) { const uint32_t b = s1[j]; skip = b == 0u; op = tabG + (size_t)j * 256u + b; }
+    else if (j < 64u) { const uint32_t b = s2[j - 32u]; skip = b == 0u; op = tabH + (size_t)(j - 32u) * 256u + b; }
+    else if (j == 64u) op = four + 3;                      // B
+    else op = four + (j - 65u);                            // A, T_1, U_1
+    if (j == 65u) { Dp = acc; acc = xyzz_identity(); }
+    fp x, y; uint32_t flags;
+    load_affine(op, x, y, flags);
+    if (!skip && !(flags & 1u)) acc = xyzz_madd(acc, x, y);
+  }
+  // one inversion for both: 1 / (ZZ_D ZZZ_D ZZ_A ZZZ_A)
+  const fp one = fp_one();
+  const fp tD = Dp.inf ? one : fp_mul(Dp.ZZ, Dp.ZZZ), tA = acc.inf ? one : fp_mul(acc.ZZ, acc.ZZZ);
+  const fp inv = fp_inv(fp_mul(tD, tA));
+  const fp iD = fp_mul(inv, tA), iA = fp_mul(inv, tD);     // 1 / (ZZ ZZZ) of each
+  uint32_t w[24];
+  if (!Dp.inf) { fp_to_words(fp_mul(Dp.X, fp_mul(iD, Dp.ZZZ)), w); fp_to_words(fp_mul(Dp.Y, fp_mul(iD, Dp.ZZ)), w + 12); }
+  compress48(w, Dp.inf != 0, orow + 32u * (pr.K + 2u));
+  if (!acc.inf) { fp_to_words(fp_mul(acc.X, fp_mul(iA, acc.ZZZ)), w); fp_to_words(fp_mul(acc.Y, fp_mul(iA, acc.ZZ)), w + 12); }
+  compress48(w, acc.inf != 0, orow + 32u * (pr.K + 4u));
+}
+
+__device__ __noinline__ void step_final(uint8_t* orow, const Params& pr, uint8_t* __restrict__ block_out) {
+  const cg1rows::RowIn R{pr.ell, pr.lg};
+  // inverses of gamma[0..lg) and gamma_m[0..lg) with one inversion (fr_batch_inv of the host front-end, per vector there; the
+  // inverse of a field element is unique, so sharing the inversion across both vectors gives the same bytes)
+  const uint32_t m = 2u * pr.lg;
+  fr acc = cg1fr::fr_one();
+  for (uint32_t i = 0; i < m; ++i) {                       // prefix products parked in the inverse slots
+    fst(orow, (uint32_t)R.gam_inv() + i, acc);
+    acc = fmul(acc, fld(orow, (uint32_t)R.gam() + i));
+  }
+  fr inv = finv(acc);
+  for (uint32_t i = m; i-- > 0;) {
+    const fr pre = fld(orow, (uint32_t)R.gam_inv() + i);
+    fst(orow, (uint32_t)R.gam_inv() + i, fmul(inv, pre));
+    inv = fmul(inv, fld(orow, (uint32_t)R.gam() + i));
+  }
+  const uint4* src = reinterpret_cast<const uint4*>(orow);
+  uint4* dst = reinterpret_cast<uint4*>(block_out);
+  for (uint32_t i = 0; i < 2u * pr.K; ++i) dst[i] = src[i];
+}
+
+// grid = ceil(n / lanes_used) blocks of LANES threads.  aux: per proof r_p c_fin d_fin z_k z_t z_u x_fin | rho[12] (19 x 32 bytes, as they
+// stand in the proof / as the caller drew them).  scratch: n x out_stride bytes.  rowin: n x K x 32.  status: n front-end codes.
+__global__ void __launch_bounds__(LANES) k_shuffle_front_end(const uint8_t* __restrict__ init_state, const COp* __restrict__ ops, uint32_t nops,
+                                                             const uint32_t* __restrict__ label_table, uint32_t nlabels, const uint8_t* __restrict__ consts,
+                                                             const uint8_t* __restrict__ wire, const uint8_t* __restrict__ aux,
+                                                             const cg1::PreparedPoint* __restrict__ four, const cg1::PreparedPoint* __restrict__ tabG,
+                                                             const cg1::PreparedPoint* __restrict__ tabH, Params pr, uint8_t* __restrict__ scratch,
+                                                             uint8_t* __restrict__ rowin, int32_t* __restrict__ status, uint32_t n, uint32_t lanes_used) {
+  __shared__ uint32_t lds[52 * LANES];
+  __shared__ uint32_t lds_drawn[8 * LANES];
+  __shared__ uint32_t lds_labels[cg1merlin::MAX_LABELS * 8];
+  const uint32_t t = blockIdx.x * lanes_used + threadIdx.x;
+  const bool live = threadIdx.x < lanes_used && t < n;
+  for (uint32_t j = threadIdx.x; j < nlabels * 8u; j += LANES) lds_labels[j] = label_table[j];
+  Machine m;
+  m.w = lds + threadIdx.x;
+  m.drawn = lds_drawn + threadIdx.x;
+  m.labels = lds_labels;
+  m.consts = consts;
+  for (int i = 0; i < 50; ++i) m.w[i * LANES] = reinterpret_cast<const uint32_t*>(init_state)[i];
+  m.pos = init_state[200]; m.pos_begin = init_state[201]; m.cur_flags = init_state[202];
+  m.k = 0; m.ph = 0; m.i = 0; m.hdr = 0; m.stage = 0; m.k_loaded = 0xffffffffu; m.rec = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+  const size_t me = live ? t : 0;
+  const uint8_t* row = wire + me * (size_t)pr.L * 48u;
+  uint8_t* orow = scratch + me * (size_t)pr.out_stride;
+  bool done = !live;
+  if (live) {
+    // parse: the proof's Fr fields and the weights must be canonical (Scalar.from_le_bytes raises, util.py:149-153); vec_T[0] must
+    // not be the identity (curdleproofs.py:173-174).  Same precedence as prepare_one: scalar, T[0], weight.
+    const cg1rows::RowIn R{pr.ell, pr.lg};
+    const uint8_t* a = aux + me * (19u * 32u);
+    int32_t st = 0;
+    for (uint32_t k = 0; k < 19u; ++k) {
+      uint64_t v[4];
+      for (int q = 0; q < 4; ++q) { uint64_t x = 0; for (int b = 7; b >= 0; --b) x = (x << 8) | a[32u * k + 8u * q + b]; v[q] = x; }
+      const bool ok = !cg1fr::geq_r(v);
+      if (!ok && k < 7u && st != CG1_SHUFFLE_BAD_SCALAR) st = CG1_SHUFFLE_BAD_SCALAR;
+      if (!ok && k >= 7u && st == 0) st = CG1_SHUFFLE_BAD_WEIGHT;
+      const uint32_t slot = k == 0u ? pr.K + 1u : (k < 7u ? (uint32_t)R.fields() + (k - 1u) : (uint32_t)R.rho() + (k - 7u));
+      for (int q = 0; q < 4; ++q) reinterpret_cast<uint64_t*>(orow + 32u * slot)[q] = v[q];
+    }
+    if (st != CG1_SHUFFLE_BAD_SCALAR && (row[(size_t)pr.idx_T0 * 48u] & 0x40u)) st = CG1_SHUFFLE_T0_INFINITY;
+    status[t] = st;
+    if (st) {                                               // rejected before any hashing, like the host front-end: an all-zero block
+      uint4* dst = reinterpret_cast<uint4*>(rowin + (size_t)t * pr.K * 32u);
+      for (uint32_t i = 0; i < 2u * pr.K; ++i) dst[i] = make_uint4(0, 0, 0, 0);
+      done = true;
+    }
+  }
+  for (;;) {
+    bool needf = false, blocked = false;
+    if (!done) needf = m.advance(ops, nops, row, orow, done, blocked);
+    if (__ballot(needf) != 0ull) {
+      if (needf) { cg1merlin::keccak_words(m.w); m.pos = 0; m.pos_begin = 0; }
+      continue;
+    }
+    if (__ballot(blocked) == 0ull) break;                   // nobody hashes, nobody waits at a step: every lane is done
+    // every lane that is not done stands at the same barrier operation (same program, and nobody passes a barrier alone)
+    if (blocked) {
+      const uint32_t kind = m.rec.x & 0xffu;
+      if (kind == X_GPROD) step_gprod(orow, pr);
+      else if (kind == X_DA) step_da(orow, pr, tabG, tabH, four + 4u * me);
+      else step_final(orow, pr, rowin + (size_t)t * pr.K * 32u);
+      ++m.k; m.ph = 0; m.i = 0; m.stage = 0;
+    }
+  }
+}
+
+}  // namespace cg1fe

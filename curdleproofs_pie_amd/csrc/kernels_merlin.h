@@ -17,7 +17,11 @@ constexpr uint8_t FLAG_I = 1, FLAG_A = 2, FLAG_C = 4, FLAG_T = 8, FLAG_M = 16, F
 constexpr int LANES = 64;                    // threads per block
 
 // operation kinds of the batch interpreter
-enum : uint8_t { OP_APPEND = 0, OP_CHALLENGE = 1, OP_CHALLENGE_SCALAR = 2, OP_APPEND_OUT = 3 };
+enum : uint8_t { OP_APPEND = 0, OP_CHALLENGE = 1, OP_CHALLENGE_SCALAR = 2, OP_APPEND_OUT = 3,
+                 // k_merlin_batch_sync / k_shuffle_front_end only (not part of the public cg1_merlin_op):
+                 OP_APPEND_POINT = 4,       // 48 bytes of the data row, an encoding with the infinity flag absorbed as the canonical 0xC0 00..00
+                 OP_APPEND_CONST = 5,       // bytes of the launch's constant block
+                 OP_BARRIER = 16 };         // >= 16: a compute step every lane of the wave takes together (csrc/kernels_frontend.h)
 struct Op {                                  // 48 bytes, the same for every lane
   uint8_t kind, label_len;
   uint16_t pad;
@@ -239,6 +243,7 @@ struct Machine {
   uint32_t* w;                               // &lds[lane]; sponge word i at w[i * LANES]
   uint32_t* drawn;                           // &lds_drawn[lane]; word j of the challenge being drawn at drawn[j * LANES]
   const uint32_t* labels;                    // LDS label table: label L word j at labels[L * 8 + j]
+  const uint8_t* consts;                     // the launch's constant block (OP_APPEND_CONST; its first 48 bytes: the canonical infinity encoding)
   uint32_t pos, pos_begin, cur_flags;
   uint32_t k, ph, i, hdr, stage;             // op index, phase within the op, byte index within the phase, the two begin_op bytes, 0/1: challenge / append half of OP_CHALLENGE_SCALAR
   uint4 rec;                                 // the operation record of op `k_loaded`
@@ -330,12 +335,16 @@ struct Machine {
 
   // Run this lane's program until a permutation is due (returns true; the caller permutes, then sets pos = pos_begin = 0) or the
   // program ends (returns false with done = true).
-  __device__ __forceinline__ bool advance(const COp* __restrict__ ops, uint32_t nops, const uint8_t* __restrict__ row, uint8_t* __restrict__ orow, bool& done) {
+  // ... or a barrier operation is reached (returns false with blocked = true and k at that operation).
+  __device__ __forceinline__ bool advance(const COp* __restrict__ ops, uint32_t nops, const uint8_t* __restrict__ row, uint8_t* __restrict__ orow, bool& done,
+                                          bool& blocked) {
     for (;;) {
       if (k >= nops) { done = true; return false; }
       if (k != k_loaded) { rec = *reinterpret_cast<const uint4*>(ops + k); k_loaded = k; }      // one 16-byte load per operation
       const uint32_t kind = rec.x & 0xffu, lab = (rec.x >> 8) & 0xffu, llen = rec.x >> 16;
-      const bool as_append = kind == OP_APPEND || kind == OP_APPEND_OUT || (kind == OP_CHALLENGE_SCALAR && stage == 1u);
+      if (kind >= OP_BARRIER) { blocked = true; return false; }
+      const bool as_append = kind == OP_APPEND || kind == OP_APPEND_OUT || kind == OP_APPEND_POINT || kind == OP_APPEND_CONST ||
+                             (kind == OP_CHALLENGE_SCALAR && stage == 1u);
       const uint32_t len = kind == OP_CHALLENGE_SCALAR ? 32u : rec.y;
       switch (ph) {
         case 0: begin(FLAG_M | FLAG_A); i = 0; ph = 1; [[fallthrough]];       // frame: meta_ad(label), merlin_transcript.py:11-15 / :20-24
@@ -347,6 +356,11 @@ struct Machine {
         case 6: {                                                             // ad(message)
           bool full;
           if (kind == OP_CHALLENGE_SCALAR) full = absorb_lds(drawn, LANES, 32u);       // the accepted draw, still in LDS
+          else if (kind == OP_APPEND_POINT) {
+            const uint8_t* pt = row + rec.z;
+            full = absorb_global((pt[0] & 0xC0u) == 0xC0u ? consts : pt, 48u);        // util.py:27-32: points are hashed as re-serialised
+          }
+          else if (kind == OP_APPEND_CONST) full = absorb_global(consts + rec.z, len);
           else full = absorb_global(kind == OP_APPEND ? row + rec.z : orow + rec.w, len);
           if (full) return true;
           ++k; ph = 0; i = 0; stage = 0;
@@ -413,6 +427,7 @@ __global__ void __launch_bounds__(LANES) k_merlin_batch_sync(const uint8_t* __re
   m.w = lds + threadIdx.x;
   m.drawn = lds_drawn + threadIdx.x;
   m.labels = lds_labels;
+  m.consts = nullptr;
   for (int i = 0; i < 50; ++i) m.w[i * LANES] = reinterpret_cast<const uint32_t*>(init_state)[i];
   m.pos = init_state[200]; m.pos_begin = init_state[201]; m.cur_flags = init_state[202];
   m.k = 0; m.ph = 0; m.i = 0; m.hdr = 0; m.stage = 0; m.k_loaded = 0xffffffffu; m.rec = make_uint4(0, 0, 0, 0);
@@ -425,7 +440,9 @@ __global__ void __launch_bounds__(LANES) k_merlin_batch_sync(const uint8_t* __re
   for (;;) {
     bool needf = false;
     const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-    if (!done) needf = m.advance(ops, nops, row, orow, done);
+    bool blocked = false;
+    if (!done) needf = m.advance(ops, nops, row, orow, done, blocked);
+    if (blocked) done = true;                        // (no compute steps in a plain transcript program: treat as its end)
     const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     if (__ballot(needf) == 0ull) break;              // a lane only stops for a permutation or at its end: nobody waits -> everyone is done
     if (needf) { keccak_words(m.w); m.pos = 0; m.pos_begin = 0; }

@@ -33,6 +33,7 @@
 #include <cstdio>
 #include <cstring>
 #include <vector>
+#include <string>
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -58,6 +59,7 @@ int pick_window(size_t n);
 }  // namespace cg1
 #include "kernels_rows.h"
 #include "kernels_merlin.h"
+#include "kernels_frontend.h"
 namespace cg1 {
 
 // ------------------------------------------------------------------ host-side context
@@ -1376,6 +1378,185 @@ int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg
 // The scalar rows of a batch of shuffle statements, built on the device from the host front-end's input blocks
 // (cg1_shuffle_prepare_inputs), and the sum of the live proofs' CRS rows written behind the own-point scalars
 // (d_out_scalars: n_proofs x (4 ell + 19 + 10 lg) scalars, then ell + 9).  Asynchronous on the compute stream.
+}  // extern "C" (reopened below)
+
+// ---------------------------------------------------------------- the shuffle verifier's front-end on the device (kernels_frontend.h)
+struct cg1_shuffle_fe {
+  int device = 0;
+  cg1fe::Params pr{};
+  uint32_t nops = 0, nlabels = 0;
+  void *d_init = nullptr, *d_ops = nullptr, *d_labels = nullptr, *d_consts = nullptr, *d_tabG = nullptr, *d_tabH = nullptr;
+  void *d_four = nullptr, *d_scratch = nullptr; size_t cap_n = 0;
+  char err[200] = {0};
+};
+
+namespace {
+// The verifier's transcript as an operation list: the mirror of prepare_one (csrc/shuffle_verify.cpp), which follows
+// curdleproofs.py:176-180, same_perm.py:91-96, grand_prod.py:137-143, ipa.py:204-212 + :168-176, same_scalar.py:82-99,
+// same_msm.py:194-206 + :158-173.  Challenges land in their slots of the row-input block (cg1rows::RowIn).
+struct FeProgram {
+  std::vector<cg1merlin::COp> ops;
+  std::vector<uint32_t> table;
+  std::vector<std::string> labels;
+  uint32_t label(const char* s) {
+    for (size_t i = 0; i < labels.size(); ++i) if (labels[i] == s) return (uint32_t)i;
+    labels.emplace_back(s);
+    uint8_t padded[32] = {0};
+    memcpy(padded, s, strlen(s));
+    for (int j = 0; j < 8; ++j) { uint32_t v; memcpy(&v, padded + 4 * j, 4); table.push_back(v); }
+    return (uint32_t)labels.size() - 1;
+  }
+  void op(uint8_t kind, const char* lab, uint32_t len, uint32_t data_off, uint32_t out_off) {
+    const uint32_t li = lab ? label(lab) : 0u, ll = lab ? (uint32_t)strlen(lab) : 0u;
+    ops.push_back(cg1merlin::COp{(uint32_t)kind | (li << 8) | (ll << 16), len, data_off, out_off});
+  }
+  void point(const char* lab, size_t idx) { op(cg1merlin::OP_APPEND_POINT, lab, 48, (uint32_t)(idx * 48), 0); }
+  void out(const char* lab, size_t slot, uint32_t len) { op(cg1merlin::OP_APPEND_OUT, lab, len, 0, (uint32_t)(slot * 32)); }
+  void cst(const char* lab, uint32_t off) { op(cg1merlin::OP_APPEND_CONST, lab, 48, off, 0); }
+  void challenge(const char* lab, size_t slot) { op(cg1merlin::OP_CHALLENGE_SCALAR, lab, 32, 0, (uint32_t)(slot * 32)); }
+};
+
+void fe_build_program(size_t ell, size_t lg, FeProgram& P) {
+  const cg1rows::RowIn R{ell, lg};
+  const size_t K = R.count(), base = 4 * ell;
+  // own-point indices (csrc/shuffle_verify.cpp Layout)
+  const size_t M = base, A = base + 1, T1 = base + 2, T2 = base + 3, U1 = base + 4, U2 = base + 5, Rp = base + 6, Sp = base + 7, B = base + 8, C = base + 9,
+               Bc = base + 10, Bd = base + 11, LC = base + 12, RC = LC + lg, LD = LC + 2 * lg, RD = LC + 3 * lg, cmA1 = base + 12 + 4 * lg,
+               Ba = cmA1 + 4, Bt = cmA1 + 5, Bu = cmA1 + 6, LA = cmA1 + 7, LT = LA + lg, LU = LA + 2 * lg, RA = LA + 3 * lg, RT = LA + 4 * lg, RU = LA + 5 * lg;
+  for (size_t i = 0; i < 4 * ell; ++i) P.point("curdleproofs_step1", i);
+  P.point("curdleproofs_step1", M);
+  for (size_t i = 0; i < ell; ++i) P.challenge("curdleproofs_vec_a", R.a() + i);
+  P.point("same_perm_step1", A); P.point("same_perm_step1", M);
+  for (size_t i = 0; i < ell; ++i) P.out("same_perm_step1", R.a() + i, 32);
+  P.challenge("same_perm_alpha", R.head() + 0); P.challenge("same_perm_beta", R.head() + 1);
+  P.op(cg1fe::X_GPROD, nullptr, 0, 0, 0);
+  P.point("gprod_step1", B); P.out("gprod_step1", K + 0, 32);
+  P.challenge("gprod_alpha", R.head() + 2);
+  P.point("gprod_step2", C); P.out("gprod_step2", K + 1, 32);
+  P.challenge("gprod_beta", R.head() + 3);
+  P.op(cg1fe::X_DA, nullptr, 0, 0, 0);
+  P.point("ipa_step1", C); P.out("ipa_step1", K + 2, 48); P.out("ipa_step1", R.inner_prod(), 32); P.point("ipa_step1", Bc); P.point("ipa_step1", Bd);
+  P.challenge("ipa_alpha", R.head() + 4); P.challenge("ipa_beta", R.head() + 5);
+  for (size_t j = 0; j < lg; ++j) {
+    P.point("ipa_loop", LC + j); P.point("ipa_loop", LD + j); P.point("ipa_loop", RC + j); P.point("ipa_loop", RD + j);
+    P.challenge("ipa_gamma", R.gam() + j);
+  }
+  {
+    const size_t order[10] = {Rp, Sp, T1, T2, U1, U2, cmA1, cmA1 + 1, cmA1 + 2, cmA1 + 3};
+    for (size_t k = 0; k < 10; ++k) P.point("sameexp_points", order[k]);
+  }
+  P.challenge("same_scalar_alpha", R.head() + 6);
+  P.out("same_msm_step1", K + 4, 48); P.point("same_msm_step1", T2); P.point("same_msm_step1", U2);
+  for (size_t i = 0; i < ell; ++i) P.point("same_msm_step1", 2 * ell + i);
+  P.cst("same_msm_step1", 0); P.cst("same_msm_step1", 0); P.cst("same_msm_step1", 48); P.cst("same_msm_step1", 0);       // Z Z H Z
+  for (size_t i = 0; i < ell; ++i) P.point("same_msm_step1", 3 * ell + i);
+  P.cst("same_msm_step1", 0); P.cst("same_msm_step1", 0); P.cst("same_msm_step1", 0); P.cst("same_msm_step1", 48);       // Z Z Z H
+  P.point("same_msm_step1", Ba); P.point("same_msm_step1", Bt); P.point("same_msm_step1", Bu);
+  P.challenge("same_msm_alpha", R.head() + 7);
+  for (size_t j = 0; j < lg; ++j) {
+    P.point("same_msm_loop", LA + j); P.point("same_msm_loop", LT + j); P.point("same_msm_loop", LU + j);
+    P.point("same_msm_loop", RA + j); P.point("same_msm_loop", RT + j); P.point("same_msm_loop", RU + j);
+    P.challenge("same_msm_gamma", R.gm() + j);
+  }
+  P.op(cg1fe::X_FINAL, nullptr, 0, 0, 0);
+}
+}  // namespace
+
+extern "C" {
+
+void cg1_shuffle_fe_destroy(cg1_shuffle_fe* fe) {
+  if (!fe) return;
+  (void)hipSetDevice(fe->device);
+  for (void* p : {fe->d_init, fe->d_ops, fe->d_labels, fe->d_consts, fe->d_tabG, fe->d_tabH, fe->d_four, fe->d_scratch}) if (p) (void)hipFree(p);
+  delete fe;
+}
+
+// crs_affine96 / crs48: the ell + 9 CRS points (crs.py:92-101 order) decoded and as they stand on the wire
+cg1_shuffle_fe* cg1_shuffle_fe_create(cg1_ctx* ctx, size_t ell, size_t lg, const uint8_t* crs_affine96, const uint8_t* crs48) {
+  if (!ctx || !crs_affine96 || !crs48 || ell == 0 || lg == 0 || lg > 20 || ((ell + 4) != ((size_t)1 << lg))) return nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  cg1_shuffle_fe* fe = new cg1_shuffle_fe();
+  fe->device = ctx->device;
+  const cg1rows::RowIn R{ell, lg};
+  cg1fe::Params& pr = fe->pr;
+  pr.ell = (uint32_t)ell; pr.lg = (uint32_t)lg; pr.L = (uint32_t)(4 * ell + 19 + 10 * lg); pr.K = (uint32_t)R.count();
+  pr.out_stride = (pr.K + 6u) * 32u;
+  pr.idx_A = (uint32_t)(4 * ell + 1); pr.idx_T1 = (uint32_t)(4 * ell + 2); pr.idx_U1 = (uint32_t)(4 * ell + 4); pr.idx_B = (uint32_t)(4 * ell + 8);
+  pr.idx_T0 = (uint32_t)(2 * ell);
+  FeProgram P;
+  fe_build_program(ell, lg, P);
+  if (P.labels.size() > (size_t)cg1merlin::MAX_LABELS) { delete fe; return nullptr; }
+  fe->nops = (uint32_t)P.ops.size(); fe->nlabels = (uint32_t)P.labels.size();
+  uint8_t init[CG1_MERLIN_STATE_BYTES];
+  cg1_merlin_init(init, (const uint8_t*)"curdleproofs", 12);                      // CurdleproofsTranscript(b"curdleproofs"), curdleproofs.py:172
+  uint8_t consts[96];
+  memset(consts, 0, sizeof consts);
+  consts[0] = 0xC0;                                                               // Z1 as the wheel serialises it
+  memcpy(consts + 48, crs48 + (ell + 4) * 48, 48);                                // crs.H
+  bool ok = hipMalloc(&fe->d_init, sizeof init) == hipSuccess && hipMalloc(&fe->d_ops, P.ops.size() * sizeof(cg1merlin::COp)) == hipSuccess &&
+            hipMalloc(&fe->d_labels, P.table.size() * 4) == hipSuccess && hipMalloc(&fe->d_consts, sizeof consts) == hipSuccess &&
+            hipMalloc(&fe->d_tabG, 8192 * sizeof(cg1::PreparedPoint)) == hipSuccess && hipMalloc(&fe->d_tabH, 8192 * sizeof(cg1::PreparedPoint)) == hipSuccess;
+  ok = ok && hipMemcpy(fe->d_init, init, sizeof init, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(fe->d_ops, P.ops.data(), P.ops.size() * sizeof(cg1merlin::COp), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(fe->d_labels, P.table.data(), P.table.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(fe->d_consts, consts, sizeof consts, hipMemcpyHostToDevice) == hipSuccess;
+  // fixed-base tables: entry [w][b] = b * 2^(8 w) * base for the two bases of D (grand_prod.py:157), as 128-byte Montgomery records
+  if (ok) {
+    std::vector<uint8_t> sc(8192 * 32, 0);
+    for (int w = 0; w < 32; ++w) for (int b = 0; b < 256; ++b) sc[((size_t)w * 256 + b) * 32 + w] = (uint8_t)b;
+    DevBuf dsc, dbase, dout, dflags;
+    ok = dsc.alloc(sc.size()) == hipSuccess && dbase.alloc(96) == hipSuccess && dout.alloc(8192 * 96) == hipSuccess && dflags.alloc(8192 + 16) == hipSuccess &&
+         hipMemcpy(dsc.p, sc.data(), sc.size(), hipMemcpyHostToDevice) == hipSuccess;
+    for (int which = 0; which < 2 && ok; ++which) {
+      const uint8_t* src = crs_affine96 + (ell + 4 + 3 + which) * 96;              // G_sum, H_sum
+      ok = hipMemcpy(dbase.p, src, 96, hipMemcpyHostToDevice) == hipSuccess &&
+           cg1_batch_mul_device(ctx, dbase.p, 1, dsc.p, dout.p, 8192) == CG1_OK;
+      if (ok) {
+        hipLaunchKernelGGL(cg1::k_prepare_points, dim3(32), dim3(256), 0, ctx->stream, (const uint32_t*)dout.p,
+                           (cg1::PreparedPoint*)(which ? fe->d_tabH : fe->d_tabG), (uint8_t*)dflags.p, 8192u);
+        ok = hipStreamSynchronize(ctx->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+      }
+    }
+  }
+  if (!ok) { cg1_shuffle_fe_destroy(fe); return nullptr; }
+  return fe;
+}
+
+size_t cg1_shuffle_fe_aux_bytes(void) { return 19 * 32; }
+
+// Enqueue the front-end of n proofs on ctx's compute stream (no wait: cg1_stream_sync).  d_wire48: n x L own points as gathered from
+// the wire (cg1_shuffle_gather_points); d_pts_affine96: the same points decoded (cg1_batch_decompress_*); d_aux: n x 19 x 32 bytes
+// (cg1_shuffle_gather_aux); outputs as cg1_shuffle_prepare_inputs: d_rowin n x cg1_shuffle_rowin_scalars() x 32, d_status n codes.
+int cg1_shuffle_fe_enqueue(cg1_shuffle_fe* fe, cg1_ctx* ctx, size_t n, const void* d_wire48, const void* d_pts_affine96, const void* d_aux,
+                           void* d_rowin, void* d_status, int lanes_per_wave) {
+  if (!fe || !ctx) return CG1_ERR_ARG;
+  if (n == 0) return CG1_OK;
+  if (!d_wire48 || !d_pts_affine96 || !d_aux || !d_rowin || !d_status || n >= (1u << 24) || ctx->device != fe->device) return CG1_ERR_ARG;
+  if (lanes_per_wave < 1 || lanes_per_wave > cg1merlin::LANES) lanes_per_wave = cg1merlin::LANES;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (n > fe->cap_n) {
+    if (fe->d_four) (void)hipFree(fe->d_four);
+    if (fe->d_scratch) (void)hipFree(fe->d_scratch);
+    fe->d_four = fe->d_scratch = nullptr; fe->cap_n = 0;
+    HIPCHK(hipMalloc(&fe->d_four, n * 4 * sizeof(cg1::PreparedPoint)));
+    HIPCHK(hipMalloc(&fe->d_scratch, n * (size_t)fe->pr.out_stride));
+    fe->cap_n = n;
+  }
+  hipLaunchKernelGGL(cg1fe::k_fe_gather4, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_pts_affine96, fe->pr, (uint32_t)n,
+                     (cg1::PreparedPoint*)fe->d_four);
+  const unsigned nblk = (unsigned)((n + lanes_per_wave - 1) / lanes_per_wave);
+  hipLaunchKernelGGL(cg1fe::k_shuffle_front_end, dim3(nblk), dim3(cg1merlin::LANES), 0, ctx->stream, (const uint8_t*)fe->d_init, (const cg1merlin::COp*)fe->d_ops,
+                     fe->nops, (const uint32_t*)fe->d_labels, fe->nlabels, (const uint8_t*)fe->d_consts, (const uint8_t*)d_wire48, (const uint8_t*)d_aux,
+                     (const cg1::PreparedPoint*)fe->d_four, (const cg1::PreparedPoint*)fe->d_tabG, (const cg1::PreparedPoint*)fe->d_tabH, fe->pr,
+                     (uint8_t*)fe->d_scratch, (uint8_t*)d_rowin, (int32_t*)d_status, (uint32_t)n, (uint32_t)lanes_per_wave);
+  HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 int cg1_shuffle_rows_device(cg1_ctx* ctx, size_t ell, size_t lg, size_t n_proofs, const void* d_rowin, const void* d_host_status,
                             const void* d_point_status, void* d_out_scalars, void* d_crs_rows, void* d_status_out) {
   if (!ctx) return CG1_ERR_HIP;

@@ -1133,6 +1133,25 @@ int cg1_shuffle_gather_points(const cg1_shuffle_crs* crs_, size_t n_proofs, cons
   return CG1_OK;
 }
 
+// What the device front-end needs besides the points (csrc/kernels_frontend.h): per proof the seven Fr fields of the wire proof in
+// wire order (r_p c_final d_final z_k z_t z_u x_final) followed by the proof's 12 weights, 19 x 32 bytes.
+int cg1_shuffle_gather_aux(const cg1_shuffle_crs* crs_, size_t n_proofs, const uint8_t* proofs, const uint8_t* weights, uint8_t* out_aux) {
+  if (!crs_ || (n_proofs && (!proofs || !weights || !out_aux))) return CG1_ERR_ARG;
+  const Crs& crs = *reinterpret_cast<const Crs*>(crs_);
+  const size_t lg = crs.lg, proof_b = proof_wire_bytes(lg);
+  const size_t off_rp = 48 * 10, off_cd = off_rp + 32 + 48 * (2 + 4 * lg), off_z = off_cd + 64 + 48 * 4, off_x = off_z + 96 + 48 * (3 + 6 * lg);
+  for (size_t i = 0; i < n_proofs; ++i) {
+    const uint8_t* p = proofs + i * proof_b;
+    uint8_t* o = out_aux + i * 19 * 32;
+    memcpy(o, p + off_rp, 32);
+    memcpy(o + 32, p + off_cd, 64);
+    memcpy(o + 96, p + off_z, 96);
+    memcpy(o + 192, p + off_x, 32);
+    memcpy(o + 224, weights + i * 12 * 32, 12 * 32);
+  }
+  return CG1_OK;
+}
+
 // Fold the GPU decompression verdicts (one status byte per own point) into the per-proof status: a proof with any
 // undecodable point is rejected (BufReader.read_g1 raises, util.py:143-147) and its scalars are zeroed.
 int cg1_shuffle_apply_point_status(int32_t* status, const uint8_t* point_status, size_t n_proofs, size_t points_per_proof,

@@ -313,6 +313,18 @@ int cg1_shuffle_rows_device(cg1_ctx* ctx, size_t ell, size_t lg, size_t n_proofs
  * point outside G1 (cg1_subgroup_flags_enqueue / CG1_ERR_NOT_IN_SUBGROUP): the four same-scalar equalities of one shuffle
  * proof (same_scalar.py:101-108; *ok = 1 iff all hold), and the two equalities of one tracker-opening proof
  * (opening.py:73-76).  Points are decoded unchecked, scalars act as integers in [0, r), as in the reference. */
+/* The front-end ON THE DEVICE (csrc/kernels_frontend.h): what cg1_shuffle_prepare_inputs does on the host -- the Fiat-Shamir transcript
+ * (curdleproofs_transcript.py:15-25 over merlin_transcripts), the grand-product scalar (same_perm.py:98-101), D (grand_prod.py:157) and
+ * A' (curdleproofs.py:210) with their encodings, inner_prod (grand_prod.py:164-166), the challenge inverses -- one proof per lane on the
+ * wire points already in HBM.  Same outputs, byte for byte: the row-input blocks and the per-proof front-end codes.
+ * cg1_shuffle_gather_aux collects what the kernel needs besides the points: per proof r_p c_final d_final z_k z_t z_u x_final | 12 weights. */
+typedef struct cg1_shuffle_fe cg1_shuffle_fe;
+cg1_shuffle_fe* cg1_shuffle_fe_create(cg1_ctx* ctx, size_t ell, size_t lg, const uint8_t* crs_affine96, const uint8_t* crs48);   /* NULL on failure */
+void   cg1_shuffle_fe_destroy(cg1_shuffle_fe* fe);
+size_t cg1_shuffle_fe_aux_bytes(void);
+int cg1_shuffle_gather_aux(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8_t* proofs, const uint8_t* weights, uint8_t* out_aux);
+int cg1_shuffle_fe_enqueue(cg1_shuffle_fe* fe, cg1_ctx* ctx, size_t n, const void* d_wire48, const void* d_pts_affine96, const void* d_aux,
+                           void* d_rowin, void* d_status, int lanes_per_wave /* 1..64 transcripts per wave; 0 = 64 */);
 int cg1_shuffle_exact_same_scalar(const cg1_shuffle_crs* crs, const uint8_t* instance, const uint8_t* proof, int* ok);
 int cg1_opening_exact(const uint8_t* tracker96 /* r_G | k_r_G */, const uint8_t* k_commitment48, const uint8_t* proof128, int* ok);
 /* just the gather step: every proof's own points (instance, then the proof's points in wire order) */
