@@ -119,7 +119,10 @@ def decompress_mads_per_point():
     return (nsqr + 2) * MADS_SQR + (nmul + 4.5) * MADS_MUL, nsqr, nmul
 
 
-def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu_leg=True, peak_T=None):
+FE_KEY = "front_end (transcript + D / A' + Fr algebra: host threads, or one device launch per batch)"
+
+
+def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu_leg=True, peak_T=None, front_end="auto"):
     """Stream `steps` batches of `batch` distinct-proof slots through the GPU verifier; returns the `secondary` object."""
     from curdleproofs_pie_amd import _native as N
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
@@ -127,10 +130,13 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
     if peak_T is None:
         peak_T = mad_peak_same_run(ctx)["peak_T"]
     fx = load_batch_fixture()
-    v = ShuffleBatchVerifier(fx.crs, ctx, threads=threads)
+    v = ShuffleBatchVerifier(fx.crs, ctx, threads=threads, device_front_end={"auto": None, "host": False, "device": True}[front_end])
     inst, proofs, want = fx.tiled(batch)
     for _ in range(warmup):
         assert not any(v.verify_packed(inst, proofs, batch, mode=verify_mode))
+    if v.device_front_end and warmup:             # every front-end lane builds its tables on first use: untimed, like the warm-up steps
+        for st in v.verify_stream(((inst, proofs, batch) for _ in range(v.fe_lanes + 2)), mode=verify_mode):
+            assert not any(st)
     acc = {}
     ctx.sync()
     t0 = time.perf_counter()
@@ -166,8 +172,9 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
         "data": "tests/golden/shuffle_batch_ell124{,_more}.bin: %d distinct proofs made by the reference prover over one CRS (cycled when the "
                 "batch is larger), fresh OS-random weights per slot; inputs are wire bytes in host memory (H2D included)" % fx.count,
         "points_per_step": points + C, "host_threads": threads,
+        "front_end": ("device (k_shuffle_front_end, %d launches side by side)" % v.fe_lanes) if v.device_front_end else "host",
         "phases_ms_per_step": {"decompress_stage (H2D + k_batch_decompress + D2H, GPU thread)": 1e3 * acc.get("decompress_s", 0) / steps,
-                               "front_end (host: transcript + Fr algebra, all threads)": 1e3 * acc.get("front_end_s", 0) / steps,
+                               FE_KEY: 1e3 * acc.get("front_end_s", 0) / steps,
                                "merged_msm (one regime-A MSM of all points, GPU)": 1e3 * acc.get("merged_msm_s", 0) / steps,
                                "note": "the three stages of consecutive batches overlap; they do not add up to ms_per_step"},
         "roofline_int_mad": {"kernel": "k_batch_decompress<false>", "bound": "valu v_mad_u64_u32", "kernel_ms": dec_ms, "points_per_launch": points,
@@ -178,7 +185,7 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
     if cpu_leg:
         # CPU port beside it: the same statement builder on ONE core + the statement's MSM by the CPU oracle (bucket method)
         from oracle.shuffle_check import oracle_verdicts
-        v1 = ShuffleBatchVerifier(v.crs, ctx, threads=1)
+        v1 = ShuffleBatchVerifier(v.crs, ctx, threads=1, device_front_end=False)
         m = 8
         i1, p1, _ = fx.tiled(m)
         t1 = time.perf_counter()
@@ -238,12 +245,12 @@ def verify_mode(args, rank, local_rank, world):
     threads = max(1, cores // world)
     if comm:
         comm.barrier()
-    out = verify_measure(ctx, threads, args.steps, args.warmup, args.batch, args.verify_mode, cpu_leg=(rank == 0 and not args.no_cpu_baseline))
+    out = verify_measure(ctx, threads, args.steps, args.warmup, args.batch, args.verify_mode, cpu_leg=(rank == 0 and not args.no_cpu_baseline),
+                         front_end=args.front_end)
     el = out["ms_per_step"] * args.steps / 1e3
     per_rank = max_over_ranks(el, comm)
     # a core-starved run must be visible: every rank's front-end time and thread count travel to rank 0
-    fe_key = "front_end (host: transcript + Fr algebra, all threads)"
-    fe = max_over_ranks(out["phases_ms_per_step"][fe_key], comm)
+    fe = max_over_ranks(out["phases_ms_per_step"][FE_KEY], comm)
     el = max(per_rank)
     if rank == 0:
         out.update({"value": world * args.batch * args.steps / el, "ms_per_step": el / args.steps * 1e3, "n_gpus": world, "scaling": "weak",
@@ -402,6 +409,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024, help="proofs per step (secondary metric / --mode verify)")
     ap.add_argument("--verify-steps", type=int, default=20)
     ap.add_argument("--verify-mode", choices=["merged", "independent"], default="merged")
+    ap.add_argument("--front-end", choices=["auto", "host", "device"], default="auto",
+                    help="verifier front-end (transcript, D / A', challenge algebra): host threads, k_shuffle_front_end, or by the threads available")
     ap.add_argument("--mode", choices=["msm", "batched", "pcie", "verify"], default="msm",
                     help="msm: the driver's line (headline MSM + secondary proofs/s). batched: BASELINE config 3's MSM content (1024 independent "
                          "627-term accumulator MSMs per step, regime B). verify: BASELINE config 3 end to end alone (and config 5's structure at "
@@ -658,7 +667,7 @@ def main():
             wl.free()
         if world == 1 and not args.no_secondary:
             cores = int(N.cg1_shuffle_default_threads())
-            out["secondary"] = verify_measure(ctx, cores, args.verify_steps, 2, args.batch, args.verify_mode, cpu_leg=not args.no_cpu_baseline, peak_T=peak["peak_T"])
+            out["secondary"] = verify_measure(ctx, cores, args.verify_steps, 2, args.batch, args.verify_mode, cpu_leg=not args.no_cpu_baseline, peak_T=peak["peak_T"], front_end=args.front_end)
         print(json.dumps(out), flush=True)
 
     if comm:

@@ -30,6 +30,10 @@ if not os.path.exists(LIB_PATH):
         "(hipcc --offload-arch=gfx950).  There is no pure-Python fallback."
     )
 
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A verifier with the front-end
+# on the device keeps seven or more streams busy (decoding, MSM, copies, several front-end launches): with four queues only two of
+# its front-end launches ever ran side by side (profiles/r03_frontend_device_bench.txt).  Read by the runtime at its first call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 lib = ctypes.CDLL(LIB_PATH)
 
 
@@ -75,6 +79,7 @@ cg1_batch_compress = _proto("cg1_batch_compress", None, _buf, _u8p, c_size_t)
 # device
 cg1_device_count = _proto("cg1_device_count", c_int)
 cg1_ctx_create = _proto("cg1_ctx_create", c_void_p, c_int)
+cg1_ctx_create_cu_mask = _proto("cg1_ctx_create_cu_mask", c_void_p, c_int, POINTER(ctypes.c_uint32), c_size_t)
 cg1_ctx_destroy = _proto("cg1_ctx_destroy", None, c_void_p)
 cg1_ctx_error = _proto("cg1_ctx_error", c_char_p, c_void_p)
 cg1_dev_malloc = _proto("cg1_dev_malloc", c_void_p, c_void_p, c_size_t)
@@ -196,7 +201,7 @@ EXPORTED_SYMBOLS = [
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_h2d_async", "cg1_copy_fence", "cg1_stream_sync", "cg1_batch_decompress_enqueue", "cg1_host_alloc", "cg1_host_free", "cg1_ctx_sync", "cg1_ctx_set_param",
     "cg1_msm", "cg1_msm_device", "cg1_msm_device_begin", "cg1_msm_device_end", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_get_last_counts", "cg1_timer_begin", "cg1_timer_end", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
-    "cg1_shuffle_fe_create", "cg1_shuffle_fe_destroy", "cg1_shuffle_fe_aux_bytes", "cg1_shuffle_gather_aux", "cg1_shuffle_fe_enqueue",
+    "cg1_ctx_create_cu_mask", "cg1_shuffle_fe_create", "cg1_shuffle_fe_destroy", "cg1_shuffle_fe_aux_bytes", "cg1_shuffle_gather_aux", "cg1_shuffle_fe_enqueue",
     "cg1_merlin_last_passes", "cg1_probe_mad_rate", "cg1_batch_sum_device", "cg1_batch_sum", "cg1_ctx_device", "cg1_ctx_stream", "cg1_msm_multi_device",
     "cg1_comm_create", "cg1_comm_port", "cg1_comm_rank", "cg1_comm_connect", "cg1_comm_set_timeout", "cg1_comm_attach_rccl", "cg1_comm_transport",
     "cg1_comm_world_seen", "cg1_comm_error", "cg1_comm_allgather", "cg1_comm_allgather_host", "cg1_comm_barrier", "cg1_comm_allreduce_g1", "cg1_comm_destroy",
@@ -262,9 +267,17 @@ class DeviceBuffer:
 class Context:
     """One per GPU: owns the HIP stream, the scratch buffers of the MSM pipeline and phase timers."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, cu_mask=None):
+        """cu_mask: iterable of CU indices the context's kernels may run on (None = the whole chip)."""
         self.device = device
-        self.handle = cg1_ctx_create(device)
+        if cu_mask is None:
+            self.handle = cg1_ctx_create(device)
+        else:
+            words = [0] * 16
+            for cu in cu_mask:
+                words[cu >> 5] |= 1 << (cu & 31)
+            arr = (ctypes.c_uint32 * 16)(*words)
+            self.handle = cg1_ctx_create_cu_mask(device, arr, 16)
         if not self.handle:
             raise NativeError(
                 f"cg1_ctx_create({device}) failed: no MI355X/HIP device visible "

@@ -110,6 +110,7 @@ struct Ctx {
   hipStream_t stream = nullptr;
   hipStream_t copy_stream = nullptr;    // H2D staging copies that overlap kernels on `stream` (cg1_h2d_async / cg1_copy_fence)
   hipEvent_t copy_ev = nullptr;
+  std::vector<uint32_t> cu_mask;        // non-empty: the compute and side streams are confined to these CUs
   hipStream_t side_stream = nullptr;    // small latency-bound kernels that run BESIDE the compute stream (cg1_subgroup_flags_enqueue)
   hipEvent_t side_ev = nullptr;
   hipEvent_t sync_ev = nullptr;         // blocking-sync event: waits sleep on an interrupt instead of spinning a core
@@ -926,13 +927,23 @@ int cg1_device_count(void) {
   return n;
 }
 
-cg1_ctx* cg1_ctx_create(int device) {
+// cu_mask (n_words x 32 bits, bit i = compute unit i; NULL = every CU): the context's compute and side streams only run on those CUs
+// (hipExtStreamCreateWithCUMask).  The verifier with its front-end on the device gives its latency-bound front-end launches a few CUs
+// of their own and keeps the throughput kernels (decompression, MSM) off them.
+cg1_ctx* cg1_ctx_create_cu_mask(int device, const uint32_t* cu_mask, size_t n_words) {
   int n = cg1_device_count();
   if (device < 0 || device >= n) return nullptr;
   if (hipSetDevice(device) != hipSuccess) return nullptr;
   cg1_ctx* ctx = new cg1_ctx();
   ctx->device = device;
-  if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+  hipError_t e;
+  if (cu_mask && n_words) {
+    e = hipExtStreamCreateWithCUMask(&ctx->stream, (uint32_t)n_words, cu_mask);
+    ctx->cu_mask.assign(cu_mask, cu_mask + n_words);
+  } else {
+    e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  }
+  if (e != hipSuccess) { delete ctx; return nullptr; }
   if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { delete ctx; return nullptr; }
@@ -941,6 +952,7 @@ cg1_ctx* cg1_ctx_create(int device) {
   *ctx->h_flag = 0;
   return ctx;
 }
+cg1_ctx* cg1_ctx_create(int device) { return cg1_ctx_create_cu_mask(device, nullptr, 0); }
 void cg1_ctx_destroy(cg1_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
@@ -1281,7 +1293,8 @@ int cg1_subgroup_flags_enqueue(cg1_ctx* ctx, const void* d_affine96, size_t stri
   for (size_t j = 0; j < k; ++j) if (offsets[j] >= stride_points) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->side_stream) {
-    HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    if (!ctx->cu_mask.empty()) HIPCHK(hipExtStreamCreateWithCUMask(&ctx->side_stream, (uint32_t)ctx->cu_mask.size(), ctx->cu_mask.data()));
+    else HIPCHK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&ctx->side_ev, hipEventDisableTiming));
   }
   HIPCHK(hipEventRecord(ctx->side_ev, ctx->stream));

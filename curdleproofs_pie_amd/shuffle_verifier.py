@@ -121,7 +121,7 @@ class Prepared:
 
 class ShuffleBatchVerifier:
     def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True,
-                 blocking_sync: Optional[bool] = None):
+                 blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: int = 5, fe_cus: int = 0):
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
@@ -131,8 +131,35 @@ class ShuffleBatchVerifier:
         env = os.environ.get("CURDLE_G1_BLOCKING_SYNC")
         self.blocking_sync = (env == "1") if env is not None else bool(blocking_sync)
         self.chunk = chunk                  # sub-batch of the decompress / front-end pipeline
-        self._gpu_threads = [None, None]
-        self._gpu_jobs = [None, None]
+        # device_front_end: the transcript, D / A' and the challenge algebra run on the GPU too (csrc/kernels_frontend.h, one proof per
+        # lane; byte-identical row-input blocks: tests/test_shuffle_frontend_gpu.py).  One launch takes ~26 ms whatever its size (a
+        # transcript is ~750 dependent Keccak permutations) but occupies only n / 64 of the chip's 1024 SIMDs, so `fe_lanes` launches of
+        # consecutive batches run side by side, each on its own context, and the stream keeps fe_lanes + 3 batches in flight.  The
+        # host then only packs bytes: proofs/s no longer depends on the host's core count.
+        # Measured on MI355X (profiles/r03_verify_fe_ab.txt, batches of 1024): 74-83 K proofs/s whatever the host, against 24 K / 45 K /
+        # 91 K / 131 K proofs/s with the host front-end on 2 / 4 / 8 / 16 threads -- so None (the default) turns it on when fewer than
+        # six host threads are available to this verifier (e.g. eight ranks sharing a 32-core host), and leaves the host front-end on
+        # otherwise.  CURDLE_G1_DEVICE_FRONT_END=0/1 overrides.
+        env = os.environ.get("CURDLE_G1_DEVICE_FRONT_END")
+        if env in ("0", "1"):
+            device_front_end = env == "1"
+        if device_front_end is None:
+            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < 6
+        self.device_front_end = bool(device_front_end)
+        self.fe_lanes = max(1, int(fe_lanes)) if self.device_front_end else 0
+        # fe_cus > 0 (A/B switch, off): the front-end launches get that many compute units of their own (the last ones) and the
+        # throughput kernels are confined to the others (hipExtStreamCreateWithCUMask).  Measured a loss: the masked decompression
+        # stream took 30 ms instead of 6 per batch (profiles/r03_verify_fe_ab.txt)
+        self.fe_cus = int(fe_cus) if self.device_front_end else 0
+        self._cu_total = 256
+        if self.fe_cus and self._ctx is not None:
+            self._user_ctx = self._ctx                 # the caller's context stays untouched: this mode drives contexts of its own
+            self._ctx = N.Context(self._user_ctx.device, cu_mask=range(0, self._cu_total - self.fe_cus))
+            self._own_ctx = True
+        self._gpu_threads = [None, None] + [None] * self.fe_lanes
+        self._gpu_jobs = [None, None] + [None] * self.fe_lanes
+        self._fe = [None] * self.fe_lanes              # (context, cg1_shuffle_fe handle) per front-end lane
+        self._fe_next = 0
         self._ctx_msm = None
         self.prefetch_big = True            # two large decompress launches for batches decoded a batch ahead (A/B switch)
         # True: the host front-end emits only the challenges (+ a few derived scalars) per proof and the GPU expands them into
@@ -140,7 +167,8 @@ class ShuffleBatchVerifier:
         # of the front-end's arithmetic off the host.  False: rows on the host (A/B switch; what `prepare()` always does).
         self.device_rows = device_rows
         self._rowin_scalars = N.cg1_shuffle_rowin_scalars(self.crs.handle)
-        self._slots = [None, None, None]
+        self._nslots = 3 + self.fe_lanes + (1 if self.fe_lanes else 0)
+        self._slots = [None] * self._nslots
         self._next_slot = 0
         self.last_stats = {}
         self.last_status = []
@@ -152,7 +180,7 @@ class ShuffleBatchVerifier:
     def close(self) -> None:
         """Stop the two GPU threads (after what is queued has drained) and release the buffer slots and the MSM context.
         The verifier must not be used afterwards.  Idempotent; also run by __del__ and on cache eviction."""
-        for lane in (0, 1):
+        for lane in range(len(self._gpu_threads)):
             t, q = self._gpu_threads[lane], self._gpu_jobs[lane]
             if t is not None:
                 q.put(None)
@@ -169,9 +197,20 @@ class ShuffleBatchVerifier:
         if self._ctx_msm is not None:
             self._ctx_msm.close()
             self._ctx_msm = None
+        for k, pair in enumerate(getattr(self, "_fe", [])):
+            if pair is not None:
+                cx, fe, aux_h, aux_d = pair
+                N.cg1_shuffle_fe_destroy(fe)
+                aux_h.free(); aux_d.free()
+                cx.close()
+                self._fe[k] = None
         if getattr(self, "_ctx_blocking", False) and self._ctx is not None and self._ctx.handle:
             self._ctx.set_param("blocking_sync", 0)
             self._ctx_blocking = False
+        if getattr(self, "_own_ctx", False) and self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+            self._own_ctx = False
 
     def __del__(self):
         try:
@@ -235,7 +274,11 @@ class ShuffleBatchVerifier:
     @property
     def ctx(self) -> "N.Context":
         if self._ctx is None:
-            self._ctx = N.default_context()
+            if self.fe_cus:
+                self._ctx = N.Context(N.default_context().device, cu_mask=range(0, self._cu_total - self.fe_cus))
+                self._own_ctx = True
+            else:
+                self._ctx = N.default_context()
         if self.blocking_sync and not getattr(self, "_ctx_blocking", False):
             self._ctx.set_param("blocking_sync", 1)        # (a shared context: close() sets it back)
             self._ctx_blocking = True
@@ -246,7 +289,7 @@ class ShuffleBatchVerifier:
         """A second context on the same GPU for the MSM stage: its kernels, its host Horner tail and its dependent reduce
         kernels then overlap the decompression of the next batch (which runs on `ctx` from another thread)."""
         if self._ctx_msm is None:
-            self._ctx_msm = N.Context(self.ctx.device)
+            self._ctx_msm = N.Context(self.ctx.device, cu_mask=range(0, self._cu_total - self.fe_cus) if self.fe_cus else None)
             self._ctx_msm.set_param("blocking_sync", 1 if self.blocking_sync else 0)
         return self._ctx_msm
 
@@ -297,12 +340,12 @@ class ShuffleBatchVerifier:
         All three are allocated together the first time a batch size is seen (page-locking tens of MB takes
         milliseconds: not something to meet again in the middle of a stream)."""
         idx = self._next_slot
-        self._next_slot = (idx + 1) % 3
+        self._next_slot = (idx + 1) % self._nslots
         b = self._slots[idx]
         if b is not None and b["busy"] is not None:
             b["busy"].wait()                                  # its previous batch must have left the GPU
         if b is None or b["cap"] < n:
-            for j in range(3):
+            for j in range(self._nslots):
                 o = self._slots[j]
                 if o is None or (o["cap"] < n and (o["busy"] is None or o["busy"].is_set())):
                     self._slots[j] = self._alloc_slot(n)
@@ -483,6 +526,83 @@ class ShuffleBatchVerifier:
         N.cg1_add(tmp, own, shared)
         return bool(N.cg1_is_identity(tmp.raw))
 
+    def _fe_lane(self, k: int, n: int):
+        """Front-end lane k: its own context (stream), device front-end handle and aux staging, created on first use."""
+        pair = self._fe[k]
+        if pair is None or pair[2].nbytes < n * 19 * 32:
+            if pair is not None:
+                cx, fe, aux_h, aux_d = pair
+                aux_h.free(); aux_d.free()
+            else:
+                cx = N.Context(self.ctx.device, cu_mask=range(self._cu_total - self.fe_cus, self._cu_total) if self.fe_cus else None)
+                fe = N.cg1_shuffle_fe_create(cx.handle, self.crs.ell, self.crs.lg, self.crs.affine96, self.crs.bytes)
+                if not fe:
+                    raise N.NativeError("cg1_shuffle_fe_create failed")
+            pair = self._fe[k] = (cx, fe, N.PinnedBuffer(cx, n * 19 * 32), cx.alloc(n * 19 * 32))
+        return pair
+
+    def _front_end_device(self, tk: dict) -> None:
+        """Stage 2 on the GPU (asynchronous): once the batch is decoded, one k_shuffle_front_end launch on the next front-end lane
+        writes the row-input blocks and the front-end codes straight into the slot's device buffers."""
+        import threading
+        import time
+
+        k = self._fe_next
+        self._fe_next = (k + 1) % self.fe_lanes
+        tk["device_rows"] = True
+        tk["prep"] = None
+        tk["fe_done"] = threading.Event()
+        b, n = tk["slot"], tk["n"]
+
+        def job():
+            try:
+                for _ in tk["bounds"]:
+                    r = tk["chunks"].get()
+                    if isinstance(r, BaseException):
+                        raise r
+                t0 = time.perf_counter()
+                cx, fe, aux_h, aux_d = self._fe_lane(k, n)
+                cx.check(N.cg1_shuffle_gather_aux(self.crs.handle, n, _addr(tk["proofs"]), _addr(tk["weights"]), aux_h.ptr))
+                cx.check(N.cg1_h2d(cx.handle, aux_d.ptr, aux_h.ptr, n * 19 * 32))
+                cx.check(N.cg1_shuffle_fe_enqueue(fe, cx.handle, n, b["wire"].ptr, b["pts"].ptr, aux_d.ptr, b["rowin"].ptr, b["hstat"].ptr, 0))
+                cx.check(N.cg1_stream_sync(cx.handle))
+                pre = tk["pre_status"]
+                if pre is not None and any(pre):                  # proofs rejected while packing (bad lengths): their codes win
+                    hs = (ctypes.c_int32 * n).from_buffer_copy(b["hstat"].download(4 * n))
+                    for i, s_ in enumerate(pre):
+                        if s_:
+                            hs[i] = s_
+                    b["hstat"].upload(bytes(hs))
+                tk["front_end_s"] = time.perf_counter() - t0
+            except BaseException as e:
+                tk["error"] = e
+            finally:
+                tk["fe_done"].set()
+
+        self._gpu_submit(job, lane=2 + k)
+
+    def _verify_stream_device(self, batches, mode: str, rng):
+        """verify_stream with the front-end on the GPU: up to fe_lanes + 2 batches in flight (decoding | front-end launches side by
+        side | rows + merged MSM), verdicts yielded in order."""
+        from collections import deque
+
+        inflight = deque()
+        depth = self.fe_lanes + 2
+        try:
+            for batch in batches:
+                tk = self._begin(batch, mode, rng, prefetched=True)
+                self._front_end_device(tk)
+                self._enqueue_msm(tk)
+                inflight.append(tk)
+                while len(inflight) > depth:
+                    yield self._finish(inflight.popleft())
+            while inflight:
+                yield self._finish(inflight.popleft())
+        finally:
+            left = [t for t in inflight if not t["done"].is_set()]
+            for t in left:
+                t["done"].wait()
+
     def _enqueue_msm(self, tk: dict) -> None:
         """Stage 3 (asynchronous, GPU thread): scalars H2D, the merged MSM, and -- if it is not the identity, or in mode
         "independent" -- the per-proof MSMs that name the invalid proofs."""
@@ -494,6 +614,10 @@ class ShuffleBatchVerifier:
 
         def gpu_stage():
             try:
+                if tk.get("fe_done") is not None:                 # device front-end: its launch wrote the blocks and codes into the slot
+                    tk["fe_done"].wait()
+                    if tk["error"] is not None:
+                        raise tk["error"]
                 t0 = time.perf_counter()
                 ctx.check(N.cg1_copy_fence(ctx.handle))          # the scalars / input blocks queued by _front_end
                 if tk["device_rows"]:
@@ -570,6 +694,9 @@ class ShuffleBatchVerifier:
         """Verify a sequence of batches, three stages overlapped across batches: while the host front-end works on batch k,
         the GPU finishes the MSM of batch k-1 and already decompresses batch k+1.
         `batches` yields (instances, proofs, n[, pre_status[, weights]]); yields one status list (0 = valid) per batch."""
+        if self.device_front_end:
+            yield from self._verify_stream_device(batches, mode, rng)
+            return
         it = iter(batches)
         cur = next(it, None)
         if cur is None:
@@ -662,9 +789,6 @@ class OpeningBatchVerifier:
     def ctx(self) -> "N.Context":
         if self._ctx is None:
             self._ctx = N.default_context()
-        if self.blocking_sync and not getattr(self, "_ctx_blocking", False):
-            self._ctx.set_param("blocking_sync", 1)        # (a shared context: close() sets it back)
-            self._ctx_blocking = True
         return self._ctx
 
     def prepare(self, items, rng=None):

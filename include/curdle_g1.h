@@ -67,6 +67,8 @@ void cg1_batch_compress(uint8_t* out48, const uint8_t* blobs, size_t n);
 /* ---------------- device context --------------------------------------------------------------- */
 int  cg1_device_count(void);                                         /* 0 when no GPU is visible */
 cg1_ctx* cg1_ctx_create(int device);                                 /* NULL on failure (no GPU) */
+/* the same with the context's compute / side streams confined to the CUs whose bit is set (bit i of word i / 32 = CU i) */
+cg1_ctx* cg1_ctx_create_cu_mask(int device, const uint32_t* cu_mask, size_t n_words);
 void cg1_ctx_destroy(cg1_ctx* ctx);
 const char* cg1_ctx_error(const cg1_ctx* ctx);                       /* message of the last failure */
 void* cg1_dev_malloc(cg1_ctx* ctx, size_t bytes);                    /* NULL on failure */

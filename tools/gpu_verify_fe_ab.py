@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Same-box A/B of the batch verifier with its front-end on the host (all cores) and on the GPU (k_shuffle_front_end, `fe_lanes`
+launches side by side): the distinct-proof fixture, batches of 1024, streamed."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+from batch_fixture import ShuffleBatch
+from curdleproofs_pie_amd import _native as N
+from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+fx = ShuffleBatch()
+n = int(os.environ.get("BATCH", "1024"))
+inst, proofs, _ = fx.tiled(n)
+ctx = N.Context(0)
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+threads = int(os.environ.get("THREADS", "0"))
+configs = [("host front-end", dict(device_front_end=False))] + [(f"device front-end, {f} lanes, {c} CUs of their own", dict(device_front_end=True, fe_lanes=f, fe_cus=c))
+                                            for f, c in ((5, 0), (5, 24), (6, 32), (6, 48), (8, 64))]
+for rnd in range(2):
+    for name, kw in configs:
+        v = ShuffleBatchVerifier(fx.crs, ctx, threads=threads, **kw)
+        list(v.verify_stream([(inst, proofs, n)] * (4 + kw.get("fe_lanes", 0))))
+        acc = {}
+        t0 = time.perf_counter()
+        for st in v.verify_stream(((inst, proofs, n) for _ in range(K))):
+            assert not any(st)
+            for k, x in v.last_stats.items():
+                if k.endswith("_s"):
+                    acc[k] = acc.get(k, 0.0) + x
+        dt = time.perf_counter() - t0
+        print(f"{name} (host threads {threads or 'all'}): {1e3*dt/K:.2f} ms per batch = {n*K/dt:.0f} proofs/s | " + " ".join(f"{k}={1e3*x/K:.2f}" for k, x in acc.items()), flush=True)
+        v.close()
