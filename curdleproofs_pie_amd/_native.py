@@ -32,8 +32,10 @@ if not os.path.exists(LIB_PATH):
 
 # The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A verifier with the front-end
 # on the device keeps seven or more streams busy (decoding, MSM, copies, several front-end launches): with four queues only two of
-# its front-end launches ever ran side by side (profiles/r03_frontend_device_bench.txt).  Read by the runtime at its first call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# its front-end launches ever ran side by side (profiles/r03_frontend_device_bench.txt), and with eight a 26 ms front-end launch still
+# shared a queue with the decoding or MSM stream behind it: 13.5 ms per batch of 1024 proofs, against 7.8 ms with 24 queues
+# (profiles/r03_verify_fe_ab.txt; the MSM benchmark itself is indifferent: 3.03 ms either way).  Read by the runtime at its first call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 lib = ctypes.CDLL(LIB_PATH)
 
 

@@ -33,6 +33,7 @@ struct Params {
   uint32_t ell, lg, L, K;                 // own points per proof, scalars of a row-input block
   uint32_t out_stride;                    // bytes of a lane's private out row: (K + 6) * 32  [block | gprod | r_p | D48 (64 B) | A'48 (64 B)]
   uint32_t idx_A, idx_T1, idx_U1, idx_B, idx_T0;   // own-point indices (csrc/shuffle_verify.cpp Layout)
+  uint32_t prio;                          // wave priority (s_setprio): a front-end wave is one long dependent chain sharing its SIMD with throughput kernels
 };
 
 __device__ __noinline__ fr fmul(const fr& a, const fr& b) { return cg1fr::fr_mul(a, b); }
@@ -171,6 +172,9 @@ __global__ void __launch_bounds__(LANES) k_shuffle_front_end(const uint8_t* __re
   __shared__ uint32_t lds[52 * LANES];
   __shared__ uint32_t lds_drawn[8 * LANES];
   __shared__ uint32_t lds_labels[cg1merlin::MAX_LABELS * 8];
+  if (pr.prio == 1u) __builtin_amdgcn_s_setprio(1);
+  else if (pr.prio == 2u) __builtin_amdgcn_s_setprio(2);
+  else if (pr.prio == 3u) __builtin_amdgcn_s_setprio(3);
   const uint32_t t = blockIdx.x * lanes_used + threadIdx.x;
   const bool live = threadIdx.x < lanes_used && t < n;
   for (uint32_t j = threadIdx.x; j < nlabels * 8u; j += LANES) lds_labels[j] = label_table[j];

@@ -140,6 +140,7 @@ struct Ctx {
   int tree_half = 1;                    // k_small_tree_quad: 2 lanes per element (a quad takes two elements) instead of 4 (A/B switch)
   int merlin_sync = 1;                  // k_merlin_batch_sync (lanes permute together) instead of k_merlin_batch (A/B switch)
   uint32_t merlin_clk[2] = {0, 0};
+  int fe_prio = 0;                      // "fe_prio": wave priority of k_shuffle_front_end (s_setprio 0 .. 3)
   int merlin_lanes = 64;                // transcripts per wave of k_merlin_batch_sync ("merlin_lanes": 1 .. 64)
   uint32_t merlin_passes = 0;           // of the last cg1_merlin_batch_device call: Keccak passes of the slowest wave
   int batch_mul_quad_max = 8192;        // k_batch_mul_quad up to this many outputs ("batch_mul_quad_max"; 0 = always one lane per output)
@@ -1066,6 +1067,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "batched_host_horner_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batched_host_horner_max = value; return CG1_OK; }
   if (!strcmp(name, "batch_mul_quad_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batch_mul_quad_max = value; return CG1_OK; }
   if (!strcmp(name, "merlin_sync")) { ctx->merlin_sync = value != 0; return CG1_OK; }
+  if (!strcmp(name, "fe_prio")) { if (value < 0 || value > 3) return CG1_ERR_ARG; ctx->fe_prio = value; return CG1_OK; }
   if (!strcmp(name, "merlin_lanes")) { if (value < 1 || value > 64) return CG1_ERR_ARG; ctx->merlin_lanes = value; return CG1_OK; }
   if (!strcmp(name, "tree_half")) { ctx->tree_half = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
@@ -1558,6 +1560,7 @@ int cg1_shuffle_fe_enqueue(cg1_shuffle_fe* fe, cg1_ctx* ctx, size_t n, const voi
   hipLaunchKernelGGL(cg1fe::k_fe_gather4, dim3((unsigned)((4 * n + 255) / 256)), dim3(256), 0, ctx->stream, (const uint32_t*)d_pts_affine96, fe->pr, (uint32_t)n,
                      (cg1::PreparedPoint*)fe->d_four);
   const unsigned nblk = (unsigned)((n + lanes_per_wave - 1) / lanes_per_wave);
+  fe->pr.prio = (uint32_t)ctx->fe_prio;
   hipLaunchKernelGGL(cg1fe::k_shuffle_front_end, dim3(nblk), dim3(cg1merlin::LANES), 0, ctx->stream, (const uint8_t*)fe->d_init, (const cg1merlin::COp*)fe->d_ops,
                      fe->nops, (const uint32_t*)fe->d_labels, fe->nlabels, (const uint8_t*)fe->d_consts, (const uint8_t*)d_wire48, (const uint8_t*)d_aux,
                      (const cg1::PreparedPoint*)fe->d_four, (const cg1::PreparedPoint*)fe->d_tabG, (const cg1::PreparedPoint*)fe->d_tabH, fe->pr,

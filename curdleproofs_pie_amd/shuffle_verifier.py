@@ -121,7 +121,7 @@ class Prepared:
 
 class ShuffleBatchVerifier:
     def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True,
-                 blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: int = 5, fe_cus: int = 0):
+                 blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: int = 5, fe_cus: int = 0, fe_prio: int = 0):
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
@@ -136,21 +136,22 @@ class ShuffleBatchVerifier:
         # transcript is ~750 dependent Keccak permutations) but occupies only n / 64 of the chip's 1024 SIMDs, so `fe_lanes` launches of
         # consecutive batches run side by side, each on its own context, and the stream keeps fe_lanes + 3 batches in flight.  The
         # host then only packs bytes: proofs/s no longer depends on the host's core count.
-        # Measured on MI355X (profiles/r03_verify_fe_ab.txt, batches of 1024): 74-83 K proofs/s whatever the host, against 24 K / 45 K /
-        # 91 K / 131 K proofs/s with the host front-end on 2 / 4 / 8 / 16 threads -- so None (the default) turns it on when fewer than
-        # six host threads are available to this verifier (e.g. eight ranks sharing a 32-core host), and leaves the host front-end on
-        # otherwise.  CURDLE_G1_DEVICE_FRONT_END=0/1 overrides.
+        # Measured on MI355X (profiles/r03_verify_fe_ab.txt, batches of 1024, GPU_MAX_HW_QUEUES = 24): 120-132 K proofs/s whatever the
+        # host (1 / 2 / 4 / 16 threads), against 13 K / 24 K / 49 K / 91 K / 120-157 K proofs/s with the host front-end on 1 / 2 / 4 / 8 /
+        # 16 threads -- so None (the default) turns it on when fewer than twelve host threads are available to this verifier (e.g.
+        # eight ranks sharing a 64-thread host), and leaves the host front-end on otherwise.  CURDLE_G1_DEVICE_FRONT_END=0/1 overrides.
         env = os.environ.get("CURDLE_G1_DEVICE_FRONT_END")
         if env in ("0", "1"):
             device_front_end = env == "1"
         if device_front_end is None:
-            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < 6
+            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < 12
         self.device_front_end = bool(device_front_end)
         self.fe_lanes = max(1, int(fe_lanes)) if self.device_front_end else 0
         # fe_cus > 0 (A/B switch, off): the front-end launches get that many compute units of their own (the last ones) and the
         # throughput kernels are confined to the others (hipExtStreamCreateWithCUMask).  Measured a loss: the masked decompression
         # stream took 30 ms instead of 6 per batch (profiles/r03_verify_fe_ab.txt)
         self.fe_cus = int(fe_cus) if self.device_front_end else 0
+        self.fe_prio = int(fe_prio)
         self._cu_total = 256
         if self.fe_cus and self._ctx is not None:
             self._user_ctx = self._ctx                 # the caller's context stays untouched: this mode drives contexts of its own
@@ -535,6 +536,7 @@ class ShuffleBatchVerifier:
                 aux_h.free(); aux_d.free()
             else:
                 cx = N.Context(self.ctx.device, cu_mask=range(self._cu_total - self.fe_cus, self._cu_total) if self.fe_cus else None)
+                cx.set_param("fe_prio", self.fe_prio)
                 fe = N.cg1_shuffle_fe_create(cx.handle, self.crs.ell, self.crs.lg, self.crs.affine96, self.crs.bytes)
                 if not fe:
                     raise N.NativeError("cg1_shuffle_fe_create failed")

@@ -14,9 +14,13 @@ inst, proofs, _ = fx.tiled(n)
 ctx = N.Context(0)
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 threads = int(os.environ.get("THREADS", "0"))
-configs = [("host front-end", dict(device_front_end=False))] + [(f"device front-end, {f} lanes, {c} CUs of their own", dict(device_front_end=True, fe_lanes=f, fe_cus=c))
-                                            for f, c in ((5, 0), (5, 24), (6, 32), (6, 48), (8, 64))]
-for rnd in range(2):
+# CONFIGS = "lanes:cus:prio,..." (front-end launches side by side : compute units of their own : wave priority of the front-end kernel)
+spec = os.environ.get("CONFIGS", "5:0:0,5:0:3,8:0:3")
+configs = [("host front-end", dict(device_front_end=False))] + [
+    (f"device front-end, {f} lanes, {c} CUs of their own, priority {pr}", dict(device_front_end=True, fe_lanes=int(f), fe_cus=int(c), fe_prio=int(pr)))
+    for f, c, pr in (x.split(":") for x in spec.split(","))]
+print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES"), flush=True)
+for rnd in range(int(os.environ.get('ROUNDS', '2'))):
     for name, kw in configs:
         v = ShuffleBatchVerifier(fx.crs, ctx, threads=threads, **kw)
         list(v.verify_stream([(inst, proofs, n)] * (4 + kw.get("fe_lanes", 0))))
