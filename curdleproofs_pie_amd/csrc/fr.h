@@ -1,7 +1,7 @@
 // BLS12-381 scalar field Fr (r = 0x73eda753...00000001, 255 bits): 4 x 64-bit limbs, Montgomery radix 2^256,
 // header-only, ONE source for the host (csrc/shuffle_verify.cpp) and the device (csrc/kernels_rows.h: the same functions
-// compiled __host__ __device__, so both sides produce the same bytes by construction; the device code is not tuned --
-// a verification needs a few thousand Fr products against ~10^5 Fp products).
+// compiled __host__ __device__, so both sides produce the same bytes by construction; on the device only the product is tuned:
+// 32-bit limbs, round 3 -- a verification needs a few thousand Fr products against ~10^5 Fp products).
 // Backs the verifier-side scalar work of the shuffle argument:
 // the reference does this with one Python `Scalar` object per operation over the Rust wheel
 // (py_arkworks_bls12381-stubs/__init__.pyi:32-54; ipa.py:164-186,216,227-229; same_msm.py:155-182,213;
@@ -70,6 +70,39 @@ CG1FR_HD fr fr_sub(const fr& a, const fr& b) { return fr_add(a, fr_neg(b)); }
 
 // Montgomery product a * b / 2^256 mod r (CIOS)
 CG1FR_HD fr fr_mul(const fr& a, const fr& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // device: the same CIOS over eight 32-bit limbs -- a step is one v_mad_u64_u32 and one 64-bit add (a 64 x 64 -> 128 product costs
+  // four of them plus the carries of the 128-bit accumulations: 857 instructions per product against ~420 here).  The result is the
+  // canonical representative either way: the same bytes as the 64-bit code below.
+  uint32_t A[8], B[8], M[8], t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    A[2 * i] = (uint32_t)a.l[i]; A[2 * i + 1] = (uint32_t)(a.l[i] >> 32);
+    B[2 * i] = (uint32_t)b.l[i]; B[2 * i + 1] = (uint32_t)(b.l[i] >> 32);
+    M[2 * i] = (uint32_t)cg1::H_FR[i]; M[2 * i + 1] = (uint32_t)(cg1::H_FR[i] >> 32);
+  }
+  const uint32_t ninv = (uint32_t)cg1::H_FR_INV;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint64_t p = (uint64_t)A[j] * B[i] + t[j] + c; t[j] = (uint32_t)p; c = (uint32_t)(p >> 32); }
+    const uint64_t s = (uint64_t)t[8] + c;
+    t[8] = (uint32_t)s;
+    const uint32_t t9 = (uint32_t)(s >> 32);
+    const uint32_t m = t[0] * ninv;
+    c = (uint32_t)(((uint64_t)m * M[0] + t[0]) >> 32);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) { const uint64_t p = (uint64_t)m * M[j] + t[j] + c; t[j - 1] = (uint32_t)p; c = (uint32_t)(p >> 32); }
+    const uint64_t s2 = (uint64_t)t[8] + c;
+    t[7] = (uint32_t)s2;
+    t[8] = t9 + (uint32_t)(s2 >> 32);
+  }
+  fr r{{(uint64_t)t[0] | ((uint64_t)t[1] << 32), (uint64_t)t[2] | ((uint64_t)t[3] << 32), (uint64_t)t[4] | ((uint64_t)t[5] << 32),
+        (uint64_t)t[6] | ((uint64_t)t[7] << 32)}};
+  if (t[8] || geq_r(r.l)) sub_r(r.l);
+  return r;
+#else
   uint64_t t[6] = {0, 0, 0, 0, 0, 0};
   for (int i = 0; i < 4; ++i) {
     u128 c = 0;
@@ -96,6 +129,7 @@ CG1FR_HD fr fr_mul(const fr& a, const fr& b) {
   fr r{{t[0], t[1], t[2], t[3]}};
   if (t[4] || geq_r(r.l)) sub_r(r.l);
   return r;
+#endif
 }
 CG1FR_HD fr fr_sqr(const fr& a) { return fr_mul(a, a); }
 

@@ -85,15 +85,31 @@ __global__ void __launch_bounds__(256) k_fe_gather4(const uint32_t* __restrict__
 }
 
 // ---- the barrier steps (all lanes of the wave that are live take them together)
+// 32 little-endian bytes of an out-row slot as they stand (a canonical scalar, NOT in Montgomery form) / back
+__device__ __forceinline__ fr fld_raw(const uint8_t* base, uint32_t slot) {
+  const uint64_t* q = reinterpret_cast<const uint64_t*>(base + 32u * slot);
+  return fr{{q[0], q[1], q[2], q[3]}};
+}
+__device__ __forceinline__ void fst_raw(uint8_t* base, uint32_t slot, const fr& v) {
+  uint64_t* q = reinterpret_cast<uint64_t*>(base + 32u * slot);
+  q[0] = v.l[0]; q[1] = v.l[1]; q[2] = v.l[2]; q[3] = v.l[3];
+}
+
 __device__ __noinline__ void step_gprod(uint8_t* orow, const Params& pr) {
   const cg1rows::RowIn R{pr.ell, pr.lg};
-  const fr alpha = fld(orow, (uint32_t)R.head()), beta = fld(orow, (uint32_t)R.head() + 1u);
-  fr t = beta, g = cg1fr::fr_one();                          // i * alpha + beta, built by repeated addition (same_perm.py:98-101)
-  for (uint32_t i = 0; i < pr.ell; ++i) {
-    g = fmul(g, cg1fr::fr_add(fld(orow, (uint32_t)R.a() + i), t));
+  // prod_i (a_i + i alpha + beta), i alpha + beta built by repeated addition (same_perm.py:98-101).  The factors stay as they are
+  // read (no conversion into Montgomery form): a Montgomery product of two plain values is x y / R, so the running product after
+  // ell factors is off by R^-(ell-1), and ONE product with R^ell (= the Montgomery form of R^(ell-1)) at the end puts that right --
+  // ell + ~12 products instead of 3 ell.
+  const fr alpha = fld_raw(orow, (uint32_t)R.head()), beta = fld_raw(orow, (uint32_t)R.head() + 1u);
+  fr t = cg1fr::fr_add(beta, alpha);
+  fr g = cg1fr::fr_add(fld_raw(orow, (uint32_t)R.a()), beta);
+  for (uint32_t i = 1; i < pr.ell; ++i) {
+    g = fmul(g, cg1fr::fr_add(fld_raw(orow, (uint32_t)R.a() + i), t));
     t = cg1fr::fr_add(t, alpha);
   }
-  fst(orow, pr.K, g);
+  const fr r2{{cg1::H_FR_R2[0], cg1::H_FR_R2[1], cg1::H_FR_R2[2], cg1::H_FR_R2[3]}};      // the Montgomery form of R
+  fst_raw(orow, pr.K, fmul(g, fpow(r2, pr.ell - 1u)));
 }
 
 __device__ __noinline__ void step_da(uint8_t* orow, const Params& pr, const cg1::PreparedPoint* __restrict__ tabG, const cg1::PreparedPoint* __restrict__ tabH,
@@ -115,17 +131,23 @@ __device__ __noinline__ void step_da(uint8_t* orow, const Params& pr, const cg1:
   cg1fr::fr_to_le32(cg1fr::fr_neg(beta_inv), s1);
   cg1fr::fr_to_le32(alpha_g, s2);
   xyzz acc = xyzz_identity(), Dp = xyzz_identity();
+  auto operand = [&](uint32_t j, bool& skip) -> const PreparedPoint* {
+    skip = false;
+    if (j < 32u) { const uint32_t b = s1[j]; skip = b == 0u; return tabG + (size_t)j * 256u + b; }
+    if (j < 64u) { const uint32_t b = s2[j - 32u]; skip = b == 0u; return tabH + (size_t)(j - 32u) * 256u + b; }
+    if (j == 64u) return four + 3;                          // B
+    return four + (j - 65u);                                // A, T_1, U_1
+  };
+  // (the record of addition j + 1 is fetched before addition j runs: a table entry is a 128-byte random access)
+  fp nx, ny; uint32_t nflags; bool nskip;
+  load_affine(operand(0u, nskip), nx, ny, nflags);
 #pragma unroll 1
   for (uint32_t j = 0; j < 68u; ++j) {
-    const PreparedPoint* op;
-    bool skip = false;
-    if (j < 32u) { const uint32_t b = s1[j]; skip = b == 0u; op = tabG + (size_t)j * 256u + b; }
-    else if (j < 64u) { const uint32_t b = s2[j - 32u]; skip = b == 0u; op = tabH + (size_t)(j - 32u) * 256u + b; }
-    else if (j == 64u) op = four + 3;                      // B
-    else op = four + (j - 65u);                            // A, T_1, U_1
+    const fp x = nx, y = ny;
+    const uint32_t flags = nflags;
+    const bool skip = nskip;
+    if (j + 1u < 68u) load_affine(operand(j + 1u, nskip), nx, ny, nflags);
     if (j == 65u) { Dp = acc; acc = xyzz_identity(); }
-    fp x, y; uint32_t flags;
-    load_affine(op, x, y, flags);
     if (!skip && !(flags & 1u)) acc = xyzz_madd(acc, x, y);
   }
   // one inversion for both: 1 / (ZZ_D ZZZ_D ZZ_A ZZZ_A)
@@ -143,22 +165,33 @@ __device__ __noinline__ void step_da(uint8_t* orow, const Params& pr, const cg1:
 __device__ __noinline__ void step_final(uint8_t* orow, const Params& pr, uint8_t* __restrict__ block_out) {
   const cg1rows::RowIn R{pr.ell, pr.lg};
   // inverses of gamma[0..lg) and gamma_m[0..lg) with one inversion (fr_batch_inv of the host front-end, per vector there; the
-  // inverse of a field element is unique, so sharing the inversion across both vectors gives the same bytes)
+  // inverse of a field element is unique, so sharing the inversion across both vectors gives the same bytes).  Values are read and
+  // written as they stand in the block (plain, not Montgomery): with mm(x, y) = x y / R,  mm(plain, Montgomery) is plain and
+  // mm(Montgomery, Montgomery) is Montgomery, so only the gammas are converted (one product each, twice).
   const uint32_t m = 2u * pr.lg;
-  fr acc = cg1fr::fr_one();
-  for (uint32_t i = 0; i < m; ++i) {                       // prefix products parked in the inverse slots
-    fst(orow, (uint32_t)R.gam_inv() + i, acc);
-    acc = fmul(acc, fld(orow, (uint32_t)R.gam() + i));
+  const fr r2{{cg1::H_FR_R2[0], cg1::H_FR_R2[1], cg1::H_FR_R2[2], cg1::H_FR_R2[3]}};
+  fr acc = fr{{1, 0, 0, 0}};                               // plain prefix products, parked in the inverse slots
+  for (uint32_t i = 0; i < m; ++i) {
+    fst_raw(orow, (uint32_t)R.gam_inv() + i, acc);
+    acc = fmul(acc, fmul(fld_raw(orow, (uint32_t)R.gam() + i), r2));
   }
-  fr inv = finv(acc);
+  fr inv = finv(fmul(acc, r2));                            // Montgomery form of 1 / (g_0 .. g_{m-1})
   for (uint32_t i = m; i-- > 0;) {
-    const fr pre = fld(orow, (uint32_t)R.gam_inv() + i);
-    fst(orow, (uint32_t)R.gam_inv() + i, fmul(inv, pre));
-    inv = fmul(inv, fld(orow, (uint32_t)R.gam() + i));
+    const fr pre = fld_raw(orow, (uint32_t)R.gam_inv() + i);
+    fst_raw(orow, (uint32_t)R.gam_inv() + i, fmul(inv, pre));
+    inv = fmul(inv, fmul(fld_raw(orow, (uint32_t)R.gam() + i), r2));
   }
-  const uint4* src = reinterpret_cast<const uint4*>(orow);
-  uint4* dst = reinterpret_cast<uint4*>(block_out);
-  for (uint32_t i = 0; i < 2u * pr.K; ++i) dst[i] = src[i];
+  const uint4* __restrict__ src = reinterpret_cast<const uint4*>(orow);
+  uint4* __restrict__ dst = reinterpret_cast<uint4*>(block_out);
+  uint32_t i = 0;
+  for (; i + 8u <= 2u * pr.K; i += 8u) {                   // eight loads in flight per round trip (the block is a lane's own 5.8 KB)
+    uint4 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[i + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dst[i + k] = v[k];
+  }
+  for (; i < 2u * pr.K; ++i) dst[i] = src[i];
 }
 
 // grid = ceil(n / lanes_used) blocks of LANES threads.  aux: per proof r_p c_fin d_fin z_k z_t z_u x_fin | rho[12] (19 x 32 bytes, as they
@@ -230,6 +263,230 @@ __global__ void __launch_bounds__(LANES) k_shuffle_front_end(const uint8_t* __re
       else step_final(orow, pr, rowin + (size_t)t * pr.K * 32u);
       ++m.k; m.ph = 0; m.i = 0; m.stage = 0;
     }
+  }
+}
+
+
+// ------------------------------------------------------------------ the same front-end over a BLOCK PROGRAM (round 3, second form)
+// k_shuffle_front_end above spends 2/3 of a pass outside Keccak-f: its lanes stand at different byte positions after their first
+// rejected challenge draws, so the STROBE byte machine runs as the union of the lanes' phases, and every message is an exposed
+// global load.  But the verifier's transcript has a STATIC shape: every message length is fixed by ell, and a challenge always
+// leaves the sponge at (pos, pos_begin) = (32, 0) however many draws it took (the PRF's C flag forces a permutation before each
+// draw) -- so the whole byte stream between two permutations is known per NODE of a small control-flow graph:
+//     plain node -> next node;     squeeze node -accepted-> next node,  -rejected-> its redo node (frame + PRF header at pos 32) -> itself / next
+// The host cuts the operation list into those nodes once per ell (fe_build_nodes in msm_gpu.hip: a symbolic run of strobe.py:55-107
+// and merlin_transcript.py:11-24 that records, per sponge byte, the constant XOR-ed into it or where the byte comes from);
+// k_fe_fill_rows then writes, for every proof, one 192-byte ROW per node: 42 words = everything XOR-ed into the rate between two
+// permutations that is known before hashing starts (framing, labels, lengths, STROBE's own marks, the proof's and the instance's
+// point encodings -- canonicalised where flagged as infinity, util.py:27-32), 1 word of node information and 5 piece descriptors
+// for what is not (re-appended challenges, the grand product, D, inner_prod, A': copied from the lane's LDS / out row when the lane
+// gets there).  A pass of the hashing kernel is then: XOR the pieces, issue the loads of BOTH successor rows, Keccak-f with the
+// current row folded into its load of the sponge, pick the successor.  No byte machine, no exposed latency, the same code for
+// every lane whatever node it stands at.  Same outputs, byte for byte (tests/test_shuffle_frontend_gpu.py runs both forms).
+constexpr uint32_t ROW_WORDS = 48;                 // 42 content words (bytes 0 .. 167 of the sponge), info, 5 pieces
+constexpr uint32_t N_PLAIN = 0, N_SQUEEZE = 1, N_END = 2;
+constexpr uint32_t MAX_PIECES = 5;
+// info word:  type [0,2) | barrier [2,4): 0 none, 1 X_GPROD, 2 X_DA, 3 X_FINAL | accept delta [4,6) | reject delta [6,8) | challenge slot [8,24)
+// piece word: len [0,6) (0 = none) | sponge byte offset [6,14) | source [14]: 0 = the challenge just drawn, 1 = the lane's out row | source byte offset [15,32)
+struct RowDesc {                                   // per (node, word): the constant part and where the proof-dependent bytes come from
+  uint32_t tword;
+  uint32_t src;                                    // 0 = none; else 1 | first byte [1,3) | byte count - 1 [3,5) | byte within the point [5,11) | point index [11,32)
+};
+
+// Rows are laid out [wave][node][lane of the wave][48 words]: the lanes of a wave stand at nearby nodes (they drift apart by rejected
+// draws only: a few dozen nodes), so what a wave reads in one pass lies within a few hundred KB instead of in 64 regions 136 KB apart.
+__device__ __forceinline__ size_t row_word_index(uint32_t proof, uint32_t node, uint32_t nodes, uint32_t lanes_used) {
+  const uint32_t wave = proof / lanes_used, lane = proof - wave * lanes_used;
+  return (((size_t)wave * nodes + node) * lanes_used + lane) * ROW_WORDS;
+}
+
+__global__ void __launch_bounds__(256) k_fe_fill_rows(const RowDesc* __restrict__ desc, uint32_t nodes, const uint8_t* __restrict__ wire, uint32_t L,
+                                                      uint32_t n, uint32_t lanes_used, uint32_t* __restrict__ rows) {
+  const size_t per = (size_t)nodes * ROW_WORDS;
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= per * n) return;
+  const size_t proof = t / per, k = t - proof * per;
+  const RowDesc d = desc[k];
+  uint32_t v = d.tword;
+  if (d.src) {
+    const uint32_t lo = (d.src >> 1) & 3u, cnt = ((d.src >> 3) & 3u) + 1u, k0 = (d.src >> 5) & 63u, p = d.src >> 11;
+    const uint8_t* pt = wire + ((size_t)proof * L + p) * 48u;
+    const bool inf = (pt[0] & 0xC0u) == 0xC0u;                            // hashed as the wheel re-serialises it: C0 00 .. 00
+    for (uint32_t b = 0; b < cnt; ++b) {
+      const uint32_t byte = inf ? (k0 + b == 0u ? 0xC0u : 0u) : (uint32_t)pt[k0 + b];
+      v ^= byte << (8u * (lo + b));
+    }
+  }
+  const uint32_t node = (uint32_t)(k / ROW_WORDS), word = (uint32_t)(k - (size_t)node * ROW_WORDS);
+  rows[row_word_index((uint32_t)proof, node, nodes, lanes_used) + word] = v;
+}
+
+// One late piece: `len` <= 48 bytes from the challenge just drawn (LDS, word j at drawn[j * LANES], 9 words) or from the lane's out row
+// (global) XOR-ed into the sponge at byte `dst`.  All source words are fetched at once (one exposed latency), moved to the
+// destination's byte alignment with v_alignbyte, masked to the piece and XOR-ed in -- no loop-carried LDS round trips.
+__device__ __forceinline__ void apply_piece(uint32_t pc, uint32_t* w, const uint32_t* drawn, const uint8_t* orow) {
+  const uint32_t len = pc & 63u, dst = (pc >> 6) & 255u, from_row = (pc >> 14) & 1u, so = pc >> 15;
+  const uint32_t b = dst & 3u;
+  // destination word j (sponge word (dst >> 2) + j) = the four source bytes from byte address  so - b + 4 j  on
+  const int32_t s0 = (int32_t)so - (int32_t)b;
+  const int32_t wb = s0 >> 2;                                      // (arithmetic shift: -1 when the piece starts inside destination word 0)
+  const uint32_t sh = (uint32_t)s0 & 3u;
+  const int32_t wmax = (int32_t)((so + len - 1u) >> 2);            // last source word that holds a byte of the piece
+  uint32_t sw[14];
+  if (from_row) {
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(orow);
+#pragma unroll
+    for (int j = 0; j < 14; ++j) { int32_t k = wb + j; k = k < 0 ? 0 : (k > wmax ? wmax : k); sw[j] = g[k]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 14; ++j) { int32_t k = wb + j; k = k < 0 ? 0 : (k > 8 ? 8 : k); sw[j] = drawn[k * LANES]; }
+  }
+  const uint32_t last = b + len;                                   // piece bytes within the destination words: [b, last)
+  const uint32_t jl = last >> 2, pm = (1u << (8u * (last & 3u))) - 1u;
+  uint32_t* d = w + (dst >> 2) * LANES;
+#pragma unroll
+  for (uint32_t j = 0; j < 13u; ++j) {
+    if (j == 9u && last <= 36u) break;                             // (only a 48-byte piece, or one starting late in its word, reaches words 9 .. 12)
+    const uint32_t v = __builtin_amdgcn_alignbyte(sw[j + 1], sw[j], sh);
+    uint32_t m = j < jl ? 0xffffffffu : (j == jl ? pm : 0u);
+    if (j == 0u) m &= 0xffffffffu << (8u * b);
+    if (j < 9u) d[j * LANES] ^= v & m;
+    else if (m) d[j * LANES] ^= v & m;
+  }
+}
+
+// Keccak-f[1600] on the lane's LDS sponge with the 42 row words XOR-ed in on the way (the absorb of a whole rate block)
+__device__ __forceinline__ void keccak_absorb_row(uint32_t* w, const uint32_t (&x)[ROW_WORDS]) { cg1merlin::keccak_words<true>(w, x); }
+
+__device__ __forceinline__ void load_row(const uint4* __restrict__ src, uint32_t (&x)[ROW_WORDS]) {
+#pragma unroll
+  for (int q = 0; q < 12; ++q) { const uint4 v = src[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+}
+
+template <bool TIMED>
+__global__ void __launch_bounds__(LANES) k_shuffle_front_end_rows(const uint8_t* __restrict__ init_state, const uint32_t* __restrict__ rows, uint32_t nodes,
+                                                                  const uint8_t* __restrict__ wire, const uint8_t* __restrict__ aux,
+                                                                  const cg1::PreparedPoint* __restrict__ four, const cg1::PreparedPoint* __restrict__ tabG,
+                                                                  const cg1::PreparedPoint* __restrict__ tabH, Params pr, uint8_t* __restrict__ scratch,
+                                                                  uint8_t* __restrict__ rowin, int32_t* __restrict__ status, uint32_t n, uint32_t lanes_used,
+                                                                  uint32_t* __restrict__ passes_out) {
+  __shared__ uint32_t lds[52 * LANES];
+  __shared__ uint32_t lds_drawn[9 * LANES];                  // (+1: the word-wise copy reads one word past the challenge)
+  const uint32_t t = blockIdx.x * lanes_used + threadIdx.x;
+  const bool live = threadIdx.x < lanes_used && t < n;
+  uint32_t* w = lds + threadIdx.x;
+  uint32_t* drawn = lds_drawn + threadIdx.x;
+  drawn[8 * LANES] = 0u;
+  for (int i = 0; i < 50; ++i) w[i * LANES] = reinterpret_cast<const uint32_t*>(init_state)[i];
+  const size_t me = live ? t : 0;
+  const uint8_t* row = wire + me * (size_t)pr.L * 48u;
+  uint8_t* orow = scratch + me * (size_t)pr.out_stride;
+  bool done = !live;
+  if (live) {                                               // the same parse as k_shuffle_front_end
+    const cg1rows::RowIn R{pr.ell, pr.lg};
+    const uint8_t* a = aux + me * (19u * 32u);
+    int32_t st = 0;
+    for (uint32_t k = 0; k < 19u; ++k) {
+      uint64_t v[4];
+      for (int q = 0; q < 4; ++q) { uint64_t x = 0; for (int b = 7; b >= 0; --b) x = (x << 8) | a[32u * k + 8u * q + b]; v[q] = x; }
+      const bool ok = !cg1fr::geq_r(v);
+      if (!ok && k < 7u && st != CG1_SHUFFLE_BAD_SCALAR) st = CG1_SHUFFLE_BAD_SCALAR;
+      if (!ok && k >= 7u && st == 0) st = CG1_SHUFFLE_BAD_WEIGHT;
+      const uint32_t slot = k == 0u ? pr.K + 1u : (k < 7u ? (uint32_t)R.fields() + (k - 1u) : (uint32_t)R.rho() + (k - 7u));
+      for (int q = 0; q < 4; ++q) reinterpret_cast<uint64_t*>(orow + 32u * slot)[q] = v[q];
+    }
+    if (st != CG1_SHUFFLE_BAD_SCALAR && (row[(size_t)pr.idx_T0 * 48u] & 0x40u)) st = CG1_SHUFFLE_T0_INFINITY;
+    status[t] = st;
+    if (st) {
+      uint4* dst = reinterpret_cast<uint4*>(rowin + (size_t)t * pr.K * 32u);
+      for (uint32_t i = 0; i < 2u * pr.K; ++i) dst[i] = make_uint4(0, 0, 0, 0);
+      done = true;
+    }
+  }
+  // row of node k of this lane: my_rows + k * row_step (layout [wave][node][lane][48 words], see k_fe_fill_rows)
+  const uint4* my_rows = reinterpret_cast<const uint4*>(rows + row_word_index((uint32_t)me, 0u, nodes, lanes_used));
+  const size_t row_step = (size_t)lanes_used * (ROW_WORDS / 4);
+  uint32_t cur[ROW_WORDS], nxa[ROW_WORDS], nxr[ROW_WORDS];
+  load_row(my_rows, cur);
+  uint32_t nd = 0, passes = 0;
+  bool bar_done = false;
+  unsigned long long t_pieces = 0, t_kec = 0, t_post = 0, t_step[3] = {0, 0, 0}, t_sq = 0;      // TIMED: shader clock per part of a pass (reported per wave)
+  auto now = [&]() -> unsigned long long { return TIMED ? __builtin_amdgcn_s_memtime() : 0ull; };
+  for (;;) {
+    const unsigned long long c0 = now();
+    const uint32_t info = cur[42];
+    const uint32_t type = info & 3u, bar = (info >> 2) & 3u;
+    const bool blocked = !done && bar != 0u && !bar_done;
+    const bool act = !done && !blocked;
+    if (__ballot(act) != 0ull) {
+      if (act) {
+        if (type == N_END) {
+          done = true;
+        } else {
+          // what was not known before hashing started: the accepted challenge (LDS) or values of the lane's out row
+#pragma unroll
+          for (uint32_t q = 0; q < MAX_PIECES; ++q) {
+            const uint32_t pc = cur[43 + q];
+            const uint32_t len = pc & 63u;
+            if (len != 0u) {
+              apply_piece(pc, w, drawn, orow);
+            }
+          }
+          const uint32_t da = (info >> 4) & 3u, dr = (info >> 6) & 3u;
+          load_row(my_rows + (size_t)(nd + da) * row_step, nxa);
+          if (type == N_SQUEEZE) load_row(my_rows + (size_t)(nd + dr) * row_step, nxr);
+          const unsigned long long c1 = now();
+          keccak_absorb_row(w, cur);
+          const unsigned long long c2 = now();
+          t_pieces += c1 - c0; t_kec += c2 - c1;
+          bool accept = true;
+          uint32_t dv[8];
+          if (type == N_SQUEEZE) {                                            // strobe.py:77-87 from pos 0, curdleproofs_transcript.py:15-25
+            uint64_t wv[4], any = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { dv[j] = w[j * LANES]; w[j * LANES] = 0u; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wv[j] = (uint64_t)dv[2 * j] | ((uint64_t)dv[2 * j + 1] << 32); any |= wv[j]; }
+            accept = any != 0;
+            if (accept) { accept = false; for (int j = 3; j >= 0; --j) if (wv[j] != cg1::H_FR[j]) { accept = wv[j] < cg1::H_FR[j]; break; } }
+            if (accept) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) drawn[j * LANES] = dv[j];
+            }
+          }
+          nd += accept ? da : dr;
+          t_sq += now() - c2;
+#pragma unroll
+          for (uint32_t j = 0; j < ROW_WORDS; ++j) cur[j] = accept ? nxa[j] : nxr[j];
+          // the accepted challenge goes to its slot of the out row AFTER the successor row has been waited for: a store issued before
+          // that wait would be waited for as well (one counter for loads and stores), ~5 K clocks per pass
+          asm volatile("" ::: "memory");
+          if (type == N_SQUEEZE && accept) {
+            uint32_t* o = reinterpret_cast<uint32_t*>(orow + 32u * ((info >> 8) & 0xffffu));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = dv[j];
+          }
+          bar_done = false;
+        }
+      }
+      ++passes;
+      t_post += now() - c0;
+      continue;
+    }
+    if (__ballot(blocked) == 0ull) break;
+    if (blocked) {                                            // every lane that is not done stands at the same barrier
+      if (bar == 1u) step_gprod(orow, pr);
+      else if (bar == 2u) step_da(orow, pr, tabG, tabH, four + 4u * me);
+      else step_final(orow, pr, rowin + (size_t)t * pr.K * 32u);
+      bar_done = true;
+    }
+    if (TIMED) { const unsigned long long dt = now() - c0; const uint32_t b = __builtin_amdgcn_readfirstlane(blocked ? bar : 0u); if (b) t_step[b - 1u] += dt; }
+  }
+  if (passes_out && threadIdx.x == 0) {                     // passes | clocks / 256: pieces + row loads issued, Keccak-f, whole passes, draw + range check, the three barrier steps
+    passes_out[8 * blockIdx.x] = passes;
+    passes_out[8 * blockIdx.x + 1] = (uint32_t)(t_pieces >> 8); passes_out[8 * blockIdx.x + 2] = (uint32_t)(t_kec >> 8);
+    passes_out[8 * blockIdx.x + 3] = (uint32_t)(t_post >> 8); passes_out[8 * blockIdx.x + 4] = (uint32_t)(t_sq >> 8);
+    for (int k = 0; k < 3; ++k) passes_out[8 * blockIdx.x + 5 + k] = (uint32_t)(t_step[k] >> 8);
   }
 }
 

@@ -140,6 +140,8 @@ struct Ctx {
   int tree_half = 1;                    // k_small_tree_quad: 2 lanes per element (a quad takes two elements) instead of 4 (A/B switch)
   int merlin_sync = 1;                  // k_merlin_batch_sync (lanes permute together) instead of k_merlin_batch (A/B switch)
   uint32_t merlin_clk[2] = {0, 0};
+  int fe_timed = 0;                     // "fe_timed": the block-program kernel reads the shader clock around the parts of a pass (cg1_shuffle_fe_last_split)
+  int fe_rows = 1;                      // "fe_rows": 1 = the front-end's block-program kernel (k_shuffle_front_end_rows), 0 = the byte machine
   int fe_prio = 0;                      // "fe_prio": wave priority of k_shuffle_front_end (s_setprio 0 .. 3)
   int merlin_lanes = 64;                // transcripts per wave of k_merlin_batch_sync ("merlin_lanes": 1 .. 64)
   uint32_t merlin_passes = 0;           // of the last cg1_merlin_batch_device call: Keccak passes of the slowest wave
@@ -1067,6 +1069,8 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "batched_host_horner_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batched_host_horner_max = value; return CG1_OK; }
   if (!strcmp(name, "batch_mul_quad_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batch_mul_quad_max = value; return CG1_OK; }
   if (!strcmp(name, "merlin_sync")) { ctx->merlin_sync = value != 0; return CG1_OK; }
+  if (!strcmp(name, "fe_timed")) { ctx->fe_timed = value != 0; return CG1_OK; }
+  if (!strcmp(name, "fe_rows")) { ctx->fe_rows = value != 0; return CG1_OK; }
   if (!strcmp(name, "fe_prio")) { if (value < 0 || value > 3) return CG1_ERR_ARG; ctx->fe_prio = value; return CG1_OK; }
   if (!strcmp(name, "merlin_lanes")) { if (value < 1 || value > 64) return CG1_ERR_ARG; ctx->merlin_lanes = value; return CG1_OK; }
   if (!strcmp(name, "tree_half")) { ctx->tree_half = value != 0; return CG1_OK; }
@@ -1402,6 +1406,8 @@ struct cg1_shuffle_fe {
   uint32_t nops = 0, nlabels = 0;
   void *d_init = nullptr, *d_ops = nullptr, *d_labels = nullptr, *d_consts = nullptr, *d_tabG = nullptr, *d_tabH = nullptr;
   void *d_four = nullptr, *d_scratch = nullptr; size_t cap_n = 0;
+  // the block program (kernels_frontend.h, second form): row descriptors per (node, word); the rows of a launch; passes per wave
+  void *d_desc = nullptr, *d_rows = nullptr, *d_passes = nullptr; uint32_t n_nodes = 0; size_t cap_rows = 0, cap_blocks = 0, last_blocks = 0; uint32_t last_split[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   char err[200] = {0};
 };
 
@@ -1475,6 +1481,123 @@ void fe_build_program(size_t ell, size_t lg, FeProgram& P) {
   }
   P.op(cg1fe::X_FINAL, nullptr, 0, 0, 0);
 }
+
+// The operation list cut into the nodes of kernels_frontend.h's block program: a symbolic run of STROBE (strobe.py:55-107) and of
+// Merlin's framing (merlin_transcript.py:11-24, curdleproofs_transcript.py:15-25) that keeps, per byte of the sponge's rate, the
+// constant XOR-ed into it and / or the place the byte comes from.  false = the program does not fit the row format (more than
+// MAX_PIECES late pieces in a node, an offset too large): the caller keeps the byte-machine kernel.
+struct FeNodes {
+  struct Byte { uint8_t kind = 0; uint32_t src = 0; };              // 0 none, 1 wire point byte (src = point * 48 + k), 2 the challenge just drawn, 3 the out row
+  struct Node { uint8_t T[168]; Byte D[168]; uint32_t type = cg1fe::N_PLAIN, bar = 0, da = 1, dr = 0, slot = 0; Node() { memset(T, 0, sizeof T); } };
+  std::vector<Node> nodes;
+  Node cur;
+  uint32_t pos = 0, pos_begin = 0;
+  bool ok = true;
+  int last_closed = -1;
+
+  void run_f() {
+    cur.T[pos] ^= (uint8_t)pos_begin; cur.T[pos + 1] ^= 0x04; cur.T[cg1merlin::STROBE_R + 1] ^= 0x80;
+    nodes.push_back(cur);
+    last_closed = (int)nodes.size() - 1;
+    cur = Node();
+    pos = 0; pos_begin = 0;
+  }
+  void put(uint8_t v) { cur.T[pos] ^= v; if (++pos == (uint32_t)cg1merlin::STROBE_R) run_f(); }
+  void put_src(uint8_t kind, uint32_t src) { cur.D[pos].kind = kind; cur.D[pos].src = src; if (++pos == (uint32_t)cg1merlin::STROBE_R) run_f(); }
+  void begin_op(uint8_t flags) {
+    const uint32_t old = pos_begin;
+    pos_begin = pos + 1;
+    put((uint8_t)old); put(flags);
+    if ((flags & (cg1merlin::FLAG_C | cg1merlin::FLAG_K)) && pos != 0) run_f();
+  }
+  void frame(const std::string& label, uint32_t len) {
+    begin_op(cg1merlin::FLAG_M | cg1merlin::FLAG_A);
+    for (char c : label) put((uint8_t)c);
+    for (int j = 0; j < 4; ++j) put((uint8_t)(len >> (8 * j)));
+  }
+  void barrier(uint32_t kind) { if (cur.bar) ok = false; cur.bar = kind; }
+};
+
+bool fe_build_nodes(const FeProgram& P, const uint8_t* init, const uint8_t* consts, std::vector<cg1fe::RowDesc>& desc, uint32_t& n_nodes) {
+  using namespace cg1merlin;
+  FeNodes S;
+  S.pos = init[200]; S.pos_begin = init[201];
+  for (const COp& op : P.ops) {
+    const uint32_t kind = op.kind_label & 0xffu, lab = (op.kind_label >> 8) & 0xffu, llen = op.kind_label >> 16;
+    if (kind >= OP_BARRIER) { S.barrier(kind == cg1fe::X_GPROD ? 1u : (kind == cg1fe::X_DA ? 2u : 3u)); continue; }
+    const std::string label = P.labels[lab].substr(0, llen);
+    if (kind == OP_CHALLENGE_SCALAR) {
+      S.frame(label, 32);
+      S.begin_op(FLAG_I | FLAG_A | FLAG_C);                              // the permutation the C flag forces closes the node the draw follows
+      if (S.pos != 0 || S.last_closed != (int)S.nodes.size() - 1 || S.last_closed < 0) return false;
+      FeNodes::Node& sq = S.nodes[S.last_closed];
+      if (sq.type != cg1fe::N_PLAIN) return false;
+      sq.type = cg1fe::N_SQUEEZE; sq.da = 2; sq.dr = 1; sq.slot = op.out_off / 32u;
+      // the redo node: the same frame and PRF header from (pos, pos_begin) = (32, 0), where every draw leaves the sponge
+      S.pos = 32; S.pos_begin = 0;
+      const size_t before = S.nodes.size();
+      S.frame(label, 32);
+      S.begin_op(FLAG_I | FLAG_A | FLAG_C);
+      if (S.nodes.size() != before + 1 || S.pos != 0) return false;
+      FeNodes::Node& rd = S.nodes.back();
+      rd.type = cg1fe::N_SQUEEZE; rd.da = 1; rd.dr = 0; rd.slot = op.out_off / 32u;
+      // accepted: append_message(label, the 32 bytes), again from (32, 0)
+      S.pos = 32; S.pos_begin = 0;
+      S.frame(label, 32);
+      S.begin_op(FLAG_A);
+      for (uint32_t k = 0; k < 32; ++k) S.put_src(2, k);
+      continue;
+    }
+    if (kind != OP_APPEND_POINT && kind != OP_APPEND_CONST && kind != OP_APPEND_OUT) return false;
+    S.frame(label, op.len);
+    S.begin_op(FLAG_A);
+    for (uint32_t k = 0; k < op.len; ++k) {
+      if (kind == OP_APPEND_CONST) S.put(consts[op.data_off + k]);
+      else if (kind == OP_APPEND_POINT) S.put_src(1, op.data_off + k);
+      else S.put_src(3, op.out_off + k);
+    }
+  }
+  S.cur.type = cg1fe::N_END;                                              // what is left in the open node is never permuted: the verifier draws nothing after it
+  S.nodes.push_back(S.cur);
+  if (!S.ok) return false;
+  n_nodes = (uint32_t)S.nodes.size();
+  desc.assign((size_t)n_nodes * cg1fe::ROW_WORDS, cg1fe::RowDesc{0, 0});
+  for (uint32_t nd = 0; nd < n_nodes; ++nd) {
+    const FeNodes::Node& N = S.nodes[nd];
+    cg1fe::RowDesc* row = desc.data() + (size_t)nd * cg1fe::ROW_WORDS;
+    for (uint32_t j = 0; j < 42; ++j) {
+      uint32_t tw = 0;
+      for (int b = 0; b < 4; ++b) tw |= (uint32_t)N.T[4 * j + b] << (8 * b);
+      row[j].tword = tw;
+      // wire bytes of this word: one run from one point (a message is framed by >= 8 constant bytes)
+      int lo = -1, cnt = 0;
+      for (int b = 0; b < 4; ++b) if (N.D[4 * j + b].kind == 1) { if (lo < 0) lo = b; ++cnt; }
+      if (cnt) {
+        const uint32_t s0 = N.D[4 * j + lo].src;
+        for (int b = 0; b < cnt; ++b) if (N.D[4 * j + lo + b].kind != 1 || N.D[4 * j + lo + b].src != s0 + b) return false;
+        const uint32_t point = s0 / 48u, k0 = s0 % 48u;
+        if (k0 + cnt > 48u || point >= (1u << 21)) return false;
+        row[j].src = 1u | ((uint32_t)lo << 1) | ((uint32_t)(cnt - 1) << 3) | (k0 << 5) | (point << 11);
+      }
+    }
+    if (N.type == cg1fe::N_END) { row[42].tword = cg1fe::N_END | (N.bar << 2); continue; }
+    if (N.slot >= (1u << 16)) return false;
+    row[42].tword = N.type | (N.bar << 2) | (N.da << 4) | (N.dr << 6) | (N.slot << 8);
+    // late pieces: runs of bytes of kind 2 / 3 with consecutive sources
+    uint32_t np = 0;
+    for (uint32_t p = 0; p < (uint32_t)STROBE_R;) {
+      const uint8_t k = N.D[p].kind;
+      if (k < 2) { ++p; continue; }
+      uint32_t len = 1;
+      while (p + len < (uint32_t)STROBE_R && len < 48u && N.D[p + len].kind == k && N.D[p + len].src == N.D[p].src + len) ++len;
+      if (np == cg1fe::MAX_PIECES || N.D[p].src >= (1u << 17)) return false;
+      row[43 + np].tword = len | (p << 6) | ((k == 3 ? 1u : 0u) << 14) | (N.D[p].src << 15);
+      ++np;
+      p += len;
+    }
+  }
+  return true;
+}
 }  // namespace
 
 extern "C" {
@@ -1482,7 +1605,8 @@ extern "C" {
 void cg1_shuffle_fe_destroy(cg1_shuffle_fe* fe) {
   if (!fe) return;
   (void)hipSetDevice(fe->device);
-  for (void* p : {fe->d_init, fe->d_ops, fe->d_labels, fe->d_consts, fe->d_tabG, fe->d_tabH, fe->d_four, fe->d_scratch}) if (p) (void)hipFree(p);
+  for (void* p : {fe->d_init, fe->d_ops, fe->d_labels, fe->d_consts, fe->d_tabG, fe->d_tabH, fe->d_four, fe->d_scratch, fe->d_desc, fe->d_rows, fe->d_passes})
+    if (p) (void)hipFree(p);
   delete fe;
 }
 
@@ -1515,6 +1639,15 @@ cg1_shuffle_fe* cg1_shuffle_fe_create(cg1_ctx* ctx, size_t ell, size_t lg, const
        hipMemcpy(fe->d_ops, P.ops.data(), P.ops.size() * sizeof(cg1merlin::COp), hipMemcpyHostToDevice) == hipSuccess &&
        hipMemcpy(fe->d_labels, P.table.data(), P.table.size() * 4, hipMemcpyHostToDevice) == hipSuccess &&
        hipMemcpy(fe->d_consts, consts, sizeof consts, hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) {
+    std::vector<cg1fe::RowDesc> desc;
+    uint32_t nn = 0;
+    if (fe_build_nodes(P, init, consts, desc, nn)) {
+      ok = hipMalloc(&fe->d_desc, desc.size() * sizeof(cg1fe::RowDesc)) == hipSuccess &&
+           hipMemcpy(fe->d_desc, desc.data(), desc.size() * sizeof(cg1fe::RowDesc), hipMemcpyHostToDevice) == hipSuccess;
+      fe->n_nodes = nn;
+    }
+  }
   // fixed-base tables: entry [w][b] = b * 2^(8 w) * base for the two bases of D (grand_prod.py:157), as 128-byte Montgomery records
   if (ok) {
     std::vector<uint8_t> sc(8192 * 32, 0);
@@ -1539,6 +1672,24 @@ cg1_shuffle_fe* cg1_shuffle_fe_create(cg1_ctx* ctx, size_t ell, size_t lg, const
 
 size_t cg1_shuffle_fe_aux_bytes(void) { return 19 * 32; }
 
+// Nodes of the block program (0: the program of this ell does not fit the row format and the byte-machine kernel is used).
+size_t cg1_shuffle_fe_nodes(const cg1_shuffle_fe* fe) { return fe ? fe->n_nodes : 0; }
+
+// Keccak passes of the slowest wave of the last launch enqueued on `ctx` (waits for the stream; 0 if that launch used the byte machine).
+size_t cg1_shuffle_fe_last_passes(cg1_shuffle_fe* fe, cg1_ctx* ctx) {
+  if (!fe || !ctx || !fe->last_blocks || !fe->d_passes) return 0;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return 0;
+  std::vector<uint32_t> h(fe->last_blocks * 8);
+  if (hipMemcpy(h.data(), fe->d_passes, h.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  size_t best = 0;
+  for (size_t b = 0; b < fe->last_blocks; ++b) if (h[8 * b] > h[8 * best]) best = b;
+  for (int k = 0; k < 8; ++k) fe->last_split[k] = h[8 * best + k];
+  return h[8 * best];
+}
+// ... and that wave's shader-clock split (launches with cg1_ctx_set_param("fe_timed", 1)): out[0..7) = clocks / 256 spent in (late pieces +
+// issuing the row loads, Keccak-f, whole passes, draw + range check, X_GPROD, X_DA, X_FINAL); valid after cg1_shuffle_fe_last_passes.
+void cg1_shuffle_fe_last_split(const cg1_shuffle_fe* fe, uint32_t* out7) { for (int k = 0; k < 7; ++k) out7[k] = fe ? fe->last_split[k + 1] : 0; }
+
 // Enqueue the front-end of n proofs on ctx's compute stream (no wait: cg1_stream_sync).  d_wire48: n x L own points as gathered from
 // the wire (cg1_shuffle_gather_points); d_pts_affine96: the same points decoded (cg1_batch_decompress_*); d_aux: n x 19 x 32 bytes
 // (cg1_shuffle_gather_aux); outputs as cg1_shuffle_prepare_inputs: d_rowin n x cg1_shuffle_rowin_scalars() x 32, d_status n codes.
@@ -1561,6 +1712,29 @@ int cg1_shuffle_fe_enqueue(cg1_shuffle_fe* fe, cg1_ctx* ctx, size_t n, const voi
                      (cg1::PreparedPoint*)fe->d_four);
   const unsigned nblk = (unsigned)((n + lanes_per_wave - 1) / lanes_per_wave);
   fe->pr.prio = (uint32_t)ctx->fe_prio;
+  if (fe->n_nodes && ctx->fe_rows) {
+    const size_t row_words = (size_t)fe->n_nodes * cg1fe::ROW_WORDS;
+    const size_t need = (size_t)nblk * lanes_per_wave * row_words;          // rows are laid out per wave: the last wave's unused lanes count
+    if (need > fe->cap_rows || nblk > fe->cap_blocks) {
+      if (fe->d_rows) (void)hipFree(fe->d_rows);
+      if (fe->d_passes) (void)hipFree(fe->d_passes);
+      fe->d_rows = fe->d_passes = nullptr; fe->cap_rows = 0; fe->cap_blocks = 0; fe->last_blocks = 0;
+      HIPCHK(hipMalloc(&fe->d_rows, need * 4));
+      HIPCHK(hipMalloc(&fe->d_passes, (size_t)nblk * 32));
+      fe->cap_rows = need; fe->cap_blocks = nblk;
+    }
+    fe->last_blocks = nblk;
+    const size_t total = n * row_words;
+    hipLaunchKernelGGL(cg1fe::k_fe_fill_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const cg1fe::RowDesc*)fe->d_desc, fe->n_nodes,
+                       (const uint8_t*)d_wire48, fe->pr.L, (uint32_t)n, (uint32_t)lanes_per_wave, (uint32_t*)fe->d_rows);
+    hipLaunchKernelGGL(ctx->fe_timed ? cg1fe::k_shuffle_front_end_rows<true> : cg1fe::k_shuffle_front_end_rows<false>, dim3(nblk), dim3(cg1merlin::LANES), 0, ctx->stream, (const uint8_t*)fe->d_init, (const uint32_t*)fe->d_rows,
+                       fe->n_nodes, (const uint8_t*)d_wire48, (const uint8_t*)d_aux, (const cg1::PreparedPoint*)fe->d_four, (const cg1::PreparedPoint*)fe->d_tabG,
+                       (const cg1::PreparedPoint*)fe->d_tabH, fe->pr, (uint8_t*)fe->d_scratch, (uint8_t*)d_rowin, (int32_t*)d_status, (uint32_t)n,
+                       (uint32_t)lanes_per_wave, (uint32_t*)fe->d_passes);
+    HIPCHK(hipGetLastError());
+    return CG1_OK;
+  }
+  fe->last_blocks = 0;
   hipLaunchKernelGGL(cg1fe::k_shuffle_front_end, dim3(nblk), dim3(cg1merlin::LANES), 0, ctx->stream, (const uint8_t*)fe->d_init, (const cg1merlin::COp*)fe->d_ops,
                      fe->nops, (const uint32_t*)fe->d_labels, fe->nlabels, (const uint8_t*)fe->d_consts, (const uint8_t*)d_wire48, (const uint8_t*)d_aux,
                      (const cg1::PreparedPoint*)fe->d_four, (const cg1::PreparedPoint*)fe->d_tabG, (const cg1::PreparedPoint*)fe->d_tabH, fe->pr,

@@ -121,7 +121,7 @@ class Prepared:
 
 class ShuffleBatchVerifier:
     def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True,
-                 blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: int = 5, fe_cus: int = 0, fe_prio: int = 0):
+                 blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: int = 3, fe_cus: int = 0, fe_prio: int = 0):
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
@@ -132,12 +132,12 @@ class ShuffleBatchVerifier:
         self.blocking_sync = (env == "1") if env is not None else bool(blocking_sync)
         self.chunk = chunk                  # sub-batch of the decompress / front-end pipeline
         # device_front_end: the transcript, D / A' and the challenge algebra run on the GPU too (csrc/kernels_frontend.h, one proof per
-        # lane; byte-identical row-input blocks: tests/test_shuffle_frontend_gpu.py).  One launch takes ~26 ms whatever its size (a
-        # transcript is ~750 dependent Keccak permutations) but occupies only n / 64 of the chip's 1024 SIMDs, so `fe_lanes` launches of
-        # consecutive batches run side by side, each on its own context, and the stream keeps fe_lanes + 3 batches in flight.  The
-        # host then only packs bytes: proofs/s no longer depends on the host's core count.
-        # Measured on MI355X (profiles/r03_verify_fe_ab.txt, batches of 1024, GPU_MAX_HW_QUEUES = 24): 120-132 K proofs/s whatever the
-        # host (1 / 2 / 4 / 16 threads), against 13 K / 24 K / 49 K / 91 K / 120-157 K proofs/s with the host front-end on 1 / 2 / 4 / 8 /
+        # lane; byte-identical row-input blocks: tests/test_shuffle_frontend_gpu.py).  One launch takes ~11 ms whatever its size (a
+        # transcript is ~800 dependent Keccak permutations: 24 K clocks each for the one wave a SIMD runs) but occupies only n / 64 of
+        # the chip's 1024 SIMDs, so `fe_lanes` launches of consecutive batches run side by side, each on its own context, and the
+        # stream keeps fe_lanes + 3 batches in flight.  The host then only packs bytes: proofs/s no longer depends on its core count.
+        # Measured on MI355X (profiles/r03_verify_fe_ab.txt, batches of 1024, GPU_MAX_HW_QUEUES = 24): 134-144 K proofs/s whatever
+        # the host (2 or 16 threads), against 13 K / 25 K / 49 K / 91 K / 130-157 K proofs/s with the host front-end on 1 / 2 / 4 / 8 /
         # 16 threads -- so None (the default) turns it on when fewer than twelve host threads are available to this verifier (e.g.
         # eight ranks sharing a 64-thread host), and leaves the host front-end on otherwise.  CURDLE_G1_DEVICE_FRONT_END=0/1 overrides.
         env = os.environ.get("CURDLE_G1_DEVICE_FRONT_END")

@@ -324,6 +324,12 @@ typedef struct cg1_shuffle_fe cg1_shuffle_fe;
 cg1_shuffle_fe* cg1_shuffle_fe_create(cg1_ctx* ctx, size_t ell, size_t lg, const uint8_t* crs_affine96, const uint8_t* crs48);   /* NULL on failure */
 void   cg1_shuffle_fe_destroy(cg1_shuffle_fe* fe);
 size_t cg1_shuffle_fe_aux_bytes(void);
+/* The kernel runs a BLOCK PROGRAM: the transcript of a given ell cut on the host into the rate blocks between two permutations
+ * ("nodes"; 0 = this ell does not fit the format and the byte-level state machine is used; cg1_ctx_set_param("fe_rows", 0) forces
+ * that one).  _last_passes: Keccak passes of the slowest wave of the last launch enqueued on ctx (waits for the stream). */
+size_t cg1_shuffle_fe_nodes(const cg1_shuffle_fe* fe);
+size_t cg1_shuffle_fe_last_passes(cg1_shuffle_fe* fe, cg1_ctx* ctx);
+void   cg1_shuffle_fe_last_split(const cg1_shuffle_fe* fe, uint32_t* out7);   /* ("fe_timed" launches) that wave's shader clocks / 256: late pieces + row loads issued | Keccak-f | whole passes | draw + range check | X_GPROD | X_DA | X_FINAL */
 int cg1_shuffle_gather_aux(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8_t* proofs, const uint8_t* weights, uint8_t* out_aux);
 int cg1_shuffle_fe_enqueue(cg1_shuffle_fe* fe, cg1_ctx* ctx, size_t n, const void* d_wire48, const void* d_pts_affine96, const void* d_aux,
                            void* d_rowin, void* d_status, int lanes_per_wave /* 1..64 transcripts per wave; 0 = 64 */);

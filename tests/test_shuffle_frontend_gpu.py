@@ -23,7 +23,7 @@ def gold():
         return json.load(f)
 
 
-def both_front_ends(N, ctx, v, items, weights, lanes=0):
+def both_front_ends(N, ctx, v, items, weights, lanes=0, fe_rows=1):
     crs = v.crs
     n = len(items)
     inst, proofs, _ = v.pack(items)
@@ -45,8 +45,12 @@ def both_front_ends(N, ctx, v, items, weights, lanes=0):
     d_aux.upload(aux.raw)
     fe = N.cg1_shuffle_fe_create(ctx.handle, crs.ell, crs.lg, crs.affine96, crs.bytes)
     assert fe
+    assert N.cg1_shuffle_fe_nodes(fe) > 0                     # every golden ell fits the block-program format
+    ctx.set_param("fe_rows", fe_rows)                         # 1: block program (k_shuffle_front_end_rows), 0: byte machine (k_shuffle_front_end)
     ctx.check(N.cg1_shuffle_fe_enqueue(fe, ctx.handle, n, d_wire.ptr, d_pts.ptr, d_aux.ptr, d_rowin.ptr, d_st.ptr, lanes))
     ctx.sync()
+    assert (N.cg1_shuffle_fe_last_passes(fe, ctx.handle) > 0) == bool(fe_rows)
+    ctx.set_param("fe_rows", 1)
     rowin = d_rowin.download()
     st = list((ctypes.c_int32 * n).from_buffer_copy(d_st.download()))
     N.cg1_shuffle_fe_destroy(fe)
@@ -54,7 +58,8 @@ def both_front_ends(N, ctx, v, items, weights, lanes=0):
     return h_rowin.raw, list(h_status), rowin, st, K, [any(pst[i * L: (i + 1) * L]) for i in range(n)]
 
 
-def test_device_front_end_equals_host_front_end(native_lib, gold):
+@pytest.mark.parametrize("fe_rows", [1, 0])
+def test_device_front_end_equals_host_front_end(native_lib, gold, fe_rows):
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
     from test_shuffle_verifier import apply_edits
 
@@ -65,7 +70,7 @@ def test_device_front_end_equals_host_front_end(native_lib, gold):
         items = [apply_edits(case, [])] + [apply_edits(case, x["edits"]) for x in case["variants"]]
         items = items * 3                                     # > one wave: lanes of a wave drift apart by rejected draws
         w = v.draw_weights(len(items), random.Random(case["seed"]))
-        h_rowin, h_st, d_rowin, d_st, K, bad_pt = both_front_ends(N, ctx, v, items, w)
+        h_rowin, h_st, d_rowin, d_st, K, bad_pt = both_front_ends(N, ctx, v, items, w, fe_rows=fe_rows)
         assert d_st == h_st, case["ell"]
         assert any(s == 0 for s in h_st)
         for i, s in enumerate(h_st):

@@ -48,11 +48,21 @@ for _ in range(2):
     assert N.cg1_shuffle_prepare_inputs(crs.handle, n, inst, proofs, w, decoded, 768, h_pts, h_rowin, h_status, 0) == 0
     host_ms = (time.perf_counter() - t) * 1e3
 print(f"host front-end (cg1_shuffle_prepare_inputs, {int(N.cg1_shuffle_default_threads())} threads): {host_ms:.2f} ms per {n} proofs", flush=True)
-for lanes in (64, 16, 4, 1):
-    s0.run(lanes)
-    t = time.perf_counter(); s0.run(lanes); dt = (time.perf_counter() - t) * 1e3
-    ok = s0.d_rowin.download() == h_rowin.raw and list((ctypes.c_int32 * n).from_buffer_copy(s0.d_st.download())) == list(h_status)
-    print(f"device front-end, {lanes:2d} transcripts per wave ({(n + lanes - 1) // lanes} waves): {dt:.2f} ms per launch of {n} proofs; blocks equal the host's: {ok}", flush=True)
+print(f"block program: {N.cg1_shuffle_fe_nodes(s0.fe)} nodes", flush=True)
+for fe_rows, timed in ((1, 0), (1, 1), (0, 0)):
+    ctx.set_param("fe_rows", fe_rows)
+    ctx.set_param("fe_timed", timed)
+    for lanes in ((64, 16, 4, 1) if not timed else (64,)):
+        s0.run(lanes)
+        t = time.perf_counter(); s0.run(lanes); dt = (time.perf_counter() - t) * 1e3
+        passes = N.cg1_shuffle_fe_last_passes(s0.fe, ctx.handle)
+        sp = (ctypes.c_uint32 * 7)()
+        N.cg1_shuffle_fe_last_split(s0.fe, sp)
+        split = " (kclk per pass: pieces+loads %.1f, keccak %.1f, whole %.1f, draw %.1f; steps: gprod %.0f + D/A' %.0f + final %.0f kclk)" % tuple([256e-3 * x / max(1, passes) for x in sp[:4]] + [256e-3 * x for x in sp[4:7]]) if passes and timed else ""
+        ok = s0.d_rowin.download() == h_rowin.raw and list((ctypes.c_int32 * n).from_buffer_copy(s0.d_st.download())) == list(h_status)
+        print(f"device front-end ({'block program' if fe_rows else 'byte machine'}), {lanes:2d} transcripts per wave ({(n + lanes - 1) // lanes} waves): {dt:.2f} ms per launch of {n} "
+              f"proofs; passes of the slowest wave: {passes}{split}; blocks equal the host's: {ok}", flush=True)
+ctx.set_param("fe_rows", 1); ctx.set_param("fe_timed", 0)
 slots = [s0] + [Slot(N.Context(0)) for _ in range(5)]
 for lanes in (64, 16):
     for k in (2, 4, 6):
