@@ -668,6 +668,10 @@ def main():
         if world == 1 and not args.no_secondary:
             cores = int(N.cg1_shuffle_default_threads())
             out["secondary"] = verify_measure(ctx, cores, args.verify_steps, 2, args.batch, args.verify_mode, cpu_leg=not args.no_cpu_baseline, peak_T=peak["peak_T"], front_end=args.front_end)
+            if not out["secondary"]["front_end"].startswith("device"):
+                # the same stream with the front-end on the GPU and TWO host threads: what a rank gets on a host shared by many GPUs
+                dv = verify_measure(ctx, 2, args.verify_steps, 1, args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
+                out["secondary"]["device_front_end_on_2_host_threads"] = {k: dv[k] for k in ("value", "unit", "ms_per_step", "steps", "front_end", "host_threads", "phases_ms_per_step")}
         print(json.dumps(out), flush=True)
 
     if comm:
