@@ -1672,6 +1672,94 @@ cg1_shuffle_fe* cg1_shuffle_fe_create(cg1_ctx* ctx, size_t ell, size_t lg, const
 
 size_t cg1_shuffle_fe_aux_bytes(void) { return 19 * 32; }
 
+// Host only (no GPU needed; test support): walk the block program of one proof on the CPU exactly as k_shuffle_front_end_rows does --
+// rows as k_fe_fill_rows builds them, late pieces, both kinds of squeeze node -- up to the first barrier step (the grand product),
+// and return the out row (the challenges drawn so far sit in their slots: vec_a, alpha, beta of same_perm).  wire = the proof's L own
+// points as cg1_shuffle_gather_points packs them; out_row: (K + 6) * 32 bytes, zero where nothing was drawn.  *passes = permutations.
+int cg1_shuffle_fe_emulate_to_first_barrier(size_t ell, size_t lg, const uint8_t* crs_h48, const uint8_t* wire, uint8_t* out_row, size_t out_row_bytes,
+                                            uint32_t* passes) {
+  if (!wire || !out_row || !crs_h48 || ell == 0 || lg == 0 || lg > 20 || ((ell + 4) != ((size_t)1 << lg))) return CG1_ERR_ARG;
+  const cg1rows::RowIn R{ell, lg};
+  if (out_row_bytes < (R.count() + 6) * 32) return CG1_ERR_ARG;
+  FeProgram P;
+  fe_build_program(ell, lg, P);
+  uint8_t init[CG1_MERLIN_STATE_BYTES], consts[96];
+  cg1_merlin_init(init, (const uint8_t*)"curdleproofs", 12);
+  memset(consts, 0, sizeof consts);
+  consts[0] = 0xC0;
+  memcpy(consts + 48, crs_h48, 48);
+  std::vector<cg1fe::RowDesc> desc;
+  uint32_t nn = 0;
+  if (P.labels.size() > (size_t)cg1merlin::MAX_LABELS || !fe_build_nodes(P, init, consts, desc, nn)) return CG1_ERR_ARG;
+  memset(out_row, 0, out_row_bytes);
+  uint8_t sponge[200], drawn[32] = {0};
+  memcpy(sponge, init, 200);
+  uint32_t nd = 0, np = 0;
+  for (;;) {
+    const cg1fe::RowDesc* row = desc.data() + (size_t)nd * cg1fe::ROW_WORDS;
+    const uint32_t info = row[42].tword, type = info & 3u;
+    if (((info >> 2) & 3u) != 0u || type == cg1fe::N_END) break;
+    for (uint32_t q = 0; q < cg1fe::MAX_PIECES; ++q) {
+      const uint32_t pc = row[43 + q].tword, len = pc & 63u;
+      if (!len) break;
+      const uint32_t dst = (pc >> 6) & 255u, from_row = (pc >> 14) & 1u, so = pc >> 15;
+      for (uint32_t i = 0; i < len; ++i) sponge[dst + i] ^= from_row ? out_row[so + i] : drawn[so + i];
+    }
+    for (uint32_t j = 0; j < 42; ++j) {                      // the row as k_fe_fill_rows writes it
+      uint32_t v = row[j].tword;
+      if (row[j].src) {
+        const uint32_t lo = (row[j].src >> 1) & 3u, cnt = ((row[j].src >> 3) & 3u) + 1u, k0 = (row[j].src >> 5) & 63u, p = row[j].src >> 11;
+        const uint8_t* pt = wire + (size_t)p * 48;
+        const bool inf = (pt[0] & 0xC0u) == 0xC0u;
+        for (uint32_t b = 0; b < cnt; ++b) v ^= (uint32_t)(inf ? (k0 + b == 0 ? 0xC0u : 0u) : pt[k0 + b]) << (8 * (lo + b));
+      }
+      for (int b = 0; b < 4; ++b) sponge[4 * j + b] ^= (uint8_t)(v >> (8 * b));
+    }
+    cg1_keccak_f1600(sponge);
+    ++np;
+    bool accept = true;
+    if (type == cg1fe::N_SQUEEZE) {
+      uint8_t dv[32];
+      memcpy(dv, sponge, 32);
+      memset(sponge, 0, 32);
+      cg1fr::fr tmp;
+      bool nonzero = false;
+      for (int i = 0; i < 32; ++i) nonzero |= dv[i] != 0;
+      accept = nonzero && cg1fr::fr_from_le32(dv, tmp);
+      if (accept) { memcpy(out_row + 32 * ((info >> 8) & 0xffffu), dv, 32); memcpy(drawn, dv, 32); }
+    }
+    nd += accept ? (info >> 4) & 3u : (info >> 6) & 3u;
+  }
+  if (passes) *passes = np;
+  return CG1_OK;
+}
+
+// Host only (no GPU needed): the shape of the block program for a given ell -- operations of the verifier's transcript, nodes they are
+// cut into (0: does not fit the row format), squeeze nodes (two per challenge: first draw and redo) and the largest number of late
+// pieces in a node.  out4 = {operations, nodes, squeeze nodes, max pieces}.
+int cg1_shuffle_fe_program_shape(size_t ell, size_t lg, uint32_t* out4) {
+  if (!out4 || ell == 0 || lg == 0 || lg > 20 || ((ell + 4) != ((size_t)1 << lg))) return CG1_ERR_ARG;
+  FeProgram P;
+  fe_build_program(ell, lg, P);
+  uint8_t init[CG1_MERLIN_STATE_BYTES], consts[96];
+  cg1_merlin_init(init, (const uint8_t*)"curdleproofs", 12);
+  memset(consts, 0, sizeof consts);
+  consts[0] = 0xC0;
+  std::vector<cg1fe::RowDesc> desc;
+  uint32_t nn = 0;
+  out4[0] = (uint32_t)P.ops.size(); out4[1] = out4[2] = out4[3] = 0;
+  if (P.labels.size() > (size_t)cg1merlin::MAX_LABELS || !fe_build_nodes(P, init, consts, desc, nn)) return CG1_OK;
+  out4[1] = nn;
+  for (uint32_t nd = 0; nd < nn; ++nd) {
+    const cg1fe::RowDesc* row = desc.data() + (size_t)nd * cg1fe::ROW_WORDS;
+    if ((row[42].tword & 3u) == cg1fe::N_SQUEEZE) ++out4[2];
+    uint32_t np = 0;
+    for (uint32_t q = 0; q < cg1fe::MAX_PIECES; ++q) if (row[43 + q].tword & 63u) ++np;
+    out4[3] = std::max(out4[3], np);
+  }
+  return CG1_OK;
+}
+
 // Nodes of the block program (0: the program of this ell does not fit the row format and the byte-machine kernel is used).
 size_t cg1_shuffle_fe_nodes(const cg1_shuffle_fe* fe) { return fe ? fe->n_nodes : 0; }
 

@@ -328,6 +328,9 @@ size_t cg1_shuffle_fe_aux_bytes(void);
  * ("nodes"; 0 = this ell does not fit the format and the byte-level state machine is used; cg1_ctx_set_param("fe_rows", 0) forces
  * that one).  _last_passes: Keccak passes of the slowest wave of the last launch enqueued on ctx (waits for the stream). */
 size_t cg1_shuffle_fe_nodes(const cg1_shuffle_fe* fe);
+int    cg1_shuffle_fe_emulate_to_first_barrier(size_t ell, size_t lg, const uint8_t* crs_h48, const uint8_t* wire, uint8_t* out_row, size_t out_row_bytes,
+                                               uint32_t* passes);   /* host only, test support: the block program of ONE proof walked on the CPU up to the grand-product step; out_row >= (cg1_shuffle_rowin_scalars + 6) * 32 bytes, the drawn challenges in their slots */
+int    cg1_shuffle_fe_program_shape(size_t ell, size_t lg, uint32_t* out4);   /* host only: {operations, nodes (0 = does not fit), squeeze nodes, max late pieces per node} */
 size_t cg1_shuffle_fe_last_passes(cg1_shuffle_fe* fe, cg1_ctx* ctx);
 void   cg1_shuffle_fe_last_split(const cg1_shuffle_fe* fe, uint32_t* out7);   /* ("fe_timed" launches) that wave's shader clocks / 256: late pieces + row loads issued | Keccak-f | whole passes | draw + range check | X_GPROD | X_DA | X_FINAL */
 int cg1_shuffle_gather_aux(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8_t* proofs, const uint8_t* weights, uint8_t* out_aux);
