@@ -276,92 +276,15 @@ __global__ void __launch_bounds__(LANES) k_shuffle_front_end(const uint8_t* __re
 //     plain node -> next node;     squeeze node -accepted-> next node,  -rejected-> its redo node (frame + PRF header at pos 32) -> itself / next
 // The host cuts the operation list into those nodes once per ell (fe_build_nodes in msm_gpu.hip: a symbolic run of strobe.py:55-107
 // and merlin_transcript.py:11-24 that records, per sponge byte, the constant XOR-ed into it or where the byte comes from);
-// k_fe_fill_rows then writes, for every proof, one 192-byte ROW per node: 42 words = everything XOR-ed into the rate between two
+// cg1merlin::k_fill_rows then writes, for every proof, one 192-byte ROW per node: 42 words = everything XOR-ed into the rate between two
 // permutations that is known before hashing starts (framing, labels, lengths, STROBE's own marks, the proof's and the instance's
 // point encodings -- canonicalised where flagged as infinity, util.py:27-32), 1 word of node information and 5 piece descriptors
 // for what is not (re-appended challenges, the grand product, D, inner_prod, A': copied from the lane's LDS / out row when the lane
 // gets there).  A pass of the hashing kernel is then: XOR the pieces, issue the loads of BOTH successor rows, Keccak-f with the
 // current row folded into its load of the sponge, pick the successor.  No byte machine, no exposed latency, the same code for
 // every lane whatever node it stands at.  Same outputs, byte for byte (tests/test_shuffle_frontend_gpu.py runs both forms).
-constexpr uint32_t ROW_WORDS = 48;                 // 42 content words (bytes 0 .. 167 of the sponge), info, 5 pieces
-constexpr uint32_t N_PLAIN = 0, N_SQUEEZE = 1, N_END = 2;
-constexpr uint32_t MAX_PIECES = 5;
-// info word:  type [0,2) | barrier [2,4): 0 none, 1 X_GPROD, 2 X_DA, 3 X_FINAL | accept delta [4,6) | reject delta [6,8) | challenge slot [8,24)
-// piece word: len [0,6) (0 = none) | sponge byte offset [6,14) | source [14]: 0 = the challenge just drawn, 1 = the lane's out row | source byte offset [15,32)
-struct RowDesc {                                   // per (node, word): the constant part and where the proof-dependent bytes come from
-  uint32_t tword;
-  uint32_t src;                                    // 0 = none; else 1 | first byte [1,3) | byte count - 1 [3,5) | byte within the point [5,11) | point index [11,32)
-};
-
-// Rows are laid out [wave][node][lane of the wave][48 words]: the lanes of a wave stand at nearby nodes (they drift apart by rejected
-// draws only: a few dozen nodes), so what a wave reads in one pass lies within a few hundred KB instead of in 64 regions 136 KB apart.
-__device__ __forceinline__ size_t row_word_index(uint32_t proof, uint32_t node, uint32_t nodes, uint32_t lanes_used) {
-  const uint32_t wave = proof / lanes_used, lane = proof - wave * lanes_used;
-  return (((size_t)wave * nodes + node) * lanes_used + lane) * ROW_WORDS;
-}
-
-__global__ void __launch_bounds__(256) k_fe_fill_rows(const RowDesc* __restrict__ desc, uint32_t nodes, const uint8_t* __restrict__ wire, uint32_t L,
-                                                      uint32_t n, uint32_t lanes_used, uint32_t* __restrict__ rows) {
-  const size_t per = (size_t)nodes * ROW_WORDS;
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= per * n) return;
-  const size_t proof = t / per, k = t - proof * per;
-  const RowDesc d = desc[k];
-  uint32_t v = d.tword;
-  if (d.src) {
-    const uint32_t lo = (d.src >> 1) & 3u, cnt = ((d.src >> 3) & 3u) + 1u, k0 = (d.src >> 5) & 63u, p = d.src >> 11;
-    const uint8_t* pt = wire + ((size_t)proof * L + p) * 48u;
-    const bool inf = (pt[0] & 0xC0u) == 0xC0u;                            // hashed as the wheel re-serialises it: C0 00 .. 00
-    for (uint32_t b = 0; b < cnt; ++b) {
-      const uint32_t byte = inf ? (k0 + b == 0u ? 0xC0u : 0u) : (uint32_t)pt[k0 + b];
-      v ^= byte << (8u * (lo + b));
-    }
-  }
-  const uint32_t node = (uint32_t)(k / ROW_WORDS), word = (uint32_t)(k - (size_t)node * ROW_WORDS);
-  rows[row_word_index((uint32_t)proof, node, nodes, lanes_used) + word] = v;
-}
-
-// One late piece: `len` <= 48 bytes from the challenge just drawn (LDS, word j at drawn[j * LANES], 9 words) or from the lane's out row
-// (global) XOR-ed into the sponge at byte `dst`.  All source words are fetched at once (one exposed latency), moved to the
-// destination's byte alignment with v_alignbyte, masked to the piece and XOR-ed in -- no loop-carried LDS round trips.
-__device__ __forceinline__ void apply_piece(uint32_t pc, uint32_t* w, const uint32_t* drawn, const uint8_t* orow) {
-  const uint32_t len = pc & 63u, dst = (pc >> 6) & 255u, from_row = (pc >> 14) & 1u, so = pc >> 15;
-  const uint32_t b = dst & 3u;
-  // destination word j (sponge word (dst >> 2) + j) = the four source bytes from byte address  so - b + 4 j  on
-  const int32_t s0 = (int32_t)so - (int32_t)b;
-  const int32_t wb = s0 >> 2;                                      // (arithmetic shift: -1 when the piece starts inside destination word 0)
-  const uint32_t sh = (uint32_t)s0 & 3u;
-  const int32_t wmax = (int32_t)((so + len - 1u) >> 2);            // last source word that holds a byte of the piece
-  uint32_t sw[14];
-  if (from_row) {
-    const uint32_t* g = reinterpret_cast<const uint32_t*>(orow);
-#pragma unroll
-    for (int j = 0; j < 14; ++j) { int32_t k = wb + j; k = k < 0 ? 0 : (k > wmax ? wmax : k); sw[j] = g[k]; }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 14; ++j) { int32_t k = wb + j; k = k < 0 ? 0 : (k > 8 ? 8 : k); sw[j] = drawn[k * LANES]; }
-  }
-  const uint32_t last = b + len;                                   // piece bytes within the destination words: [b, last)
-  const uint32_t jl = last >> 2, pm = (1u << (8u * (last & 3u))) - 1u;
-  uint32_t* d = w + (dst >> 2) * LANES;
-#pragma unroll
-  for (uint32_t j = 0; j < 13u; ++j) {
-    if (j == 9u && last <= 36u) break;                             // (only a 48-byte piece, or one starting late in its word, reaches words 9 .. 12)
-    const uint32_t v = __builtin_amdgcn_alignbyte(sw[j + 1], sw[j], sh);
-    uint32_t m = j < jl ? 0xffffffffu : (j == jl ? pm : 0u);
-    if (j == 0u) m &= 0xffffffffu << (8u * b);
-    if (j < 9u) d[j * LANES] ^= v & m;
-    else if (m) d[j * LANES] ^= v & m;
-  }
-}
-
-// Keccak-f[1600] on the lane's LDS sponge with the 42 row words XOR-ed in on the way (the absorb of a whole rate block)
-__device__ __forceinline__ void keccak_absorb_row(uint32_t* w, const uint32_t (&x)[ROW_WORDS]) { cg1merlin::keccak_words<true>(w, x); }
-
-__device__ __forceinline__ void load_row(const uint4* __restrict__ src, uint32_t (&x)[ROW_WORDS]) {
-#pragma unroll
-  for (int q = 0; q < 12; ++q) { const uint4 v = src[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
-}
+using cg1merlin::ROW_WORDS; using cg1merlin::N_PLAIN; using cg1merlin::N_SQUEEZE; using cg1merlin::N_END; using cg1merlin::MAX_PIECES;
+using cg1merlin::RowDesc; using cg1merlin::row_word_index; using cg1merlin::apply_piece; using cg1merlin::keccak_absorb_row; using cg1merlin::load_row;
 
 template <bool TIMED>
 __global__ void __launch_bounds__(LANES) k_shuffle_front_end_rows(const uint8_t* __restrict__ init_state, const uint32_t* __restrict__ rows, uint32_t nodes,

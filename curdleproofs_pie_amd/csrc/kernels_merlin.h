@@ -482,4 +482,182 @@ __global__ void __launch_bounds__(LANES) k_merlin_batch_sync(const uint8_t* __re
   }
 }
 
+
+// ------------------------------------------------------------------ block programs (round 3; the idea and the FE's use of it: kernels_frontend.h)
+// A transcript whose operation list and message lengths are the same for every lane has a STATIC byte layout between two
+// permutations (a challenge always leaves the sponge at pos = its length, pos_begin = 0, however many draws it took), so the host
+// cuts it into NODES (build_block_program in msm_gpu.hip) and the device hashes whole rate blocks: rows of 48 words per node and lane.
+constexpr uint32_t ROW_WORDS = 48;                 // 42 content words (bytes 0 .. 167 of the sponge), info, 5 pieces
+constexpr uint32_t N_PLAIN = 0, N_SQUEEZE = 1, N_END = 2, N_SQUEEZE_RAW = 3;     // (RAW: challenge_bytes without the Fr range check; k_merlin_batch_rows only)
+constexpr uint32_t MAX_PIECES = 5;
+// info word:  type [0,2) | barrier [2,4): 0 none, 1 X_GPROD, 2 X_DA, 3 X_FINAL | accept delta [4,6) | reject delta [6,8) | challenge slot [8,24)
+// piece word: len [0,6) (0 = none) | sponge byte offset [6,14) | source [14]: 0 = the challenge just drawn, 1 = the lane's out row | source byte offset [15,32)
+struct RowDesc {                                   // per (node, word): the constant part and where the proof-dependent bytes come from
+  uint32_t tword;
+  uint32_t src;                                    // 0 = none; else 1 | first byte [1,3) | byte count - 1 [3,5) | byte offset in the lane's data row [5,32)
+};
+
+// Rows are laid out [wave][node][lane of the wave][48 words]: the lanes of a wave stand at nearby nodes (they drift apart by rejected
+// draws only: a few dozen nodes), so what a wave reads in one pass lies within a few hundred KB instead of in 64 regions 136 KB apart.
+__device__ __forceinline__ size_t row_word_index(uint32_t proof, uint32_t node, uint32_t nodes, uint32_t lanes_used) {
+  const uint32_t wave = proof / lanes_used, lane = proof - wave * lanes_used;
+  return (((size_t)wave * nodes + node) * lanes_used + lane) * ROW_WORDS;
+}
+
+// data: n rows of `stride` bytes (the FE: a proof's L wire points).  canon48: the rows are arrays of 48-byte point encodings and one
+// flagged as infinity is hashed as the wheel re-serialises it, C0 00 .. 00 (util.py:27-32).
+__global__ void __launch_bounds__(256) k_fill_rows(const RowDesc* __restrict__ desc, uint32_t nodes, const uint8_t* __restrict__ data, size_t stride,
+                                                   uint32_t canon48, uint32_t n, uint32_t lanes_used, uint32_t* __restrict__ rows) {
+  const size_t per = (size_t)nodes * ROW_WORDS;
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= per * n) return;
+  const size_t proof = t / per, k = t - proof * per;
+  const RowDesc d = desc[k];
+  uint32_t v = d.tword;
+  if (d.src) {
+    const uint32_t lo = (d.src >> 1) & 3u, cnt = ((d.src >> 3) & 3u) + 1u, off = d.src >> 5;
+    const uint8_t* src = data + proof * stride + off;
+    bool inf = false;
+    uint32_t k0 = 0;
+    if (canon48) { k0 = off % 48u; inf = (src[-(int)k0] & 0xC0u) == 0xC0u; }
+    for (uint32_t b = 0; b < cnt; ++b) {
+      const uint32_t byte = inf ? (k0 + b == 0u ? 0xC0u : 0u) : (uint32_t)src[b];
+      v ^= byte << (8u * (lo + b));
+    }
+  }
+  const uint32_t node = (uint32_t)(k / ROW_WORDS), word = (uint32_t)(k - (size_t)node * ROW_WORDS);
+  rows[row_word_index((uint32_t)proof, node, nodes, lanes_used) + word] = v;
+}
+
+// One late piece: `len` <= 48 bytes from the challenge just drawn (LDS, word j at drawn[j * LANES], 9 words) or from the lane's out row
+// (global) XOR-ed into the sponge at byte `dst`.  All source words are fetched at once (one exposed latency), moved to the
+// destination's byte alignment with v_alignbyte, masked to the piece and XOR-ed in -- no loop-carried LDS round trips.
+__device__ __forceinline__ void apply_piece(uint32_t pc, uint32_t* w, const uint32_t* drawn, const uint8_t* orow) {
+  const uint32_t len = pc & 63u, dst = (pc >> 6) & 255u, from_row = (pc >> 14) & 1u, so = pc >> 15;
+  const uint32_t b = dst & 3u;
+  // destination word j (sponge word (dst >> 2) + j) = the four source bytes from byte address  so - b + 4 j  on
+  const int32_t s0 = (int32_t)so - (int32_t)b;
+  const int32_t wb = s0 >> 2;                                      // (arithmetic shift: -1 when the piece starts inside destination word 0)
+  const uint32_t sh = (uint32_t)s0 & 3u;
+  const int32_t wmax = (int32_t)((so + len - 1u) >> 2);            // last source word that holds a byte of the piece
+  uint32_t sw[14];
+  if (from_row) {
+    const uint32_t* g = reinterpret_cast<const uint32_t*>(orow);
+#pragma unroll
+    for (int j = 0; j < 14; ++j) { int32_t k = wb + j; k = k < 0 ? 0 : (k > wmax ? wmax : k); sw[j] = g[k]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 14; ++j) { int32_t k = wb + j; k = k < 0 ? 0 : (k > 8 ? 8 : k); sw[j] = drawn[k * LANES]; }
+  }
+  const uint32_t last = b + len;                                   // piece bytes within the destination words: [b, last)
+  const uint32_t jl = last >> 2, pm = (1u << (8u * (last & 3u))) - 1u;
+  uint32_t* d = w + (dst >> 2) * LANES;
+#pragma unroll
+  for (uint32_t j = 0; j < 13u; ++j) {
+    if (j == 9u && last <= 36u) break;                             // (only a 48-byte piece, or one starting late in its word, reaches words 9 .. 12)
+    const uint32_t v = __builtin_amdgcn_alignbyte(sw[j + 1], sw[j], sh);
+    uint32_t m = j < jl ? 0xffffffffu : (j == jl ? pm : 0u);
+    if (j == 0u) m &= 0xffffffffu << (8u * b);
+    if (j < 9u) d[j * LANES] ^= v & m;
+    else if (m) d[j * LANES] ^= v & m;
+  }
+}
+
+// Keccak-f[1600] on the lane's LDS sponge with the 42 row words XOR-ed in on the way (the absorb of a whole rate block)
+__device__ __forceinline__ void keccak_absorb_row(uint32_t* w, const uint32_t (&x)[ROW_WORDS]) { keccak_words<true>(w, x); }
+
+__device__ __forceinline__ void load_row(const uint4* __restrict__ src, uint32_t (&x)[ROW_WORDS]) {
+#pragma unroll
+  for (int q = 0; q < 12; ++q) { const uint4 v = src[q]; x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w; }
+}
+
+
+// ------------------------------------------------------------------ cg1_merlin_batch_device over a block program
+// The general form of the above for any operation list of the public interface (append / challenge_bytes / rejection-sampled Fr
+// challenge / append-what-you-produced): no compute steps, the final sponge written as a 208-byte state blob.  Row words 43 .. 46:
+// up to FOUR late pieces; word 47: the out-row byte offset of a squeeze node, or (END) pos | pos_begin << 8 | cur_flags << 16.
+__global__ void __launch_bounds__(LANES) k_merlin_batch_rows(const uint8_t* __restrict__ init_state, const uint32_t* __restrict__ rows, uint32_t nodes,
+                                                             uint8_t* __restrict__ out, size_t out_stride, uint8_t* __restrict__ states_out, uint32_t n,
+                                                             uint32_t lanes_used, uint32_t* __restrict__ passes_out) {
+  __shared__ uint32_t lds[52 * LANES];
+  __shared__ uint32_t lds_drawn[9 * LANES];
+  const uint32_t t = blockIdx.x * lanes_used + threadIdx.x;
+  const bool live = threadIdx.x < lanes_used && t < n;
+  uint32_t* w = lds + threadIdx.x;
+  uint32_t* drawn = lds_drawn + threadIdx.x;
+  drawn[8 * LANES] = 0u;
+  for (int i = 0; i < 50; ++i) w[i * LANES] = reinterpret_cast<const uint32_t*>(init_state)[i];
+  const size_t me = live ? t : 0;
+  uint8_t* orow = out + me * out_stride;
+  const uint4* my_rows = reinterpret_cast<const uint4*>(rows + row_word_index((uint32_t)me, 0u, nodes, lanes_used));
+  const size_t row_step = (size_t)lanes_used * (ROW_WORDS / 4);
+  uint32_t cur[ROW_WORDS], nxa[ROW_WORDS], nxr[ROW_WORDS];
+  load_row(my_rows, cur);
+  uint32_t nd = 0, passes = 0;
+  bool done = !live;
+  while (__ballot(!done) != 0ull) {
+    if (!done) {
+      const uint32_t info = cur[42], type = info & 3u;
+#pragma unroll
+      for (uint32_t q = 0; q < 4u; ++q) {
+        const uint32_t pc = cur[43 + q];
+        if ((pc & 63u) != 0u) apply_piece(pc, w, drawn, orow);
+      }
+      if (type == N_END) {                                                  // what is left in the open block; no permutation follows
+#pragma unroll
+        for (int i = 0; i < 42; ++i) w[i * LANES] ^= cur[i];
+        if (states_out) {
+          uint8_t* so = states_out + (size_t)t * 208;
+          for (int i = 0; i < 50; ++i) reinterpret_cast<uint32_t*>(so)[i] = w[i * LANES];
+          reinterpret_cast<uint32_t*>(so)[50] = cur[47] & 0xffffffu;        // pos, pos_begin, cur_flags, 0
+          reinterpret_cast<uint32_t*>(so)[51] = 0u;
+        }
+        done = true;
+      } else {
+        const uint32_t da = (info >> 4) & 3u, dr = (info >> 6) & 3u;
+        load_row(my_rows + (size_t)(nd + da) * row_step, nxa);
+        if (type == N_SQUEEZE) load_row(my_rows + (size_t)(nd + dr) * row_step, nxr);
+        keccak_absorb_row(w, cur);
+        bool accept = true;
+        uint32_t dv[8];
+        if (type == N_SQUEEZE) {                                            // strobe.py:77-87 from pos 0, curdleproofs_transcript.py:15-25
+          uint64_t wv[4], any = 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { dv[j] = w[j * LANES]; w[j * LANES] = 0u; }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { wv[j] = (uint64_t)dv[2 * j] | ((uint64_t)dv[2 * j + 1] << 32); any |= wv[j]; }
+          accept = any != 0;
+          if (accept) { accept = false; for (int j = 3; j >= 0; --j) if (wv[j] != cg1::H_FR[j]) { accept = wv[j] < cg1::H_FR[j]; break; } }
+          if (accept) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) drawn[j * LANES] = dv[j];
+          }
+        }
+        const uint32_t aux = cur[47];
+        nd += accept ? da : dr;
+#pragma unroll
+        for (uint32_t j = 0; j < ROW_WORDS; ++j) cur[j] = accept ? nxa[j] : nxr[j];
+        asm volatile("" ::: "memory");
+        if (type == N_SQUEEZE && accept) {
+          uint32_t* o = reinterpret_cast<uint32_t*>(orow + aux);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = dv[j];
+        } else if (type == N_SQUEEZE_RAW) {                                 // challenge_bytes(label, len): len <= 164 bytes from pos 0, zeroed as they are taken
+          const uint32_t len = (info >> 8) & 0xffu;
+          for (uint32_t j = 0; 4u * j < len; ++j) {
+            const uint32_t v = w[j * LANES], rem = len - 4u * j;
+            if (rem >= 4u) { w[j * LANES] = 0u; *reinterpret_cast<uint32_t*>(orow + aux + 4u * j) = v; }
+            else {
+              w[j * LANES] = v & (0xffffffffu << (8u * rem));
+              for (uint32_t b = 0; b < rem; ++b) orow[aux + 4u * j + b] = (uint8_t)(v >> (8u * b));
+            }
+          }
+        }
+      }
+    }
+    ++passes;
+  }
+  if (passes_out && threadIdx.x == 0) passes_out[blockIdx.x] = passes;
+}
+
 }  // namespace cg1merlin

@@ -143,6 +143,9 @@ struct Ctx {
   int fe_timed = 0;                     // "fe_timed": the block-program kernel reads the shader clock around the parts of a pass (cg1_shuffle_fe_last_split)
   int fe_rows = 1;                      // "fe_rows": 1 = the front-end's block-program kernel (k_shuffle_front_end_rows), 0 = the byte machine
   int fe_prio = 0;                      // "fe_prio": wave priority of k_shuffle_front_end (s_setprio 0 .. 3)
+  int merlin_last_kernel = 0;           // which kernel served the last cg1_merlin_batch_device call: 2 block program, 1 byte machine, 0 one lane at a time
+  int merlin_rows = 1;                  // "merlin_rows": 1 = cg1_merlin_batch_device hashes whole rate blocks (k_merlin_batch_rows) when the program fits, 0 = byte machine
+  void* d_merlin_rows = nullptr; size_t merlin_rows_cap = 0;      // the rows of the last such call (kept: 134 KB per shuffle-shaped transcript)
   int merlin_lanes = 64;                // transcripts per wave of k_merlin_batch_sync ("merlin_lanes": 1 .. 64)
   uint32_t merlin_passes = 0;           // of the last cg1_merlin_batch_device call: Keccak passes of the slowest wave
   int batch_mul_quad_max = 8192;        // k_batch_mul_quad up to this many outputs ("batch_mul_quad_max"; 0 = always one lane per output)
@@ -960,6 +963,7 @@ void cg1_ctx_destroy(cg1_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   cg1::free_bufs(ctx);
+  if (ctx->d_merlin_rows) (void)hipFree(ctx->d_merlin_rows);
   if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
   if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
   if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
@@ -1047,6 +1051,7 @@ int cg1_ctx_sync(cg1_ctx* ctx) {
   return CG1_OK;
 }
 int cg1_merlin_last_passes(const cg1_ctx* ctx) { return ctx ? (int)ctx->merlin_passes : -1; }
+int cg1_merlin_last_kernel(const cg1_ctx* ctx) { return ctx ? ctx->merlin_last_kernel : -1; }
 int cg1_ctx_device(const cg1_ctx* ctx) { return ctx ? ctx->device : -1; }
 void* cg1_ctx_stream(cg1_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
@@ -1072,6 +1077,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "fe_timed")) { ctx->fe_timed = value != 0; return CG1_OK; }
   if (!strcmp(name, "fe_rows")) { ctx->fe_rows = value != 0; return CG1_OK; }
   if (!strcmp(name, "fe_prio")) { if (value < 0 || value > 3) return CG1_ERR_ARG; ctx->fe_prio = value; return CG1_OK; }
+  if (!strcmp(name, "merlin_rows")) { ctx->merlin_rows = value != 0; return CG1_OK; }
   if (!strcmp(name, "merlin_lanes")) { if (value < 1 || value > 64) return CG1_ERR_ARG; ctx->merlin_lanes = value; return CG1_OK; }
   if (!strcmp(name, "tree_half")) { ctx->tree_half = value != 0; return CG1_OK; }
   if (!strcmp(name, "wave_agg")) {
@@ -1323,6 +1329,12 @@ int cg1_side_sync(cg1_ctx* ctx) {
 }
 // n Merlin transcripts on the device, one per lane, all running the same operation list on their own data rows
 // (k_merlin_batch).  init_state208: MerlinTranscript(label) as the host left it (cg1_merlin_init); ops: host array.
+}  // extern "C"
+namespace {
+bool build_block_program(const std::vector<cg1merlin::COp>& ops, const std::vector<std::string>& labels, const uint8_t* init, const uint8_t* consts, bool generic,
+                         std::vector<cg1merlin::RowDesc>& desc, uint32_t& n_nodes);      // (defined with the front-end's program below)
+}
+extern "C" {
 int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg1_merlin_op* ops, size_t nops, const void* d_data,
                             size_t data_stride, void* d_out, size_t out_stride, void* d_states_out, size_t n) {
   if (!ctx) return CG1_ERR_HIP;
@@ -1361,6 +1373,42 @@ int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg
       }
       cops[k] = cg1merlin::COp{(uint32_t)o.kind | (idx << 8) | ((uint32_t)o.label_len << 16), o.len, o.data_off, o.out_off};
     }
+    if (fits && ctx->merlin_rows) {
+      // the block program (kernels_merlin.h): whole rate blocks per pass; falls through to the byte machine when the program does not
+      // fit the row format (a challenge longer than 164 bytes, more than four late pieces in a block, unaligned output offsets)
+      std::vector<std::string> labels(seen.size());
+      for (const auto& e : seen) labels[e.second] = std::string(e.first.begin(), e.first.end());
+      std::vector<cg1merlin::RowDesc> desc;
+      uint32_t nn = 0;
+      const unsigned lanes_used = (unsigned)ctx->merlin_lanes;
+      const unsigned nb = (unsigned)((n + lanes_used - 1) / lanes_used);
+      const size_t need = build_block_program(cops, labels, init_state208, nullptr, true, desc, nn) ? (size_t)nb * lanes_used * nn * cg1merlin::ROW_WORDS * 4 : 0;
+      if (need && need <= ((size_t)8 << 30)) {
+        if (need > ctx->merlin_rows_cap) {
+          if (ctx->d_merlin_rows) (void)hipFree(ctx->d_merlin_rows);
+          ctx->d_merlin_rows = nullptr; ctx->merlin_rows_cap = 0;
+          HIPCHK(hipMalloc(&ctx->d_merlin_rows, need));
+          ctx->merlin_rows_cap = need;
+        }
+        DevBuf ddesc, dpass;
+        HIPCHK(ddesc.alloc(desc.size() * sizeof(cg1merlin::RowDesc)));
+        HIPCHK(dpass.alloc(4 * (size_t)nb));
+        HIPCHK(hipMemcpyAsync(ddesc.p, desc.data(), desc.size() * sizeof(cg1merlin::RowDesc), hipMemcpyHostToDevice, ctx->stream));
+        const size_t total = n * (size_t)nn * cg1merlin::ROW_WORDS;
+        hipLaunchKernelGGL(cg1merlin::k_fill_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const cg1merlin::RowDesc*)ddesc.p, nn,
+                           (const uint8_t*)d_data, data_stride, 0u, (uint32_t)n, lanes_used, (uint32_t*)ctx->d_merlin_rows);
+        hipLaunchKernelGGL(cg1merlin::k_merlin_batch_rows, dim3(nb), dim3(cg1merlin::LANES), 0, ctx->stream, (const uint8_t*)dst.p, (const uint32_t*)ctx->d_merlin_rows, nn,
+                           (uint8_t*)d_out, out_stride, (uint8_t*)d_states_out, (uint32_t)n, lanes_used, (uint32_t*)dpass.p);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipGetLastError());
+        std::vector<uint32_t> hp(nb);
+        HIPCHK(hipMemcpy(hp.data(), dpass.p, 4 * (size_t)nb, hipMemcpyDeviceToHost));
+        ctx->merlin_passes = *std::max_element(hp.begin(), hp.end());
+        ctx->merlin_clk[0] = ctx->merlin_clk[1] = 0;
+        ctx->merlin_last_kernel = 2;
+        return CG1_OK;
+      }
+    }
     if (fits) {
       DevBuf dpass, dcops, dtab;
       const unsigned lanes_used = (unsigned)ctx->merlin_lanes;
@@ -1382,11 +1430,13 @@ int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg
         if (hp[4 * b] >= ctx->merlin_passes) { ctx->merlin_passes = hp[4 * b]; ctx->merlin_clk[0] = hp[4 * b + 1]; ctx->merlin_clk[1] = hp[4 * b + 2]; }
       if (getenv("CG1_MERLIN_TRACE"))
         fprintf(stderr, "k_merlin_batch_sync: %u passes; s_memtime ticks / 256 in advance %u, in Keccak %u (slowest wave)\n", ctx->merlin_passes, ctx->merlin_clk[0], ctx->merlin_clk[1]);
+      ctx->merlin_last_kernel = 1;
       return CG1_OK;
     }
     // more than MAX_LABELS distinct labels: the round-2 kernel takes the program as it is
   }
   ctx->merlin_passes = 0;
+  ctx->merlin_last_kernel = 0;
   hipLaunchKernelGGL(cg1merlin::k_merlin_batch, dim3(nblk), dim3(cg1merlin::LANES), 0, ctx->stream,
                      (const uint8_t*)dst.p, (const cg1merlin::Op*)dops.p, (uint32_t)nops, (const uint8_t*)d_data, data_stride,
                      (uint8_t*)d_out, out_stride, (uint8_t*)d_states_out, (uint32_t)n);
@@ -1487,11 +1537,11 @@ void fe_build_program(size_t ell, size_t lg, FeProgram& P) {
 // constant XOR-ed into it and / or the place the byte comes from.  false = the program does not fit the row format (more than
 // MAX_PIECES late pieces in a node, an offset too large): the caller keeps the byte-machine kernel.
 struct FeNodes {
-  struct Byte { uint8_t kind = 0; uint32_t src = 0; };              // 0 none, 1 wire point byte (src = point * 48 + k), 2 the challenge just drawn, 3 the out row
-  struct Node { uint8_t T[168]; Byte D[168]; uint32_t type = cg1fe::N_PLAIN, bar = 0, da = 1, dr = 0, slot = 0; Node() { memset(T, 0, sizeof T); } };
+  struct Byte { uint8_t kind = 0; uint32_t src = 0; };              // 0 none, 1 byte of the lane's data row (src = its offset), 2 the challenge just drawn, 3 the out row
+  struct Node { uint8_t T[168]; Byte D[168]; uint32_t type = cg1fe::N_PLAIN, bar = 0, da = 1, dr = 0, out_off = 0, len = 0; Node() { memset(T, 0, sizeof T); } };
   std::vector<Node> nodes;
   Node cur;
-  uint32_t pos = 0, pos_begin = 0;
+  uint32_t pos = 0, pos_begin = 0, cur_flags = 0;
   bool ok = true;
   int last_closed = -1;
 
@@ -1507,6 +1557,7 @@ struct FeNodes {
   void begin_op(uint8_t flags) {
     const uint32_t old = pos_begin;
     pos_begin = pos + 1;
+    cur_flags = flags;
     put((uint8_t)old); put(flags);
     if ((flags & (cg1merlin::FLAG_C | cg1merlin::FLAG_K)) && pos != 0) run_f();
   }
@@ -1518,21 +1569,34 @@ struct FeNodes {
   void barrier(uint32_t kind) { if (cur.bar) ok = false; cur.bar = kind; }
 };
 
-bool fe_build_nodes(const FeProgram& P, const uint8_t* init, const uint8_t* consts, std::vector<cg1fe::RowDesc>& desc, uint32_t& n_nodes) {
+bool build_block_program(const std::vector<cg1merlin::COp>& ops, const std::vector<std::string>& labels, const uint8_t* init, const uint8_t* consts, bool generic,
+                         std::vector<cg1merlin::RowDesc>& desc, uint32_t& n_nodes) {
   using namespace cg1merlin;
   FeNodes S;
-  S.pos = init[200]; S.pos_begin = init[201];
-  for (const COp& op : P.ops) {
+  S.pos = init[200]; S.pos_begin = init[201]; S.cur_flags = init[202];
+  if (S.pos >= (uint32_t)STROBE_R) return false;
+  const uint32_t max_pieces = generic ? 4u : MAX_PIECES;            // (generic rows keep word 47 for the out-row offset / the final position)
+  for (const COp& op : ops) {
     const uint32_t kind = op.kind_label & 0xffu, lab = (op.kind_label >> 8) & 0xffu, llen = op.kind_label >> 16;
-    if (kind >= OP_BARRIER) { S.barrier(kind == cg1fe::X_GPROD ? 1u : (kind == cg1fe::X_DA ? 2u : 3u)); continue; }
-    const std::string label = P.labels[lab].substr(0, llen);
-    if (kind == OP_CHALLENGE_SCALAR) {
-      S.frame(label, 32);
+    if (kind >= OP_BARRIER) {
+      if (generic) return false;
+      S.barrier(kind == cg1fe::X_GPROD ? 1u : (kind == cg1fe::X_DA ? 2u : 3u));
+      continue;
+    }
+    if (lab >= labels.size()) return false;
+    const std::string label = labels[lab].substr(0, llen);
+    if (kind == OP_CHALLENGE_SCALAR || kind == OP_CHALLENGE) {
+      const bool scalar = kind == OP_CHALLENGE_SCALAR;
+      const uint32_t len = scalar ? 32u : op.len;
+      if (len > 164u || (op.out_off & 3u) || (!scalar && !generic)) return false;
+      S.frame(label, len);
       S.begin_op(FLAG_I | FLAG_A | FLAG_C);                              // the permutation the C flag forces closes the node the draw follows
-      if (S.pos != 0 || S.last_closed != (int)S.nodes.size() - 1 || S.last_closed < 0) return false;
+      if (S.pos != 0 || S.last_closed < 0) return false;
       FeNodes::Node& sq = S.nodes[S.last_closed];
-      if (sq.type != cg1fe::N_PLAIN) return false;
-      sq.type = cg1fe::N_SQUEEZE; sq.da = 2; sq.dr = 1; sq.slot = op.out_off / 32u;
+      if (sq.type != N_PLAIN) return false;
+      sq.out_off = op.out_off; sq.len = len;
+      if (!scalar) { sq.type = N_SQUEEZE_RAW; sq.da = 1; sq.dr = 0; S.pos = len; S.pos_begin = 0; continue; }
+      sq.type = N_SQUEEZE; sq.da = 2; sq.dr = 1;
       // the redo node: the same frame and PRF header from (pos, pos_begin) = (32, 0), where every draw leaves the sponge
       S.pos = 32; S.pos_begin = 0;
       const size_t before = S.nodes.size();
@@ -1540,7 +1604,7 @@ bool fe_build_nodes(const FeProgram& P, const uint8_t* init, const uint8_t* cons
       S.begin_op(FLAG_I | FLAG_A | FLAG_C);
       if (S.nodes.size() != before + 1 || S.pos != 0) return false;
       FeNodes::Node& rd = S.nodes.back();
-      rd.type = cg1fe::N_SQUEEZE; rd.da = 1; rd.dr = 0; rd.slot = op.out_off / 32u;
+      rd.type = N_SQUEEZE; rd.da = 1; rd.dr = 0; rd.out_off = op.out_off; rd.len = 32;
       // accepted: append_message(label, the 32 bytes), again from (32, 0)
       S.pos = 32; S.pos_begin = 0;
       S.frame(label, 32);
@@ -1548,41 +1612,47 @@ bool fe_build_nodes(const FeProgram& P, const uint8_t* init, const uint8_t* cons
       for (uint32_t k = 0; k < 32; ++k) S.put_src(2, k);
       continue;
     }
-    if (kind != OP_APPEND_POINT && kind != OP_APPEND_CONST && kind != OP_APPEND_OUT) return false;
+    if (kind != OP_APPEND && kind != OP_APPEND_POINT && kind != OP_APPEND_CONST && kind != OP_APPEND_OUT) return false;
+    if (kind == OP_APPEND_CONST && !consts) return false;
     S.frame(label, op.len);
     S.begin_op(FLAG_A);
     for (uint32_t k = 0; k < op.len; ++k) {
       if (kind == OP_APPEND_CONST) S.put(consts[op.data_off + k]);
-      else if (kind == OP_APPEND_POINT) S.put_src(1, op.data_off + k);
-      else S.put_src(3, op.out_off + k);
+      else if (kind == OP_APPEND_OUT) S.put_src(3, op.out_off + k);
+      else S.put_src(1, op.data_off + k);
     }
   }
-  S.cur.type = cg1fe::N_END;                                              // what is left in the open node is never permuted: the verifier draws nothing after it
+  S.cur.type = N_END;                                                     // what is left in the open node is never permuted
+  S.cur.out_off = S.pos | (S.pos_begin << 8) | (S.cur_flags << 16);
   S.nodes.push_back(S.cur);
   if (!S.ok) return false;
   n_nodes = (uint32_t)S.nodes.size();
-  desc.assign((size_t)n_nodes * cg1fe::ROW_WORDS, cg1fe::RowDesc{0, 0});
+  desc.assign((size_t)n_nodes * ROW_WORDS, RowDesc{0, 0});
   for (uint32_t nd = 0; nd < n_nodes; ++nd) {
     const FeNodes::Node& N = S.nodes[nd];
-    cg1fe::RowDesc* row = desc.data() + (size_t)nd * cg1fe::ROW_WORDS;
+    RowDesc* row = desc.data() + (size_t)nd * ROW_WORDS;
     for (uint32_t j = 0; j < 42; ++j) {
       uint32_t tw = 0;
       for (int b = 0; b < 4; ++b) tw |= (uint32_t)N.T[4 * j + b] << (8 * b);
       row[j].tword = tw;
-      // wire bytes of this word: one run from one point (a message is framed by >= 8 constant bytes)
+      // data-row bytes of this word: one run of consecutive source bytes (a message is framed by >= 8 constant bytes)
       int lo = -1, cnt = 0;
       for (int b = 0; b < 4; ++b) if (N.D[4 * j + b].kind == 1) { if (lo < 0) lo = b; ++cnt; }
       if (cnt) {
         const uint32_t s0 = N.D[4 * j + lo].src;
         for (int b = 0; b < cnt; ++b) if (N.D[4 * j + lo + b].kind != 1 || N.D[4 * j + lo + b].src != s0 + b) return false;
-        const uint32_t point = s0 / 48u, k0 = s0 % 48u;
-        if (k0 + cnt > 48u || point >= (1u << 21)) return false;
-        row[j].src = 1u | ((uint32_t)lo << 1) | ((uint32_t)(cnt - 1) << 3) | (k0 << 5) | (point << 11);
+        if (s0 >= (1u << 27) || (!generic && s0 % 48u + cnt > 48u)) return false;
+        row[j].src = 1u | ((uint32_t)lo << 1) | ((uint32_t)(cnt - 1) << 3) | (s0 << 5);
       }
     }
-    if (N.type == cg1fe::N_END) { row[42].tword = cg1fe::N_END | (N.bar << 2); continue; }
-    if (N.slot >= (1u << 16)) return false;
-    row[42].tword = N.type | (N.bar << 2) | (N.da << 4) | (N.dr << 6) | (N.slot << 8);
+    if (generic) {
+      row[42].tword = N.type | (N.da << 4) | (N.dr << 6) | ((N.type == N_SQUEEZE_RAW ? N.len : 0u) << 8);
+      row[47].tword = N.out_off;
+    } else {
+      if (N.type != N_END && ((N.out_off & 31u) || (N.out_off >> 5) >= (1u << 16))) return false;
+      row[42].tword = N.type == N_END ? (N_END | (N.bar << 2)) : (N.type | (N.bar << 2) | (N.da << 4) | (N.dr << 6) | ((N.out_off >> 5) << 8));
+    }
+    if (N.type == N_END && !generic) continue;
     // late pieces: runs of bytes of kind 2 / 3 with consecutive sources
     uint32_t np = 0;
     for (uint32_t p = 0; p < (uint32_t)STROBE_R;) {
@@ -1590,13 +1660,16 @@ bool fe_build_nodes(const FeProgram& P, const uint8_t* init, const uint8_t* cons
       if (k < 2) { ++p; continue; }
       uint32_t len = 1;
       while (p + len < (uint32_t)STROBE_R && len < 48u && N.D[p + len].kind == k && N.D[p + len].src == N.D[p].src + len) ++len;
-      if (np == cg1fe::MAX_PIECES || N.D[p].src >= (1u << 17)) return false;
+      if (np == max_pieces || N.D[p].src >= (1u << 17)) return false;
       row[43 + np].tword = len | (p << 6) | ((k == 3 ? 1u : 0u) << 14) | (N.D[p].src << 15);
       ++np;
       p += len;
     }
   }
   return true;
+}
+bool fe_build_nodes(const FeProgram& P, const uint8_t* init, const uint8_t* consts, std::vector<cg1fe::RowDesc>& desc, uint32_t& n_nodes) {
+  return build_block_program(P.ops, P.labels, init, consts, false, desc, n_nodes);
 }
 }  // namespace
 
@@ -1673,7 +1746,7 @@ cg1_shuffle_fe* cg1_shuffle_fe_create(cg1_ctx* ctx, size_t ell, size_t lg, const
 size_t cg1_shuffle_fe_aux_bytes(void) { return 19 * 32; }
 
 // Host only (no GPU needed; test support): walk the block program of one proof on the CPU exactly as k_shuffle_front_end_rows does --
-// rows as k_fe_fill_rows builds them, late pieces, both kinds of squeeze node -- up to the first barrier step (the grand product),
+// rows as k_fill_rows builds them, late pieces, both kinds of squeeze node -- up to the first barrier step (the grand product),
 // and return the out row (the challenges drawn so far sit in their slots: vec_a, alpha, beta of same_perm).  wire = the proof's L own
 // points as cg1_shuffle_gather_points packs them; out_row: (K + 6) * 32 bytes, zero where nothing was drawn.  *passes = permutations.
 int cg1_shuffle_fe_emulate_to_first_barrier(size_t ell, size_t lg, const uint8_t* crs_h48, const uint8_t* wire, uint8_t* out_row, size_t out_row_bytes,
@@ -1705,11 +1778,11 @@ int cg1_shuffle_fe_emulate_to_first_barrier(size_t ell, size_t lg, const uint8_t
       const uint32_t dst = (pc >> 6) & 255u, from_row = (pc >> 14) & 1u, so = pc >> 15;
       for (uint32_t i = 0; i < len; ++i) sponge[dst + i] ^= from_row ? out_row[so + i] : drawn[so + i];
     }
-    for (uint32_t j = 0; j < 42; ++j) {                      // the row as k_fe_fill_rows writes it
+    for (uint32_t j = 0; j < 42; ++j) {                      // the row as k_fill_rows writes it
       uint32_t v = row[j].tword;
       if (row[j].src) {
-        const uint32_t lo = (row[j].src >> 1) & 3u, cnt = ((row[j].src >> 3) & 3u) + 1u, k0 = (row[j].src >> 5) & 63u, p = row[j].src >> 11;
-        const uint8_t* pt = wire + (size_t)p * 48;
+        const uint32_t lo = (row[j].src >> 1) & 3u, cnt = ((row[j].src >> 3) & 3u) + 1u, off = row[j].src >> 5, k0 = off % 48u;
+        const uint8_t* pt = wire + (size_t)(off - k0);
         const bool inf = (pt[0] & 0xC0u) == 0xC0u;
         for (uint32_t b = 0; b < cnt; ++b) v ^= (uint32_t)(inf ? (k0 + b == 0 ? 0xC0u : 0u) : pt[k0 + b]) << (8 * (lo + b));
       }
@@ -1813,8 +1886,8 @@ int cg1_shuffle_fe_enqueue(cg1_shuffle_fe* fe, cg1_ctx* ctx, size_t n, const voi
     }
     fe->last_blocks = nblk;
     const size_t total = n * row_words;
-    hipLaunchKernelGGL(cg1fe::k_fe_fill_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const cg1fe::RowDesc*)fe->d_desc, fe->n_nodes,
-                       (const uint8_t*)d_wire48, fe->pr.L, (uint32_t)n, (uint32_t)lanes_per_wave, (uint32_t*)fe->d_rows);
+    hipLaunchKernelGGL(cg1merlin::k_fill_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const cg1fe::RowDesc*)fe->d_desc, fe->n_nodes,
+                       (const uint8_t*)d_wire48, (size_t)fe->pr.L * 48, 1u, (uint32_t)n, (uint32_t)lanes_per_wave, (uint32_t*)fe->d_rows);
     hipLaunchKernelGGL(ctx->fe_timed ? cg1fe::k_shuffle_front_end_rows<true> : cg1fe::k_shuffle_front_end_rows<false>, dim3(nblk), dim3(cg1merlin::LANES), 0, ctx->stream, (const uint8_t*)fe->d_init, (const uint32_t*)fe->d_rows,
                        fe->n_nodes, (const uint8_t*)d_wire48, (const uint8_t*)d_aux, (const cg1::PreparedPoint*)fe->d_four, (const cg1::PreparedPoint*)fe->d_tabG,
                        (const cg1::PreparedPoint*)fe->d_tabH, fe->pr, (uint8_t*)fe->d_scratch, (uint8_t*)d_rowin, (int32_t*)d_status, (uint32_t)n,

@@ -295,6 +295,10 @@ typedef struct cg1_merlin_op {
 /* Keccak passes the slowest wave of the last cg1_merlin_batch_device call executed (the lanes of a wave permute together;
  * a shuffle-shaped program needs ~750 permutations per transcript). */
 int cg1_merlin_last_passes(const cg1_ctx* ctx);
+/* Which kernel served that call: 2 = block program (whole rate blocks per pass; the default when the operation list fits its row format:
+ * challenges of at most 164 bytes, 4-byte aligned output offsets, at most four self-produced pieces per block), 1 = byte-level state
+ * machine ("merlin_rows" = 0, or the program does not fit), 0 = one lane at a time ("merlin_sync" = 0, or more than 48 distinct labels). */
+int cg1_merlin_last_kernel(const cg1_ctx* ctx);
 int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg1_merlin_op* ops, size_t nops, const void* d_data,
                             size_t data_stride, void* d_out, size_t out_stride, void* d_states_out, size_t n);
 

@@ -22,6 +22,18 @@ def M(native_lib):
     return m
 
 
+@pytest.fixture(params=["block program", "byte machine", "one lane at a time"], autouse=True)
+def kernel_form(request, native_lib):
+    """Every test runs on the three kernels behind cg1_merlin_batch_device."""
+    ctx = native_lib.default_context()
+    rows, sync = {"block program": (1, 1), "byte machine": (0, 1), "one lane at a time": (0, 0)}[request.param]
+    ctx.set_param("merlin_rows", rows)
+    ctx.set_param("merlin_sync", sync)
+    yield {"block program": 2, "byte machine": 1, "one lane at a time": 0}[request.param]
+    ctx.set_param("merlin_rows", 1)
+    ctx.set_param("merlin_sync", 1)
+
+
 def test_merlin_known_answer_on_every_lane(M):
     prog = M.TranscriptProgram.__new__(M.TranscriptProgram)
     # test_merlin.py:33-41 uses a plain MerlinTranscript(b"test protocol")
@@ -68,7 +80,7 @@ def test_opening_proof_challenges_match_the_reference(M):
     assert [o[c: c + 32].hex() for o in outs] == [case["challenge"] for case in gold["cases"]]
 
 
-def test_shuffle_shaped_program_equals_host_transcript_per_lane(M):
+def test_shuffle_shaped_program_equals_host_transcript_per_lane(M, kernel_form, native_lib):
     """300 operations of the shuffle verifier's shape (48-byte points, 32-byte scalars, rejection-sampled challenges, a
     challenge appended back under another label), 200 lanes with different data: outputs AND final sponge states equal the
     host transcript's, lane by lane."""
@@ -92,6 +104,7 @@ def test_shuffle_shaped_program_equals_host_transcript_per_lane(M):
             plan.append(("bytes", b"raw", o, 17))
     rows = [bytes(rng.randrange(256) for _ in range(off)) for _ in range(n)]
     outs, states = prog.run(rows, want_states=True)
+    assert native_lib.cg1_merlin_last_kernel(native_lib.default_context().handle) == kernel_form       # (no silent fall-back to another kernel)
     for i in (0, 1, 63, 64, 127, 199):
         t = M.CurdleproofsTranscript(b"curdleproofs")
         for kind, lab, o, ln in plan:

@@ -41,16 +41,20 @@ print(f"program: {nap} appended messages, {nch} challenges, {off[0]} data bytes 
 ctx = N.Context(0)
 rng = random.Random(1)
 base = bytes(rng.randrange(256) for _ in range(off[0]))
-for sync, lanes in ((0, 64), (1, 64), (1, 16), (1, 4), (1, 2), (1, 1)):
+for rows_form, sync, lanes in ((0, 0, 64), (0, 1, 64), (1, 1, 64), (1, 1, 16), (0, 1, 16), (0, 1, 1)):
+    ctx.set_param("merlin_rows", rows_form)
     ctx.set_param("merlin_sync", sync)
     ctx.set_param("merlin_lanes", lanes)
-    print(f"k_merlin_batch_sync (lanes of a wave permute together), {lanes} transcripts per wave" if sync else "k_merlin_batch (round 2: every lane permutes where its own transcript needs it)", flush=True)
+    print((f"k_merlin_batch_rows (block program: whole rate blocks per pass), {lanes} transcripts per wave" if rows_form else
+           f"k_merlin_batch_sync (byte-level state machine, lanes of a wave permute together), {lanes} transcripts per wave") if sync
+          else "k_merlin_batch (round 2: every lane permutes where its own transcript needs it)", flush=True)
     for n in ((64, 1024, 4096, 16384) if lanes == 64 else (1024, 4096)):
         rows = [base[i % 97:] + base[: i % 97] for i in range(n)]
         prog.run(rows[:64], ctx)
         t0 = time.perf_counter(); outs, _ = prog.run(rows, ctx); dt = time.perf_counter() - t0
         print(f"  n={n}: device call {prog.last_call_ms:.2f} ms ({n/prog.last_call_ms*1e3:.0f} transcripts/s), Keccak passes of the slowest wave {prog.last_passes}; "
               f"{1e3*dt:.1f} ms wall incl. H2D of {n*off[0]/1e6:.0f} MB and Python packing", flush=True)
+    assert N.cg1_merlin_last_kernel(ctx.handle) == (2 if rows_form else sync)
     if sync == 0:
         ref_outs = outs
     else:
