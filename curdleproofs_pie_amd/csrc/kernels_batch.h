@@ -286,8 +286,10 @@ __device__ __forceinline__ fp fp_sqrt_chain(const fp& a) {
 
 // CHECK is a template parameter: the unchecked instantiation (the reference's default, util.py:35-36) must not carry the
 // register footprint of the subgroup test's scalar multiplication (256 VGPRs + spills, 1 wave/SIMD when it did).
-template <bool CHECK>
-__global__ void __launch_bounds__(128) k_batch_decompress(const uint8_t* __restrict__ in48, uint32_t* __restrict__ out_raw,
+// WAVES (per SIMD) is a template parameter too: at 3 the compiler keeps half of the chain's table in scratch (168 VGPRs, 224 bytes, 45
+// scratch loads per point against 148 862 multiplies) and a third wave shares the multiplier; 2 = the table in registers (214 VGPRs).
+template <bool CHECK, int WAVES>
+__global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) k_batch_decompress(const uint8_t* __restrict__ in48, uint32_t* __restrict__ out_raw,
                                                           uint8_t* __restrict__ status, uint32_t n) {
   uint32_t i = blockIdx.x * 128 + threadIdx.x;
   if (i >= n) return;

@@ -143,6 +143,7 @@ struct Ctx {
   int fe_timed = 0;                     // "fe_timed": the block-program kernel reads the shader clock around the parts of a pass (cg1_shuffle_fe_last_split)
   int fe_rows = 1;                      // "fe_rows": 1 = the front-end's block-program kernel (k_shuffle_front_end_rows), 0 = the byte machine
   int fe_prio = 0;                      // "fe_prio": wave priority of k_shuffle_front_end (s_setprio 0 .. 3)
+  int decompress_waves = 3;             // "decompress_waves": waves per SIMD k_batch_decompress<false> is compiled for (2: table in registers, 3: half of it in scratch)
   int merlin_last_kernel = 0;           // which kernel served the last cg1_merlin_batch_device call: 2 block program, 1 byte machine, 0 one lane at a time
   int merlin_rows = 1;                  // "merlin_rows": 1 = cg1_merlin_batch_device hashes whole rate blocks (k_merlin_batch_rows) when the program fits, 0 = byte machine
   void* d_merlin_rows = nullptr; size_t merlin_rows_cap = 0;      // the rows of the last such call (kept: 134 KB per shuffle-shaped transcript)
@@ -1077,6 +1078,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "fe_timed")) { ctx->fe_timed = value != 0; return CG1_OK; }
   if (!strcmp(name, "fe_rows")) { ctx->fe_rows = value != 0; return CG1_OK; }
   if (!strcmp(name, "fe_prio")) { if (value < 0 || value > 3) return CG1_ERR_ARG; ctx->fe_prio = value; return CG1_OK; }
+  if (!strcmp(name, "decompress_waves")) { if (value != 2 && value != 3) return CG1_ERR_ARG; ctx->decompress_waves = value; return CG1_OK; }
   if (!strcmp(name, "merlin_rows")) { ctx->merlin_rows = value != 0; return CG1_OK; }
   if (!strcmp(name, "merlin_lanes")) { if (value < 1 || value > 64) return CG1_ERR_ARG; ctx->merlin_lanes = value; return CG1_OK; }
   if (!strcmp(name, "tree_half")) { ctx->tree_half = value != 0; return CG1_OK; }
@@ -1263,18 +1265,26 @@ int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases, size_t nbase, const ui
   HIPCHK(hipMemcpy(out, dout.p, n * 96, hipMemcpyDeviceToHost));
   return CG1_OK;
 }
+}  // extern "C"
+namespace {
+void launch_decompress(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup) {
+  const dim3 grid((unsigned)((n + 127) / 128)), block(128);
+  if (check_subgroup)
+    hipLaunchKernelGGL((cg1::k_batch_decompress<true, 2>), grid, block, 0, ctx->stream, (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
+  else if (ctx->decompress_waves == 3)
+    hipLaunchKernelGGL((cg1::k_batch_decompress<false, 3>), grid, block, 0, ctx->stream, (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
+  else
+    hipLaunchKernelGGL((cg1::k_batch_decompress<false, 2>), grid, block, 0, ctx->stream, (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
+}
+}
+extern "C" {
 // n compressed48 (device) -> n affine96 + n status bytes (device); returns CG1_OK when the kernel ran
 int cg1_batch_decompress_device(cg1_ctx* ctx, const void* d_in48, void* d_out_affine96, void* d_status, size_t n, int check_subgroup) {
   if (!ctx) return CG1_ERR_HIP;
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  if (check_subgroup)
-    hipLaunchKernelGGL(cg1::k_batch_decompress<true>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                       (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
-  else
-    hipLaunchKernelGGL(cg1::k_batch_decompress<false>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                       (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
+  launch_decompress(ctx, d_in48, d_out_affine96, d_status, n, check_subgroup);
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   return CG1_OK;
@@ -1285,12 +1295,7 @@ int cg1_batch_decompress_enqueue(cg1_ctx* ctx, const void* d_in48, void* d_out_a
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) return CG1_ERR_ARG;
   HIPCHK(hipSetDevice(ctx->device));
-  if (check_subgroup)
-    hipLaunchKernelGGL(cg1::k_batch_decompress<true>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                       (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
-  else
-    hipLaunchKernelGGL(cg1::k_batch_decompress<false>, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, ctx->stream,
-                       (const uint8_t*)d_in48, (uint32_t*)d_out_affine96, (uint8_t*)d_status, (uint32_t)n);
+  launch_decompress(ctx, d_in48, d_out_affine96, d_status, n, check_subgroup);
   HIPCHK(hipGetLastError());
   return CG1_OK;
 }
