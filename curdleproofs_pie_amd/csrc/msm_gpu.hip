@@ -1750,6 +1750,76 @@ cg1_shuffle_fe* cg1_shuffle_fe_create(cg1_ctx* ctx, size_t ell, size_t lg, const
 
 size_t cg1_shuffle_fe_aux_bytes(void) { return 19 * 32; }
 
+// Host only (no GPU needed; test support): ONE transcript of cg1_merlin_batch_device's interface run through the block program on the
+// CPU -- build_block_program's tables walked as k_fill_rows + k_merlin_batch_rows walk them (rows, late pieces, first-draw / redo /
+// raw squeeze nodes, the open block at the end).  Returns CG1_ERR_ARG when the operation list does not fit the row format (the device
+// entry point then serves the call with the byte-level machine).  state_out208 may be NULL.
+int cg1_merlin_block_program_emulate(const uint8_t* init_state208, const cg1_merlin_op* ops, size_t nops, const uint8_t* data_row, size_t data_bytes,
+                                     uint8_t* out_row, size_t out_bytes, uint8_t* state_out208, uint32_t* passes) {
+  if (!init_state208 || (nops && !ops) || !out_row) return CG1_ERR_ARG;
+  std::vector<cg1merlin::COp> cops(nops);
+  std::vector<std::string> labels;
+  for (size_t k = 0; k < nops; ++k) {
+    const cg1_merlin_op& o = ops[k];
+    if (o.kind > 3 || o.label_len > 32) return CG1_ERR_ARG;
+    if (o.kind == 0 && (size_t)o.data_off + o.len > data_bytes) return CG1_ERR_ARG;
+    if (o.kind != 0 && (size_t)o.out_off + (o.kind == 2 ? 32 : o.len) > out_bytes) return CG1_ERR_ARG;
+    const std::string lb((const char*)o.label, o.label_len);
+    size_t idx = 0;
+    while (idx < labels.size() && labels[idx] != lb) ++idx;
+    if (idx == labels.size()) { if (labels.size() >= (size_t)cg1merlin::MAX_LABELS) return CG1_ERR_ARG; labels.push_back(lb); }
+    cops[k] = cg1merlin::COp{(uint32_t)o.kind | ((uint32_t)idx << 8) | ((uint32_t)o.label_len << 16), o.len, o.data_off, o.out_off};
+  }
+  std::vector<cg1merlin::RowDesc> desc;
+  uint32_t nn = 0;
+  if (!build_block_program(cops, labels, init_state208, nullptr, true, desc, nn)) return CG1_ERR_ARG;
+  uint8_t sponge[200], drawn[36] = {0};
+  memcpy(sponge, init_state208, 200);
+  uint32_t nd = 0, np = 0;
+  for (;;) {
+    const cg1merlin::RowDesc* row = desc.data() + (size_t)nd * cg1merlin::ROW_WORDS;
+    const uint32_t info = row[42].tword, type = info & 3u, aux = row[47].tword;
+    for (uint32_t q = 0; q < 4; ++q) {
+      const uint32_t pc = row[43 + q].tword, len = pc & 63u;
+      if (!len) continue;
+      const uint32_t dst = (pc >> 6) & 255u, from_row = (pc >> 14) & 1u, so = pc >> 15;
+      for (uint32_t i = 0; i < len; ++i) sponge[dst + i] ^= from_row ? out_row[so + i] : drawn[so + i];
+    }
+    for (uint32_t j = 0; j < 42; ++j) {
+      uint32_t v = row[j].tword;
+      if (row[j].src) {
+        const uint32_t lo = (row[j].src >> 1) & 3u, cnt = ((row[j].src >> 3) & 3u) + 1u, off = row[j].src >> 5;
+        for (uint32_t b = 0; b < cnt; ++b) v ^= (uint32_t)data_row[off + b] << (8 * (lo + b));
+      }
+      for (int b = 0; b < 4; ++b) sponge[4 * j + b] ^= (uint8_t)(v >> (8 * b));
+    }
+    if (type == cg1merlin::N_END) {
+      if (state_out208) { memcpy(state_out208, sponge, 200); state_out208[200] = (uint8_t)aux; state_out208[201] = (uint8_t)(aux >> 8); state_out208[202] = (uint8_t)(aux >> 16); memset(state_out208 + 203, 0, 5); }
+      break;
+    }
+    cg1_keccak_f1600(sponge);
+    ++np;
+    bool accept = true;
+    if (type == cg1merlin::N_SQUEEZE) {
+      uint8_t dv[32];
+      memcpy(dv, sponge, 32);
+      memset(sponge, 0, 32);
+      cg1fr::fr tmp;
+      bool nonzero = false;
+      for (int i = 0; i < 32; ++i) nonzero |= dv[i] != 0;
+      accept = nonzero && cg1fr::fr_from_le32(dv, tmp);
+      if (accept) { memcpy(out_row + aux, dv, 32); memcpy(drawn, dv, 32); }
+    } else if (type == cg1merlin::N_SQUEEZE_RAW) {
+      const uint32_t len = (info >> 8) & 0xffu;
+      memcpy(out_row + aux, sponge, len);
+      memset(sponge, 0, len);
+    }
+    nd += accept ? (info >> 4) & 3u : (info >> 6) & 3u;
+  }
+  if (passes) *passes = np;
+  return CG1_OK;
+}
+
 // Host only (no GPU needed; test support): walk the block program of one proof on the CPU exactly as k_shuffle_front_end_rows does --
 // rows as k_fill_rows builds them, late pieces, both kinds of squeeze node -- up to the first barrier step (the grand product),
 // and return the out row (the challenges drawn so far sit in their slots: vec_a, alpha, beta of same_perm).  wire = the proof's L own

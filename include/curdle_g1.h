@@ -299,6 +299,10 @@ int cg1_merlin_last_passes(const cg1_ctx* ctx);
  * challenges of at most 164 bytes, 4-byte aligned output offsets, at most four self-produced pieces per block), 1 = byte-level state
  * machine ("merlin_rows" = 0, or the program does not fit), 0 = one lane at a time ("merlin_sync" = 0, or more than 48 distinct labels). */
 int cg1_merlin_last_kernel(const cg1_ctx* ctx);
+/* Host only, test support: ONE transcript of that interface run through the block program on the CPU (the tables the device kernels
+ * consume, walked the way they walk them); CG1_ERR_ARG when the operation list does not fit the row format. */
+int cg1_merlin_block_program_emulate(const uint8_t* init_state208, const cg1_merlin_op* ops, size_t nops, const uint8_t* data_row, size_t data_bytes,
+                                     uint8_t* out_row, size_t out_bytes, uint8_t* state_out208 /* may be NULL */, uint32_t* passes);
 int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg1_merlin_op* ops, size_t nops, const void* d_data,
                             size_t data_stride, void* d_out, size_t out_stride, void* d_states_out, size_t n);
 
