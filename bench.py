@@ -135,7 +135,7 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
     for _ in range(warmup):
         assert not any(v.verify_packed(inst, proofs, batch, mode=verify_mode))
     if v.device_front_end and warmup:             # every front-end lane builds its tables on first use: untimed, like the warm-up steps
-        for st in v.verify_stream(((inst, proofs, batch) for _ in range(v.fe_lanes + 2)), mode=verify_mode):
+        for st in v.verify_stream(((inst, proofs, batch) for _ in range(v.pipelines * (v.fe_lanes + 2))), mode=verify_mode):
             assert not any(st)
     acc = {}
     ctx.sync()
@@ -172,7 +172,7 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
         "data": "tests/golden/shuffle_batch_ell124{,_more}.bin: %d distinct proofs made by the reference prover over one CRS (cycled when the "
                 "batch is larger), fresh OS-random weights per slot; inputs are wire bytes in host memory (H2D included)" % fx.count,
         "points_per_step": points + C, "host_threads": threads,
-        "front_end": ("device (k_shuffle_front_end_rows, %d launches side by side)" % v.fe_lanes) if v.device_front_end else "host",
+        "front_end": ("device (k_shuffle_front_end_rows; %d pipeline(s) x %d launches side by side)" % (v.pipelines, v.fe_lanes)) if v.device_front_end else "host",
         "phases_ms_per_step": {"decompress_stage (H2D + k_batch_decompress + D2H, GPU thread)": 1e3 * acc.get("decompress_s", 0) / steps,
                                FE_KEY: 1e3 * acc.get("front_end_s", 0) / steps,
                                "merged_msm (one regime-A MSM of all points, GPU)": 1e3 * acc.get("merged_msm_s", 0) / steps,

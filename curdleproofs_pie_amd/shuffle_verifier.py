@@ -121,7 +121,8 @@ class Prepared:
 
 class ShuffleBatchVerifier:
     def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True,
-                 blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: int = 3, fe_cus: int = 0, fe_prio: int = 0):
+                 blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: Optional[int] = None, fe_cus: int = 0, fe_prio: int = 0,
+                 pipelines: Optional[int] = None):
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
@@ -136,16 +137,25 @@ class ShuffleBatchVerifier:
         # transcript is ~800 dependent Keccak permutations: 24 K clocks each for the one wave a SIMD runs) but occupies only n / 64 of
         # the chip's 1024 SIMDs, so `fe_lanes` launches of consecutive batches run side by side, each on its own context, and the
         # stream keeps fe_lanes + 3 batches in flight.  The host then only packs bytes: proofs/s no longer depends on its core count.
-        # Measured on MI355X (profiles/r03_verify_fe_ab.txt, batches of 1024, GPU_MAX_HW_QUEUES = 24): 134-144 K proofs/s whatever
-        # the host (2 or 16 threads), against 13 K / 25 K / 49 K / 91 K / 130-157 K proofs/s with the host front-end on 1 / 2 / 4 / 8 /
-        # 16 threads -- so None (the default) turns it on when fewer than twelve host threads are available to this verifier (e.g.
-        # eight ranks sharing a 64-thread host), and leaves the host front-end on otherwise.  CURDLE_G1_DEVICE_FRONT_END=0/1 overrides.
+        # Measured on MI355X (profiles/r03_verify_fe_ab.txt, batches of 1024, GPU_MAX_HW_QUEUES = 24): 156-158 K proofs/s on 2 or 4 host
+        # threads with two pipelines (below), 131-145 K with one; host front-end: 13 K / 25 K / 49 K / 91 K / 130-168 K proofs/s on 1 / 2 /
+        # 4 / 8 / 16 threads -- so None (the default) turns the device front-end on when fewer than sixteen host threads are available to
+        # this verifier (e.g. eight ranks sharing a 64-thread host), and leaves the host front-end on otherwise.
+        # CURDLE_G1_DEVICE_FRONT_END=0/1 overrides.
         env = os.environ.get("CURDLE_G1_DEVICE_FRONT_END")
         if env in ("0", "1"):
             device_front_end = env == "1"
         if device_front_end is None:
-            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < 12
+            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < 16
         self.device_front_end = bool(device_front_end)
+        # pipelines (device front-end only): that many complete pipelines -- decoding lane, front-end launches, MSM lane, each on contexts
+        # of its own -- take the batches of a stream in turn.  One pipeline leaves the GPU idle between its dependent kernels (the
+        # reduce chains of an MSM, the waits of a decoding lane): two give 6.5 instead of 7.2-7.7 ms per batch, 1.57e5 proofs/s
+        # (profiles/r03_two_pipelines.txt); with the host front-end a second pipeline only fights for the cores (11 ms), so it stays 1.
+        self.pipelines = max(1, int(pipelines if pipelines is not None else (2 if self.device_front_end else 1))) if self.device_front_end else 1
+        if fe_lanes is None:
+            fe_lanes = 2 if self.pipelines > 1 else 3
+        self._kids = None
         self.fe_lanes = max(1, int(fe_lanes)) if self.device_front_end else 0
         # fe_cus > 0 (A/B switch, off): the front-end launches get that many compute units of their own (the last ones) and the
         # throughput kernels are confined to the others (hipExtStreamCreateWithCUMask).  Measured a loss: the masked decompression
@@ -198,6 +208,9 @@ class ShuffleBatchVerifier:
         if self._ctx_msm is not None:
             self._ctx_msm.close()
             self._ctx_msm = None
+        for kid in (getattr(self, "_kids", None) or []):
+            kid.close()
+        self._kids = None
         for k, pair in enumerate(getattr(self, "_fe", [])):
             if pair is not None:
                 cx, fe, aux_h, aux_d = pair
@@ -583,10 +596,81 @@ class ShuffleBatchVerifier:
 
         self._gpu_submit(job, lane=2 + k)
 
+    def _verify_stream_pipelines(self, batches, mode: str, rng):
+        """verify_stream over `pipelines` child verifiers (same CRS, own contexts and threads) that take the batches in turn; verdicts
+        are yielded in the order of the input."""
+        import queue
+        import threading
+        from collections import deque
+
+        if self._kids is None:
+            dev = self.ctx.device
+            self._kids = [ShuffleBatchVerifier(self.crs, N.Context(dev), threads=self.threads, chunk=self.chunk, device_rows=self.device_rows,
+                                               blocking_sync=self.blocking_sync, device_front_end=True, fe_lanes=self.fe_lanes, fe_prio=self.fe_prio, pipelines=1)
+                          for _ in range(self.pipelines)]
+            for k in self._kids:
+                k._own_ctx = True
+        P = len(self._kids)
+        depth = self.fe_lanes + 3
+        in_q = [queue.Queue(maxsize=depth) for _ in range(P)]
+        out_q = [queue.Queue() for _ in range(P)]
+
+        def run(kid, qi, qo):
+            try:
+                for st in kid.verify_stream(iter(qi.get, None), mode, rng):
+                    qo.put((st, dict(kid.last_stats)))
+            except BaseException as e:                      # (reported to the consumer at this batch's turn)
+                qo.put(e)
+                while qi.get() is not None:                 # keep the feeder from blocking on a full queue
+                    pass
+
+        ths = [threading.Thread(target=run, args=(self._kids[i], in_q[i], out_q[i]), daemon=True) for i in range(P)]
+        for t in ths:
+            t.start()
+        order = deque()
+
+        def pop():
+            r = out_q[order.popleft()].get()
+            if isinstance(r, BaseException):
+                raise r
+            self.last_status, self.last_stats = r[0], r[1]
+            return r[0]
+
+        try:
+            k = 0
+            for batch in batches:
+                in_q[k % P].put(batch)
+                order.append(k % P)
+                k += 1
+                while len(order) > P * depth:
+                    yield pop()
+            for q in in_q:
+                q.put(None)
+            while order:
+                yield pop()
+        finally:
+            for q, t in zip(in_q, ths):                      # (also when abandoned mid-way: drop what was not started, let the child drain)
+                while t.is_alive():
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        pass
+                    try:
+                        q.put(None, timeout=0.05)
+                        break
+                    except queue.Full:
+                        continue
+            for t in ths:
+                t.join()
+
     def _verify_stream_device(self, batches, mode: str, rng):
         """verify_stream with the front-end on the GPU: up to fe_lanes + 2 batches in flight (decoding | front-end launches side by
         side | rows + merged MSM), verdicts yielded in order."""
         from collections import deque
+
+        if self.pipelines > 1:
+            yield from self._verify_stream_pipelines(batches, mode, rng)
+            return
 
         inflight = deque()
         depth = self.fe_lanes + 2

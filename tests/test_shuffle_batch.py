@@ -136,13 +136,16 @@ def test_config5_16384_proofs_sharded_proof_per_gpu(native_lib, fx):
 
 
 @pytest.mark.gpu
-def test_device_front_end_stream_verdicts_equal_reference(native_lib, fx):
+@pytest.mark.parametrize("pipelines", [2, 1])
+def test_device_front_end_stream_verdicts_equal_reference(native_lib, fx, pipelines):
     """The whole verifier with its front-end on the GPU (device_front_end=True: transcript, D / A', challenge algebra in
     k_shuffle_front_end): a stream of 1024-proof batches -- clean, tampered at known slots, clean, tampered -- with several batches in
-    flight; verdicts equal the fixture's (the reference verifier's), in both MSM modes."""
+    flight, over one pipeline and over two that take the batches in turn; verdicts equal the fixture's (the reference verifier's), in
+    order, in both MSM modes; a consumer that stops early leaves nothing running."""
     from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
 
-    v = ShuffleBatchVerifier(fx.crs, native_lib.Context(0), device_front_end=True)
+    v = ShuffleBatchVerifier(fx.crs, native_lib.Context(0), device_front_end=True, pipelines=pipelines)
+    assert v.pipelines == pipelines
     clean = fx.tiled(1024)
     bad = fx.tiled(1024, SLOTS_1024)
     seq = [clean, bad, clean, bad, clean, clean, bad, clean, clean]
@@ -152,4 +155,8 @@ def test_device_front_end_stream_verdicts_equal_reference(native_lib, fx):
     assert [s == 0 for s in st] == bad[2]
     small = fx.tiled(37, {5: 2, 36: 7})
     assert [s == 0 for s in v.verify_packed(small[0], small[1], 37)] == small[2]
+    gen = v.verify_stream([(x[0], x[1], 1024) for x in seq])
+    assert [s == 0 for s in next(gen)] == clean[2]
+    gen.close()                                               # abandoned after the first verdict
+    assert [[s == 0 for s in st] for st in v.verify_stream([(bad[0], bad[1], 1024)])] == [bad[2]]
     v.close()

@@ -17,13 +17,14 @@ threads = int(os.environ.get("THREADS", "0"))
 # CONFIGS = "lanes:cus:prio,..." (front-end launches side by side : compute units of their own : wave priority of the front-end kernel)
 spec = os.environ.get("CONFIGS", "5:0:0,5:0:3,8:0:3")
 configs = [("host front-end", dict(device_front_end=False))] + [
-    (f"device front-end, {f} lanes, {c} CUs of their own, priority {pr}", dict(device_front_end=True, fe_lanes=int(f), fe_cus=int(c), fe_prio=int(pr)))
+    (f"device front-end, {f} lanes, {c} CUs of their own, priority {pr}, {os.environ.get('PIPELINES', '1')} pipeline(s)",
+     dict(device_front_end=True, fe_lanes=int(f), fe_cus=int(c), fe_prio=int(pr), pipelines=int(os.environ.get("PIPELINES", "1"))))
     for f, c, pr in (x.split(":") for x in spec.split(","))]
 print("GPU_MAX_HW_QUEUES =", os.environ.get("GPU_MAX_HW_QUEUES"), flush=True)
 for rnd in range(int(os.environ.get('ROUNDS', '2'))):
     for name, kw in configs:
         v = ShuffleBatchVerifier(fx.crs, ctx, threads=threads, **kw)
-        list(v.verify_stream([(inst, proofs, n)] * (4 + kw.get("fe_lanes", 0))))
+        list(v.verify_stream([(inst, proofs, n)] * ((4 + kw.get("fe_lanes", 0)) * kw.get("pipelines", 1))))
         acc = {}
         t0 = time.perf_counter()
         for st in v.verify_stream(((inst, proofs, n) for _ in range(K))):
