@@ -508,6 +508,21 @@ def main():
         # ~50 ms of work run at a ramping clock (the same kernels measure 28 T mad/s there and 33 once warm: profiles/r03_v2_bench.json)
         ctx.probe_mad_rate(2, 200)
         results = stream(warmup)
+        # ... and let the step time settle (untimed, reported as settle_steps): blocks of five further steps until a block is within 1.5 %
+        # of the one before -- the first steps of a process also pay for host threads and pages that are touched for the first time
+        # (profiles/r03_v4_bench.json: 3.24 ms for the first 20 timed steps of a process, 2.98 / 3.00 ms for the next two runs)
+        settle, prev = 0, None
+        while settle < 40:
+            ts = time.perf_counter()
+            results += stream(5)
+            settle += 5
+            blk = (time.perf_counter() - ts) / 5
+            done = prev is not None and abs(blk - prev) <= 0.015 * prev
+            prev = blk
+            if comm:                                          # every rank takes the same number of steps: stop when all have settled
+                done = max(max_over_ranks(0.0 if done else 1.0, comm)) < 0.5
+            if done:
+                break
         ex["t"], ex["n"] = 0.0, 0
         phase_acc.clear()
         barrier_sync()
@@ -539,7 +554,7 @@ def main():
                "phases_ms": {k: v / steps for k, v in phase_acc.items() if k != "window_c"}, "counts": counts,
                "phases_ms_window_c": phase_acc.get("window_c", 0) / steps,
                "layout": (w_rank, w_groups, p_rank, p_groups), "n_local": wl.n, "depth": len(ctxs),
-               "exchange_ms": (ex["t"] / ex["n"] * 1e3) if ex["n"] else None, "result": results[-1], "closed_form_ok": closed}
+               "exchange_ms": (ex["t"] / ex["n"] * 1e3) if ex["n"] else None, "result": results[-1], "closed_form_ok": closed, "settle_steps": settle}
         wl.free()
         return rec
 
@@ -602,6 +617,7 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
+            "settle_steps": r["settle_steps"],              # further untimed steps, taken until the step time stops moving (see run())
             "ms_per_step": r["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
