@@ -151,7 +151,8 @@ class ShuffleBatchVerifier:
         # pipelines (device front-end only): that many complete pipelines -- decoding lane, front-end launches, MSM lane, each on contexts
         # of its own -- take the batches of a stream in turn.  One pipeline leaves the GPU idle between its dependent kernels (the
         # reduce chains of an MSM, the waits of a decoding lane): two give 6.5 instead of 7.2-7.7 ms per batch, 1.57e5 proofs/s
-        # (profiles/r03_two_pipelines.txt); with the host front-end a second pipeline only fights for the cores (11 ms), so it stays 1.
+        # (profiles/r03_two_pipelines.txt); three or four are worse again (6.9-9.9 ms: profiles/r03_verify_fe_ab.txt); with the host front-end a
+        # second pipeline only fights for the cores (11 ms), so it stays 1.
         self.pipelines = max(1, int(pipelines if pipelines is not None else (2 if self.device_front_end else 1))) if self.device_front_end else 1
         if fe_lanes is None:
             fe_lanes = 2 if self.pipelines > 1 else 3
