@@ -88,7 +88,17 @@ int  cg1_d2h_2d(cg1_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_
 int  cg1_ctx_sync(cg1_ctx* ctx);                                     /* hipDeviceSynchronize on the context's GPU */
 int  cg1_ctx_device(const cg1_ctx* ctx);                             /* the HIP device ordinal the context was created on */
 void* cg1_ctx_stream(cg1_ctx* ctx);                                  /* the context's compute stream (a hipStream_t), for callers ordering their own work */
-int  cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value);   /* "chunk_len" (L0), "seg_m", "profile" */
+/* Tuning and A/B switches of a context (defaults are the measured best; DESIGN.md section 9 has the measurements):
+ *   MSM plan / phases   "chunk_len" "seg_m" "auto_plan" "stage_sort" "partition_sort" "big_bins" "wave_agg" "quad" "reduce_2d" "rowcol_quad"
+ *                       "rowcol_quad_max" "fold_pass" "tree_half" "scan_one" "host_split" "horner_threads" "zero_copy" "batched_host_horner_max"
+ *                       "batch_mul_quad_max"
+ *   waiting             "blocking_sync" (sleep instead of spinning on the stream), "profile" (0: no events, 1: around k_accumulate, 2: every phase)
+ *   codec               "decompress_waves" (2 | 3: waves per SIMD k_batch_decompress is compiled for)
+ *   transcripts         "merlin_rows" (1: block program when the operation list fits), "merlin_sync" (1: lanes of a wave permute together),
+ *                       "merlin_lanes" (1..64 transcripts per wave)
+ *   verifier front-end  "fe_rows" (1: block program, 0: byte-level machine), "fe_timed" (shader-clock split of a launch), "fe_prio" (0..3)
+ * Unknown names and out-of-range values return CG1_ERR_ARG. */
+int  cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value);
 
 /* ---------------- the hot path: compute_MSM  (msm_accumulator.py:6-12) ------------------------- */
 /* sum_i scalars[i] * points[i], inputs in host memory (copied to the device by the call). */
