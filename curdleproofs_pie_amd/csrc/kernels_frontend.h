@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(LANES) k_shuffle_front_end(const uint8_t* __re
 // leaves the sponge at (pos, pos_begin) = (32, 0) however many draws it took (the PRF's C flag forces a permutation before each
 // draw) -- so the whole byte stream between two permutations is known per NODE of a small control-flow graph:
 //     plain node -> next node;     squeeze node -accepted-> next node,  -rejected-> its redo node (frame + PRF header at pos 32) -> itself / next
-// The host cuts the operation list into those nodes once per ell (fe_build_nodes in msm_gpu.hip: a symbolic run of strobe.py:55-107
+// The host cuts the operation list into those nodes once per ell (build_block_program in msm_gpu.hip: a symbolic run of strobe.py:55-107
 // and merlin_transcript.py:11-24 that records, per sponge byte, the constant XOR-ed into it or where the byte comes from);
 // cg1merlin::k_fill_rows then writes, for every proof, one 192-byte ROW per node: 42 words = everything XOR-ed into the rate between two
 // permutations that is known before hashing starts (framing, labels, lengths, STROBE's own marks, the proof's and the instance's
@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(LANES) k_shuffle_front_end_rows(const uint8_t*
       done = true;
     }
   }
-  // row of node k of this lane: my_rows + k * row_step (layout [wave][node][lane][48 words], see k_fe_fill_rows)
+  // row of node k of this lane: my_rows + k * row_step (layout [wave][node][lane][48 words], see cg1merlin::k_fill_rows)
   const uint4* my_rows = reinterpret_cast<const uint4*>(rows + row_word_index((uint32_t)me, 0u, nodes, lanes_used));
   const size_t row_step = (size_t)lanes_used * (ROW_WORDS / 4);
   uint32_t cur[ROW_WORDS], nxa[ROW_WORDS], nxr[ROW_WORDS];
