@@ -407,7 +407,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the proofs-verified/s object and the extra N>1 records")
     ap.add_argument("--batch", type=int, default=1024, help="proofs per step (secondary metric / --mode verify)")
-    ap.add_argument("--verify-steps", type=int, default=20)
+    ap.add_argument("--verify-steps", type=int, default=40, help="batches of the secondary stream (its fill and drain are inside the timed region)")
     ap.add_argument("--verify-mode", choices=["merged", "independent"], default="merged")
     ap.add_argument("--front-end", choices=["auto", "host", "device"], default="auto",
                     help="verifier front-end (transcript, D / A', challenge algebra): host threads, k_shuffle_front_end, or by the threads available")
