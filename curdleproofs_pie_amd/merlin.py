@@ -163,21 +163,3 @@ class TranscriptProgram:
             d_st.free()
         d_data.free(); d_out.free()
         return outs, states
-
-    def emulate_block_program(self, row: bytes):
-        """ONE transcript through the block program ON THE HOST (test support, no GPU): the tables the device kernels consume, walked
-        the way k_fill_rows / k_merlin_batch_rows walk them.  -> (output row, 208-byte state, permutations), or None when the
-        operation list does not fit the row format (cg1_merlin_batch_device then uses the byte-level kernel)."""
-        row = bytes(row)
-        if len(row) < self.data_bytes:
-            raise ValueError("the data row is shorter than the program reads")
-        ops = (N.MerlinOp * max(1, len(self._ops)))(*self._ops)
-        out = ctypes.create_string_buffer(max(4, self.out_bytes))
-        st = ctypes.create_string_buffer(N.MERLIN_STATE_BYTES)
-        passes = ctypes.c_uint32(0)
-        rc = N.cg1_merlin_block_program_emulate(self._init, ops, len(self._ops), row + b"\0" * 4, len(row), out, len(out), st, ctypes.byref(passes))
-        if rc == N.ERR_ARG:
-            return None
-        if rc:
-            raise N.NativeError(f"cg1_merlin_block_program_emulate failed ({rc})")
-        return out.raw, st.raw, passes.value

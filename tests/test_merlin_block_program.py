@@ -1,4 +1,4 @@
-"""cg1_merlin_batch_device's BLOCK PROGRAM checked without a GPU: `TranscriptProgram.emulate_block_program` runs one transcript through
+"""cg1_merlin_batch_device's BLOCK PROGRAM checked without a GPU: `cg1_merlin_block_program_emulate` (test support in the library) runs one transcript through
 the node tables the device kernels consume (build_block_program in csrc/msm_gpu.hip, walked on the CPU the way k_fill_rows /
 k_merlin_batch_rows walk them) -- random operation lists over merlin_transcript.py:11-24 / curdleproofs_transcript.py:15-25 against the
 host transcript (itself pinned by the reference's known answers and recorded sequences, tests/test_merlin.py), outputs AND the final
@@ -19,6 +19,25 @@ def M(native_lib):
     import curdleproofs_pie_amd.merlin as m
 
     return m
+
+
+def emulate_block_program(prog, row):
+    """ONE transcript through the block program on the host (cg1_merlin_block_program_emulate, test support in the library: the node
+    tables walked the way the kernels walk them).  -> (output row, 208-byte state, permutations), or None when the operation list
+    does not fit the row format (cg1_merlin_batch_device then uses the byte-level kernel)."""
+    from curdleproofs_pie_amd import _native as N
+
+    row = bytes(row)
+    assert len(row) >= prog.data_bytes
+    ops = (N.MerlinOp * max(1, len(prog._ops)))(*prog._ops)
+    out = ctypes.create_string_buffer(max(4, prog.out_bytes))
+    st = ctypes.create_string_buffer(N.MERLIN_STATE_BYTES)
+    passes = ctypes.c_uint32(0)
+    rc = N.cg1_merlin_block_program_emulate(prog._init, ops, len(prog._ops), row + b"\0" * 4, len(row), out, len(out), st, ctypes.byref(passes))
+    if rc == N.ERR_ARG:
+        return None
+    assert rc == 0
+    return out.raw, st.raw, passes.value
 
 
 def random_program(M, rng, nops, max_len=300):
@@ -68,7 +87,7 @@ def test_random_programs_equal_the_host_transcript(M):
     for case in range(60):
         prog, plan, nbytes = random_program(M, random.Random(case), rng.randrange(1, 60))
         row = bytes(rng.randrange(256) for _ in range(max(1, nbytes)))
-        got = prog.emulate_block_program(row)
+        got = emulate_block_program(prog, row)
         if got is None:                                    # e.g. five self-produced pieces in one block: the byte-level kernel's case
             continue
         fitted += 1
@@ -83,12 +102,12 @@ def test_random_programs_equal_the_host_transcript(M):
 def test_programs_outside_the_row_format_are_refused(M):
     prog = M.TranscriptProgram(b"t")
     prog.challenge_bytes(b"long", 165)                     # a squeeze that would cross the rate
-    assert prog.emulate_block_program(b"") is None
+    assert emulate_block_program(prog, b"") is None
     prog = M.TranscriptProgram(b"t")
     c = [prog.challenge_scalar(b"c") for _ in range(6)]
     for o in c:
         prog.append_output(b"", o, 8)                      # six self-produced pieces land in one block (four fit a row)
-    assert prog.emulate_block_program(b"") is None
+    assert emulate_block_program(prog, b"") is None
 
 
 def test_shuffle_shaped_program_on_the_host(M):
@@ -113,7 +132,7 @@ def test_shuffle_shaped_program_on_the_host(M):
             plan.append(("bytes", b"raw", o, 17))
             plan.append(("echo", b"echo", o, 17))
     row = bytes(rng.randrange(256) for _ in range(off))
-    out, state, passes = prog.emulate_block_program(row)
+    out, state, passes = emulate_block_program(prog, row)
     want, want_state = host_run_with_prog_label(M, prog, plan, row)
     assert all(out[o: o + len(v)] == v for o, v in want.items()) and state[:203] == want_state
     assert passes > 100
