@@ -120,6 +120,8 @@ class Prepared:
 
 
 class ShuffleBatchVerifier:
+    SPLIT = 2048                            # verify_packed cuts calls of more than 2 * SPLIT proofs into pieces of this many
+
     def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True,
                  blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: Optional[int] = None, fe_cus: int = 0, fe_prio: int = 0,
                  pipelines: Optional[int] = None):
@@ -816,6 +818,26 @@ class ShuffleBatchVerifier:
         crs.proof_bytes.  Returns the per-proof status (0 = valid, else a reject code of REJECT_NAMES)."""
         if n == 0:
             return []
+        if n > 2 * self.SPLIT:
+            # a very large call (BASELINE config 5 hands over 16 384 proofs) goes through the stream in pieces of SPLIT proofs: buffers
+            # stay at the size of a piece and the stages of consecutive pieces overlap (profiles/r03_verify_batchsize.txt: 2048 per
+            # piece is where proofs/s levels off)
+            ib, pb = 4 * self.crs.ell * 48, self.crs.proof_bytes
+            inst, prf = memoryview(instances), memoryview(proofs)
+            w = memoryview(weights) if weights is not None else None
+
+            def pieces():
+                for a in range(0, n, self.SPLIT):
+                    m = min(self.SPLIT, n - a)
+                    yield (bytes(inst[a * ib: (a + m) * ib]), bytes(prf[a * pb: (a + m) * pb]), m,
+                           None if pre_status is None else list(pre_status[a: a + m]),
+                           None if w is None else bytes(w[a * N_WEIGHTS * 32: (a + m) * N_WEIGHTS * 32]))
+
+            out: List[int] = []
+            for st in self.verify_stream(pieces(), mode=mode, rng=rng):
+                out += st
+            self.last_status = out
+            return out
         return next(self.verify_stream([(instances, proofs, n, pre_status, weights)], mode=mode, rng=rng))
 
     def verify_many(self, items, mode: str = "merged", rng=None) -> List[bool]:

@@ -160,3 +160,26 @@ def test_device_front_end_stream_verdicts_equal_reference(native_lib, fx, pipeli
     gen.close()                                               # abandoned after the first verdict
     assert [[s == 0 for s in st] for st in v.verify_stream([(bad[0], bad[1], 1024)])] == [bad[2]]
     v.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_front_end", [False, True])
+def test_large_call_is_streamed_in_pieces(native_lib, fx, device_front_end):
+    """verify_packed with more than 2 * SPLIT proofs (4100 here; BASELINE config 5 hands a node 16 384) goes through the stream in
+    pieces of SPLIT: same verdicts, at the tampered slots of every piece, with caller-supplied weights and pre-rejected slots."""
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    n = 2 * ShuffleBatchVerifier.SPLIT + 4
+    slots = {3: 0, 2047: 5, 2048: 7, 4095: 2, 4096: 9, n - 1: 11}
+    inst, proofs, want = fx.tiled(n, slots)
+    v = ShuffleBatchVerifier(fx.crs, native_lib.Context(0), device_front_end=device_front_end)
+    got = v.verify_packed(inst, proofs, n)
+    assert [s == 0 for s in got] == want and len(v.last_status) == n
+    w = v.draw_weights(n, random.Random(3))
+    pre = [0] * n
+    pre[100] = pre[3000] = 1                                  # REJECT_LENGTH from pack()
+    got = v.verify_packed(inst, proofs, n, weights=w, pre_status=pre)
+    want2 = list(want)
+    want2[100] = want2[3000] = False
+    assert [s == 0 for s in got] == want2 and got[100] == 1 and got[3000] == 1
+    v.close()
