@@ -682,12 +682,17 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl.d_pts, wl.d_sc, 1 << args.cpu_sample_logn)
             wl.free()
         if world == 1 and not args.no_secondary:
+            ctx2.close()                                      # (its streams would keep hardware queues the verifier's lanes need: a process has 24)
             cores = int(N.cg1_shuffle_default_threads())
             out["secondary"] = verify_measure(ctx, cores, args.verify_steps, 2, args.batch, args.verify_mode, cpu_leg=not args.no_cpu_baseline, peak_T=peak["peak_T"], front_end=args.front_end)
             if not out["secondary"]["front_end"].startswith("device"):
                 # the same stream with the front-end on the GPU and TWO host threads: what a rank gets on a host shared by many GPUs
                 dv = verify_measure(ctx, 2, args.verify_steps, 1, args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
                 out["secondary"]["device_front_end_on_2_host_threads"] = {k: dv[k] for k in ("value", "unit", "ms_per_step", "steps", "front_end", "host_threads", "phases_ms_per_step")}
+                # ... and with 2048 proofs per batch: BASELINE config 5's share of one GPU (16 384 proofs over 8)
+                dv2 = verify_measure(ctx, 2, max(10, args.verify_steps // 2), 1, 2 * args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
+                out["secondary"]["device_front_end_on_2_host_threads_batches_of_%d" % (2 * args.batch)] = {
+                    k: dv2[k] for k in ("value", "unit", "ms_per_step", "steps", "batch", "front_end", "host_threads")}
         print(json.dumps(out), flush=True)
 
     if comm:

@@ -108,7 +108,9 @@ struct Ctx {
   int device = 0;
   Helper helper[3];                     // the host Horner tail runs on up to four threads (this one + three helpers)
   hipStream_t stream = nullptr;
-  hipStream_t copy_stream = nullptr;    // H2D staging copies that overlap kernels on `stream` (cg1_h2d_async / cg1_copy_fence)
+  std::atomic<hipStream_t> copy_stream{nullptr};    // H2D staging copies that overlap kernels on `stream` (cg1_h2d_async / cg1_copy_fence); created at the first
+  std::once_flag copy_once;              // such copy: a context that never stages (the verifier's front-end lanes) holds ONE stream -- a process
+                                        // has 24 hardware queues, and streams that share one run one after the other
   hipEvent_t copy_ev = nullptr;
   std::vector<uint32_t> cu_mask;        // non-empty: the compute and side streams are confined to these CUs
   hipStream_t side_stream = nullptr;    // small latency-bound kernels that run BESIDE the compute stream (cg1_subgroup_flags_enqueue)
@@ -951,8 +953,7 @@ cg1_ctx* cg1_ctx_create_cu_mask(int device, const uint32_t* cu_mask, size_t n_wo
     e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   }
   if (e != hipSuccess) { delete ctx; return nullptr; }
-  if (hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess ||
+  if (hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { delete ctx; return nullptr; }
   for (int i = 0; i <= CG1_NPHASE; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return nullptr; }
   if (hipHostMalloc((void**)&ctx->h_flag, 64) != hipSuccess || hipHostGetDevicePointer((void**)&ctx->h_flag_dev, ctx->h_flag, 0) != hipSuccess) { delete ctx; return nullptr; }
@@ -973,7 +974,7 @@ void cg1_ctx_destroy(cg1_ctx* ctx) {
   if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
   if (ctx->sync_ev) (void)hipEventDestroy(ctx->sync_ev);
   for (int i = 0; i < 2; ++i) if (ctx->tm_ev[i]) (void)hipEventDestroy(ctx->tm_ev[i]);
-  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->copy_stream.load()) (void)hipStreamDestroy(ctx->copy_stream.load());
   if (ctx->side_ev) (void)hipEventDestroy(ctx->side_ev);
   if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
   delete ctx;
@@ -1007,7 +1008,10 @@ int cg1_h2d_async(cg1_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx) return CG1_ERR_HIP;
   if (bytes == 0) return CG1_OK;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->copy_stream));
+  std::call_once(ctx->copy_once, [ctx]() { hipStream_t s = nullptr; if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess) ctx->copy_stream.store(s); });
+  hipStream_t cs = ctx->copy_stream.load();
+  if (!cs) { snprintf(ctx->err, sizeof ctx->err, "could not create the copy stream"); return CG1_ERR_HIP; }
+  HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs));
   return CG1_OK;
 }
 // wait for the context's compute stream only (cg1_ctx_sync waits for the whole device, other contexts included)
@@ -1019,7 +1023,9 @@ int cg1_stream_sync(cg1_ctx* ctx) {
 int cg1_copy_fence(cg1_ctx* ctx) {
   if (!ctx) return CG1_ERR_HIP;
   HIPCHK(hipSetDevice(ctx->device));
-  HIPCHK(hipEventRecord(ctx->copy_ev, ctx->copy_stream));
+  hipStream_t cs = ctx->copy_stream.load();
+  if (!cs) return CG1_OK;                                  // nothing was ever queued on it
+  HIPCHK(hipEventRecord(ctx->copy_ev, cs));
   HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->copy_ev, 0));
   return CG1_OK;
 }
