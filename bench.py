@@ -685,14 +685,17 @@ def main():
             ctx2.close()                                      # (its streams would keep hardware queues the verifier's lanes need: a process has 24)
             cores = int(N.cg1_shuffle_default_threads())
             out["secondary"] = verify_measure(ctx, cores, args.verify_steps, 2, args.batch, args.verify_mode, cpu_leg=not args.no_cpu_baseline, peak_T=peak["peak_T"], front_end=args.front_end)
-            if not out["secondary"]["front_end"].startswith("device"):
-                # the same stream with the front-end on the GPU and TWO host threads: what a rank gets on a host shared by many GPUs
-                dv = verify_measure(ctx, 2, args.verify_steps, 1, args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
-                out["secondary"]["device_front_end_on_2_host_threads"] = {k: dv[k] for k in ("value", "unit", "ms_per_step", "steps", "front_end", "host_threads", "phases_ms_per_step")}
-                # ... and with 2048 proofs per batch: BASELINE config 5's share of one GPU (16 384 proofs over 8)
-                dv2 = verify_measure(ctx, 2, max(10, args.verify_steps // 2), 1, 2 * args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
-                out["secondary"]["device_front_end_on_2_host_threads_batches_of_%d" % (2 * args.batch)] = {
-                    k: dv2[k] for k in ("value", "unit", "ms_per_step", "steps", "batch", "front_end", "host_threads")}
+            keys = ("value", "unit", "ms_per_step", "steps", "batch", "front_end", "host_threads", "phases_ms_per_step")
+            if out["secondary"]["front_end"].startswith("device"):
+                # the same stream with the front-end on the host's threads (what a verifier with >= 24 threads to itself would run)
+                hv = verify_measure(ctx, cores, args.verify_steps, 1, args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="host")
+                out["secondary"]["host_front_end_on_all_host_threads"] = {k: hv[k] for k in keys}
+            # the device front-end with TWO host threads: what a rank gets on a host shared by many GPUs
+            dv = verify_measure(ctx, 2, args.verify_steps, 1, args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
+            out["secondary"]["device_front_end_on_2_host_threads"] = {k: dv[k] for k in keys}
+            # ... and with 2048 proofs per batch: BASELINE config 5's share of one GPU (16 384 proofs over 8)
+            dv2 = verify_measure(ctx, 2, max(10, args.verify_steps // 2), 1, 2 * args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
+            out["secondary"]["device_front_end_on_2_host_threads_batches_of_%d" % (2 * args.batch)] = {k: dv2[k] for k in keys if k != "phases_ms_per_step"}
         print(json.dumps(out), flush=True)
 
     if comm:

@@ -139,23 +139,23 @@ class ShuffleBatchVerifier:
         # transcript is ~800 dependent Keccak permutations: 24 K clocks each for the one wave a SIMD runs) but occupies only n / 64 of
         # the chip's 1024 SIMDs, so `fe_lanes` launches of consecutive batches run side by side, each on its own context, and the
         # stream keeps fe_lanes + 3 batches in flight.  The host then only packs bytes: proofs/s no longer depends on its core count.
-        # Measured on MI355X (profiles/r03_verify_fe_ab.txt, batches of 1024, GPU_MAX_HW_QUEUES = 24): 156-158 K proofs/s on 2 or 4 host
-        # threads with two pipelines (below), 131-145 K with one; host front-end: 13 K / 25 K / 49 K / 91 K / 130-168 K proofs/s on 1 / 2 /
-        # 4 / 8 / 16 threads -- so None (the default) turns the device front-end on when fewer than sixteen host threads are available to
-        # this verifier (e.g. eight ranks sharing a 64-thread host), and leaves the host front-end on otherwise.
-        # CURDLE_G1_DEVICE_FRONT_END=0/1 overrides.
+        # Measured on MI355X (profiles/r03_verify_fe_ab.txt, profiles/r03_v7_bench.json; batches of 1024, GPU_MAX_HW_QUEUES = 24):
+        # 158-167 K proofs/s on 2 or 4 host threads with three pipelines (below), whatever the box; host front-end: 13 K / 25 K / 49 K /
+        # 91 K proofs/s on 1 / 2 / 4 / 8 threads and 124-168 K on 16, depending on the box's cores -- so None (the default) turns the
+        # device front-end on when fewer than twenty-four host threads are available to this verifier and leaves the host front-end on
+        # otherwise (a single isolated batch comes back sooner from the host: 19 against ~45 ms).  CURDLE_G1_DEVICE_FRONT_END=0/1 overrides.
         env = os.environ.get("CURDLE_G1_DEVICE_FRONT_END")
         if env in ("0", "1"):
             device_front_end = env == "1"
         if device_front_end is None:
-            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < 16
+            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < 24
         self.device_front_end = bool(device_front_end)
         # pipelines (device front-end only): that many complete pipelines -- decoding lane, front-end launches, MSM lane, each on contexts
         # of its own -- take the batches of a stream in turn.  One pipeline leaves the GPU idle between its dependent kernels (the
-        # reduce chains of an MSM, the waits of a decoding lane): two give 6.5 instead of 7.2-7.7 ms per batch, 1.57e5 proofs/s
-        # (profiles/r03_two_pipelines.txt); three or four are worse again (6.9-9.9 ms: profiles/r03_verify_fe_ab.txt); with the host front-end a
-        # second pipeline only fights for the cores (11 ms), so it stays 1.
-        self.pipelines = max(1, int(pipelines if pipelines is not None else (2 if self.device_front_end else 1))) if self.device_front_end else 1
+        # reduce chains of an MSM, the waits of a decoding lane): 7.0-7.8 ms per batch of 1024; two 6.4-6.6; three 6.16-6.33 (1.62-1.66e5
+        # proofs/s); four are worse again (6.9-8.0: the process runs out of hardware queues) -- profiles/r03_verify_fe_ab.txt.  With the
+        # host front-end a second pipeline only fights for the cores (11 ms), so it stays 1.
+        self.pipelines = max(1, int(pipelines if pipelines is not None else (3 if self.device_front_end else 1))) if self.device_front_end else 1
         if fe_lanes is None:
             fe_lanes = 2 if self.pipelines > 1 else 3
         self._kids = None

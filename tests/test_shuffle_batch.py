@@ -136,7 +136,7 @@ def test_config5_16384_proofs_sharded_proof_per_gpu(native_lib, fx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pipelines", [2, 1])
+@pytest.mark.parametrize("pipelines", [3, 1])
 def test_device_front_end_stream_verdicts_equal_reference(native_lib, fx, pipelines):
     """The whole verifier with its front-end on the GPU (device_front_end=True: transcript, D / A', challenge algebra in
     k_shuffle_front_end): a stream of 1024-proof batches -- clean, tampered at known slots, clean, tampered -- with several batches in
