@@ -75,6 +75,7 @@ cg1_compress = _proto("cg1_compress", None, _buf, _u8p)
 cg1_decompress = _proto("cg1_decompress", c_int, _buf, _u8p, c_int)
 cg1_to_affine96 = _proto("cg1_to_affine96", None, _buf, _u8p)
 cg1_from_affine96 = _proto("cg1_from_affine96", c_int, _buf, _u8p, c_int)
+cg1_batch_from_affine96 = _proto("cg1_batch_from_affine96", c_int, _buf, c_void_p, c_size_t)
 cg1_batch_to_affine96 = _proto("cg1_batch_to_affine96", None, _buf, _u8p, c_size_t)
 cg1_batch_decompress = _proto("cg1_batch_decompress", c_int, _buf, _u8p, c_size_t, c_int, POINTER(c_size_t))
 cg1_batch_compress = _proto("cg1_batch_compress", None, _buf, _u8p, c_size_t)
@@ -118,6 +119,12 @@ cg1_msm = _proto("cg1_msm", c_int, c_void_p, _u8p, _u8p, c_size_t, _buf)
 cg1_msm_device = _proto("cg1_msm_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, _buf)
 cg1_msm_device_begin = _proto("cg1_msm_device_begin", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int)
 cg1_msm_device_end = _proto("cg1_msm_device_end", c_int, c_void_p, _buf)
+cg1_msm_blobs = _proto("cg1_msm_blobs", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, _buf)
+cg1_vec_create = _proto("cg1_vec_create", c_void_p, c_void_p, c_void_p, c_size_t, c_int)
+cg1_vec_destroy = _proto("cg1_vec_destroy", None, c_void_p)
+cg1_vec_len = _proto("cg1_vec_len", c_size_t, c_void_p)
+cg1_msm_vec = _proto("cg1_msm_vec", c_int, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, _buf)
+cg1_batch_normalize = _proto("cg1_batch_normalize", c_int, c_void_p, c_size_t, c_void_p, c_void_p)
 cg1_msm_batched_device = _proto("cg1_msm_batched_device", c_int, c_void_p, c_void_p, c_void_p, POINTER(ctypes.c_uint32), c_size_t, c_int, _buf)
 cg1_msm_batched = _proto("cg1_msm_batched", c_int, c_void_p, _u8p, _u8p, POINTER(ctypes.c_uint32), c_size_t, _buf)
 cg1_get_timings = _proto("cg1_get_timings", c_int, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_int))
@@ -214,6 +221,7 @@ EXPORTED_SYMBOLS = [
     "cg1_merlin_last_passes", "cg1_merlin_last_kernel", "cg1_merlin_block_program_emulate", "cg1_probe_mad_rate", "cg1_batch_sum_device", "cg1_batch_sum", "cg1_ctx_device", "cg1_ctx_stream", "cg1_msm_multi_device",
     "cg1_comm_create", "cg1_comm_port", "cg1_comm_rank", "cg1_comm_connect", "cg1_comm_set_timeout", "cg1_comm_attach_rccl", "cg1_comm_transport",
     "cg1_comm_world_seen", "cg1_comm_error", "cg1_comm_allgather", "cg1_comm_allgather_host", "cg1_comm_barrier", "cg1_comm_allreduce_g1", "cg1_comm_destroy",
+    "cg1_msm_blobs", "cg1_vec_create", "cg1_vec_destroy", "cg1_vec_len", "cg1_msm_vec", "cg1_batch_normalize", "cg1_batch_from_affine96",
 ]
 
 
@@ -312,6 +320,20 @@ class Context:
         assert len(points_affine96) >= 96 * n and len(scalars32) >= 32 * n
         out = ctypes.create_string_buffer(POINT_BYTES)
         self.check(cg1_msm(self.handle, points_affine96, scalars32, n, out))
+        return out.raw
+
+    def msm_blobs(self, blobs144, scalars32, n: int, all_normalised: bool = False) -> bytes:
+        """compute_MSM over n host point blobs (bytes / ctypes buffer / raw address of page-locked memory) as G1Point objects hold them."""
+        out = ctypes.create_string_buffer(POINT_BYTES)
+        self.check(cg1_msm_blobs(self.handle, blobs144, scalars32, n, 1 if all_normalised else 0, out))
+        return out.raw
+
+    def vec(self, blobs144, n: int, all_normalised: bool = False) -> "Vec":
+        return Vec(self, blobs144, n, all_normalised)
+
+    def msm_vec(self, vec: "Vec", scalars32, n: int, first: int = 0) -> bytes:
+        out = ctypes.create_string_buffer(POINT_BYTES)
+        self.check(cg1_msm_vec(self.handle, vec.handle, first, n, scalars32, out))
         return out.raw
 
     def msm_device(self, d_points, d_scalars, n: int, window_c: int = 0, shard_rank: int = 0, shard_world: int = 1) -> bytes:
@@ -433,6 +455,56 @@ class Context:
             self.close()
         except Exception:
             pass
+
+
+class Vec:
+    """A point vector resident on the device (cg1_vec): n prepared records made once from the host objects' blobs."""
+
+    def __init__(self, ctx: Context, blobs144, n: int, all_normalised: bool = False):
+        self.ctx, self.n = ctx, int(n)
+        self.handle = cg1_vec_create(ctx.handle, blobs144, self.n, 1 if all_normalised else 0)
+        if not self.handle:
+            raise NativeError(f"cg1_vec_create({n} points) failed")
+
+    def free(self) -> None:
+        if self.handle:
+            cg1_vec_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Staging:
+    """Page-locked staging of the Python face on one context: the point blobs and scalars of a call are gathered out of the Python
+    objects straight into it (csrc/pyface.c) and uploaded from it at full PCIe rate.  Grown geometrically, kept by the context."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self.pts = None
+        self.sc = None
+        self.cap_pts = self.cap_sc = 0
+
+    def points(self, n: int) -> int:
+        if n > self.cap_pts:
+            if self.pts is not None:
+                self.pts.free()
+            cap = max(1024, n + n // 4)
+            self.pts = PinnedBuffer(self.ctx, POINT_BYTES * cap)
+            self.cap_pts = cap
+        return self.pts.ptr
+
+    def scalars(self, n: int) -> int:
+        if n > self.cap_sc:
+            if self.sc is not None:
+                self.sc.free()
+            cap = max(1024, n + n // 4)
+            self.sc = PinnedBuffer(self.ctx, 32 * cap)
+            self.cap_sc = cap
+        return self.sc.ptr
 
 
 def msm_multi_device(ctxs, d_points, d_scalars, ns, window_c: int = 0) -> bytes:

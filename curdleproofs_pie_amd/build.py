@@ -209,9 +209,45 @@ def build_variant(out_path: str, extra_flags, verbose: bool = True, pipeline: st
     return out_path
 
 
+PYFACE_SRC = os.path.join(CSRC, "pyface.c")
+
+
+def pyface_path() -> str:
+    import sysconfig
+
+    return os.path.join(HERE, "_pyface" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_pyface(force: bool = False, verbose: bool = True) -> str:
+    """The marshalling helper of the Python face (csrc/pyface.c: a CPython extension, plain gcc, no GPU code).  Optional: without
+    it -- no compiler or no Python.h -- the Python face packs its lists in pure Python."""
+    import hashlib
+    import sysconfig
+
+    out = pyface_path()
+    with open(PYFACE_SRC, "rb") as f:
+        want = hashlib.sha256(f.read()).hexdigest()
+    stamp = out + ".srchash"
+    if not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+        return out
+    inc = sysconfig.get_paths()["include"]
+    if not os.path.exists(os.path.join(inc, "Python.h")):
+        raise RuntimeError(f"Python.h not found under {inc}")
+    tmp = f"{out}.tmp.{os.getpid()}"
+    _run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", f"-I{inc}", PYFACE_SRC, "-o", tmp], verbose)
+    os.replace(tmp, out)
+    with open(stamp, "w") as f:
+        f.write(want)
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     """Build if the sources changed.  Safe under concurrent callers (e.g. 8 bench ranks on a fresh box): an flock
     serialises them, the staleness check is repeated under the lock and the .so is replaced atomically."""
+    try:
+        build_pyface(force, verbose)
+    except (subprocess.CalledProcessError, RuntimeError, OSError) as e:
+        print(f"[curdleproofs_pie_amd.build] note: _pyface not built ({e}); the Python face packs its lists in pure Python", file=sys.stderr, flush=True)
     if not force and not needs_build():
         return LIB
     import fcntl

@@ -42,6 +42,105 @@ __global__ void __launch_bounds__(256) k_prepare_points(const uint32_t* __restri
   for (uint32_t j = t; j < cnt * 8u; j += 256u) dst[j] = stage[j];
 }
 
+// ------------------------------------------------------------------ k_prepare_blobs
+// The same 128-B records straight from the HOST library's point blobs (144 B: Jacobian X | Y | Z, each 6 x 64-bit limbs in
+// Montgomery radix 2^384 -- what a G1Point object holds, csrc/host_g1.h), so that compute_MSM(bases, scalars) over lists of
+// G1Point (msm_accumulator.py:6-12) needs no normalisation pass on the host: the blobs are uploaded as they are.
+//   NORM = false: every blob has Z = 1 or Z = 0 (decoded / generated points): two radix conversions per point.
+//   NORM = true:  x = X / Z^2, y = Y / Z^3 with Montgomery's trick over the K consecutive points of a lane: ONE inversion
+//                 (Fermat, ~470 products) per lane + 11 products per point.  The running products and the converted Z of
+//                 the forward pass are parked in the point's own output record (read back by the same lane in the backward
+//                 pass before the record gets its final contents).
+// A coordinate word-triple v = X * 2^384 mod p (an integer < p) becomes the device's Montgomery form with one product:
+// montmul(v, 2^400 mod p) = v * 2^8 = X * 2^392.
+__device__ __forceinline__ fp fp_from_host_words(const uint32_t w[12]) {
+  constexpr uint32_t kt[NL] = {D_H2D[0], D_H2D[1], D_H2D[2], D_H2D[3], D_H2D[4], D_H2D[5], D_H2D[6], D_H2D[7], D_H2D[8], D_H2D[9], D_H2D[10], D_H2D[11], D_H2D[12], D_H2D[13]};
+  fp k; for (int i = 0; i < NL; ++i) k.l[i] = kt[i];
+  return fp_mul(fp_from_words(w), k);
+}
+__device__ __forceinline__ void load_words12(const uint32_t* p, uint32_t w[12]) {
+  const uint4* q = reinterpret_cast<const uint4*>(p);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { uint4 v = q[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+}
+__device__ __forceinline__ void store_fp14(uint32_t* dst, const fp& a) {      // 14 words at a 8-byte aligned address
+  uint2* q = reinterpret_cast<uint2*>(dst);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) q[k] = make_uint2(a.l[2 * k], a.l[2 * k + 1]);
+}
+__device__ __forceinline__ fp load_fp14(const uint32_t* src) {
+  const uint2* q = reinterpret_cast<const uint2*>(src);
+  fp a;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) { uint2 v = q[k]; a.l[2 * k] = v.x; a.l[2 * k + 1] = v.y; }
+  return a;
+}
+template <bool NORM>
+__global__ void __launch_bounds__(128) k_prepare_blobs(const uint32_t* __restrict__ blobs, PreparedPoint* __restrict__ out,
+                                                       uint8_t* __restrict__ inf_flag, uint32_t n, uint32_t K,
+                                                       uint32_t* __restrict__ status_words) {
+  if (status_words && blockIdx.x == 0 && threadIdx.x < 4) status_words[threadIdx.x] = 0;
+  const uint32_t t = blockIdx.x * 128 + threadIdx.x;
+  const uint64_t first = (uint64_t)t * K;
+  if (first >= n) return;
+  const uint32_t i0 = (uint32_t)first, i1 = (n - i0 < K) ? n : i0 + K;
+  uint32_t w[12];
+  if (!NORM) {
+    for (uint32_t i = i0; i < i1; ++i) {
+      const uint32_t* b = blobs + 36ull * i;
+      uint32_t* o = reinterpret_cast<uint32_t*>(out + i);
+      load_words12(b + 24, w);
+      uint32_t zany = 0;
+#pragma unroll
+      for (int k = 0; k < 12; ++k) zany |= w[k];
+      load_words12(b, w);
+      const fp x = fp_from_host_words(w);
+      load_words12(b + 12, w);
+      const fp y = fp_from_host_words(w);
+      store_fp14(o, zany ? x : fp_zero());
+      store_fp14(o + NL, zany ? y : fp_zero());
+      reinterpret_cast<uint4*>(o)[7] = make_uint4(zany ? 0u : 1u, 0u, 0u, 0u);
+      inf_flag[i] = zany ? 0 : 1;
+    }
+    return;
+  }
+  // forward: running product of the non-zero Z's; record i keeps the product BEFORE its own Z (x slot) and its converted Z (y slot)
+  fp acc = fp_one();
+  for (uint32_t i = i0; i < i1; ++i) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + i);
+    load_words12(blobs + 36ull * i + 24, w);
+    uint32_t zany = 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) zany |= w[k];
+    inf_flag[i] = zany ? 0 : 1;
+    if (!zany) continue;
+    const fp z = fp_from_host_words(w);
+    store_fp14(o, acc);
+    store_fp14(o + NL, z);
+    acc = fp_mul(acc, z);
+  }
+  fp inv = fp_inv(acc);                                   // (acc = 1 when every Z of the lane is 0: harmless)
+  for (uint32_t i = i1; i-- > i0;) {
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + i);
+    if (inf_flag[i]) {
+      store_fp14(o, fp_zero()); store_fp14(o + NL, fp_zero());
+      reinterpret_cast<uint4*>(o)[7] = make_uint4(1u, 0u, 0u, 0u);
+      continue;
+    }
+    const fp pref = load_fp14(o), z = load_fp14(o + NL);
+    const fp zi = fp_mul(inv, pref);                      // 1 / Z_i
+    inv = fp_mul(inv, z);
+    const fp zi2 = fp_sqr(zi);
+    load_words12(blobs + 36ull * i, w);
+    const fp x = fp_mul(fp_from_host_words(w), zi2);
+    load_words12(blobs + 36ull * i + 12, w);
+    const fp y = fp_mul(fp_from_host_words(w), fp_mul(zi2, zi));
+    store_fp14(o, x);
+    store_fp14(o + NL, y);
+    reinterpret_cast<uint4*>(o)[7] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+
 // ------------------------------------------------------------------ signed digit recoding
 // The 256 bit positions of a scalar are cut into nwin windows of widths width[w] <= cmax starting at bit off[w]
 // (uniform: width = c, off = c w; balanced plans mix cmax and cmax - 1 so that EVERY window keeps >= cmax - 2 scalar bits:

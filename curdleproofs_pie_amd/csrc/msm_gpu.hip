@@ -186,7 +186,7 @@ struct Ctx {
   int zero_copy = 1;                    // 1: export kernel + flag polling instead of a D2H copy + stream wait (A/B switch)
   int horner_threads = 4;               // host threads of the Horner tail: 1, 2 or 4 (A/B switch; host_split = 0 forces 1)
   // staging for host-pointer entry points
-  void* d_stage_pts = nullptr; void* d_stage_sc = nullptr; size_t cap_stage = 0;
+  void* d_stage_pts = nullptr; void* d_stage_sc = nullptr; size_t cap_stage_pts = 0, cap_stage_sc = 0;      // bytes
   // timing
   hipEvent_t ev[CG1_NPHASE + 1];
   float phase_ms[CG1_NPHASE] = {0};
@@ -397,9 +397,42 @@ static int wait_stream(Ctx* ctx) {
   return CG1_OK;
 }
 
+// Where an MSM's points come from (all device memory):
+//   AFFINE96  n x 96 B standard-form affine records (the C ABI's "affine96")                      -> k_prepare_points
+//   BLOBS     n x 144 B host point blobs as G1Point objects hold them (Jacobian, radix 2^384)     -> k_prepare_blobs
+//   PREPARED  n x 128 B records + n identity flags made earlier by one of the two (a cg1_vec)    -> nothing to do
+struct PtSrc {
+  enum Kind { AFFINE96 = 0, BLOBS = 1, PREPARED = 2 } kind = AFFINE96;
+  const void* p = nullptr;
+  const uint8_t* flags = nullptr;       // PREPARED only
+  bool normalised = false;              // BLOBS only: every Z is 0 or 1 (no inversion needed)
+  PtSrc() {}
+  PtSrc(const void* affine96) : p(affine96) {}
+};
+
+// points per lane of k_prepare_blobs<true>: one Fermat inversion per lane, so few lanes for big inputs -- but never fewer than
+// ~2 waves per SIMD's worth, where the launch turns from latency- into throughput-bound
+static uint32_t blob_points_per_lane(size_t n) {
+  size_t K = (n + (1u << 17) - 1) >> 17;
+  return (uint32_t)(K < 1 ? 1 : (K > 16 ? 16 : K));
+}
+
+// records + flags from `src` into (out, flags_out) on `st`; clears the call's status words (like k_prepare_points)
+static void launch_prepare(hipStream_t st, const PtSrc& src, PreparedPoint* out, uint8_t* flags_out, uint32_t n32, uint32_t* status_words) {
+  if (src.kind == PtSrc::AFFINE96) {
+    hipLaunchKernelGGL(k_prepare_points, dim3((n32 + 255) / 256), dim3(256), 0, st, (const uint32_t*)src.p, out, flags_out, n32, status_words);
+  } else if (src.normalised) {
+    hipLaunchKernelGGL((k_prepare_blobs<false>), dim3((n32 + 127) / 128), dim3(128), 0, st, (const uint32_t*)src.p, out, flags_out, n32, 1u, status_words);
+  } else {
+    const uint32_t K = blob_points_per_lane(n32);
+    const uint32_t lanes = (n32 + K - 1) / K;
+    hipLaunchKernelGGL((k_prepare_blobs<true>), dim3((lanes + 127) / 128), dim3(128), 0, st, (const uint32_t*)src.p, out, flags_out, n32, K, status_words);
+  }
+}
+
 // Enqueue the whole launch chain of this context's share of an MSM (windows w = rank mod world of the plan) up to the D2H of
 // the window sums; nothing waits.
-static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, const WinPlan& plan, int rank, int world) {
+static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan, int rank, int world) {
   ctx->pend.active = false;
   HIPCHK(hipSetDevice(ctx->device));
   const int c = plan.cmax, nwin = plan.nwin;
@@ -426,12 +459,14 @@ static int msm_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32
   const uint32_t gn = (n32 + 255) / 256;
   const int profile = ctx->profile;
   auto h0 = std::chrono::steady_clock::now();
-  const PreparedPoint* pts = ctx->d_pts;
-  const uint8_t* flags = ctx->d_flags;
+  const bool resident = src.kind == PtSrc::PREPARED;
+  const PreparedPoint* pts = resident ? static_cast<const PreparedPoint*>(src.p) : ctx->d_pts;
+  const uint8_t* flags = resident ? src.flags : ctx->d_flags;
   const size_t nout_words = (size_t)nlw * nitems;
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // [0] set by the digit kernels: a scalar >= 2^255; [1], [2]: counts
   if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[0], st));
-  hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, n32, bad_flag);
+  if (resident) HIPCHK(hipMemsetAsync(bad_flag, 0, 16, st));
+  else launch_prepare(st, src, ctx->d_pts, ctx->d_flags, n32, bad_flag);
   if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[1], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
@@ -664,7 +699,7 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
 // msm_begin enqueues the whole launch chain and returns; msm_end waits for it and runs the host tail.  Two contexts on one
 // GPU can thus keep two MSMs in flight: the sort phases of the next one run under this one's k_accumulate (they need few
 // registers and co-reside with its waves), and this one's reduction tree, D2H and host Horner run under the next one's.
-int msm_begin(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world) {
+int msm_begin(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int c, int rank, int world) {
   ctx->pend.active = false;
   ctx->pend_c = 0;
   if (n == 0) return CG1_OK;
@@ -675,16 +710,16 @@ int msm_begin(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t 
   if (cabs < 4 || cabs > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
   const WinPlan plan = make_plan(c);
   ctx->pend_c = c;
-  return msm_enqueue(ctx, d_points96, d_scalars32, n, plan, rank, world);
+  return msm_enqueue(ctx, src, d_scalars32, n, plan, rank, world);
 }
 int msm_end(Ctx* ctx, cg1h::jac& result) {
   int rc = msm_finish(ctx, result);
   if (ctx->pend_c) ctx->last_c = ctx->pend_c;          // negative: a balanced plan (cg1_get_timings reports it)
   return rc;
 }
-int msm_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
+int msm_device(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int c, int rank, int world, cg1h::jac& result) {
   result = cg1h::jac_identity();
-  int rc = msm_begin(ctx, d_points96, d_scalars32, n, c, rank, world);
+  int rc = msm_begin(ctx, src, d_scalars32, n, c, rank, world);
   if (rc) return rc;
   return msm_end(ctx, result);
 }
@@ -893,6 +928,13 @@ int cg1_from_affine96(uint8_t* out, const uint8_t* in96, int check_on_curve) {
   cg1h::jac j = cg1h::jac_from_affine(x, y);
   if (check_on_curve && !cg1h::jac_on_curve(j)) return CG1_ERR_NOT_ON_CURVE;
   blob_out(out, j);
+  return CG1_OK;
+}
+int cg1_batch_from_affine96(uint8_t* out_blobs, const uint8_t* in96, size_t n) {
+  for (size_t i = 0; i < n; ++i) {
+    int rc = cg1_from_affine96(out_blobs + CG1_POINT_BYTES * i, in96 + 96 * i, 0);
+    if (rc) return rc;
+  }
   return CG1_OK;
 }
 void cg1_batch_to_affine96(uint8_t* out96, const uint8_t* blobs, size_t n) {
@@ -1146,21 +1188,121 @@ int cg1_msm_multi_device(cg1_ctx* const* ctxs, size_t n_ctx, const void* const* 
   return rc;
 }
 
+// device staging for the host-pointer entry points (grown geometrically, kept by the context)
+static int ensure_stage(cg1_ctx* ctx, size_t pts_bytes, size_t sc_bytes) {
+  if (pts_bytes > ctx->cap_stage_pts) {
+    if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
+    ctx->d_stage_pts = nullptr; ctx->cap_stage_pts = 0;
+    const size_t want = pts_bytes + pts_bytes / 4 + 256;
+    HIPCHK(hipMalloc(&ctx->d_stage_pts, want));
+    ctx->cap_stage_pts = want;
+  }
+  if (sc_bytes > ctx->cap_stage_sc) {
+    if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
+    ctx->d_stage_sc = nullptr; ctx->cap_stage_sc = 0;
+    const size_t want = sc_bytes + sc_bytes / 4 + 256;
+    HIPCHK(hipMalloc(&ctx->d_stage_sc, want));
+    ctx->cap_stage_sc = want;
+  }
+  return CG1_OK;
+}
+
 int cg1_msm(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars, size_t n, uint8_t* out) {
   if (!ctx) return CG1_ERR_HIP;
   if (n == 0) { blob_out(out, cg1h::jac_identity()); return CG1_OK; }
   HIPCHK(hipSetDevice(ctx->device));
-  if (n > ctx->cap_stage) {
-    if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
-    if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
-    ctx->d_stage_pts = ctx->d_stage_sc = nullptr; ctx->cap_stage = 0;
-    HIPCHK(hipMalloc(&ctx->d_stage_pts, n * 96));
-    HIPCHK(hipMalloc(&ctx->d_stage_sc, n * 32));
-    ctx->cap_stage = n;
-  }
+  { int src = ensure_stage(ctx, n * 96, n * 32); if (src) return src; }
   HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
   return cg1_msm_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, n, 0, 0, 1, out);
+}
+
+// compute_MSM over the point blobs G1Point objects hold (host memory; page-locked staging copies at full PCIe rate): uploaded as
+// they are, normalised on the device (k_prepare_blobs).  all_normalised != 0: the caller knows every Z is 0 or 1.
+int cg1_msm_blobs(cg1_ctx* ctx, const uint8_t* blobs144, const uint8_t* scalars32, size_t n, int all_normalised, uint8_t* out) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) { blob_out(out, cg1h::jac_identity()); return CG1_OK; }
+  if (!blobs144 || !scalars32) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  { int src = ensure_stage(ctx, n * CG1_POINT_BYTES, n * 32); if (src) return src; }
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, blobs144, n * CG1_POINT_BYTES, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, scalars32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  cg1::PtSrc src;
+  src.kind = cg1::PtSrc::BLOBS; src.p = ctx->d_stage_pts; src.normalised = all_normalised != 0;
+  cg1h::jac r;
+  int rc = cg1::msm_device(ctx, src, ctx->d_stage_sc, n, 0, 0, 1, r);
+  if (rc == CG1_OK) blob_out(out, r);
+  return rc;
+}
+}  // extern "C"
+
+// A vector of points kept on the device in the accumulation kernels' own record format (128 B per point + a flag byte): made once
+// from the host objects' blobs, used by any number of MSMs (crs.vec_G / vec_H across a prover's dozens of compute_MSM calls).
+struct cg1_vec {
+  int device = 0;
+  size_t n = 0;
+  cg1::PreparedPoint* d_pts = nullptr;
+  uint8_t* d_flags = nullptr;
+};
+
+extern "C" {
+cg1_vec* cg1_vec_create(cg1_ctx* ctx, const uint8_t* blobs144, size_t n, int all_normalised) {
+  if (!ctx || (!blobs144 && n) || n >= (1ull << 31)) return nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+  cg1_vec* v = new cg1_vec();
+  v->device = ctx->device; v->n = n;
+  if (hipMalloc(&v->d_pts, (n ? n : 1) * sizeof(cg1::PreparedPoint)) != hipSuccess || hipMalloc(&v->d_flags, n + 16) != hipSuccess) { cg1_vec_destroy(v); return nullptr; }
+  if (n == 0) return v;
+  if (ensure_stage(ctx, n * CG1_POINT_BYTES, 0) != CG1_OK) { cg1_vec_destroy(v); return nullptr; }
+  if (hipMemcpyAsync(ctx->d_stage_pts, blobs144, n * CG1_POINT_BYTES, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { cg1_vec_destroy(v); return nullptr; }
+  cg1::PtSrc src;
+  src.kind = cg1::PtSrc::BLOBS; src.p = ctx->d_stage_pts; src.normalised = all_normalised != 0;
+  cg1::launch_prepare(ctx->stream, src, v->d_pts, v->d_flags, (uint32_t)n, nullptr);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) { cg1_vec_destroy(v); return nullptr; }
+  return v;
+}
+void cg1_vec_destroy(cg1_vec* v) {
+  if (!v) return;
+  (void)hipSetDevice(v->device);
+  if (v->d_pts) (void)hipFree(v->d_pts);
+  if (v->d_flags) (void)hipFree(v->d_flags);
+  delete v;
+}
+size_t cg1_vec_len(const cg1_vec* v) { return v ? v->n : 0; }
+// sum_{i < n} scalars[i] * vec[first + i]; scalars in host memory
+int cg1_msm_vec(cg1_ctx* ctx, const cg1_vec* vec, size_t first, size_t n, const uint8_t* scalars32, uint8_t* out) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (!vec || first > vec->n || n > vec->n - first || vec->device != ctx->device) return CG1_ERR_ARG;
+  if (n == 0) { blob_out(out, cg1h::jac_identity()); return CG1_OK; }
+  if (!scalars32) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  { int src = ensure_stage(ctx, 0, n * 32); if (src) return src; }
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, scalars32, n * 32, hipMemcpyHostToDevice, ctx->stream));
+  cg1::PtSrc src;
+  src.kind = cg1::PtSrc::PREPARED; src.p = vec->d_pts + first; src.flags = vec->d_flags + first;
+  cg1h::jac r;
+  int rc = cg1::msm_device(ctx, src, ctx->d_stage_sc, n, 0, 0, 1, r);
+  if (rc == CG1_OK) blob_out(out, r);
+  return rc;
+}
+// Host: n point blobs -> affine96 and / or compressed48 (either may be NULL) with ONE shared inversion -- what
+// MSMAccumulator.accumulate_check needs of its bases: the map key (48-byte compression, msm_accumulator.py:54) and the affine form
+int cg1_batch_normalize(const uint8_t* blobs, size_t n, uint8_t* out_affine96, uint8_t* out_comp48) {
+  if (n && !blobs) return CG1_ERR_ARG;
+  std::vector<cg1h::jac> pts(n);
+  std::vector<cg1h::fe> xs(n), ys(n);
+  std::vector<uint8_t> inf(n);
+  for (size_t i = 0; i < n; ++i) pts[i] = blob_in(blobs + CG1_POINT_BYTES * i);
+  cg1h::jac_batch_to_affine(pts.data(), n, xs.data(), ys.data(), inf.data());
+  for (size_t i = 0; i < n; ++i) {
+    if (out_affine96) {
+      uint8_t* o = out_affine96 + 96 * i;
+      if (inf[i]) memset(o, 0, 96);
+      else { cg1h::fe_to_le48(xs[i], o); cg1h::fe_to_le48(ys[i], o + 48); }
+    }
+    if (out_comp48) cg1h::g1_compress_affine(xs[i], ys[i], inf[i] != 0, out_comp48 + 48 * i);
+  }
+  return CG1_OK;
 }
 
 int cg1_msm_batched_device(cg1_ctx* ctx, const void* d_points, const void* d_scalars, const uint32_t* offsets, size_t n_msm,
@@ -1181,14 +1323,7 @@ int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars,
   const size_t n = offsets[n_msm];
   if (n == 0) { for (size_t j = 0; j < n_msm; ++j) blob_out(out_blobs + CG1_POINT_BYTES * j, cg1h::jac_identity()); return CG1_OK; }
   HIPCHK(hipSetDevice(ctx->device));
-  if (n > ctx->cap_stage) {
-    if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
-    if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
-    ctx->d_stage_pts = ctx->d_stage_sc = nullptr; ctx->cap_stage = 0;
-    HIPCHK(hipMalloc(&ctx->d_stage_pts, n * 96));
-    HIPCHK(hipMalloc(&ctx->d_stage_sc, n * 32));
-    ctx->cap_stage = n;
-  }
+  { int src = ensure_stage(ctx, n * 96, n * 32); if (src) return src; }
   HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
   return cg1_msm_batched_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, offsets, n_msm, 0, out_blobs);

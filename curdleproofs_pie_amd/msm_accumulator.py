@@ -7,13 +7,77 @@ There is no CPU fallback: without a GPU (or without libcurdle_g1.so) these raise
 """
 from __future__ import annotations
 
+from collections import OrderedDict
 from typing import Dict, Iterable, List, Tuple
 
 from . import _native as N
-from .py_arkworks_bls12381 import CURVE_ORDER, G1Point, Scalar, points_to_affine96, points_to_compressed
+from .py_arkworks_bls12381 import (CURVE_ORDER, G1Point, Scalar, ensure_normalised, ident, pack_points, pack_scalars, points_from_blobs,
+                                   points_to_affine96, points_to_compressed, same_items)
 from .util import random_scalar
 
 _ZERO96 = bytes(96)
+
+
+# ---------------------------------------------------------------- staging and the resident-vector cache
+# One Staging (page-locked host buffers) per context; a small LRU of device-resident point vectors keyed by the IDENTITIES of a
+# list's elements (G1Point objects are immutable): the prover passes crs.vec_G / vec_H / vec_R ... to dozens of compute_MSM calls
+# (curdleproofs.py:77,94,95,319; grand_prod.py:54,90; ipa.py:97,98) -- from the second sighting on only the scalars are uploaded.
+_stagings: Dict[int, "N.Staging"] = {}
+_VEC_CACHE_MAX_ENTRIES = 64
+_VEC_CACHE_MAX_POINTS = 1 << 23          # ~1 GiB of prepared records on the device, of 288
+_vec_cache: "OrderedDict[int, tuple]" = OrderedDict()      # fingerprint -> (tuple of the point objects, N.Vec)
+_vec_seen: "OrderedDict[int, None]" = OrderedDict()        # fingerprints met once (a vector is made resident at its second sighting)
+_vec_cache_points = 0
+last_path = ""                           # which path served the last compute_MSM: "resident" | "blobs" | "blobs_normalised" (tests, bench)
+
+
+def _staging(ctx) -> "N.Staging":
+    st = _stagings.get(id(ctx))
+    if st is None or st.ctx is not ctx:
+        st = _stagings[id(ctx)] = N.Staging(ctx)
+    return st
+
+
+def clear_vec_cache() -> None:
+    global _vec_cache_points
+    for _, v in _vec_cache.values():
+        v.free()
+    _vec_cache.clear()
+    _vec_seen.clear()
+    _vec_cache_points = 0
+
+
+def _resident(ctx, bases, n: int):
+    """The device-resident form of `bases[:n]` if this very sequence of objects was met before; None the first time."""
+    global _vec_cache_points
+    if n < 2:
+        return None
+    _, fp = ident(bases)
+    hit = _vec_cache.get(fp)
+    if hit is not None:
+        if hit[1].ctx is ctx and hit[1].handle and same_items(bases, hit[0]):
+            _vec_cache.move_to_end(fp)
+            return hit[1]
+        return None
+    if fp not in _vec_seen:
+        _vec_seen[fp] = None
+        if len(_vec_seen) > 4 * _VEC_CACHE_MAX_ENTRIES:
+            _vec_seen.popitem(last=False)
+        return None
+    if n > _VEC_CACHE_MAX_POINTS:
+        return None
+    st = _staging(ctx)
+    addr = st.points(n)
+    _, normalised = pack_points(bases, addr, st.cap_pts)
+    vec = ctx.vec(addr, n, bool(normalised))
+    del _vec_seen[fp]
+    _vec_cache[fp] = (tuple(bases), vec)
+    _vec_cache_points += n
+    while len(_vec_cache) > _VEC_CACHE_MAX_ENTRIES or _vec_cache_points > _VEC_CACHE_MAX_POINTS:
+        _, (_, old) = _vec_cache.popitem(last=False)
+        _vec_cache_points -= old.n
+        old.free()
+    return vec
 
 
 def compute_MSM(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> G1Point:
@@ -21,15 +85,35 @@ def compute_MSM(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> G1Point:
 
     `zip` semantics like the reference: any iterables, truncated to the shorter (the reference's tests pass a
     `map` object, test_curdleproofs.py:432).  Neither argument is retained or mutated.
+
+    Host side of a call: two C walks over the lists straight into page-locked staging (csrc/pyface.c), no field arithmetic --
+    the point blobs go up as the objects hold them and are normalised on the device (k_prepare_blobs); a base list met before
+    (same objects) is already resident there and only the scalars move.
     """
-    pairs = list(zip(bases, scalars))
-    n = len(pairs)
+    global last_path
+    if not (isinstance(bases, (list, tuple)) and isinstance(scalars, (list, tuple))):
+        pairs = list(zip(bases, scalars))  # generators, map objects, ...
+        bases = [p for p, _ in pairs]
+        scalars = [s for _, s in pairs]
+    n = min(len(bases), len(scalars))
     if n == 0:
         return G1Point.identity()  # msm_accumulator.py:9
-    pts = points_to_affine96([p for p, _ in pairs])
-    sc = b"".join(s._v.to_bytes(32, "little") for _, s in pairs)
-    out = N.default_context().msm_host(pts, sc, n)
-    return G1Point._from_blob(out)
+    if len(bases) != n:
+        bases = bases[:n]
+    if len(scalars) != n:
+        scalars = scalars[:n]
+    ctx = N.default_context()
+    st = _staging(ctx)
+    sc_addr = st.scalars(n)
+    pack_scalars(scalars, sc_addr, st.cap_sc)
+    vec = _resident(ctx, bases, n)
+    if vec is not None:
+        last_path = "resident"
+        return G1Point._from_blob(ctx.msm_vec(vec, sc_addr, n))
+    pt_addr = st.points(n)
+    _, normalised = pack_points(bases, pt_addr, st.cap_pts)
+    last_path = "blobs_normalised" if normalised else "blobs"
+    return G1Point._from_blob(ctx.msm_blobs(pt_addr, sc_addr, n, bool(normalised)))
 
 
 def compute_MSM_batch(jobs: Iterable[Tuple[Iterable[G1Point], Iterable[Scalar]]]) -> List[G1Point]:
@@ -43,7 +127,7 @@ def compute_MSM_batch(jobs: Iterable[Tuple[Iterable[G1Point], Iterable[Scalar]]]
     for bases, scalars in jobs:
         pairs = list(zip(bases, scalars))
         all_pts.extend(p for p, _ in pairs)
-        sc_parts.extend(s._v.to_bytes(32, "little") for _, s in pairs)
+        sc_parts.append(_scalars32([s for _, s in pairs]))
         offsets.append(len(all_pts))
     if len(offsets) == 1:
         return []
@@ -53,16 +137,23 @@ def compute_MSM_batch(jobs: Iterable[Tuple[Iterable[G1Point], Iterable[Scalar]]]
     return [G1Point._from_blob(b) for b in blobs]
 
 
+def _scalars32(values) -> bytes:
+    """32-byte little-endian encodings of a list of Scalar / int, concatenated (one C walk)."""
+    import ctypes
+
+    n = len(values)
+    buf = ctypes.create_string_buffer(32 * max(n, 1))
+    pack_scalars(values, ctypes.addressof(buf), n)
+    return buf.raw[: 32 * n]
+
+
 def _blobs_from_affine96(raw: bytes, n: int) -> List[G1Point]:
     import ctypes
 
-    out = []
-    for i in range(n):
-        b = ctypes.create_string_buffer(N.POINT_BYTES)
-        rc = N.cg1_from_affine96(b, raw[96 * i: 96 * i + 96], 0)
-        assert rc == N.OK
-        out.append(G1Point._from_blob(b.raw))
-    return out
+    blobs = ctypes.create_string_buffer(N.POINT_BYTES * max(n, 1))
+    rc = N.cg1_batch_from_affine96(blobs, raw, n)
+    assert rc == N.OK
+    return points_from_blobs(blobs, n)
 
 
 def batch_mul(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> List[G1Point]:
@@ -72,7 +163,7 @@ def batch_mul(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> List[G1Poi
     if n == 0:
         return []
     raw = N.default_context().batch_mul_add_host(points_to_affine96([p for p, _ in pairs]), n,
-                                                 b"".join(s._v.to_bytes(32, "little") for _, s in pairs), n, None, n)
+                                                 _scalars32([s for _, s in pairs]), n, None, n)
     return _blobs_from_affine96(raw, n)
 
 
@@ -105,7 +196,7 @@ def batch_fold_scalars(left: Iterable[G1Point], right: Iterable[G1Point], scalar
     n = len(trip)
     if n == 0:
         return []
-    raw = N.default_context().batch_mul_add_host(points_to_affine96([r for _, r, _ in trip]), n, b"".join(s._v.to_bytes(32, "little") for _, _, s in trip), n,
+    raw = N.default_context().batch_mul_add_host(points_to_affine96([r for _, r, _ in trip]), n, _scalars32([s for _, _, s in trip]), n,
                                                  points_to_affine96([l for l, _, _ in trip]), n)
     return _blobs_from_affine96(raw, n)
 
@@ -174,34 +265,32 @@ class MSMAccumulator:
         if n == 0:
             return G1Point.identity()
         out = N.default_context().msm_host(b"".join(a for a, _ in self._lhs),
-                                           b"".join(r.to_bytes(32, "little") for _, r in self._lhs), n)
+                                           _scalars32([r for _, r in self._lhs]), n)
         return G1Point._from_blob(out)
 
     def accumulate_check(self, C: G1Point, bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> None:
         random_factor = random_scalar()  # :43  (exactly one draw per call)
         rho = random_factor._v
         pairs = list(zip(bases, scalars))  # :47
-        pts = [C] + [b for b, _ in pairs]
-        aff = points_to_affine96(pts)
-        keys = points_to_compressed(pts)
-        self._lhs.append((aff[:96], rho))
+        pts = [C]
+        pts.extend(b for b, _ in pairs)
+        ensure_normalised(pts)             # ONE inversion for the points not met before; CRS points keep their normal form
+        self._lhs.append((C._a, rho))
         m = self.base_scalar_map
-        for i, (_, scalar) in enumerate(pairs, start=1):
-            a = aff[96 * i: 96 * i + 96]
+        for base, scalar in pairs:
+            a = base._a
             if a == _ZERO96:  # :49-50 zero bases contribute nothing
                 continue
-            k = keys[i]
-            ent = m.get(k)
+            ent = m.get(base._k)  # :54 the 48-byte compression is the key
             if ent is None:
-                m[k] = [rho * scalar._v % CURVE_ORDER, a]
+                m[base._k] = [rho * scalar._v % CURVE_ORDER, a]
             else:
                 ent[0] = (ent[0] + rho * scalar._v) % CURVE_ORDER  # :58
 
     def _final_msm_terms(self) -> Tuple[bytes, bytes, int]:
         ents = list(self.base_scalar_map.values())
         pts = b"".join(e[1] for e in ents) + b"".join(a for a, _ in self._lhs)
-        sc = b"".join(e[0].to_bytes(32, "little") for e in ents) + b"".join(
-            ((-r) % CURVE_ORDER).to_bytes(32, "little") for _, r in self._lhs)
+        sc = _scalars32([e[0] for e in ents] + [(-r) % CURVE_ORDER for _, r in self._lhs])
         return pts, sc, len(ents) + len(self._lhs)
 
     @staticmethod
@@ -226,8 +315,7 @@ class MSMAccumulator:
             raise ValueError("not enough values to unpack (expected 2, got 0)")
         ents = list(self.base_scalar_map.values())
         pts = b"".join(e[1] for e in ents) + b"".join(a for a, _ in self._lhs)
-        sc = b"".join(e[0].to_bytes(32, "little") for e in ents) + b"".join(
-            ((-r) % CURVE_ORDER).to_bytes(32, "little") for _, r in self._lhs)
+        sc = _scalars32([e[0] for e in ents] + [(-r) % CURVE_ORDER for _, r in self._lhs])
         n = len(ents) + len(self._lhs)
         out = N.default_context().msm_host(pts, sc, n)
         assert N.cg1_is_identity(out) == 1  # computed == self.A_c  (:68)

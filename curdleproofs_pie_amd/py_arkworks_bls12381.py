@@ -10,6 +10,9 @@ Surface and semantics follow what the reference pins:
 Single-element operators run in the host C++ of libcurdle_g1.so (a kernel launch per `P + Q` would be
 absurd); `G1Point.multiexp_unchecked` and everything batched run on the GPU (msm_accumulator.py).
 Values are immutable; every operator returns a new object.
+
+Marshalling (lists of objects -> contiguous buffers) goes through the optional C helper `_pyface` (csrc/pyface.c): one call per
+list, straight into page-locked staging.  It moves bytes only; without it the same functions run as Python loops.
 """
 from __future__ import annotations
 
@@ -17,6 +20,11 @@ import ctypes
 from typing import Any, Iterable, List
 
 from . import _native as N
+
+try:
+    from . import _pyface
+except ImportError:  # not built (no compiler / Python.h): pure-Python packing below
+    _pyface = None
 
 CURVE_ORDER = 52435875175126190479447740508185965837690552500527637822603658699938581184513  # util.py:7
 
@@ -45,6 +53,9 @@ class _PinnedDir(type):
 
 def _new_blob():
     return ctypes.create_string_buffer(N.POINT_BYTES)
+
+
+_set = object.__setattr__
 
 
 class Scalar(metaclass=_PinnedDir):
@@ -131,13 +142,18 @@ class G1Point(metaclass=_PinnedDir):
     """Element of the BLS12-381 G1 group.  `G1Point()` is the generator (util.py:9)."""
 
     _PINNED_DIR = _G1_DIR
-    __slots__ = ("_b",)
+    # _b: the 144-byte point blob (host Jacobian).  _a / _k: the point's affine96 record and 48-byte compression once some call
+    # has normalised it (None until then) -- values are immutable, so CRS points met by every accumulate_check
+    # (msm_accumulator.py:54) and every transcript append are normalised once, not once per call.
+    __slots__ = ("_b", "_a", "_k")
     __hash__ = None  # unhashable, test_curdleproofs.py:186-188
 
     def __init__(self) -> None:
         b = _new_blob()
         N.cg1_generator(b)
-        object.__setattr__(self, "_b", b.raw)
+        _set(self, "_b", b.raw)
+        _set(self, "_a", None)
+        _set(self, "_k", None)
 
     def __setattr__(self, k, v):
         raise AttributeError("G1Point is immutable")
@@ -145,7 +161,9 @@ class G1Point(metaclass=_PinnedDir):
     @staticmethod
     def _from_blob(raw: bytes) -> "G1Point":
         p = object.__new__(G1Point)
-        object.__setattr__(p, "_b", raw)
+        _set(p, "_b", raw)
+        _set(p, "_a", None)
+        _set(p, "_k", None)
         return p
 
     @staticmethod
@@ -196,9 +214,13 @@ class G1Point(metaclass=_PinnedDir):
         return not self.__eq__(o)
 
     def to_compressed_bytes(self) -> bytes:
-        out = ctypes.create_string_buffer(48)
-        N.cg1_compress(out, self._b)
-        return out.raw
+        k = self._k
+        if k is None:
+            out = ctypes.create_string_buffer(48)
+            N.cg1_compress(out, self._b)
+            k = out.raw
+            _set(self, "_k", k)
+        return k
 
     def __str__(self) -> str:  # test_curdleproofs.py:179
         return self.to_compressed_bytes().hex()
@@ -233,19 +255,83 @@ class G1Point(metaclass=_PinnedDir):
         return compute_MSM(bases, scalars)
 
 
-def points_to_affine96(points: List[G1Point]) -> bytes:
-    """n point blobs -> n affine96 records (one inversion for the whole batch)."""
+# ---------------------------------------------------------------- marshalling: lists of objects <-> contiguous buffers
+if _pyface is not None:
+    _pyface.bind(G1Point, Scalar)
+
+
+def pack_points(points, addr: int, capacity: int):
+    """Write the blobs of `points` (list / tuple of G1Point) to addr + 144 i; returns (n, every blob has Z in {0, 1})."""
+    if _pyface is not None:
+        return _pyface.pack_points(points, addr, capacity)
     n = len(points)
-    out = ctypes.create_string_buffer(96 * n if n else 1)
-    if n:
-        N.cg1_batch_to_affine96(out, b"".join(p._b for p in points), n)
-    return out.raw[: 96 * n]
+    if n > capacity:
+        raise ValueError("staging buffer too small")
+    raw = b"".join(p._b for p in points)
+    ctypes.memmove(addr, raw, len(raw))
+    return n, all(p._b[96:] in (_MONT_ONE, _ZERO48) for p in points)
+
+
+def pack_scalars(scalars, addr: int, capacity: int) -> int:
+    """Write int(s) of every Scalar (or plain int) of `scalars` as 32 little-endian bytes to addr + 32 i."""
+    if _pyface is not None:
+        return _pyface.pack_scalars(scalars, addr, capacity)
+    n = len(scalars)
+    if n > capacity:
+        raise ValueError("staging buffer too small")
+    raw = b"".join((s._v if isinstance(s, Scalar) else s).to_bytes(32, "little") for s in scalars)
+    ctypes.memmove(addr, raw, len(raw))
+    return n
+
+
+def points_from_blobs(raw, n: int) -> List[G1Point]:
+    """n G1Point objects over the consecutive 144-byte blobs of `raw`."""
+    if _pyface is not None:
+        return _pyface.points_from_blobs(raw, n)
+    raw = bytes(raw)
+    return [G1Point._from_blob(raw[144 * i: 144 * i + 144]) for i in range(n)]
+
+
+def ident(points):
+    """(n, fingerprint of the element identities) of a list / tuple: the key of the resident-vector cache."""
+    if _pyface is not None:
+        return _pyface.ident(points)
+    return len(points), hash(tuple(map(id, points)))
+
+
+def same_items(a, b) -> bool:
+    if _pyface is not None:
+        return _pyface.same_items(a, b)
+    return len(a) == len(b) and all(x is y for x, y in zip(a, b))
+
+
+_MONT_ONE = bytes.fromhex("fdff02000000097602000cc40b00f4ebba58c7535798485f455752705358ce776dec56a2971a075c93e480fac35ef615")
+_ZERO48 = bytes(48)
+
+
+def ensure_normalised(points) -> None:
+    """Fill the `_a` (affine96) / `_k` (compressed48) caches of every point that lacks them: ONE shared inversion for the lot
+    (cg1_batch_normalize).  After this, p._a and p._k are bytes for every p in points."""
+    todo = [p for p in points if p._a is None]
+    n = len(todo)
+    if n == 0:
+        return
+    blobs = b"".join([p._b for p in todo])
+    aff = ctypes.create_string_buffer(96 * n)
+    cmp_ = ctypes.create_string_buffer(48 * n)
+    N.cg1_batch_normalize(blobs, n, aff, cmp_)
+    aff, cmp_ = aff.raw, cmp_.raw
+    for i, p in enumerate(todo):
+        _set(p, "_a", aff[96 * i: 96 * i + 96])
+        _set(p, "_k", cmp_[48 * i: 48 * i + 48])
+
+
+def points_to_affine96(points: List[G1Point]) -> bytes:
+    """n points -> n affine96 records (one inversion for those not normalised before)."""
+    ensure_normalised(points)
+    return b"".join([p._a for p in points])
 
 
 def points_to_compressed(points: List[G1Point]) -> List[bytes]:
-    n = len(points)
-    out = ctypes.create_string_buffer(48 * n if n else 1)
-    if n:
-        N.cg1_batch_compress(out, b"".join(p._b for p in points), n)
-    raw = out.raw
-    return [raw[48 * i: 48 * i + 48] for i in range(n)]
+    ensure_normalised(points)
+    return [p._k for p in points]

@@ -58,6 +58,8 @@ void cg1_compress(uint8_t out48[48], const uint8_t* a);               /* to_comp
 int  cg1_decompress(uint8_t out[CG1_POINT_BYTES], const uint8_t in48[48], int check_subgroup);
 void cg1_to_affine96(uint8_t out96[96], const uint8_t* a);
 int  cg1_from_affine96(uint8_t out[CG1_POINT_BYTES], const uint8_t in96[96], int check_on_curve);
+/* n affine96 records (as the batched device entry points return them; zeros = identity; not checked against the curve) -> n blobs */
+int  cg1_batch_from_affine96(uint8_t* out_blobs, const uint8_t* in96, size_t n);
 /* n point blobs -> n affine96 records with ONE field inversion (input marshalling for the MSM) */
 void cg1_batch_to_affine96(uint8_t* out96, const uint8_t* blobs, size_t n);
 /* n compressed48 -> n point blobs; stops at the first bad encoding and returns its status, *bad_index set */
@@ -126,6 +128,24 @@ int cg1_msm_device_begin(cg1_ctx* ctx, const void* d_points_affine96, const void
 int cg1_msm_device_end(cg1_ctx* ctx, uint8_t out[CG1_POINT_BYTES]);
 int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points_affine96, const uint8_t* scalars32,
                     const uint32_t* offsets, size_t n_msm, uint8_t* out_blobs);
+/* ---- the same call as the reference's callers make it: over the G1Point OBJECTS' own blobs (msm_accumulator.py:6-12 takes lists
+ * of G1Point / Scalar; a G1Point here holds a 144-byte point blob, generally not normalised).  The blobs are uploaded as they are
+ * and normalised on the device (k_prepare_blobs: Montgomery's trick, one inversion per GPU lane), so the host does no field
+ * arithmetic per call.  all_normalised != 0: every blob has Z = 1 or Z = 0 (the caller checked): no inversion at all. */
+int cg1_msm_blobs(cg1_ctx* ctx, const uint8_t* blobs144, const uint8_t* scalars32, size_t n, int all_normalised,
+                  uint8_t out[CG1_POINT_BYTES]);
+/* A point vector resident on the device in the accumulation kernels' record format -- crs.vec_G / vec_H / vec_R ... are the
+ * bases of dozens of compute_MSM calls of one prover (curdleproofs.py:77,94,95,319; grand_prod.py:54,90; ipa.py:97,98): made
+ * once (upload + k_prepare_blobs), then each MSM uploads only its scalars.  cg1_msm_vec sums scalars[i] * vec[first + i], i < n. */
+typedef struct cg1_vec cg1_vec;
+cg1_vec* cg1_vec_create(cg1_ctx* ctx, const uint8_t* blobs144, size_t n, int all_normalised);   /* NULL on failure */
+void   cg1_vec_destroy(cg1_vec* v);
+size_t cg1_vec_len(const cg1_vec* v);
+int cg1_msm_vec(cg1_ctx* ctx, const cg1_vec* vec, size_t first, size_t n, const uint8_t* scalars32, uint8_t out[CG1_POINT_BYTES]);
+/* Host: n point blobs -> affine96 and / or compressed48 (either may be NULL) with ONE shared inversion: the map key
+ * (msm_accumulator.py:54) and the affine form of MSMAccumulator.accumulate_check's bases from a single normalisation. */
+int cg1_batch_normalize(const uint8_t* blobs, size_t n, uint8_t* out_affine96, uint8_t* out_comp48);
+
 /* per-phase GPU times (hipEvents on the context's stream) and host Horner tail of the last MSM call */
 int cg1_get_timings(const cg1_ctx* ctx, float phase_ms[CG1_NPHASE], float* host_tail_ms, int* window_c);
 

@@ -241,3 +241,87 @@ def test_compute_msm_python_face_at_config2_size(api):
     from curdleproofs_pie_amd.py_arkworks_bls12381 import points_to_affine96
     want = C.compress(C.compute_msm(points_to_affine96(bases[:m]), b"".join(int(s).to_bytes(32, "little") for s in scalars[:m]), m))
     assert bytes(A.compute_MSM(bases[:m], scalars[:m]).to_compressed_bytes()) == want
+
+
+def test_compute_msm_paths_blobs_and_resident_vectors(api):
+    """compute_MSM over the objects' own blobs (normalised on the device, k_prepare_blobs) and over a base list that has become
+    resident on the device (second sighting of the same objects): every path gives the reference loop's result."""
+    A, U = api
+    import curdleproofs_pie_amd.msm_accumulator as M
+
+    M.clear_vec_cache()
+    random.seed(21)
+    n = 200
+    bases = [U.get_random_point() for _ in range(n)]                         # G * s: projective blobs, Z != 1
+    bases[17] = U.Z1
+    bases[40] = bases[3]
+    want_of = lambda b, s: O.g1_compress(O.compute_MSM_fast([O.g1_decompress(bytes(x.to_compressed_bytes())) for x in b], [int(v) for v in s]))
+    seen = []
+    for call in range(4):
+        scalars = [U.random_scalar() for _ in range(n)]
+        got = A.compute_MSM(bases, scalars)
+        seen.append(M.last_path)
+        assert bytes(got.to_compressed_bytes()) == want_of(bases, scalars)
+    assert seen == ["blobs", "resident", "resident", "resident"]
+    # a prefix of the resident list is another sequence of objects: its own entry
+    scalars = [U.random_scalar() for _ in range(n - 9)]
+    assert bytes(A.compute_MSM(bases[: n - 9], scalars).to_compressed_bytes()) == want_of(bases[: n - 9], scalars)
+    assert M.last_path == "blobs"
+    # replacing an element of the caller's list must not hit the stale resident vector
+    bases[5] = U.get_random_point()
+    scalars = [U.random_scalar() for _ in range(n)]
+    assert bytes(A.compute_MSM(bases, scalars).to_compressed_bytes()) == want_of(bases, scalars)
+    assert M.last_path == "blobs"
+    # normal forms (decoded points) skip the inversion
+    dec = [A.G1Point.from_compressed_bytes_unchecked(b.to_compressed_bytes()) for b in bases]
+    assert bytes(A.compute_MSM(dec, scalars).to_compressed_bytes()) == want_of(bases, scalars)
+    assert M.last_path == "blobs_normalised"
+    assert A.compute_MSM(dec, scalars) == A.compute_MSM(bases, scalars) and M.last_path == "resident"
+    # every size 1 .. 40 and a few around the lane / block edges of k_prepare_blobs
+    pool = [U.get_random_point() for _ in range(64)] + [U.Z1]
+    for m in list(range(1, 41)) + [127, 128, 129, 255, 256, 257, 1023]:
+        b = [pool[random.randrange(len(pool))] for _ in range(m)]
+        s = [U.random_scalar() for _ in range(m)]
+        assert bytes(A.compute_MSM(b, s).to_compressed_bytes()) == want_of(b, s), m
+    M.clear_vec_cache()
+
+
+def test_msm_blobs_many_points_per_lane(native_lib):
+    """cg1_msm_blobs above 2^17 points: k_prepare_blobs inverts once per lane over K > 1 consecutive points (identities inside the
+    runs, a ragged last lane).  Bases are tiled from 61 projective multiples k_j G, so the result is (sum s_i k_(i mod 61)) G."""
+    import ctypes
+
+    N = native_lib
+    ctx = N.Context(0)
+    rng = random.Random(22)
+    ks = [rng.randint(1, O.R - 1) for _ in range(61)]
+    ks[13] = 0                                                            # the identity (Z = 0) inside every run
+    g = ctypes.create_string_buffer(144)
+    N.cg1_generator(g)
+    blobs = []
+    for k in ks:
+        out = ctypes.create_string_buffer(144)
+        N.cg1_mul(out, g.raw, k.to_bytes(32, "little"))
+        blobs.append(out.raw)
+    assert blobs[0][96:] != blobs[1][96:]                                 # genuinely projective
+    n = (1 << 17) * 3 + 77                                                # K = 4, last lane ragged
+    raw = b"".join(blobs) * (n // 61 + 1)
+    raw = raw[: 144 * n]
+    sc = [rng.randint(0, O.R - 1) for _ in range(n)]
+    s32 = b"".join(v.to_bytes(32, "little") for v in sc)
+    got = ctx.msm_blobs(raw, s32, n, False)
+    tot = sum(s * ks[i % 61] for i, s in enumerate(sc)) % O.R
+    out = ctypes.create_string_buffer(48)
+    N.cg1_compress(out, got)
+    assert out.raw == O.g1_compress(O.g1_mul(O.G1_GEN, tot))
+    # the resident form of the same blobs, and a window of it
+    vec = ctx.vec(raw, n, False)
+    assert N.cg1_eq(ctx.msm_vec(vec, s32, n), got) == 1
+    first, m = 12345, 5000
+    part = ctx.msm_vec(vec, s32[32 * first: 32 * (first + m)], m, first)
+    tot = sum(sc[i] * ks[i % 61] for i in range(first, first + m)) % O.R
+    N.cg1_compress(out, part)
+    assert out.raw == O.g1_compress(O.g1_mul(O.G1_GEN, tot))
+    with pytest.raises(N.NativeError):
+        ctx.msm_vec(vec, s32, n, 1)                                       # window past the end
+    vec.free()
