@@ -406,6 +406,8 @@ def main():
     ap.add_argument("--cpu-sample-logn", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the proofs-verified/s object and the extra N>1 records")
+    ap.add_argument("--no-python-face", action="store_true", help="skip the python_face / unchanged_control_flow objects (compute_MSM over G1Point / Scalar "
+                                                                  "objects at 2^16 and 2^20; the reference's own call sequence replayed)")
     ap.add_argument("--batch", type=int, default=1024, help="proofs per step (secondary metric / --mode verify)")
     ap.add_argument("--verify-steps", type=int, default=40, help="batches of the secondary stream (its fill and drain are inside the timed region)")
     ap.add_argument("--verify-mode", choices=["merged", "independent"], default="merged")
@@ -592,7 +594,8 @@ def main():
     if rank == 0:
         r = main_rec
         w_rank, w_groups, p_rank, p_groups = r["layout"]
-        acc_ms = r["phases_ms"]["accumulate"]
+        acc_ms = r["phases_ms"]["accumulate"]                 # per step: BOTH k_accumulate launches when the call ran as two chains
+        launches = max(1, r["counts"].get("accumulate_launches", 1))
         # roofline of the dominant kernel (k_accumulate): ALGORITHMIC bytes = 128 B per (point, scalar) term
         # (96 B affine point + 32 B scalar) x the terms one launch processes
         achieved = 128.0 * r["n_local"] / (acc_ms * 1e-3) / 1e9
@@ -637,7 +640,11 @@ def main():
                          "frac": achieved / 8000.0, "traffic": None,
                          "traffic_note": "PMC counters cannot be read inside this run; the per-launch HBM bytes of k_accumulate from separate "
                                          "rocprofv3 --pmc passes are kept in profiles/pmc_traffic.json",
-                         "kernel": "k_accumulate", "kernel_ms": acc_ms,
+                         "kernel": "k_accumulate", "kernel_ms": acc_ms / launches, "launches_per_step": launches, "kernel_ms_per_step": acc_ms,
+                         "launch_note": ("a call of this size runs as TWO launch chains (high / low half of the windows, two streams): each "
+                                         "k_accumulate launch takes every term through half of the windows, i.e. 64 B of the term's 128 algorithmic "
+                                         "bytes; achieved = 128 B x terms / the two launches' summed duration = 64 B x terms / one launch's average"
+                                         if launches == 2 else "one k_accumulate launch per call"),
                          "note": "path is integer-multiply (v_mad_u64_u32) bound, not HBM-bound: see roofline_int_mad and DESIGN.md"},
             # The bound that actually applies: 32x32+64 integer multiply-adds.  Algorithmic MADs of one
             # k_accumulate launch = the additions it really performs (bucket entries minus one copy per chunk, both counted on
@@ -645,7 +652,7 @@ def main():
             # measured by tools/ubench_valu.hip.
             "roofline_int_mad": {"bound": "valu v_mad_u64_u32", "achieved": mads / (acc_ms * 1e-3) / 1e12, "peak": peak["peak_T"],
                                  "unit": "T mad/s", "frac": mads / (acc_ms * 1e-3) / (peak["peak_T"] * 1e12), "kernel": "k_accumulate",
-                                 "kernel_ms": acc_ms, "peak_same_run": peak,
+                                 "kernel_ms": acc_ms / launches, "launches_per_step": launches, "kernel_ms_per_step": acc_ms, "peak_same_run": peak,
                                  "peak_round1_other_box": MAD_PEAK_T,
                                  "mixed_adds_per_launch": madds, "bucket_entries": r["counts"]["entries"], "chunks": r["counts"]["chunks"],
                                  "mads_per_mixed_add": MADS_PER_MADD, "first_additions_of_chunks": pair_adds, "mads_per_first_addition": MADS_PER_MMADD,
@@ -681,6 +688,14 @@ def main():
             wl = Workload(ctx, d_g, max(1 << 18, 1 << args.cpu_sample_logn), args.seed)
             out["cpu_baseline"] = cpu_baseline(wl.d_pts, wl.d_sc, 1 << args.cpu_sample_logn)
             wl.free()
+        if world == 1 and not args.no_python_face:
+            # the drop-in itself: compute_MSM / MSMAccumulator through the reference's signature (lists of G1Point / Scalar objects), and
+            # the reference's own backend-call sequence for one proof replayed through this backend
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import gpu_python_face
+            import replay_call_trace
+            out["python_face"] = gpu_python_face.measure(sizes=(16, 20), reps=3)
+            out["unchanged_control_flow"] = replay_call_trace.measure(reps=3)
         if world == 1 and not args.no_secondary:
             ctx2.close()                                      # (its streams would keep hardware queues the verifier's lanes need: a process has 24)
             cores = int(N.cg1_shuffle_default_threads())

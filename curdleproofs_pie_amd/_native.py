@@ -116,6 +116,9 @@ cg1_comm_barrier = _proto("cg1_comm_barrier", c_int, c_void_p)
 cg1_comm_allreduce_g1 = _proto("cg1_comm_allreduce_g1", c_int, c_void_p, _u8p, _buf, c_void_p)
 cg1_comm_destroy = _proto("cg1_comm_destroy", None, c_void_p)
 cg1_msm = _proto("cg1_msm", c_int, c_void_p, _u8p, _u8p, c_size_t, _buf)
+cg1_msm_addr = lib["cg1_msm"]       # the same entry point taking raw addresses (page-locked staging) instead of bytes objects
+cg1_msm_addr.restype = c_int
+cg1_msm_addr.argtypes = [c_void_p, c_void_p, c_void_p, c_size_t, _buf]
 cg1_msm_device = _proto("cg1_msm_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int, _buf)
 cg1_msm_device_begin = _proto("cg1_msm_device_begin", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int)
 cg1_msm_device_end = _proto("cg1_msm_device_end", c_int, c_void_p, _buf)
@@ -130,6 +133,7 @@ cg1_msm_batched = _proto("cg1_msm_batched", c_int, c_void_p, _u8p, _u8p, POINTER
 cg1_get_timings = _proto("cg1_get_timings", c_int, c_void_p, POINTER(c_float), POINTER(c_float), POINTER(c_int))
 cg1_get_host_timings = _proto("cg1_get_host_timings", c_int, c_void_p, POINTER(c_float))
 cg1_get_last_counts = _proto("cg1_get_last_counts", c_int, c_void_p, POINTER(ctypes.c_uint32), POINTER(ctypes.c_uint32))
+cg1_get_last_launches = _proto("cg1_get_last_launches", c_int, c_void_p)
 cg1_timer_begin = _proto("cg1_timer_begin", c_int, c_void_p)
 cg1_timer_end = _proto("cg1_timer_end", c_int, c_void_p, POINTER(c_float))
 cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
@@ -221,7 +225,7 @@ EXPORTED_SYMBOLS = [
     "cg1_merlin_last_passes", "cg1_merlin_last_kernel", "cg1_merlin_block_program_emulate", "cg1_probe_mad_rate", "cg1_batch_sum_device", "cg1_batch_sum", "cg1_ctx_device", "cg1_ctx_stream", "cg1_msm_multi_device",
     "cg1_comm_create", "cg1_comm_port", "cg1_comm_rank", "cg1_comm_connect", "cg1_comm_set_timeout", "cg1_comm_attach_rccl", "cg1_comm_transport",
     "cg1_comm_world_seen", "cg1_comm_error", "cg1_comm_allgather", "cg1_comm_allgather_host", "cg1_comm_barrier", "cg1_comm_allreduce_g1", "cg1_comm_destroy",
-    "cg1_msm_blobs", "cg1_vec_create", "cg1_vec_destroy", "cg1_vec_len", "cg1_msm_vec", "cg1_batch_normalize", "cg1_batch_from_affine96",
+    "cg1_msm_blobs", "cg1_vec_create", "cg1_vec_destroy", "cg1_vec_len", "cg1_msm_vec", "cg1_batch_normalize", "cg1_batch_from_affine96", "cg1_get_last_launches",
 ]
 
 
@@ -322,6 +326,12 @@ class Context:
         self.check(cg1_msm(self.handle, points_affine96, scalars32, n, out))
         return out.raw
 
+    def msm_affine(self, points_affine96_addr: int, scalars32_addr: int, n: int) -> bytes:
+        """cg1_msm over raw host addresses (the Python face's page-locked staging)."""
+        out = ctypes.create_string_buffer(POINT_BYTES)
+        self.check(cg1_msm_addr(self.handle, points_affine96_addr, scalars32_addr, n, out))
+        return out.raw
+
     def msm_blobs(self, blobs144, scalars32, n: int, all_normalised: bool = False) -> bytes:
         """compute_MSM over n host point blobs (bytes / ctypes buffer / raw address of page-locked memory) as G1Point objects hold them."""
         out = ctypes.create_string_buffer(POINT_BYTES)
@@ -377,7 +387,8 @@ class Context:
         """Of the last MSM call: bucket entries (non-zero digits), chunks, and mixed additions = entries - chunks."""
         e, c = ctypes.c_uint32(), ctypes.c_uint32()
         cg1_get_last_counts(self.handle, ctypes.byref(e), ctypes.byref(c))
-        return {"entries": int(e.value), "chunks": int(c.value), "mixed_adds": int(e.value) - int(c.value)}
+        return {"entries": int(e.value), "chunks": int(c.value), "mixed_adds": int(e.value) - int(c.value),
+                "accumulate_launches": int(cg1_get_last_launches(self.handle))}
 
     def timer_begin(self) -> None:
         self.check(cg1_timer_begin(self.handle))
@@ -558,6 +569,7 @@ class Comm:
         self.check(cg1_comm_set_timeout(self.handle, int(timeout_ms)))
 
     def attach_rccl(self, ctx: "Context") -> None:
+        self._ctx = ctx          # the communicator keeps using ctx's stream: ctx must outlive it
         self.check(cg1_comm_attach_rccl(self.handle, ctx.handle))
 
     def allgather(self, data: bytes, host_only: bool = False) -> list:

@@ -106,14 +106,16 @@ int send_all(cg1_comm* c, int fd, const void* buf, size_t n) {
   const uint8_t* p = static_cast<const uint8_t*>(buf);
   const int64_t deadline = now_ms() + c->timeout_ms;
   while (n) {
-    ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL);
+    // the sockets are blocking: wait for room with poll() (bounded by the deadline), then send without blocking -- a stalled peer
+    // can no longer hold the hub inside ::send for ever
+    pollfd pf{fd, POLLOUT, 0};
+    const int pr = poll(&pf, 1, 1000);
+    if (pr < 0 && errno == EINTR) continue;
+    if (pr < 0) return fail(c, "poll", errno);
+    if (pr == 0) { if (now_ms() > deadline) return fail(c, "send timed out (a peer rank stopped reading)"); continue; }
+    ssize_t k = ::send(fd, p, n, MSG_NOSIGNAL | MSG_DONTWAIT);
     if (k > 0) { p += k; n -= (size_t)k; continue; }
-    if (k < 0 && (errno == EINTR)) continue;
-    if (k < 0 && (errno == EAGAIN || errno == EWOULDBLOCK)) {
-      pollfd pf{fd, POLLOUT, 0};
-      if (now_ms() > deadline || poll(&pf, 1, 1000) < 0) return fail(c, "send timed out");
-      continue;
-    }
+    if (k < 0 && (errno == EINTR || errno == EAGAIN || errno == EWOULDBLOCK)) continue;
     return fail(c, "send", errno);
   }
   return CG1_OK;
@@ -373,6 +375,11 @@ int cg1_comm_allreduce_g1(cg1_comm* c, const uint8_t* partial, uint8_t* sum, uin
   for (int r = 0; r < c->world; ++r) {
     cg1h::jac p;
     memcpy(&p, c->scratch.data() + (size_t)r * CG1_POINT_BYTES, sizeof p);
+    // a peer's blob is data from another process: canonical field elements on the curve (or the identity), or the call fails
+    if (!cg1h::fe_is_canonical(p.X) || !cg1h::fe_is_canonical(p.Y) || !cg1h::fe_is_canonical(p.Z) || !cg1h::jac_on_curve(p)) {
+      snprintf(c->err, sizeof c->err, "rank %d sent a partial sum that is not a point of the curve", r);
+      return CG1_ERR_COMM;
+    }
     acc = cg1h::jac_add(acc, p);
   }
   memcpy(sum, &acc, sizeof acc);

@@ -1,6 +1,7 @@
 // Host-side BLS12-381 Fp / G1.  See host_g1.h for the role of this file.
 #include "host_g1.h"
 #include "bls_consts.h"
+#include "fe_mul_x86.h"
 #include <cstring>
 #include <vector>
 
@@ -25,6 +26,8 @@ static inline void sub_p(uint64_t* a) {
   for (int i = 0; i < 6; ++i) { u128 t = (u128)a[i] - H_P[i] - br; a[i] = (uint64_t)t; br = (t >> 64) & 1; }
 }
 
+bool fe_is_canonical(const fe& a) { return !geq_p(a.l); }
+
 fe fe_add(const fe& a, const fe& b) {
   fe r; u128 c = 0;
   for (int i = 0; i < 6; ++i) { c += (u128)a.l[i] + b.l[i]; r.l[i] = (uint64_t)c; c >>= 64; }
@@ -43,7 +46,20 @@ fe fe_neg(const fe& a) { return fe_is_zero(a) ? a : fe_sub(fe_zero(), a); }
 // CIOS with the "no-carry" shortcut: p < 2^381 leaves the top word of every partial sum below 2^63, so the
 // running value never needs a 7th word beyond one carry word (the method used by gnark/arkworks for moduli with
 // a free top bit).  Fully unrolled by the compiler (fixed trip counts).
+#if defined(__x86_64__)
+// mulx + adcx / adox when the CPU has them (fe_mul_x86.h, generated): the product's two carry chains per row run side by side
+static const bool g_has_adx = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx");
+#endif
+
 fe fe_mul(const fe& a, const fe& b) {
+#if defined(__x86_64__)
+  if (g_has_adx) {
+    fe r;
+    fe_mul_adx(r.l, a.l, b.l, H_P, H_PINV);
+    if (geq_p(r.l)) sub_p(r.l);
+    return r;
+  }
+#endif
   uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
 #pragma GCC unroll 6
   for (int i = 0; i < 6; ++i) {

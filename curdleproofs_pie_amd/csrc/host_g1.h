@@ -17,6 +17,7 @@ struct jac { fe X, Y, Z; };            // Z == 0  <=> identity
 fe fe_zero();
 fe fe_one();
 bool fe_is_zero(const fe& a);
+bool fe_is_canonical(const fe& a);             // value < p
 bool fe_eq(const fe& a, const fe& b);
 fe fe_add(const fe& a, const fe& b);
 fe fe_sub(const fe& a, const fe& b);

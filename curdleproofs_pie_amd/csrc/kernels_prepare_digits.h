@@ -150,6 +150,17 @@ struct WinPlan {
   CG1_HD int width(int w) const { return w < n_hi ? cmax : cmax - 1; }
   CG1_HD int off(int w) const { return w < n_hi ? w * cmax : n_hi * cmax + (w - n_hi) * (cmax - 1); }
 };
+// Which windows of the plan one launch chain takes, as the (rank, world) pair the kernels carry:
+//   world > 0   windows w = rank (mod world)            -- the per-GPU shares of a window-sharded MSM; (0, 1) = every window
+//   world < 0   the -world consecutive windows from `rank` -- the two halves of ONE call that run as two chains on two streams
+// win_local: the chain's local index of global window w, or -1 when the window is not its own.
+CG1_HD int win_local(int w, int rank, int world) {
+  if (world > 0) return (w % world) == rank ? w / world : -1;
+  return (w >= rank && w < rank - world) ? w - rank : -1;
+}
+CG1_HD int win_global(int lw, int rank, int world) { return world > 0 ? rank + lw * world : rank + lw; }
+CG1_HD int win_count(int nwin, int rank, int world) { return world > 0 ? (nwin - rank + world - 1) / world : -world; }
+
 struct DigitIter {
   uint32_t s[8];
   uint32_t carry;
@@ -186,9 +197,10 @@ __global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scala
   const uint32_t NB = 1u << (pl.cmax - 1);
   for (int w = 0; w < pl.nwin; ++w) {
     int d = it.next(pl, w);
-    if (d == 0 || (w % world) != rank) continue;
+    const int lw = win_local(w, rank, world);
+    if (d == 0 || lw < 0) continue;
     uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
-    atomicAdd(&hist[(uint32_t)(w / world) * NB + b], 1u);
+    atomicAdd(&hist[(uint32_t)lw * NB + b], 1u);
   }
 }
 
@@ -203,8 +215,9 @@ __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ sc
   const uint32_t NB = 1u << (pl.cmax - 1);
   for (int w = 0; w < pl.nwin; ++w) {
     int d = it.next(pl, w);
-    if (d == 0 || (w % world) != rank) continue;
-    uint32_t key = (uint32_t)(w / world) * NB + (uint32_t)(d < 0 ? -d : d) - 1u;
+    const int lw = win_local(w, rank, world);
+    if (d == 0 || lw < 0) continue;
+    uint32_t key = (uint32_t)lw * NB + (uint32_t)(d < 0 ? -d : d) - 1u;
     uint32_t slot = atomicSub(&cursor[key], 1u) - 1u;      // cursor starts at the bucket's count
     sorted[off[key] + slot] = i | (d < 0 ? 0x80000000u : 0u);
   }

@@ -52,8 +52,9 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   if (it.s[7] >> 31) *bad_flag = 1u;              // >= 2^255: the signed-digit recoding would carry out of the top window
   for (int w = 0; w < pl.nwin; ++w) {
     int d = it.next(pl, w);
-    if ((w % world) != rank) continue;
-    digits[(size_t)(w / world) * n + i] = inf ? (uint16_t)0 : (uint16_t)(d & 0xFFFF);
+    const int lw = win_local(w, rank, world);
+    if (lw < 0) continue;
+    digits[(size_t)lw * n + i] = inf ? (uint16_t)0 : (uint16_t)(d & 0xFFFF);
   }
 }
 

@@ -55,6 +55,7 @@ int pick_window(size_t n);
 #include "kernels_sort.h"
 #include "kernels_accumulate.h"
 #include "kernels_reduce.h"
+#include "kernels_small.h"
 #include "kernels_batch.h"
 }  // namespace cg1
 #include "kernels_rows.h"
@@ -165,8 +166,24 @@ struct Ctx {
     int profile = 0;                    // the level the events of THIS call were recorded under (may change before msm_finish)
     bool zero_copy = false; uint32_t seq = 0;
     size_t nout_words = 0;
+    const PointWords* hout = nullptr;   // where the exported items land (ctx->h_out, or h_small_out for k_msm_small)
     std::chrono::steady_clock::time_point h0, h1;
   } pend;
+  // "split": one large call runs as TWO launch chains on two streams -- the high half of the windows on this context, the low half on
+  // `child` (its own scratch buffers, stream and export flag; the prepared points are shared).  The low half's sort phases run under
+  // the high half's k_accumulate, the high half's reduction tree, export and host Horner under the low half's k_accumulate, so only
+  // half of every non-accumulate phase stays on the critical path (profiles/r04_split_ab.txt).
+  int split = 1;
+  size_t split_min_n = (size_t)1 << 17;
+  cg1_ctx* child = nullptr;
+  hipEvent_t ev_prep = nullptr, ev_acc = nullptr;
+  bool pend_split = false;
+  int last_acc_launches = 0;            // k_accumulate launches of the last MSM call: 2 (split), 1, or 0 (k_msm_small)
+  int small_msm = 1;                    // "small_msm": MSMs of <= SM_MAX_N terms as ONE launch (k_msm_small); 0 = the regime-A chain (A/B switch)
+  PointSum* d_small_partial = nullptr; size_t cap_small_partial = 0;
+  uint32_t* d_small_ctr = nullptr;
+  PreparedPoint* d_small_pts = nullptr; uint8_t* d_small_flags = nullptr;      // k_prepare_blobs<true> output for un-normalised blob input
+  PointWords* h_small_out = nullptr; PointWords* h_small_out_dev = nullptr;     // pinned + mapped: 64 x 9 window items + the status record
   int quad = 1;                         // quad-lane EC ops in the latency-bound kernels (A/B switch)
   int reduce_2d = 1;                    // 1: k_rowcol + k_small_tree; 0: k_seg_reduce + k_bit_tree (A/B switch)
   uint32_t* d_heavy = nullptr; size_t cap_heavy = 0;         // [0] count, then heavy bucket ids
@@ -218,10 +235,10 @@ static void free_bufs(Ctx* c) {
   c->cap_n = c->cap_nb = c->cap_chunks = c->cap_entries = c->cap_out = 0;
 }
 
-static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems, uint32_t L) {
+static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems, uint32_t L, bool need_points = true) {
   size_t entries = n * nlw;
   size_t chunks = nb_total + entries / L + 1;
-  if (n > ctx->cap_n) {
+  if (need_points && n > ctx->cap_n) {
     if (ctx->d_pts) (void)hipFree(ctx->d_pts);
     if (ctx->d_flags) (void)hipFree(ctx->d_flags);
     HIPCHK(hipMalloc(&ctx->d_pts, n * sizeof(PreparedPoint)));
@@ -318,7 +335,9 @@ static int ensure(Ctx* ctx, size_t n, size_t nb_total, size_t nlw, size_t nitems
     if (ctx->d_out) (void)hipFree(ctx->d_out);
     if (ctx->h_out) (void)hipHostFree(ctx->h_out);
     HIPCHK(hipMalloc(&ctx->d_out, (nout + 1) * sizeof(PointWords)));      // + one record: the input-validation flag word
-    HIPCHK(hipHostMalloc(&ctx->h_out, (nout + 1) * sizeof(PointWords)));
+    // mapped + coherent, said explicitly: the export kernel writes it and the host polls the flag word without any runtime call in
+    // between (with HIP_HOST_COHERENT=0 the default allocation is non-coherent and the poll would only end through its stream query)
+    HIPCHK(hipHostMalloc(&ctx->h_out, (nout + 1) * sizeof(PointWords), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&ctx->h_out_dev, ctx->h_out, 0));
     ctx->cap_out = nout;
   }
@@ -432,11 +451,19 @@ static void launch_prepare(hipStream_t st, const PtSrc& src, PreparedPoint* out,
 
 // Enqueue the whole launch chain of this context's share of an MSM (windows w = rank mod world of the plan) up to the D2H of
 // the window sums; nothing waits.
-static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan, int rank, int world) {
+// Hooks of the two-chain form of one call (msm_begin_split): `after_prepare` is recorded on the chain's stream once the prepared
+// records exist (the other chain reads them); the chain waits for `before_start` before its first launch and for
+// `before_accumulate` in front of k_accumulate; `after_accumulate` is recorded behind k_accumulate.
+struct ChainHooks {
+  hipEvent_t before_start = nullptr, after_prepare = nullptr, before_accumulate = nullptr, after_accumulate = nullptr;
+};
+
+static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan, int rank, int world,
+                       const ChainHooks& hooks = ChainHooks()) {
   ctx->pend.active = false;
   HIPCHK(hipSetDevice(ctx->device));
   const int c = plan.cmax, nwin = plan.nwin;
-  const int nlw = (nwin - rank + world - 1) / world;           // windows w = rank, rank+world, ...
+  const int nlw = win_count(nwin, rank, world);                // windows w = rank, rank+world, ... (world < 0: -world consecutive ones from rank)
   if (nlw <= 0) return CG1_OK;
   const uint32_t NB = 1u << (c - 1);
   const uint32_t m = std::min<uint32_t>(ctx->seg_m, NB);
@@ -452,7 +479,7 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   // (window-sharded ranks, skew, thin top windows) are re-joined by k_bucket_fold (<= 16 chunks) / k_heavy_combine.
   uint32_t L0 = ctx->L0;
   while (L0 < 65536u && ((uint64_t)n * (uint64_t)nlw >> 18) > (uint64_t)L0) L0 <<= 1;
-  int rc = ensure(ctx, n, nb_total, nlw, nitems, L0);
+  int rc = ensure(ctx, n, nb_total, nlw, nitems, L0, src.kind != PtSrc::PREPARED);
   if (rc) return rc;
   hipStream_t st = ctx->stream;
   const uint32_t n32 = (uint32_t)n;
@@ -464,9 +491,11 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   const uint8_t* flags = resident ? src.flags : ctx->d_flags;
   const size_t nout_words = (size_t)nlw * nitems;
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // [0] set by the digit kernels: a scalar >= 2^255; [1], [2]: counts
+  if (hooks.before_start) HIPCHK(hipStreamWaitEvent(st, hooks.before_start, 0));
   if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[0], st));
   if (resident) HIPCHK(hipMemsetAsync(bad_flag, 0, 16, st));
   else launch_prepare(st, src, ctx->d_pts, ctx->d_flags, n32, bad_flag);
+  if (hooks.after_prepare) HIPCHK(hipEventRecord(hooks.after_prepare, st));
   if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[1], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
@@ -521,9 +550,11 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
   hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
+  if (hooks.before_accumulate) HIPCHK(hipStreamWaitEvent(st, hooks.before_accumulate, 0));
   if (profile >= 1) HIPCHK(hipEventRecord(ctx->ev[4], st));
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, pts, ctx->d_sums);
   if (profile >= 1) HIPCHK(hipEventRecord(ctx->ev[5], st));
+  if (hooks.after_accumulate) HIPCHK(hipEventRecord(hooks.after_accumulate, st));
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
   // k_rowcol_quad (every addition by a DPP quad) only where the reduction is a pure latency chain: a few thousand buckets
   const bool small_quad = ctx->quad && ctx->rowcol_quad && nb_total <= (size_t)ctx->rowcol_quad_max;
@@ -574,7 +605,7 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[7], st));
   auto h1 = std::chrono::steady_clock::now();
   Ctx::Pending& pd = ctx->pend;
-  pd.zero_copy = zc; pd.seq = ctx->seq;
+  pd.zero_copy = zc; pd.seq = ctx->seq; pd.hout = ctx->h_out;
   pd.active = true; pd.c = c; pd.plan = plan; pd.rank = rank; pd.world = world; pd.nlw = nlw; pd.nbits = nbits; pd.m = m; pd.lb2 = lb2; pd.hb2 = hb2;
   pd.nitems = nitems; pd.use2d = use2d; pd.profile = profile; pd.nout_words = nout_words; pd.h0 = h0; pd.h1 = h1;
   return CG1_OK;
@@ -610,7 +641,7 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   }
   HIPCHK(hipGetLastError());
   {
-    const uint32_t* st_words = reinterpret_cast<const uint32_t*>(ctx->h_out + nout_words);    // [0] bad scalar, [1] entries, [2] chunks
+    const uint32_t* st_words = reinterpret_cast<const uint32_t*>(pd.hout + nout_words);    // [0] bad scalar, [1] entries, [2] chunks
     ctx->last_entries = st_words[1]; ctx->last_chunks = st_words[2];
     if (st_words[0]) {
       snprintf(ctx->err, sizeof ctx->err, "a scalar is >= 2^255: scalar32 must be a canonical Fr element (< r)");
@@ -637,8 +668,8 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   items.reserve((size_t)nlw * nitems);
   int e_top = 0;
   for (int lw = 0; lw < nlw; ++lw) {
-    const int w = rank + lw * world, base = plan.off(w);
-    const PointWords* row = ctx->h_out + (size_t)lw * nitems;
+    const int w = win_global(lw, rank, world), base = plan.off(w);
+    const PointWords* row = pd.hout + (size_t)lw * nitems;
     auto put = [&](int e, const PointWords* p) { if (!p->inf) { items.emplace_back(e, p); if (e > e_top) e_top = e; } };
     put(base, &row[0]);
     if (use2d) {
@@ -694,6 +725,68 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   return CG1_OK;
 }
 
+// The window width k_msm_small runs a call of n terms with (uniform signed windows; 2^(c-1) <= 256 buckets fit one workgroup's
+// LDS sort; 5 is left out: its top window would hold nothing but the recoding carry).  Chosen so that a slice of <= 256 terms puts
+// a handful of entries into a bucket: every EC addition of the kernel is a ~10 us step of a dependent chain, and the reduction costs
+// ~log2(buckets) + 4 of them per window whatever n is, so few buckets (64 at c = 7) beat the wider windows the entry count alone
+// would suggest (measured, profiles/r04_small_msm.txt: n = 627 at c = 9 waits 232 us for the GPU, at c = 7 ...).
+static int pick_small_c(size_t n) {
+  if (n <= 24) return 4;
+  if (n <= 96) return 6;
+  return 7;
+}
+
+// One launch (two when un-normalised blobs have to be inverted first) for an MSM of n <= SM_MAX_N terms; fills ctx->pend like
+// msm_enqueue, so msm_finish polls the same flag and runs the same host Horner.
+static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int c) {
+  ctx->pend.active = false;
+  HIPCHK(hipSetDevice(ctx->device));
+  const WinPlan plan = make_plan(c);
+  const uint32_t nwin = (uint32_t)plan.nwin, bb = (uint32_t)c - 1u, lb2 = (bb + 1u) / 2u, hb2 = bb - lb2, nitems = 1u + hb2 + lb2;
+  const uint32_t S = (uint32_t)((n + SM_SLICE - 1) / SM_SLICE);
+  auto h0 = std::chrono::steady_clock::now();
+  if (!ctx->h_small_out) {
+    HIPCHK(hipHostMalloc((void**)&ctx->h_small_out, (64 * 9 + 1) * sizeof(PointWords), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostGetDevicePointer((void**)&ctx->h_small_out_dev, ctx->h_small_out, 0));
+    HIPCHK(hipMalloc(&ctx->d_small_ctr, 128 * 4));
+    HIPCHK(hipMemset(ctx->d_small_ctr, 0, 128 * 4));
+    HIPCHK(hipMalloc(&ctx->d_small_pts, SM_MAX_N * sizeof(PreparedPoint)));
+    HIPCHK(hipMalloc(&ctx->d_small_flags, SM_MAX_N + 16));
+  }
+  const size_t need_partial = (size_t)nwin * S * nitems;
+  if (S > 1 && need_partial > ctx->cap_small_partial) {
+    if (ctx->d_small_partial) (void)hipFree(ctx->d_small_partial);
+    ctx->d_small_partial = nullptr; ctx->cap_small_partial = 0;
+    HIPCHK(hipMalloc(&ctx->d_small_partial, 64 * 4 * 9 * sizeof(PointSum)));
+    ctx->cap_small_partial = 64 * 4 * 9;
+  }
+  hipStream_t st = ctx->stream;
+  SmallArgs a;
+  a.src = src.p; a.flags = src.flags; a.scalars = static_cast<const uint32_t*>(d_scalars32);
+  a.n = (uint32_t)n; a.S = S; a.c = (uint32_t)c; a.nwin = nwin; a.hb = hb2; a.lb = lb2; a.nitems = nitems;
+  a.partial = ctx->d_small_partial; a.counters = ctx->d_small_ctr;
+  a.out_host = ctx->h_small_out_dev; a.flag_host = ctx->h_flag_dev; a.seq = ++ctx->seq;
+  int kind = (int)src.kind;
+  if (src.kind == PtSrc::BLOBS && !src.normalised) {           // invert first (one lane per point), then run on the prepared records
+    launch_prepare(st, src, ctx->d_small_pts, ctx->d_small_flags, (uint32_t)n, nullptr);
+    a.src = ctx->d_small_pts; a.flags = ctx->d_small_flags;
+    kind = (int)PtSrc::PREPARED;
+  }
+  const dim3 grid(nwin, S), block(512);
+  if (kind == (int)PtSrc::AFFINE96) hipLaunchKernelGGL((k_msm_small<0>), grid, block, 0, st, a);
+  else if (kind == (int)PtSrc::BLOBS) hipLaunchKernelGGL((k_msm_small<1>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((k_msm_small<2>), grid, block, 0, st, a);
+  auto h1 = std::chrono::steady_clock::now();
+  Ctx::Pending& pd = ctx->pend;
+  pd.zero_copy = true; pd.seq = ctx->seq; pd.hout = ctx->h_small_out;
+  pd.active = true; pd.c = c; pd.plan = plan; pd.rank = 0; pd.world = 1; pd.nlw = (int)nwin; pd.nbits = 0; pd.m = 1; pd.lb2 = lb2; pd.hb2 = hb2;
+  pd.nitems = nitems; pd.use2d = true; pd.profile = 0; pd.nout_words = (size_t)nwin * nitems; pd.h0 = h0; pd.h1 = h1;
+  return CG1_OK;
+}
+
+static Ctx* child_of(Ctx* ctx);
+static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan);
+
 // One MSM: this context's share (windows w = rank mod world) of sum_i scalar_i * point_i.
 // c = 0: automatic plan; 4..16: uniform windows of that width; -16..-4: the balanced plan with cmax = -c.
 // msm_begin enqueues the whole launch chain and returns; msm_end waits for it and runs the host tail.  Two contexts on one
@@ -705,15 +798,41 @@ int msm_begin(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "n too large"); return CG1_ERR_ARG; }
   if (world < 1 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
+  if (ctx->small_msm && n <= SM_MAX_N && world == 1 && (c == 0 || (c >= 4 && c <= 9 && c != 5))) {
+    if (c == 0) c = pick_small_c(n);
+    ctx->pend_c = c;
+    return msm_enqueue_small(ctx, src, d_scalars32, n, c);
+  }
   if (c == 0) c = pick_plan_c(n, ctx->auto_plan);
   const int cabs = c < 0 ? -c : c;
   if (cabs < 4 || cabs > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
   const WinPlan plan = make_plan(c);
   ctx->pend_c = c;
+  ctx->pend_split = false;
+  if (ctx->split && world == 1 && n >= ctx->split_min_n && plan.nwin >= 4) return msm_begin_split(ctx, src, d_scalars32, n, plan);
   return msm_enqueue(ctx, src, d_scalars32, n, plan, rank, world);
 }
 int msm_end(Ctx* ctx, cg1h::jac& result) {
-  int rc = msm_finish(ctx, result);
+  const bool was_small = ctx->pend.active && ctx->pend.hout == ctx->h_small_out;
+  int rc = msm_finish(ctx, result);                    // (split: the HIGH windows; their Horner runs while the GPU is still on the low half)
+  ctx->last_acc_launches = ctx->pend_split ? 2 : (was_small ? 0 : 1);
+  if (ctx->pend_split) {
+    ctx->pend_split = false;
+    Ctx* ch = child_of(ctx);
+    const float acc_hi = ctx->phase_ms[4], wait_hi = ctx->host_ms[1], tail_hi = ctx->host_ms[3], enq = ctx->host_ms[0];
+    const uint32_t e_hi = ctx->last_entries, c_hi = ctx->last_chunks;
+    cg1h::jac lo;
+    int rc2 = msm_finish(ch, lo);
+    if (rc == CG1_OK) rc = rc2;
+    if (rc2 != CG1_OK) snprintf(ctx->err, sizeof ctx->err, "%s", ch->err);
+    if (rc == CG1_OK) result = cg1h::jac_add(result, lo);
+    // the call's figures: both k_accumulate launches, both chains' entries; host: enqueue of both chains, waits, tails
+    for (int i = 0; i < CG1_NPHASE; ++i) ctx->phase_ms[i] += ch->phase_ms[i];
+    ctx->phase_ms[4] = acc_hi + ch->phase_ms[4];
+    ctx->last_entries = e_hi + ch->last_entries; ctx->last_chunks = c_hi + ch->last_chunks;
+    ctx->host_ms[0] = enq + ch->host_ms[0]; ctx->host_ms[1] = wait_hi + ch->host_ms[1]; ctx->host_ms[3] = tail_hi + ch->host_ms[3];
+    ctx->host_tail_ms = ch->host_ms[3];                 // what is left on the critical path after the GPU is done
+  }
   if (ctx->pend_c) ctx->last_c = ctx->pend_c;          // negative: a balanced plan (cg1_get_timings reports it)
   return rc;
 }
@@ -880,6 +999,45 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
 using cg1::Ctx;
 struct cg1_ctx : public cg1::Ctx {};
 
+namespace cg1 {
+static Ctx* child_of(Ctx* ctx) { return static_cast<Ctx*>(ctx->child); }
+
+// One call as two launch chains: this context takes the HIGH half of the plan's windows (and prepares the points), its child the
+// LOW half on its own stream.  The child starts once the prepared records exist, and its k_accumulate waits for this context's to
+// finish: the two dominant launches run back to back, everything around them overlaps with one of them.
+static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan) {
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->child) {
+    cg1_ctx* made = ctx->cu_mask.empty() ? cg1_ctx_create(ctx->device) : cg1_ctx_create_cu_mask(ctx->device, ctx->cu_mask.data(), ctx->cu_mask.size());
+    if (!made) { snprintf(ctx->err, sizeof ctx->err, "could not create the second launch chain's context"); return CG1_ERR_HIP; }
+    made->split = 0;
+    ctx->child = made;
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming));
+  }
+  Ctx* ch = child_of(ctx);
+  ch->profile = ctx->profile; ch->L0 = ctx->L0; ch->seg_m = ctx->seg_m; ch->quad = ctx->quad; ch->reduce_2d = ctx->reduce_2d;
+  ch->rowcol_quad = ctx->rowcol_quad; ch->rowcol_quad_max = ctx->rowcol_quad_max; ch->fold_pass = ctx->fold_pass; ch->tree_half = ctx->tree_half;
+  ch->scan_one = ctx->scan_one; ch->zero_copy = ctx->zero_copy; ch->horner_threads = ctx->horner_threads; ch->host_split = ctx->host_split;
+  ch->blocking_sync = ctx->blocking_sync; ch->stage_sort = ctx->stage_sort; ch->use_partition_sort = ctx->use_partition_sort; ch->big_bins = ctx->big_bins;
+  const int n_lo = plan.nwin / 2, n_hi = plan.nwin - n_lo;
+  ChainHooks hi;
+  hi.after_prepare = ctx->ev_prep; hi.after_accumulate = ctx->ev_acc;
+  int rc = msm_enqueue(ctx, src, d_scalars32, n, plan, n_lo, -n_hi, hi);
+  if (rc) return rc;
+  PtSrc shared;
+  shared.kind = PtSrc::PREPARED;
+  shared.p = src.kind == PtSrc::PREPARED ? src.p : ctx->d_pts;
+  shared.flags = src.kind == PtSrc::PREPARED ? src.flags : ctx->d_flags;
+  ChainHooks lo;
+  lo.before_start = ctx->ev_prep; lo.before_accumulate = ctx->ev_acc;
+  rc = msm_enqueue(ch, shared, d_scalars32, n, plan, 0, -n_lo, lo);
+  if (rc) { snprintf(ctx->err, sizeof ctx->err, "%s", ch->err); cg1h::jac dummy; (void)msm_finish(ctx, dummy); return rc; }
+  ctx->pend_split = true;
+  return CG1_OK;
+}
+}  // namespace cg1
+
 namespace {
 struct DevBuf {                       // frees on every exit path of the host-pointer convenience entry points
   void* p = nullptr;
@@ -998,7 +1156,7 @@ cg1_ctx* cg1_ctx_create_cu_mask(int device, const uint32_t* cu_mask, size_t n_wo
   if (hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->sync_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) { delete ctx; return nullptr; }
   for (int i = 0; i <= CG1_NPHASE; ++i) if (hipEventCreate(&ctx->ev[i]) != hipSuccess) { delete ctx; return nullptr; }
-  if (hipHostMalloc((void**)&ctx->h_flag, 64) != hipSuccess || hipHostGetDevicePointer((void**)&ctx->h_flag_dev, ctx->h_flag, 0) != hipSuccess) { delete ctx; return nullptr; }
+  if (hipHostMalloc((void**)&ctx->h_flag, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess || hipHostGetDevicePointer((void**)&ctx->h_flag_dev, ctx->h_flag, 0) != hipSuccess) { delete ctx; return nullptr; }
   *ctx->h_flag = 0;
   return ctx;
 }
@@ -1006,8 +1164,16 @@ cg1_ctx* cg1_ctx_create(int device) { return cg1_ctx_create_cu_mask(device, null
 void cg1_ctx_destroy(cg1_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
+  if (ctx->child) { cg1_ctx_destroy(ctx->child); ctx->child = nullptr; }
+  if (ctx->ev_prep) (void)hipEventDestroy(ctx->ev_prep);
+  if (ctx->ev_acc) (void)hipEventDestroy(ctx->ev_acc);
   cg1::free_bufs(ctx);
   if (ctx->d_merlin_rows) (void)hipFree(ctx->d_merlin_rows);
+  if (ctx->d_small_partial) (void)hipFree(ctx->d_small_partial);
+  if (ctx->d_small_ctr) (void)hipFree(ctx->d_small_ctr);
+  if (ctx->d_small_pts) (void)hipFree(ctx->d_small_pts);
+  if (ctx->d_small_flags) (void)hipFree(ctx->d_small_flags);
+  if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
   if (ctx->d_stage_pts) (void)hipFree(ctx->d_stage_pts);
   if (ctx->d_stage_sc) (void)hipFree(ctx->d_stage_sc);
   if (ctx->h_flag) (void)hipHostFree(ctx->h_flag);
@@ -1108,6 +1274,9 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "stage_sort")) { ctx->stage_sort = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "quad")) { ctx->quad = value ? 1 : 0; return CG1_OK; }
+  if (!strcmp(name, "small_msm")) { ctx->small_msm = value ? 1 : 0; return CG1_OK; }
+  if (!strcmp(name, "split")) { ctx->split = value ? 1 : 0; return CG1_OK; }
+  if (!strcmp(name, "split_min_log2n")) { if (value < 10 || value > 31) return CG1_ERR_ARG; ctx->split_min_n = (size_t)1 << value; return CG1_OK; }
   if (!strcmp(name, "reduce_2d")) { ctx->reduce_2d = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "partition_sort")) { ctx->use_partition_sort = value ? 1 : 0; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "blocking_sync")) { ctx->blocking_sync = value != 0; return CG1_OK; }
@@ -1336,6 +1505,8 @@ int cg1_get_timings(const cg1_ctx* ctx, float* phase_ms, float* host_tail_ms, in
   if (window_c) *window_c = ctx->last_c;
   return CG1_OK;
 }
+
+int cg1_get_last_launches(const cg1_ctx* ctx) { return ctx ? ctx->last_acc_launches : -1; }
 
 int cg1_get_last_counts(const cg1_ctx* ctx, uint32_t* entries, uint32_t* chunks) {
   if (!ctx) return CG1_ERR_ARG;

@@ -86,6 +86,29 @@ static PyObject* pf_pack_points(PyObject* self, PyObject* args) {
   return Py_BuildValue("ni", n, normalised);
 }
 
+/* pack_affine(seq, dst_addr, capacity_points) -> n
+ * Copies the cached affine96 record (slot `_a`, filled by py_arkworks_bls12381.ensure_normalised) of every G1Point to dst_addr + 96 i. */
+static PyObject* pf_pack_affine(PyObject* self, PyObject* args) {
+  PyObject* seq; unsigned long long addr; Py_ssize_t cap;
+  if (!PyArg_ParseTuple(args, "OKn", &seq, &addr, &cap)) return NULL;
+  if (!g_point_type || g_cache_off[0] < 0) { PyErr_SetString(PyExc_RuntimeError, "_pyface.bind() has not run"); return NULL; }
+  PyObject* fast = PySequence_Fast(seq, "pack_affine expects a sequence of G1Point");
+  if (!fast) return NULL;
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+  if (n > cap) { Py_DECREF(fast); PyErr_SetString(PyExc_ValueError, "staging buffer too small"); return NULL; }
+  PyObject** items = PySequence_Fast_ITEMS(fast);
+  uint8_t* dst = (uint8_t*)(uintptr_t)addr;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject* o = items[i];
+    if (Py_TYPE(o) != g_point_type) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd is not a G1Point", i); return NULL; }
+    PyObject* b = slot_get(o, g_cache_off[0]);
+    if (!b || !PyBytes_CheckExact(b) || PyBytes_GET_SIZE(b) != 96) { Py_DECREF(fast); PyErr_Format(PyExc_ValueError, "element %zd has not been normalised", i); return NULL; }
+    memcpy(dst + 96 * (size_t)i, PyBytes_AS_STRING(b), 96);
+  }
+  Py_DECREF(fast);
+  return PyLong_FromSsize_t(n);
+}
+
 /* pack_scalars(seq, dst_addr, capacity) -> n
  * Writes int(s) of every Scalar of `seq` as 32 little-endian bytes to dst_addr + 32 i (Scalar.to_le_bytes, one call). */
 static PyObject* pf_pack_scalars(PyObject* self, PyObject* args) {
@@ -173,6 +196,7 @@ static PyMethodDef methods[] = {
     {"same_items", pf_same_items, METH_VARARGS, "same_items(a, b) -> bool"},
     {"bind", pf_bind, METH_VARARGS, "bind(G1Point, Scalar)"},
     {"pack_points", pf_pack_points, METH_VARARGS, "pack_points(seq, dst_addr, capacity) -> (n, all_normalised)"},
+    {"pack_affine", pf_pack_affine, METH_VARARGS, "pack_affine(seq, dst_addr, capacity) -> n"},
     {"pack_scalars", pf_pack_scalars, METH_VARARGS, "pack_scalars(seq, dst_addr, capacity) -> n"},
     {"points_from_blobs", pf_points_from_blobs, METH_VARARGS, "points_from_blobs(data, n) -> list of G1Point"},
     {NULL, NULL, 0, NULL}};

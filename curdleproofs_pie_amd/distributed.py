@@ -41,11 +41,52 @@ def sum_blobs(blobs: List[bytes]) -> bytes:
     return acc.raw
 
 
+def _private_dir() -> str:
+    """A directory only this user can enter: the rendezvous file holds the hub's port AND the only authenticator (the nonce), so it
+    must not be readable -- and its name not pre-creatable -- by other local users."""
+    import stat
+
+    uid = os.getuid()
+    run = os.environ.get("XDG_RUNTIME_DIR")
+    cands = ([os.path.join(run, "cg1_rdzv")] if run else []) + [os.path.join(tempfile.gettempdir(), "cg1_rdzv_%d" % uid)]
+    err = None
+    for d in cands:
+        try:
+            os.makedirs(d, mode=0o700, exist_ok=True)
+            st = os.lstat(d)
+            if stat.S_ISDIR(st.st_mode) and st.st_uid == uid and not (st.st_mode & 0o077):
+                return d
+            err = "%s is not a private directory of uid %d" % (d, uid)
+        except OSError as e:
+            err = str(e)
+    raise N.NativeError("no private directory for the rendezvous file (%s); set CG1_RDZV_FILE" % err)
+
+
 def default_rendezvous_file() -> str:
     explicit = os.environ.get("CG1_RDZV_FILE")
     if explicit:
         return explicit
-    return os.path.join(tempfile.gettempdir(), "cg1_rdzv_%d_%d_%s" % (os.getuid(), os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    return os.path.join(_private_dir(), "rdzv_%d_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+
+
+def _read_rendezvous(path: str):
+    """(port, nonce) from a rendezvous file this user wrote (regular file, own uid, no group / other access, no symlink), else None."""
+    import stat
+
+    try:
+        fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+    except OSError:
+        return None
+    try:
+        st = os.fstat(fd)
+        if not stat.S_ISREG(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+            return None
+        port, nonce = (int(x) for x in os.read(fd, 128).split())
+        return port, nonce
+    except (OSError, ValueError):
+        return None
+    finally:
+        os.close(fd)
 
 
 def init_comm(rank: int, world: int, rendezvous_file: Optional[str] = None, timeout_s: float = 600.0) -> "N.Comm":
@@ -57,9 +98,12 @@ def init_comm(rank: int, world: int, rendezvous_file: Optional[str] = None, time
     deadline = time.monotonic() + timeout_s
     if rank == 0:
         nonce = secrets.randbits(63)
-        tmp = "%s.%d.tmp" % (path, os.getpid())
-        with open(tmp, "w") as f:
-            f.write("%d %d\n" % (comm.port, nonce))
+        tmp = "%s.%d.%x.tmp" % (path, os.getpid(), secrets.randbits(32))
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)      # never through a planted name or symlink
+        try:
+            os.write(fd, b"%d %d\n" % (comm.port, nonce))
+        finally:
+            os.close(fd)
         os.replace(tmp, path)                       # atomic: a reader sees the old file, no file, or the whole new one
         try:
             comm.check(comm.connect("", 0, nonce, int(timeout_s * 1000)))
@@ -70,11 +114,8 @@ def init_comm(rank: int, world: int, rendezvous_file: Optional[str] = None, time
                 pass
         return comm
     while True:
-        try:
-            with open(path) as f:
-                port, nonce = (int(x) for x in f.read().split())
-        except (OSError, ValueError):
-            port = None
+        got = _read_rendezvous(path)
+        port, nonce = got if got else (None, None)
         if port:
             left_ms = max(1000, int((deadline - time.monotonic()) * 1000))
             rc = comm.connect("127.0.0.1", port, nonce, left_ms)

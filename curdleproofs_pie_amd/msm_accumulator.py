@@ -11,7 +11,7 @@ from collections import OrderedDict
 from typing import Dict, Iterable, List, Tuple
 
 from . import _native as N
-from .py_arkworks_bls12381 import (CURVE_ORDER, G1Point, Scalar, ensure_normalised, ident, pack_points, pack_scalars, points_from_blobs,
+from .py_arkworks_bls12381 import (CURVE_ORDER, G1Point, Scalar, ensure_normalised, ident, pack_affine, pack_points, pack_scalars, points_from_blobs,
                                    points_to_affine96, points_to_compressed, same_items)
 from .util import random_scalar
 
@@ -23,6 +23,7 @@ _ZERO96 = bytes(96)
 # list's elements (G1Point objects are immutable): the prover passes crs.vec_G / vec_H / vec_R ... to dozens of compute_MSM calls
 # (curdleproofs.py:77,94,95,319; grand_prod.py:54,90; ipa.py:97,98) -- from the second sighting on only the scalars are uploaded.
 _stagings: Dict[int, "N.Staging"] = {}
+_HOST_NORMALISE_MAX = 1024               # up to here compute_MSM normalises on the host (cached per object); above, on the device
 _VEC_CACHE_MAX_ENTRIES = 64
 _VEC_CACHE_MAX_POINTS = 1 << 23          # ~1 GiB of prepared records on the device, of 288
 _vec_cache: "OrderedDict[int, tuple]" = OrderedDict()      # fingerprint -> (tuple of the point objects, N.Vec)
@@ -111,6 +112,12 @@ def compute_MSM(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> G1Point:
         last_path = "resident"
         return G1Point._from_blob(ctx.msm_vec(vec, sc_addr, n))
     pt_addr = st.points(n)
+    if n <= _HOST_NORMALISE_MAX:
+        # the protocol's own sizes (4 ... 627 terms): the device inversion (one Fermat chain per lane, ~0.45 ms whatever n) costs more
+        # than the call; these few points are normalised on the host, once per OBJECT (CRS points come back call after call)
+        pack_affine(bases, pt_addr, (st.cap_pts * 3) // 2)
+        last_path = "affine"
+        return G1Point._from_blob(ctx.msm_affine(pt_addr, sc_addr, n))
     _, normalised = pack_points(bases, pt_addr, st.cap_pts)
     last_path = "blobs_normalised" if normalised else "blobs"
     return G1Point._from_blob(ctx.msm_blobs(pt_addr, sc_addr, n, bool(normalised)))

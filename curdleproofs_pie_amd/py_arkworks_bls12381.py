@@ -272,6 +272,19 @@ def pack_points(points, addr: int, capacity: int):
     return n, all(p._b[96:] in (_MONT_ONE, _ZERO48) for p in points)
 
 
+def pack_affine(points, addr: int, capacity: int) -> int:
+    """Write the affine96 records of `points` (normalising, once per object, those not normalised before) to addr + 96 i."""
+    ensure_normalised(points)
+    if _pyface is not None:
+        return _pyface.pack_affine(points, addr, capacity)
+    n = len(points)
+    if n > capacity:
+        raise ValueError("staging buffer too small")
+    raw = b"".join([p._a for p in points])
+    ctypes.memmove(addr, raw, len(raw))
+    return n
+
+
 def pack_scalars(scalars, addr: int, capacity: int) -> int:
     """Write int(s) of every Scalar (or plain int) of `scalars` as 32 little-endian bytes to addr + 32 i."""
     if _pyface is not None:

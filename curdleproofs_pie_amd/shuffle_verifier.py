@@ -620,7 +620,7 @@ class ShuffleBatchVerifier:
 
         def run(kid, qi, qo):
             try:
-                for st in kid.verify_stream(iter(qi.get, None), mode, rng):
+                for st in kid.verify_stream(iter(qi.get, None), mode, None):      # (weights were drawn by the feeding thread)
                     qo.put((st, dict(kid.last_stats)))
             except BaseException as e:                      # (reported to the consumer at this batch's turn)
                 qo.put(e)
@@ -642,6 +642,12 @@ class ShuffleBatchVerifier:
         try:
             k = 0
             for batch in batches:
+                if rng is not None:
+                    # a caller's generator (tests, seeded runs) is used by THIS thread only, in batch order: reproducible weights, and
+                    # no generator is shared between the pipelines' threads
+                    batch = tuple(batch) + (None,) * (5 - len(batch))
+                    if batch[4] is None:
+                        batch = batch[:4] + (self.draw_weights(batch[2], rng),)
                 in_q[k % P].put(batch)
                 order.append(k % P)
                 k += 1
@@ -671,7 +677,9 @@ class ShuffleBatchVerifier:
         side | rows + merged MSM), verdicts yielded in order."""
         from collections import deque
 
-        if self.pipelines > 1:
+        # several pipelines pay off on a STREAM of batches; one batch alone (is_valid_whisk_shuffle_proof, verify_many) runs on this
+        # verifier's own lanes: no child verifiers, contexts or threads are made for it
+        if self.pipelines > 1 and not (isinstance(batches, (list, tuple)) and len(batches) <= 1):
             yield from self._verify_stream_pipelines(batches, mode, rng)
             return
 
@@ -834,9 +842,15 @@ class ShuffleBatchVerifier:
                            None if w is None else bytes(w[a * N_WEIGHTS * 32: (a + m) * N_WEIGHTS * 32]))
 
             out: List[int] = []
+            total: dict = {}
             for st in self.verify_stream(pieces(), mode=mode, rng=rng):
                 out += st
-            self.last_status = out
+                for k, v in (self.last_stats or {}).items():             # the call's statistics: summed over its pieces
+                    if isinstance(v, bool) or not isinstance(v, (int, float)):
+                        total[k] = v
+                    else:
+                        total[k] = total.get(k, 0) + v
+            self.last_status, self.last_stats = out, total
             return out
         return next(self.verify_stream([(instances, proofs, n, pre_status, weights)], mode=mode, rng=rng))
 

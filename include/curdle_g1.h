@@ -93,7 +93,8 @@ void* cg1_ctx_stream(cg1_ctx* ctx);                                  /* the cont
 /* Tuning and A/B switches of a context (defaults are the measured best; DESIGN.md section 9 has the measurements):
  *   MSM plan / phases   "chunk_len" "seg_m" "auto_plan" "stage_sort" "partition_sort" "big_bins" "wave_agg" "quad" "reduce_2d" "rowcol_quad"
  *                       "rowcol_quad_max" "fold_pass" "tree_half" "scan_one" "host_split" "horner_threads" "zero_copy" "batched_host_horner_max"
- *                       "batch_mul_quad_max"
+ *                       "batch_mul_quad_max" "small_msm" (1: calls of <= 1024 terms run as ONE launch, k_msm_small; 0: the regime-A chain)
+ *                       "split" (1: a call of >= 2^"split_min_log2n" terms runs as two launch chains -- high and low half of the windows -- on two streams)
  *   waiting             "blocking_sync" (sleep instead of spinning on the stream), "profile" (0: no events, 1: around k_accumulate, 2: every phase)
  *   codec               "decompress_waves" (2 | 3: waves per SIMD k_batch_decompress is compiled for)
  *   transcripts         "merlin_rows" (1: block program when the operation list fits), "merlin_sync" (1: lanes of a wave permute together),
@@ -152,6 +153,8 @@ int cg1_get_timings(const cg1_ctx* ctx, float phase_ms[CG1_NPHASE], float* host_
 /* work counts of the last MSM call: non-zero signed digits sorted into buckets (= bucket additions + first-entry copies)
  * and the chunks k_accumulate ran (one copy each), so  mixed additions = entries - chunks */
 int cg1_get_last_counts(const cg1_ctx* ctx, uint32_t* entries, uint32_t* chunks);
+/* k_accumulate launches of the last MSM call: 2 when it ran as two launch chains ("split"), 1, or 0 when k_msm_small served it */
+int cg1_get_last_launches(const cg1_ctx* ctx);
 /* hipEvent stopwatch on the context's compute stream: device time of everything enqueued between begin and end */
 int cg1_timer_begin(cg1_ctx* ctx);
 int cg1_timer_end(cg1_ctx* ctx, float* ms);

@@ -244,42 +244,44 @@ def test_compute_msm_python_face_at_config2_size(api):
 
 
 def test_compute_msm_paths_blobs_and_resident_vectors(api):
-    """compute_MSM over the objects' own blobs (normalised on the device, k_prepare_blobs) and over a base list that has become
-    resident on the device (second sighting of the same objects): every path gives the reference loop's result."""
+    """compute_MSM's three ways in: a small call over host-normalised points (normal forms cached per object), a large one over
+    the objects' own blobs (normalised on the device, k_prepare_blobs), and a base list that has become resident on the device
+    (second sighting of the same objects).  Every path gives the reference loop's result."""
     A, U = api
     import curdleproofs_pie_amd.msm_accumulator as M
 
-    M.clear_vec_cache()
-    random.seed(21)
-    n = 200
-    bases = [U.get_random_point() for _ in range(n)]                         # G * s: projective blobs, Z != 1
-    bases[17] = U.Z1
-    bases[40] = bases[3]
     want_of = lambda b, s: O.g1_compress(O.compute_MSM_fast([O.g1_decompress(bytes(x.to_compressed_bytes())) for x in b], [int(v) for v in s]))
-    seen = []
-    for call in range(4):
+    for n, first_path in ((200, "affine"), (1500, "blobs")):
+        M.clear_vec_cache()
+        random.seed(21 + n)
+        bases = [U.get_random_point() for _ in range(n)]                         # G * s: projective blobs, Z != 1
+        bases[17] = U.Z1
+        bases[40] = bases[3]
+        seen = []
+        for call in range(4):
+            scalars = [U.random_scalar() for _ in range(n)]
+            got = A.compute_MSM(bases, scalars)
+            seen.append(M.last_path)
+            assert bytes(got.to_compressed_bytes()) == want_of(bases, scalars)
+        assert seen == [first_path, "resident", "resident", "resident"]
+        # a prefix of the resident list is another sequence of objects: its own entry
+        scalars = [U.random_scalar() for _ in range(n - 9)]
+        assert bytes(A.compute_MSM(bases[: n - 9], scalars).to_compressed_bytes()) == want_of(bases[: n - 9], scalars)
+        assert M.last_path == first_path
+        # replacing an element of the caller's list must not hit the stale resident vector
+        bases[5] = U.get_random_point()
         scalars = [U.random_scalar() for _ in range(n)]
-        got = A.compute_MSM(bases, scalars)
-        seen.append(M.last_path)
-        assert bytes(got.to_compressed_bytes()) == want_of(bases, scalars)
-    assert seen == ["blobs", "resident", "resident", "resident"]
-    # a prefix of the resident list is another sequence of objects: its own entry
-    scalars = [U.random_scalar() for _ in range(n - 9)]
-    assert bytes(A.compute_MSM(bases[: n - 9], scalars).to_compressed_bytes()) == want_of(bases[: n - 9], scalars)
-    assert M.last_path == "blobs"
-    # replacing an element of the caller's list must not hit the stale resident vector
-    bases[5] = U.get_random_point()
-    scalars = [U.random_scalar() for _ in range(n)]
-    assert bytes(A.compute_MSM(bases, scalars).to_compressed_bytes()) == want_of(bases, scalars)
-    assert M.last_path == "blobs"
-    # normal forms (decoded points) skip the inversion
-    dec = [A.G1Point.from_compressed_bytes_unchecked(b.to_compressed_bytes()) for b in bases]
-    assert bytes(A.compute_MSM(dec, scalars).to_compressed_bytes()) == want_of(bases, scalars)
-    assert M.last_path == "blobs_normalised"
-    assert A.compute_MSM(dec, scalars) == A.compute_MSM(bases, scalars) and M.last_path == "resident"
-    # every size 1 .. 40 and a few around the lane / block edges of k_prepare_blobs
+        assert bytes(A.compute_MSM(bases, scalars).to_compressed_bytes()) == want_of(bases, scalars)
+        assert M.last_path == first_path
+        if n > 1024:
+            # normal forms (decoded points) skip the device inversion
+            dec = [A.G1Point.from_compressed_bytes_unchecked(b.to_compressed_bytes()) for b in bases]
+            assert bytes(A.compute_MSM(dec, scalars).to_compressed_bytes()) == want_of(bases, scalars)
+            assert M.last_path == "blobs_normalised"
+            assert A.compute_MSM(dec, scalars) == A.compute_MSM(bases, scalars) and M.last_path == "resident"
+    # every size 1 .. 40 and a few around the slice edges of the small kernel
     pool = [U.get_random_point() for _ in range(64)] + [U.Z1]
-    for m in list(range(1, 41)) + [127, 128, 129, 255, 256, 257, 1023]:
+    for m in list(range(1, 41)) + [127, 128, 129, 255, 256, 257, 1023, 1024, 1025]:
         b = [pool[random.randrange(len(pool))] for _ in range(m)]
         s = [U.random_scalar() for _ in range(m)]
         assert bytes(A.compute_MSM(b, s).to_compressed_bytes()) == want_of(b, s), m
