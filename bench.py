@@ -212,11 +212,15 @@ def open_comm(args, rank, world, ctx):
     from curdleproofs_pie_amd import _native as N
     from curdleproofs_pie_amd.distributed import init_comm
 
+    t0 = time.perf_counter()
     comm = init_comm(rank, world, timeout_s=900.0)
     comm.note = None
+    comm.rendezvous_s, comm.attach_s = time.perf_counter() - t0, None
     if args.backend == "rccl":
         try:
-            comm.attach_rccl(ctx)
+            t1 = time.perf_counter()
+            comm.attach_rccl(ctx)                               # ncclGetUniqueId + ncclCommInitRank: collective, seconds on a cold node
+            comm.attach_s = time.perf_counter() - t1
             err = b""
         except N.NativeError as e:
             err = str(e).encode()[:200]
@@ -226,6 +230,7 @@ def open_comm(args, rank, world, ctx):
             comm.barrier()
             comm.close()                                       # some ranks may hold a half-made RCCL communicator: every rank starts over
             comm = init_comm(rank, world, timeout_s=900.0)     # (rank 0 removed the rendezvous file after the first connect and writes it anew)
+            comm.rendezvous_s, comm.attach_s = time.perf_counter() - t0, None
             comm.note = "RCCL not attached (rank %d: %s): socket transport" % bad[0]
             if rank == 0:
                 print("bench.py: " + comm.note, file=sys.stderr, flush=True)
@@ -408,7 +413,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the proofs-verified/s object and the extra N>1 records")
     ap.add_argument("--no-python-face", action="store_true", help="skip the python_face / unchanged_control_flow objects (compute_MSM over G1Point / Scalar "
                                                                   "objects at 2^16 and 2^20; the reference's own call sequence replayed)")
-    ap.add_argument("--batch", type=int, default=1024, help="proofs per step (secondary metric / --mode verify)")
+    ap.add_argument("--batch", type=int, default=None, help="proofs per GPU per step (secondary metric / --mode verify): 1024 by default -- BASELINE "
+                                                            "config 3 -- and 2048 for --mode verify at N > 1 (config 5's 16 384 proofs over 8 GPUs)")
     ap.add_argument("--verify-steps", type=int, default=40, help="batches of the secondary stream (its fill and drain are inside the timed region)")
     ap.add_argument("--verify-mode", choices=["merged", "independent"], default="merged")
     ap.add_argument("--front-end", choices=["auto", "host", "device"], default="auto",
@@ -423,6 +429,8 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (implies --backend socket)")
     args = ap.parse_args()
 
+    if args.batch is None:
+        args.batch = 2048 if (args.mode == "verify" and args.gpus > 1) else 1024
     if args.backend in ("nccl", "gloo"):                      # the names torch gives the same two transports
         args.backend = {"nccl": "rccl", "gloo": "socket"}[args.backend]
     if args.same_device and not os.environ.get("CG1_BENCH_TRY_RCCL_ON_ONE_DEVICE"):
@@ -583,6 +591,7 @@ def main():
             if args.shard != "windows":
                 w = run("windows", n_per_gpu, args.seed, args.steps, args.warmup)
                 extra["windows_only"] = {"ms_per_step": w["ms_per_step"], "value": w["value"], "per_rank_ms_per_step": w["per_rank_ms_per_step"],
+                                         "input_bytes_resident_per_rank": 128 * n_per_gpu * world,      # every rank holds ALL points and scalars
                                          "same_result_as_default_shard": bool(N.cg1_eq(w["result"], main_rec["result"])),
                                          "predicted_ms_per_step_emulated": EMULATED_MS["windows"].get(world)}
             # BASELINE config 4: ONE MSM of 2^22 terms in total over the N GPUs (strong scaling)
@@ -668,7 +677,10 @@ def main():
                                  "world_seen_source": "ncclCommCount" if comm.transport == "rccl" else "ranks connected to the TCP hub",
                                  "what": "cg1_comm_allreduce_g1: all-gather of one 144-byte partial G1 sum per rank (ncclAllGather on the context's "
                                          "stream when the backend is rccl), then world-1 host additions on every rank",
-                                 "bytes_per_step": 144 * world, "ms_per_exchange": r["exchange_ms"]}
+                                 "bytes_per_step": 144 * world, "ms_per_exchange": r["exchange_ms"],
+                                 "rendezvous_s": getattr(comm, "rendezvous_s", None), "rccl_attach_s": getattr(comm, "attach_s", None)}
+            out["measured_on"] = ("%d ranks, one GPU each: a measured multi-GPU line" % world) if not args.same_device else \
+                                 ("%d ranks REHEARSING on one GPU (--same-device): not a scaling measurement" % world)
             out["predicted_ms_per_step_emulated"] = EMULATED_MS.get(args.shard, {}).get(world)
         if world == 1:
             # the practical ceiling of the same arithmetic: chains of dependent mixed additions on register-resident operands

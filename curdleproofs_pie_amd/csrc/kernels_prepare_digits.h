@@ -150,16 +150,24 @@ struct WinPlan {
   CG1_HD int width(int w) const { return w < n_hi ? cmax : cmax - 1; }
   CG1_HD int off(int w) const { return w < n_hi ? w * cmax : n_hi * cmax + (w - n_hi) * (cmax - 1); }
 };
-// Which windows of the plan one launch chain takes, as the (rank, world) pair the kernels carry:
-//   world > 0   windows w = rank (mod world)            -- the per-GPU shares of a window-sharded MSM; (0, 1) = every window
-//   world < 0   the -world consecutive windows from `rank` -- the two halves of ONE call that run as two chains on two streams
+// Which windows of the plan one launch chain takes, as the (rank, sel) pair the kernels carry:
+//   sel = world | lw0 << 8 | cnt << 16
+//   the share: windows w = rank (mod world) -- the per-GPU shares of a window-sharded MSM; world = 1: every window;
+//   of the share's windows (numbered 0, 1, ... in ascending w) the chain takes the cnt consecutive ones from lw0 (cnt = 0: all of
+//   them) -- the two halves of ONE call that run as two chains on two streams.
 // win_local: the chain's local index of global window w, or -1 when the window is not its own.
-CG1_HD int win_local(int w, int rank, int world) {
-  if (world > 0) return (w % world) == rank ? w / world : -1;
-  return (w >= rank && w < rank - world) ? w - rank : -1;
+CG1_HD int win_local(int w, int rank, int sel) {
+  const int world = sel & 0xff, lw0 = (sel >> 8) & 0xff, cnt = (sel >> 16) & 0xff;
+  if ((w % world) != rank) return -1;
+  const int lw = w / world - lw0;
+  return (lw >= 0 && (cnt == 0 || lw < cnt)) ? lw : -1;
 }
-CG1_HD int win_global(int lw, int rank, int world) { return world > 0 ? rank + lw * world : rank + lw; }
-CG1_HD int win_count(int nwin, int rank, int world) { return world > 0 ? (nwin - rank + world - 1) / world : -world; }
+CG1_HD int win_global(int lw, int rank, int sel) { return rank + (lw + ((sel >> 8) & 0xff)) * (sel & 0xff); }
+CG1_HD int win_count(int nwin, int rank, int sel) {
+  const int world = sel & 0xff, lw0 = (sel >> 8) & 0xff, cnt = (sel >> 16) & 0xff;
+  return cnt ? cnt : (nwin - rank + world - 1) / world - lw0;
+}
+CG1_HD int win_sel(int world, int lw0, int cnt) { return world | (lw0 << 8) | (cnt << 16); }
 
 struct DigitIter {
   uint32_t s[8];

@@ -169,11 +169,13 @@ struct Ctx {
     const PointWords* hout = nullptr;   // where the exported items land (ctx->h_out, or h_small_out for k_msm_small)
     std::chrono::steady_clock::time_point h0, h1;
   } pend;
-  // "split": one large call runs as TWO launch chains on two streams -- the high half of the windows on this context, the low half on
-  // `child` (its own scratch buffers, stream and export flag; the prepared points are shared).  The low half's sort phases run under
-  // the high half's k_accumulate, the high half's reduction tree, export and host Horner under the low half's k_accumulate, so only
-  // half of every non-accumulate phase stays on the critical path (profiles/r04_split_ab.txt).
-  int split = 1;
+  // "split" (A/B switch, OFF): one large call as TWO launch chains on two streams -- the high half of the windows on this context, the
+  // low half on `child` (own scratch buffers, stream and export flag; shared prepared points) -- meant to run the low half's sort under
+  // the high half's k_accumulate and the high half's reduction tail under the low half's.  MEASURED A LOSS (profiles/r04_split_ab.txt:
+  // 2^20 3.25 ms against 2.95, 2^18 1.54 against 1.22; only 2^16 gains 3 %): the resident blocks of k_accumulate hold every SIMD's
+  // registers for their whole ~1 ms life, so the other stream's kernels are dispatched only when it drains -- the two chains run one
+  // after the other, and each pays its own launch chain and the shorter chunks of half the entries.
+  int split = 0;
   size_t split_min_n = (size_t)1 << 17;
   cg1_ctx* child = nullptr;
   hipEvent_t ev_prep = nullptr, ev_acc = nullptr;
@@ -463,7 +465,7 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   ctx->pend.active = false;
   HIPCHK(hipSetDevice(ctx->device));
   const int c = plan.cmax, nwin = plan.nwin;
-  const int nlw = win_count(nwin, rank, world);                // windows w = rank, rank+world, ... (world < 0: -world consecutive ones from rank)
+  const int nlw = win_count(nwin, rank, world);                // `world` is a window selector (kernels_prepare_digits.h win_sel): the share w = rank (mod world), or a run of it
   if (nlw <= 0) return CG1_OK;
   const uint32_t NB = 1u << (c - 1);
   const uint32_t m = std::min<uint32_t>(ctx->seg_m, NB);
@@ -785,7 +787,7 @@ static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32
 }
 
 static Ctx* child_of(Ctx* ctx);
-static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan);
+static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan, int rank, int world);
 
 // One MSM: this context's share (windows w = rank mod world) of sum_i scalar_i * point_i.
 // c = 0: automatic plan; 4..16: uniform windows of that width; -16..-4: the balanced plan with cmax = -c.
@@ -797,7 +799,7 @@ int msm_begin(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int
   ctx->pend_c = 0;
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "n too large"); return CG1_ERR_ARG; }
-  if (world < 1 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
+  if (world < 1 || world > 255 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
   if (ctx->small_msm && n <= SM_MAX_N && world == 1 && (c == 0 || (c >= 4 && c <= 9 && c != 5))) {
     if (c == 0) c = pick_small_c(n);
     ctx->pend_c = c;
@@ -809,7 +811,7 @@ int msm_begin(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int
   const WinPlan plan = make_plan(c);
   ctx->pend_c = c;
   ctx->pend_split = false;
-  if (ctx->split && world == 1 && n >= ctx->split_min_n && plan.nwin >= 4) return msm_begin_split(ctx, src, d_scalars32, n, plan);
+  if (ctx->split && n >= ctx->split_min_n && win_count(plan.nwin, rank, world) >= 2) return msm_begin_split(ctx, src, d_scalars32, n, plan, rank, world);
   return msm_enqueue(ctx, src, d_scalars32, n, plan, rank, world);
 }
 int msm_end(Ctx* ctx, cg1h::jac& result) {
@@ -1005,7 +1007,7 @@ static Ctx* child_of(Ctx* ctx) { return static_cast<Ctx*>(ctx->child); }
 // One call as two launch chains: this context takes the HIGH half of the plan's windows (and prepares the points), its child the
 // LOW half on its own stream.  The child starts once the prepared records exist, and its k_accumulate waits for this context's to
 // finish: the two dominant launches run back to back, everything around them overlaps with one of them.
-static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan) {
+static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan, int rank, int world) {
   HIPCHK(hipSetDevice(ctx->device));
   if (!ctx->child) {
     cg1_ctx* made = ctx->cu_mask.empty() ? cg1_ctx_create(ctx->device) : cg1_ctx_create_cu_mask(ctx->device, ctx->cu_mask.data(), ctx->cu_mask.size());
@@ -1020,10 +1022,10 @@ static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, 
   ch->rowcol_quad = ctx->rowcol_quad; ch->rowcol_quad_max = ctx->rowcol_quad_max; ch->fold_pass = ctx->fold_pass; ch->tree_half = ctx->tree_half;
   ch->scan_one = ctx->scan_one; ch->zero_copy = ctx->zero_copy; ch->horner_threads = ctx->horner_threads; ch->host_split = ctx->host_split;
   ch->blocking_sync = ctx->blocking_sync; ch->stage_sort = ctx->stage_sort; ch->use_partition_sort = ctx->use_partition_sort; ch->big_bins = ctx->big_bins;
-  const int n_lo = plan.nwin / 2, n_hi = plan.nwin - n_lo;
+  const int n_own = win_count(plan.nwin, rank, world), n_lo = n_own / 2, n_hi = n_own - n_lo;      // this rank's windows: the upper ones here, the lower ones on the child
   ChainHooks hi;
   hi.after_prepare = ctx->ev_prep; hi.after_accumulate = ctx->ev_acc;
-  int rc = msm_enqueue(ctx, src, d_scalars32, n, plan, n_lo, -n_hi, hi);
+  int rc = msm_enqueue(ctx, src, d_scalars32, n, plan, rank, win_sel(world, n_lo, n_hi), hi);
   if (rc) return rc;
   PtSrc shared;
   shared.kind = PtSrc::PREPARED;
@@ -1031,7 +1033,7 @@ static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, 
   shared.flags = src.kind == PtSrc::PREPARED ? src.flags : ctx->d_flags;
   ChainHooks lo;
   lo.before_start = ctx->ev_prep; lo.before_accumulate = ctx->ev_acc;
-  rc = msm_enqueue(ch, shared, d_scalars32, n, plan, 0, -n_lo, lo);
+  rc = msm_enqueue(ch, shared, d_scalars32, n, plan, rank, win_sel(world, 0, n_lo), lo);
   if (rc) { snprintf(ctx->err, sizeof ctx->err, "%s", ch->err); cg1h::jac dummy; (void)msm_finish(ctx, dummy); return rc; }
   ctx->pend_split = true;
   return CG1_OK;

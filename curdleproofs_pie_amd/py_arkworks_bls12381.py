@@ -237,7 +237,13 @@ class G1Point(metaclass=_PinnedDir):
         rc = N.cg1_decompress(b, data, 1 if check else 0)
         if rc != N.OK:
             raise ValueError(f"Err From Rust: serialised data seems to be invalid (code {rc})")
-        return G1Point._from_blob(b.raw)
+        p = G1Point._from_blob(b.raw)
+        if not data[0] & 0x40:
+            # a finite point decodes from exactly one encoding (compression flag, x < p, the sign bit that selected y), so these 48
+            # bytes ARE its compression: to_compressed_bytes() of a decoded point (transcript appends, util.py:27-28) costs nothing.
+            # (The infinity flag is honoured whatever the other bits say: only then may the input differ from the canonical c0 00...)
+            _set(p, "_k", data)
+        return p
 
     @staticmethod
     def from_compressed_bytes(data) -> "G1Point":

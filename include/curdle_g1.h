@@ -94,7 +94,8 @@ void* cg1_ctx_stream(cg1_ctx* ctx);                                  /* the cont
  *   MSM plan / phases   "chunk_len" "seg_m" "auto_plan" "stage_sort" "partition_sort" "big_bins" "wave_agg" "quad" "reduce_2d" "rowcol_quad"
  *                       "rowcol_quad_max" "fold_pass" "tree_half" "scan_one" "host_split" "horner_threads" "zero_copy" "batched_host_horner_max"
  *                       "batch_mul_quad_max" "small_msm" (1: calls of <= 1024 terms run as ONE launch, k_msm_small; 0: the regime-A chain)
- *                       "split" (1: a call of >= 2^"split_min_log2n" terms runs as two launch chains -- high and low half of the windows -- on two streams)
+ *                       "split" (A/B switch, default 0: a call of >= 2^"split_min_log2n" terms as two launch chains -- high and low half of its windows -- on
+ *                       two streams; measured slower than the single chain, profiles/r04_split_ab.txt)
  *   waiting             "blocking_sync" (sleep instead of spinning on the stream), "profile" (0: no events, 1: around k_accumulate, 2: every phase)
  *   codec               "decompress_waves" (2 | 3: waves per SIMD k_batch_decompress is compiled for)
  *   transcripts         "merlin_rows" (1: block program when the operation list fits), "merlin_sync" (1: lanes of a wave permute together),

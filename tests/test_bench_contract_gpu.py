@@ -125,3 +125,24 @@ def test_rccl_refusal_falls_back_to_the_socket_transport():
     col = d["collective"]
     assert col["backend"] == "socket" and "RCCL not attached" in col["backend_note"] and col["world_seen"] == 2
     assert d["config"]["result_equals_closed_form"] is True
+
+
+def test_four_rank_rehearsal_of_both_modes():
+    """The N > 1 path with more than two ranks: 4 ranks on this one GPU (the pool allows at most 6 processes on a card, this process
+    is one of them), hybrid sharding = 2 window groups x 2 point groups, then the proof-per-GPU verify mode.  Rehearsal, not a
+    scaling measurement: the line says so."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run(["timeout", "-k", "10", "500", sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1",
+                        "--logn", "14", "--same-device", "--no-cpu-baseline", "--no-secondary"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 4 and d["collective"]["world_seen"] == 4 and d["config"]["result_equals_closed_form"] is True
+    assert d["config"]["parallelism"].startswith("windows x2 . points x2")
+    assert "REHEARSING" in d["measured_on"] and d["collective"]["rendezvous_s"] >= 0
+    r = subprocess.run(["timeout", "-k", "10", "500", sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--mode", "verify", "--steps", "2", "--warmup", "1",
+                        "--batch", "128", "--same-device", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    d = _last_json(r.stdout)
+    assert d["n_gpus"] == 4 and d["unit"] == "proofs/s" and len(d["per_rank"]["ms_per_step"]) == 4

@@ -122,3 +122,47 @@ def test_bad_encodings_raise_valueerror(B):
     G1Point.from_compressed_bytes_unchecked(bytes(enc))
     with pytest.raises(ValueError):
         G1Point.from_compressed_bytes(bytes(enc))
+
+
+def test_scalar_mul_recoding_edges(native_lib):
+    """cg1_mul (G1Point * Scalar, the width-5 NAF ladder of host_g1.cpp) against the oracle's double-and-add on scalars that stress the
+    recoding: 0, 1, every digit boundary around 15 / 16 / 17 / 31 / 32 / 33, long runs of ones, r - 1, and unreduced 256-bit values
+    (the C ABI takes any 32 bytes; the Python face only ever passes values < r)."""
+    import ctypes
+    import random
+
+    N = native_lib
+    rng = random.Random(77)
+    g = ctypes.create_string_buffer(144)
+    N.cg1_generator(g)
+    base = ctypes.create_string_buffer(144)
+    N.cg1_mul(base, g.raw, (0xABCDEF12345).to_bytes(32, "little"))          # a projective base (Z != 1)
+    base_aff = O.g1_mul(O.G1_GEN, 0xABCDEF12345)
+    ks = [0, 1, 2, 3, 15, 16, 17, 31, 32, 33, 47, 48, 49, (1 << 64) - 1, 1 << 64, (1 << 128) + 1, (1 << 255) - 1, (1 << 255), (1 << 256) - 1,
+          O.R - 1, O.R, O.R + 1, int("5" * 64, 16), int("a" * 64, 16), int("f0" * 32, 16), int("0f" * 32, 16)]
+    ks += [rng.getrandbits(256) for _ in range(40)] + [rng.getrandbits(rng.randrange(1, 257)) for _ in range(40)]
+    for k in ks:
+        out = ctypes.create_string_buffer(144)
+        N.cg1_mul(out, base.raw, k.to_bytes(32, "little"))
+        cmp_ = ctypes.create_string_buffer(48)
+        N.cg1_compress(cmp_, out.raw)
+        assert cmp_.raw == O.g1_compress(O.g1_mul(base_aff, k % O.R)), hex(k)
+    ident = ctypes.create_string_buffer(144)
+    N.cg1_identity(ident)
+    out = ctypes.create_string_buffer(144)
+    N.cg1_mul(out, ident.raw, (12345).to_bytes(32, "little"))
+    assert N.cg1_is_identity(out.raw) == 1
+
+
+def test_decoded_points_keep_their_encoding(B):
+    """from_compressed_bytes[_unchecked] of a finite point remembers the 48 bytes it came from (they are its compression); the
+    identity's encoding is remembered only through the normal path, because the decoder accepts non-canonical infinity encodings."""
+    p = B.G1Point() * B.Scalar(424242)
+    enc = bytes(p.to_compressed_bytes())
+    q = B.G1Point.from_compressed_bytes_unchecked(enc)
+    assert q._k == enc and bytes(q.to_compressed_bytes()) == enc and q == p
+    q = B.G1Point.from_compressed_bytes(enc)
+    assert q._k == enc
+    odd_inf = bytes([0xC0 | 0x20]) + bytes(46) + b"\x01"                      # infinity flag + stray bits: still the identity
+    z = B.G1Point.from_compressed_bytes_unchecked(odd_inf)
+    assert z._k is None and bytes(z.to_compressed_bytes()) == bytes([0xC0]) + bytes(47) and z == B.G1Point.identity()

@@ -473,3 +473,43 @@ def test_randomised_batched_differential(native_lib, ctx):
         for j, n in enumerate(sizes):
             want = C.compress(C.msm_bucket(p96[96 * offs[j]: 96 * offs[j + 1]], s32[32 * offs[j]: 32 * offs[j + 1]], n, 6))
             assert compress_blob(N, blobs[j]) == want, (it, j, n)
+
+
+def test_two_chain_split_equals_single_chain(native_lib, ctx):
+    """The two-chain form of a large call ("split": high / low half of its windows on two streams; an A/B switch that stays off, it
+    measured slower): same point as the single chain, for whole MSMs and for the window shares of a sharded one (the halves are then halves of the share), at the automatic
+    plan, a uniform and a balanced one; the closed form pins the value."""
+    N = native_lib
+    n = (1 << 17) + 333
+    rng = random.Random(91)
+    dk, dg, dp, ds = ctx.alloc(32 * n), ctx.alloc(96), ctx.alloc(96 * n), ctx.alloc(32 * n)
+    dg.upload(raw96(O.G1_GEN))
+    ctx.gen_scalars_device(dk, n, 91)
+    ctx.batch_mul_device(dg, 1, dk, dp, n)
+    ctx.gen_scalars_device(ds, n, 92)
+    ks, sc = dk.download(), ds.download()
+    tot = sum(int.from_bytes(ks[32 * i: 32 * i + 32], "little") * int.from_bytes(sc[32 * i: 32 * i + 32], "little") for i in range(n)) % O.R
+    want = O.g1_compress(O.g1_mul(O.G1_GEN, tot))
+    try:
+        for c in (0, 16, -13, 9):
+            ctx.set_param("split", 1)
+            ctx.set_param("split_min_log2n", 10)
+            got = ctx.msm_device(dp, ds, n, window_c=c)
+            assert ctx.last_counts()["accumulate_launches"] == 2
+            assert compress_blob(N, got) == want, c
+            ctx.set_param("split", 0)
+            single = ctx.msm_device(dp, ds, n, window_c=c)
+            assert ctx.last_counts()["accumulate_launches"] == 1 and N.cg1_eq(single, got) == 1
+        for world in (2, 3, 8):
+            for split in (1, 0):
+                ctx.set_param("split", split)
+                acc = ctypes.create_string_buffer(N.POINT_BYTES)
+                N.cg1_identity(acc)
+                for rank in range(world):
+                    N.cg1_add(acc, acc.raw, ctx.msm_device(dp, ds, n, window_c=16, shard_rank=rank, shard_world=world))
+                assert compress_blob(N, acc.raw) == want, (world, split)
+    finally:
+        ctx.set_param("split", 0)
+        ctx.set_param("split_min_log2n", 17)
+    for b in (dk, dg, dp, ds):
+        b.free()

@@ -56,7 +56,7 @@ def main():
         assert row[0][5] == row[1][5], "the two forms sort different numbers of bucket entries"
         print("2^%-3d   %8.3f (%7.3f)        %8.3f (%7.3f)      %5.1f %%     %.3f / %.3f                    %.3f / %.3f" % (
             lg, row[0][0], row[0][1], row[1][0], row[1][1], 100.0 * (row[0][0] / row[1][0] - 1.0), row[0][3], row[1][3], row[0][4], row[1][4]))
-    ctx.set_param("split", 1)
+    ctx.set_param("split", 0)
 
 
 if __name__ == "__main__":

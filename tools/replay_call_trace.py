@@ -123,8 +123,19 @@ def product_replayer(doc, blob):
     def set_rho(s):
         box["rho"] = s
 
-    M.random_scalar = lambda: box.pop("rho")          # msm_accumulator.py:43: the one draw of each accumulate_check, replayed
-    return Replayer(doc, blob, A.G1Point, A.Scalar, A.compute_MSM, A.MSMAccumulator, set_rho)
+    class ReplayAccumulator(A.MSMAccumulator):
+        """msm_accumulator.py:43 draws one random factor per accumulate_check: here the recorded one (the module's random_scalar is swapped
+        for the duration of the call only)."""
+
+        def accumulate_check(self, C, bases, scalars):
+            orig = M.random_scalar
+            M.random_scalar = lambda: box.pop("rho")
+            try:
+                super().accumulate_check(C, bases, scalars)
+            finally:
+                M.random_scalar = orig
+
+    return Replayer(doc, blob, A.G1Point, A.Scalar, A.compute_MSM, ReplayAccumulator, set_rho)
 
 
 def measure(reps=3):
