@@ -41,10 +41,9 @@ FR_ORDER = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
 MADS_PER_MADD = 3542       # XYZZ mixed add (g1_xyzz.h): 6 products x 392 + one fused double product x 588 + 2 squarings x 301
 MADS_PER_MMADD = 1974      # affine + affine (xyzz_mmadd, the first addition of a chunk): 2 x 392 + 588 + 2 x 301
 MADS_MUL, MADS_SQR = 392, 301
-# one rank's share of ONE MSM of N x 2^20 terms, emulated on one GPU in round 1 (profiles/r01_v13_shard_emulation.txt), ms
-# rank 0's share of ONE MSM of N x 2^20 terms timed on one GPU (profiles/r02_v4_shard_emulation.txt; that box ran the plain
-# single-GPU step in 2.96-3.25 ms): what an N-GPU run should show per step before the exchange
-EMULATED_MS = {"hybrid": {1: 3.0, 2: 3.36, 4: 3.26, 8: 3.28}, "windows": {1: 3.0, 2: 3.36, 4: 3.43, 8: 3.68}, "points": {1: 3.0, 2: 3.12, 4: 2.96, 8: 2.96}}
+# rank 0's share of ONE MSM of N x 2^20 terms timed on ONE GPU in round 4 (profiles/r04_shard_emulation.txt; that box ran the plain
+# single-GPU step in 3.10 ms): what an N-GPU run should show per step before the exchange.  EMULATION, not a multi-GPU measurement.
+EMULATED_MS = {"hybrid": {1: 3.10, 2: 3.25, 4: 3.24, 8: 3.26}, "windows": {1: 3.10, 2: 3.25, 4: 3.39, 8: 3.67}, "points": {1: 3.10, 2: 2.97, 4: 2.95, 8: 2.97}}
 
 
 def raw96_gen():

@@ -3,7 +3,7 @@
 // latency hop (>= 5 us of launch + drain each around kernels that keep a few waves busy).
 // Part of the single translation unit csrc/msm_gpu.hip (included inside namespace cg1).
 //
-// Grid = (windows, point slices of <= 256 terms); 512 threads = 128 DPP quads per workgroup, everything between the scalar words and
+// Grid = (windows, point slices of <= 256 terms, independent MSMs of one call); 512 threads = 128 DPP quads per workgroup, everything between the scalar words and
 // the exported window items stays in LDS (111 KB):
 //   digits      one thread per term: signed c-bit digit of ITS window (recoding carry walked up from window 0), the point converted
 //               to Montgomery limbs into LDS (affine96 / normalised blob input; prepared records are copied)
@@ -24,14 +24,18 @@ constexpr uint32_t SM_SLICE = 256;        // terms per workgroup
 constexpr uint32_t SM_L = 4;              // entries per chunk
 constexpr uint32_t SM_QUADS = 128;
 
+constexpr uint32_t SM_MAX_MSMS = 16;      // independent MSMs one launch may carry (grid.z)
+constexpr uint32_t SM_MAX_GROUPS = 512;   // ... as long as windows x slices x MSMs stays a few workgroups per CU
+
 struct SmallArgs {
   const void* src;                        // SRC 0: n x affine96; 1: n x point blob with Z in {0, 1}; 2: PreparedPoint records
   const uint8_t* flags;                   // SRC 2: identity flags
   const uint32_t* scalars;
-  uint32_t n, S, c, nwin, hb, lb, nitems;
-  PointSum* partial;                      // [nwin][S][nitems]  (S > 1)
-  uint32_t* counters;                     // [0, nwin): window tickets; [nwin]: finished windows; [nwin+1]: bad-scalar flag; [nwin+2]: entries.  Zero between calls.
-  PointWords* out_host;                   // mapped host memory: nwin x nitems records, then one record of status words
+  const uint32_t* offs;                   // M + 1 term offsets of the M MSMs inside src / scalars (device); NULL: one MSM of n terms
+  uint32_t n, M, S, c, nwin, hb, lb, nitems;
+  PointSum* partial;                      // [M][nwin][S][nitems]  (S > 1)
+  uint32_t* counters;                     // [0, M nwin): window tickets; then: finished windows | bad-scalar flag | entries.  Zero between calls.
+  PointWords* out_host;                   // mapped host memory: M x nwin x nitems records, then one record of status words
   uint32_t* flag_host;
   uint32_t seq;
 };
@@ -45,10 +49,12 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
   __shared__ uint16_t s_cstart[256], s_cbucket[256];
   __shared__ uint8_t s_clen[256];
 
-  const uint32_t tid = threadIdx.x, w = blockIdx.x, sl = blockIdx.y;
+  const uint32_t tid = threadIdx.x, w = blockIdx.x, sl = blockIdx.y, msm = blockIdx.z;
   const uint32_t c = a.c, NB = 1u << (c - 1), nwin = a.nwin, S = a.S, nitems = a.nitems;
-  const uint32_t base = sl * SM_SLICE;
-  const uint32_t ns = (a.n - base < SM_SLICE) ? a.n - base : SM_SLICE;
+  const uint32_t first = a.offs ? a.offs[msm] : 0u, n_msm = a.offs ? a.offs[msm + 1] - first : a.n;
+  const uint32_t base = sl * SM_SLICE;                          // (an MSM shorter than the launch's longest leaves its last slices empty)
+  const uint32_t ns = base >= n_msm ? 0u : ((n_msm - base < SM_SLICE) ? n_msm - base : SM_SLICE);
+  const uint32_t wslot = msm * nwin + w, gctr = a.M * nwin;     // this (MSM, window)'s slot; the launch-wide counters behind the tickets
   if (tid < 256) s_hist[tid] = 0;
   if (tid < 8) s_misc[tid] = 0;
   __syncthreads();
@@ -57,7 +63,7 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
   uint32_t my_b = 0, my_pos = 0, my_neg = 0;
   bool my_valid = false;
   if (tid < ns) {
-    const uint32_t i = base + tid;
+    const uint32_t i = first + base + tid;
     uint32_t inf;
     fp x, y;
     if (SRC == 0) {
@@ -92,7 +98,7 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
     o[2 * NL] = inf;
     DigitIter it;
     load_scalar(a.scalars, i, it);
-    if (it.s[7] >> 31) atomicOr(&a.counters[nwin + 1], 1u);        // a scalar >= 2^255: the host rejects the call
+    if (it.s[7] >> 31) atomicOr(&a.counters[gctr + 1], 1u);        // a scalar >= 2^255: the host rejects the call
     WinPlan pl;
     pl.nwin = (int)nwin; pl.cmax = (int)c; pl.n_hi = (int)nwin;
     int d = 0;
@@ -204,8 +210,8 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
     } else if (phase == PH_COMBINE) {
       const bool live = Q < nitems;
       const uint32_t item = live ? Q : 0u;
-      if (i1 == 0) acc = load_sum(a.partial + ((size_t)w * S) * nitems + item);
-      lp = a.partial + ((size_t)w * S + i1 + 1u) * nitems + item;
+      if (i1 == 0) acc = load_sum(a.partial + ((size_t)wslot * S) * nitems + item);
+      lp = a.partial + ((size_t)wslot * S + i1 + 1u) * nitems + item;
       go = live;
     }
     if (from_pts) {
@@ -249,11 +255,11 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
         const uint32_t item = Q >> 3;
         const bool mine = item < nitems && (Q & 7u) == 0u;
         if (S == 1u) { exp_live = mine; exp_item = item; phase = PH_EXPORT; break; }
-        if (mine && q == 0u) store_sum(a.partial + ((size_t)w * S + sl) * nitems + item, acc);
-        if (tid == 0) atomicAdd(&a.counters[nwin + 2], s_off[256]);
+        if (mine && q == 0u) store_sum(a.partial + ((size_t)wslot * S + sl) * nitems + item, acc);
+        if (tid == 0) atomicAdd(&a.counters[gctr + 2], s_off[256]);
         __threadfence();
         __syncthreads();
-        if (tid == 0) s_misc[2] = atomicAdd(&a.counters[w], 1u);
+        if (tid == 0) s_misc[2] = atomicAdd(&a.counters[wslot], 1u);
         __syncthreads();
         if (s_misc[2] != S - 1u) return;                       // not the last slice of this window
         __threadfence();
@@ -266,7 +272,7 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
 
   // ---- export: lane q of the item's quad converts and writes coordinate q (canonical, the host's Montgomery form)
   if (exp_live) {
-    PointWords* dst = a.out_host + (size_t)w * nitems + exp_item;
+    PointWords* dst = a.out_host + (size_t)wslot * nitems + exp_item;
     fp coord;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
@@ -285,18 +291,18 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
     d4[2] = make_uint4(ow[8], ow[9], ow[10], ow[11]);
     if (q == 0u) dst->inf = acc.inf;
   }
-  if (S == 1u && tid == 0) atomicAdd(&a.counters[nwin + 2], s_off[256]);
+  if (S == 1u && tid == 0) atomicAdd(&a.counters[gctr + 2], s_off[256]);
   __threadfence_system();
   __syncthreads();
   if (tid == 0) {
-    a.counters[w] = 0;                                         // this window's ticket word is free for the next call
-    const uint32_t done = atomicAdd(&a.counters[nwin], 1u);
-    if (done == nwin - 1u) {                                   // the last window: status words, then the flag the host polls
-      uint32_t* st = reinterpret_cast<uint32_t*>(a.out_host + (size_t)nwin * nitems);
-      st[0] = atomicAdd(&a.counters[nwin + 1], 0u);
-      st[1] = atomicAdd(&a.counters[nwin + 2], 0u);
+    a.counters[wslot] = 0;                                     // this window's ticket word is free for the next call
+    const uint32_t done = atomicAdd(&a.counters[gctr], 1u);
+    if (done == gctr - 1u) {                                   // the last window of the last MSM: status words, then the flag the host polls
+      uint32_t* st = reinterpret_cast<uint32_t*>(a.out_host + (size_t)gctr * nitems);
+      st[0] = atomicAdd(&a.counters[gctr + 1], 0u);
+      st[1] = atomicAdd(&a.counters[gctr + 2], 0u);
       st[2] = 0; st[3] = 0;
-      a.counters[nwin] = 0; a.counters[nwin + 1] = 0; a.counters[nwin + 2] = 0;
+      a.counters[gctr] = 0; a.counters[gctr + 1] = 0; a.counters[gctr + 2] = 0;
       __threadfence_system();
       __hip_atomic_store(a.flag_host, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -184,7 +184,7 @@ struct Ctx {
   int small_msm = 1;                    // "small_msm": MSMs of <= SM_MAX_N terms as ONE launch (k_msm_small); 0 = the regime-A chain (A/B switch)
   PointSum* d_small_partial = nullptr; size_t cap_small_partial = 0;
   uint32_t* d_small_ctr = nullptr;
-  PreparedPoint* d_small_pts = nullptr; uint8_t* d_small_flags = nullptr;      // k_prepare_blobs<true> output for un-normalised blob input
+  PreparedPoint* d_small_pts = nullptr; uint8_t* d_small_flags = nullptr; size_t cap_small_pts = 0;      // k_prepare_blobs<true> output for un-normalised blob input
   PointWords* h_small_out = nullptr; PointWords* h_small_out_dev = nullptr;     // pinned + mapped: 64 x 9 window items + the status record
   int quad = 1;                         // quad-lane EC ops in the latency-bound kernels (A/B switch)
   int reduce_2d = 1;                    // 1: k_rowcol + k_small_tree; 0: k_seg_reduce + k_bit_tree (A/B switch)
@@ -738,43 +738,52 @@ static int pick_small_c(size_t n) {
   return 7;
 }
 
-// One launch (two when un-normalised blobs have to be inverted first) for an MSM of n <= SM_MAX_N terms; fills ctx->pend like
-// msm_enqueue, so msm_finish polls the same flag and runs the same host Horner.
-static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int c) {
+// One launch (two when un-normalised blobs have to be inverted first) for an MSM of n <= SM_MAX_N terms -- or for M <= SM_MAX_MSMS
+// independent ones of at most max_n terms each (d_offs: their M + 1 term offsets on the device); fills ctx->pend like msm_enqueue, so
+// msm_finish polls the same flag and runs the same host Horner (M = 1), or msm_small_batched_finish does (M > 1).
+static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int c, uint32_t M = 1, const uint32_t* d_offs = nullptr, size_t max_n = 0) {
   ctx->pend.active = false;
   HIPCHK(hipSetDevice(ctx->device));
   const WinPlan plan = make_plan(c);
   const uint32_t nwin = (uint32_t)plan.nwin, bb = (uint32_t)c - 1u, lb2 = (bb + 1u) / 2u, hb2 = bb - lb2, nitems = 1u + hb2 + lb2;
-  const uint32_t S = (uint32_t)((n + SM_SLICE - 1) / SM_SLICE);
+  if (M == 1) max_n = n;
+  const uint32_t S = (uint32_t)((max_n + SM_SLICE - 1) / SM_SLICE);
   auto h0 = std::chrono::steady_clock::now();
   if (!ctx->h_small_out) {
-    HIPCHK(hipHostMalloc((void**)&ctx->h_small_out, (64 * 9 + 1) * sizeof(PointWords), hipHostMallocMapped | hipHostMallocCoherent));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_small_out, ((size_t)SM_MAX_MSMS * 64 * 9 + 1) * sizeof(PointWords), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&ctx->h_small_out_dev, ctx->h_small_out, 0));
-    HIPCHK(hipMalloc(&ctx->d_small_ctr, 128 * 4));
-    HIPCHK(hipMemset(ctx->d_small_ctr, 0, 128 * 4));
-    HIPCHK(hipMalloc(&ctx->d_small_pts, SM_MAX_N * sizeof(PreparedPoint)));
-    HIPCHK(hipMalloc(&ctx->d_small_flags, SM_MAX_N + 16));
+    HIPCHK(hipMalloc(&ctx->d_small_ctr, (SM_MAX_MSMS * 64 + 8) * 4));
+    HIPCHK(hipMemset(ctx->d_small_ctr, 0, (SM_MAX_MSMS * 64 + 8) * 4));
   }
-  const size_t need_partial = (size_t)nwin * S * nitems;
+  const size_t need_partial = (size_t)M * nwin * S * nitems;
   if (S > 1 && need_partial > ctx->cap_small_partial) {
     if (ctx->d_small_partial) (void)hipFree(ctx->d_small_partial);
     ctx->d_small_partial = nullptr; ctx->cap_small_partial = 0;
-    HIPCHK(hipMalloc(&ctx->d_small_partial, 64 * 4 * 9 * sizeof(PointSum)));
-    ctx->cap_small_partial = 64 * 4 * 9;
+    HIPCHK(hipMalloc(&ctx->d_small_partial, need_partial * sizeof(PointSum)));
+    ctx->cap_small_partial = need_partial;
   }
   hipStream_t st = ctx->stream;
   SmallArgs a;
-  a.src = src.p; a.flags = src.flags; a.scalars = static_cast<const uint32_t*>(d_scalars32);
-  a.n = (uint32_t)n; a.S = S; a.c = (uint32_t)c; a.nwin = nwin; a.hb = hb2; a.lb = lb2; a.nitems = nitems;
+  a.src = src.p; a.flags = src.flags; a.scalars = static_cast<const uint32_t*>(d_scalars32); a.offs = d_offs;
+  a.n = (uint32_t)n; a.M = M; a.S = S; a.c = (uint32_t)c; a.nwin = nwin; a.hb = hb2; a.lb = lb2; a.nitems = nitems;
   a.partial = ctx->d_small_partial; a.counters = ctx->d_small_ctr;
   a.out_host = ctx->h_small_out_dev; a.flag_host = ctx->h_flag_dev; a.seq = ++ctx->seq;
   int kind = (int)src.kind;
   if (src.kind == PtSrc::BLOBS && !src.normalised) {           // invert first (one lane per point), then run on the prepared records
+    if (n > ctx->cap_small_pts) {
+      if (ctx->d_small_pts) (void)hipFree(ctx->d_small_pts);
+      if (ctx->d_small_flags) (void)hipFree(ctx->d_small_flags);
+      ctx->d_small_pts = nullptr; ctx->d_small_flags = nullptr; ctx->cap_small_pts = 0;
+      const size_t cap = n < SM_MAX_N ? SM_MAX_N : n;
+      HIPCHK(hipMalloc(&ctx->d_small_pts, cap * sizeof(PreparedPoint)));
+      HIPCHK(hipMalloc(&ctx->d_small_flags, cap + 16));
+      ctx->cap_small_pts = cap;
+    }
     launch_prepare(st, src, ctx->d_small_pts, ctx->d_small_flags, (uint32_t)n, nullptr);
     a.src = ctx->d_small_pts; a.flags = ctx->d_small_flags;
     kind = (int)PtSrc::PREPARED;
   }
-  const dim3 grid(nwin, S), block(512);
+  const dim3 grid(nwin, S, M), block(512);
   if (kind == (int)PtSrc::AFFINE96) hipLaunchKernelGGL((k_msm_small<0>), grid, block, 0, st, a);
   else if (kind == (int)PtSrc::BLOBS) hipLaunchKernelGGL((k_msm_small<1>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((k_msm_small<2>), grid, block, 0, st, a);
@@ -782,7 +791,83 @@ static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32
   Ctx::Pending& pd = ctx->pend;
   pd.zero_copy = true; pd.seq = ctx->seq; pd.hout = ctx->h_small_out;
   pd.active = true; pd.c = c; pd.plan = plan; pd.rank = 0; pd.world = 1; pd.nlw = (int)nwin; pd.nbits = 0; pd.m = 1; pd.lb2 = lb2; pd.hb2 = hb2;
-  pd.nitems = nitems; pd.use2d = true; pd.profile = 0; pd.nout_words = (size_t)nwin * nitems; pd.h0 = h0; pd.h1 = h1;
+  pd.nitems = nitems; pd.use2d = true; pd.profile = 0; pd.nout_words = (size_t)M * nwin * nitems; pd.h0 = h0; pd.h1 = h1;
+  return CG1_OK;
+}
+
+// sum over a window-major block of exported 2-D items (1 + hb + lb per window, uniform plan) of 2^e(P) P: one Horner from the top bit
+static cg1h::jac horner_2d_items(const PointWords* rows, const WinPlan& plan, uint32_t nitems, uint32_t hb2, uint32_t lb2) {
+  constexpr int EMAX = 2 * 256 + 64;
+  std::vector<std::pair<int, const PointWords*>> items;
+  items.reserve((size_t)plan.nwin * nitems);
+  int e_top = 0;
+  for (int w = 0; w < plan.nwin; ++w) {
+    const int base = plan.off(w);
+    const PointWords* row = rows + (size_t)w * nitems;
+    auto put = [&](int e, const PointWords* p) { if (!p->inf) { items.emplace_back(e, p); if (e > e_top) e_top = e; } };
+    put(base, &row[0]);
+    for (uint32_t k = 0; k < hb2; ++k) put(base + (int)lb2 + (int)k, &row[1 + k]);
+    for (uint32_t k = 0; k < lb2; ++k) put(base + (int)k, &row[1 + hb2 + k]);
+  }
+  uint16_t first[EMAX + 1];
+  memset(first, 0, sizeof first);
+  for (const auto& it : items) ++first[it.first + 1];
+  for (int e = 0; e < EMAX; ++e) first[e + 1] = (uint16_t)(first[e + 1] + first[e]);
+  std::vector<const PointWords*> byexp(items.size());
+  {
+    uint16_t cur[EMAX];
+    memcpy(cur, first, sizeof cur);
+    for (const auto& it : items) byexp[cur[it.first]++] = it.second;
+  }
+  cg1h::jac a = cg1h::jac_identity();
+  for (int e = e_top; e >= 0; --e) {
+    a = cg1h::jac_dbl(a);
+    for (uint16_t k = first[e]; k < first[e + 1]; ++k) a = cg1h::jac_add(a, jac_from_words(*byexp[k]));
+  }
+  return a;
+}
+
+// Wait for a launch of M > 1 small MSMs and run their M host Horners (one thread each, up to four at a time).
+static int msm_small_batched_finish(Ctx* ctx, uint32_t M, std::vector<cg1h::jac>& results) {
+  const Ctx::Pending pd = ctx->pend;
+  ctx->pend.active = false;
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->blocking_sync) {
+    volatile uint32_t* flag = ctx->h_flag;
+    for (uint32_t spins = 0; *flag != pd.seq; ++spins) {
+      if ((spins & 0x3fffu) == 0x3fffu) {
+        hipError_t q = hipStreamQuery(ctx->stream);
+        if (q == hipSuccess) { if (*flag != pd.seq) { snprintf(ctx->err, sizeof ctx->err, "the stream drained without the export flag"); return CG1_ERR_HIP; } break; }
+        if (q != hipErrorNotReady) { snprintf(ctx->err, sizeof ctx->err, "stream failed: %s", hipGetErrorString(q)); return CG1_ERR_HIP; }
+      }
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  } else {
+    int wrc = wait_stream(ctx); if (wrc) return wrc;
+  }
+  HIPCHK(hipGetLastError());
+  const uint32_t* st_words = reinterpret_cast<const uint32_t*>(pd.hout + pd.nout_words);
+  ctx->last_entries = st_words[1]; ctx->last_chunks = 0;
+  if (st_words[0]) {
+    snprintf(ctx->err, sizeof ctx->err, "a scalar is >= 2^255: scalar32 must be a canonical Fr element (< r)");
+    return CG1_ERR_ENCODING;
+  }
+  auto t0 = std::chrono::steady_clock::now();
+  const size_t per = (size_t)pd.plan.nwin * pd.nitems;
+  auto one = [&](size_t j) { results[j] = horner_2d_items(pd.hout + j * per, pd.plan, pd.nitems, pd.hb2, pd.lb2); };
+  const size_t nth = std::min<size_t>(4, M);
+  for (size_t t = 1; t < nth; ++t) ctx->helper[t - 1].run([&, t]() { for (size_t j = t; j < M; j += nth) one(j); });
+  for (size_t j = 0; j < M; j += nth) one(j);
+  for (size_t t = 1; t < nth; ++t) ctx->helper[t - 1].wait();
+  auto t1 = std::chrono::steady_clock::now();
+  ctx->host_ms[0] = std::chrono::duration<float, std::milli>(pd.h1 - pd.h0).count();
+  ctx->host_ms[1] = std::chrono::duration<float, std::milli>(t0 - pd.h1).count();
+  ctx->host_ms[2] = 0;
+  ctx->host_ms[3] = ctx->host_tail_ms = std::chrono::duration<float, std::milli>(t1 - t0).count();
+  for (int i = 0; i < CG1_NPHASE; ++i) ctx->phase_ms[i] = 0.f;
+  ctx->last_c = pd.c;
+  ctx->last_acc_launches = 0;
   return CG1_OK;
 }
 
@@ -868,6 +953,28 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   if (h_offsets[0] != 0) { snprintf(ctx->err, sizeof ctx->err, "offsets[0] must be 0"); return CG1_ERR_ARG; }
   if (N == 0) return CG1_OK;
   if (N >= (1ull << 31) || M > 65535) { snprintf(ctx->err, sizeof ctx->err, "batch too large"); return CG1_ERR_ARG; }
+  {
+    // A handful of small MSMs (the 4 - 6 of a prover's halving round, prover_kernels.py): ONE k_msm_small launch carries them all
+    // (grid.z = MSM) and their Horners run side by side on the host -- the regime-B launch chain costs ~0.5 ms whatever it sums.
+    size_t max_n = 0;
+    for (size_t j = 0; j < M; ++j) max_n = std::max<size_t>(max_n, h_offsets[j + 1] - h_offsets[j]);
+    const int cs = c > 0 ? c : pick_small_c(max_n);
+    const size_t groups = (size_t)M * (size_t)(255 / cs + 1) * ((max_n + SM_SLICE - 1) / SM_SLICE);
+    if (ctx->small_msm && M <= SM_MAX_MSMS && max_n <= SM_MAX_N && groups <= SM_MAX_GROUPS && cs >= 4 && cs <= 9 && cs != 5) {
+      HIPCHK(hipSetDevice(ctx->device));
+      if ((M + 1) > ctx->cap_boffs) {
+        if (ctx->d_boffs) (void)hipFree(ctx->d_boffs);
+        ctx->d_boffs = nullptr; ctx->cap_boffs = 0;
+        HIPCHK(hipMalloc(&ctx->d_boffs, (M + 1) * 4));
+        ctx->cap_boffs = M + 1;
+      }
+      HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+      int rc = msm_enqueue_small(ctx, PtSrc(d_points96), d_scalars32, N, cs, (uint32_t)M, ctx->d_boffs, max_n);
+      if (rc) return rc;
+      if (M == 1) { cg1h::jac r; rc = msm_finish(ctx, r); ctx->last_acc_launches = 0; if (rc == CG1_OK) results[0] = r; return rc; }
+      return msm_small_batched_finish(ctx, (uint32_t)M, results);
+    }
+  }
   if (c <= 0) c = pick_window_batched((N + M - 1) / M);
   if (c < 4 || c > 9) { snprintf(ctx->err, sizeof ctx->err, "batched window width %d out of range [4,9]", c); return CG1_ERR_ARG; }
   HIPCHK(hipSetDevice(ctx->device));

@@ -177,3 +177,32 @@ def test_golden_vectors_through_the_small_kernel(native_lib, ctx, golden):
         for c in (0, 4, 6, 7, 8, 9):
             assert compress_blob(N, ctx.msm_device(dp, ds, n, window_c=c)).hex() == case["expected"], (case["name"], c)
         dp.free(); ds.free()
+
+
+def test_several_msms_in_one_launch(native_lib, ctx, pool):
+    """cg1_msm_batched with a handful of small MSMs (the 4 - 6 of a prover's halving round; compute_MSM_batch): they ride ONE
+    k_msm_small launch (grid.z = MSM).  Ragged sizes, an empty MSM in the middle, sizes across the slice edge; M = 17 falls back to
+    the regime-B launch chain -- every result against the oracle."""
+    N = native_lib
+    ks, pts = pool
+    rng = random.Random(409)
+    for sizes in ([5], [3, 0, 7], [64, 65, 64, 64], [128, 129, 1, 128, 0, 127], [257, 300, 2], [1024, 1], [33] * 16, [20] * 17, [0, 0, 9]):
+        idx = [[rng.randrange(len(pts)) for _ in range(n)] for n in sizes]
+        sc = [[rng.randint(0, O.R - 1) for _ in range(n)] for n in sizes]
+        p96 = b"".join(raw96(pts[i]) for row in idx for i in row)
+        s32 = b"".join(v.to_bytes(32, "little") for row in sc for v in row)
+        offs = [0]
+        for n in sizes:
+            offs.append(offs[-1] + n)
+        blobs = ctx.msm_batched_host(p96, s32, offs)
+        assert len(blobs) == len(sizes)
+        for j, n in enumerate(sizes):
+            tot = sum(ks[i] * s for i, s in zip(idx[j], sc[j])) % O.R
+            assert compress_blob(N, blobs[j]) == O.g1_compress(O.g1_mul(O.G1_GEN, tot)), (sizes, j)
+        if len(sizes) <= 16 and max(sizes) <= 1024:
+            assert ctx.last_counts()["accumulate_launches"] == 0              # k_msm_small served it
+    # an out-of-range scalar in one of the MSMs rejects the call and leaves the counters clean
+    bad = bytearray(s32); bad[31] |= 0x80
+    with pytest.raises(N.NativeError):
+        ctx.msm_batched_host(p96, bytes(bad), offs)
+    assert compress_blob(N, ctx.msm_batched_host(p96, s32, offs)[2]) == O.g1_compress(O.g1_mul(O.G1_GEN, sum(ks[i] * s for i, s in zip(idx[2], sc[2])) % O.R))

@@ -114,3 +114,24 @@ def test_cross_proof_batched_rounds_equal_single_prover_rounds(pv):
     for pr, got in zip(provers, many):
         alone = same_msm_rounds(*pr, mk())
         assert [enc(x) for x in got[:6]] == [enc(x) for x in alone[:6]] and got[6] == alone[6]
+
+
+def test_implicit_base_change_equals_explicit_bases(pv):
+    """ipa_rounds with G' given implicitly (the CRS points + the coefficients beta^-(i+1) of grand_prod.py:64-71) produces the very
+    L / R points and final scalars it produces over the materialised G' -- the base change then costs no scalar multiplication."""
+    from curdleproofs_pie_amd.prover_kernels import grand_product_bases, grand_product_coeffs, ipa_rounds
+
+    g, r = pv["grand_product_bases"], pv["ipa"]
+    G, H4 = [P(h) for h in g["vec_G"]], [P(h) for h in g["vec_H"]]
+    n = len(r["vec_c"])
+    assert len(G) + len(H4) >= n
+    bases = (G + H4)[:n]
+    beta_inv = S(g["beta_inv"])
+    coeffs = grand_product_coeffs(len(G), len(H4), beta_inv)[:n]
+    Gp, Hp = grand_product_bases(G, H4, beta_inv)
+    explicit = (Gp + Hp)[:n]
+    mk = lambda: (lambda gs: (lambda *pts: gs.pop(0)))([S(x) for x in r["gammas"]])
+    c, d, Hh = [S(h) for h in r["vec_c"]], [S(h) for h in r["vec_d"]], P(r["H"])
+    a = ipa_rounds(bases, explicit, Hh, c, d, mk())
+    b = ipa_rounds(bases, bases, Hh, c, d, mk(), G_prime_coeffs=coeffs)
+    assert [enc(x) for x in a[:4]] == [enc(x) for x in b[:4]] and a[4] == b[4] and a[5] == b[5]
