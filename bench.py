@@ -699,14 +699,6 @@ def main():
             wl = Workload(ctx, d_g, max(1 << 18, 1 << args.cpu_sample_logn), args.seed)
             out["cpu_baseline"] = cpu_baseline(wl.d_pts, wl.d_sc, 1 << args.cpu_sample_logn)
             wl.free()
-        if world == 1 and not args.no_python_face:
-            # the drop-in itself: compute_MSM / MSMAccumulator through the reference's signature (lists of G1Point / Scalar objects), and
-            # the reference's own backend-call sequence for one proof replayed through this backend
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
-            import gpu_python_face
-            import replay_call_trace
-            out["python_face"] = gpu_python_face.measure(sizes=(16, 20), reps=3)
-            out["unchanged_control_flow"] = replay_call_trace.measure(reps=3)
         if world == 1 and not args.no_secondary:
             ctx2.close()                                      # (its streams would keep hardware queues the verifier's lanes need: a process has 24)
             cores = int(N.cg1_shuffle_default_threads())
@@ -722,6 +714,18 @@ def main():
             # ... and with 2048 proofs per batch: BASELINE config 5's share of one GPU (16 384 proofs over 8)
             dv2 = verify_measure(ctx, 2, max(10, args.verify_steps // 2), 1, 2 * args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
             out["secondary"]["device_front_end_on_2_host_threads_batches_of_%d" % (2 * args.batch)] = {k: dv2[k] for k in keys if k != "phases_ms_per_step"}
+        if world == 1 and not args.no_python_face:
+            # the drop-in itself: compute_MSM / MSMAccumulator through the reference's signature (lists of G1Point / Scalar objects), and
+            # the reference's own backend-call sequence for one proof replayed through this backend.  (After the secondary metric: these
+            # run on the package's default context, and every further live context costs the verifier hardware queues -- DESIGN.md 9.)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import gpu_python_face
+            import replay_call_trace
+            out["python_face"] = gpu_python_face.measure(sizes=(16, 20), reps=3)
+            out["unchanged_control_flow"] = replay_call_trace.measure(reps=3)
+            import curdleproofs_pie_amd.msm_accumulator as MA
+            MA.release()
+            N.close_default_context()
         print(json.dumps(out), flush=True)
 
     if comm:

@@ -605,6 +605,15 @@ _default_ctx = None
 _default_lock = threading.Lock()
 
 
+def close_default_context() -> None:
+    """Release the process-wide context (its stream, scratch and staging buffers); the next default_context() makes a new one."""
+    global _default_ctx
+    with _default_lock:
+        if _default_ctx is not None:
+            _default_ctx.close()
+            _default_ctx = None
+
+
 def default_context() -> Context:
     """Process-wide context on the GPU named by CURDLE_G1_DEVICE / LOCAL_RANK (default 0)."""
     global _default_ctx

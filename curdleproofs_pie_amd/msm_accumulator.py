@@ -48,6 +48,17 @@ def clear_vec_cache() -> None:
     _vec_cache_points = 0
 
 
+def release() -> None:
+    """Free what this module keeps on the default context: the resident vectors and the page-locked staging (before the context is
+    closed: N.close_default_context())."""
+    clear_vec_cache()
+    for st in _stagings.values():
+        for b in (st.pts, st.sc):
+            if b is not None:
+                b.free()
+    _stagings.clear()
+
+
 def _resident(ctx, bases, n: int):
     """The device-resident form of `bases[:n]` if this very sequence of objects was met before; None the first time."""
     global _vec_cache_points

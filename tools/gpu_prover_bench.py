@@ -77,6 +77,9 @@ perm = list(range(ELL)); rng.shuffle(perm)
 t_pc = timed("shuffle_permute_and_commit_input (curdleproofs.py:301-321)", lambda: K.shuffle_permute_and_commit_input(Crs, T[:ELL], U[:ELL], perm, rs()))
 t_gp = timed("grand-product base change (grand_prod.py:64-71)", lambda: K.grand_product_bases(G[:ELL], G[ELL:], rs()))
 print("GPU-side flows of ONE ell = 124 proof: %.1f ms wall (the reference's own loops over the host backend: seconds)" % (t_ipa + t_sm + t_pc + t_gp))
+coeffs = K.grand_product_coeffs(ELL, NB, rs())
+t_ipa2 = timed("IPA rounds with the base change passed as coefficients (no G' made)", lambda: K.ipa_rounds(G, G, H, c, d, const(), G_prime_coeffs=coeffs))
+print("... with the implicit base change: %.1f ms" % (t_ipa2 + t_sm + t_pc))
 for B in (8, 64):
     ip = [(G, Gp, H, [rs() for _ in range(n)], [rs() for _ in range(n)]) for _ in range(B)]
     sm = [(G, T, U, [rs() for _ in range(n)]) for _ in range(B)]
