@@ -168,6 +168,18 @@ CG1_HD int win_count(int nwin, int rank, int sel) {
   return cnt ? cnt : (nwin - rank + world - 1) / world - lw0;
 }
 CG1_HD int win_sel(int world, int lw0, int cnt) { return world | (lw0 << 8) | (cnt << 16); }
+// The same test for w = 0, 1, 2, ... in order, without a division per window (the digit kernels walk all windows of every scalar:
+// win_local's `w % world` cost k_digits 14 of its 52 us at 2^20 terms).  step(w) returns the chain's local index of w, or -1.
+struct WinWalk {
+  int own, lw, world, cnt;
+  CG1_HD WinWalk(int rank, int sel) : own(rank), lw(-((sel >> 8) & 0xff)), world(sel & 0xff), cnt((sel >> 16) & 0xff) {}
+  CG1_HD int step(int w) {
+    if (w != own) return -1;
+    const int l = lw;
+    own += world; ++lw;
+    return (l >= 0 && (cnt == 0 || l < cnt)) ? l : -1;
+  }
+};
 
 struct DigitIter {
   uint32_t s[8];
@@ -203,9 +215,10 @@ __global__ void __launch_bounds__(256) k_hist(const uint32_t* __restrict__ scala
   load_scalar(scalars, i, it);
   if (it.s[7] >> 31) *bad_flag = 1u;
   const uint32_t NB = 1u << (pl.cmax - 1);
+  WinWalk ww(rank, world);
   for (int w = 0; w < pl.nwin; ++w) {
     int d = it.next(pl, w);
-    const int lw = win_local(w, rank, world);
+    const int lw = ww.step(w);
     if (d == 0 || lw < 0) continue;
     uint32_t b = (uint32_t)(d < 0 ? -d : d) - 1u;
     atomicAdd(&hist[(uint32_t)lw * NB + b], 1u);
@@ -221,9 +234,10 @@ __global__ void __launch_bounds__(256) k_scatter(const uint32_t* __restrict__ sc
   DigitIter it;
   load_scalar(scalars, i, it);
   const uint32_t NB = 1u << (pl.cmax - 1);
+  WinWalk ww(rank, world);
   for (int w = 0; w < pl.nwin; ++w) {
     int d = it.next(pl, w);
-    const int lw = win_local(w, rank, world);
+    const int lw = ww.step(w);
     if (d == 0 || lw < 0) continue;
     uint32_t key = (uint32_t)lw * NB + (uint32_t)(d < 0 ? -d : d) - 1u;
     uint32_t slot = atomicSub(&cursor[key], 1u) - 1u;      // cursor starts at the bucket's count

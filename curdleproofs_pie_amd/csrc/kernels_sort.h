@@ -50,9 +50,10 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   DigitIter it;
   load_scalar(scalars, i, it);
   if (it.s[7] >> 31) *bad_flag = 1u;              // >= 2^255: the signed-digit recoding would carry out of the top window
+  WinWalk ww(rank, world);
   for (int w = 0; w < pl.nwin; ++w) {
     int d = it.next(pl, w);
-    const int lw = win_local(w, rank, world);
+    const int lw = ww.step(w);
     if (lw < 0) continue;
     digits[(size_t)lw * n + i] = inf ? (uint16_t)0 : (uint16_t)(d & 0xFFFF);
   }

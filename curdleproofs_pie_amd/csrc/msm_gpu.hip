@@ -753,7 +753,9 @@ static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32
     HIPCHK(hipHostMalloc((void**)&ctx->h_small_out, ((size_t)SM_MAX_MSMS * 64 * 9 + 1) * sizeof(PointWords), hipHostMallocMapped | hipHostMallocCoherent));
     HIPCHK(hipHostGetDevicePointer((void**)&ctx->h_small_out_dev, ctx->h_small_out, 0));
     HIPCHK(hipMalloc(&ctx->d_small_ctr, (SM_MAX_MSMS * 64 + 8) * 4));
-    HIPCHK(hipMemset(ctx->d_small_ctr, 0, (SM_MAX_MSMS * 64 + 8) * 4));
+    // on the context's own stream: it is a non-blocking stream, which a memset on the null stream would NOT be ordered with -- the
+    // first launch could find its tickets zeroed under its feet ("the stream drained without the export flag")
+    HIPCHK(hipMemsetAsync(ctx->d_small_ctr, 0, (SM_MAX_MSMS * 64 + 8) * 4, ctx->stream));
   }
   const size_t need_partial = (size_t)M * nwin * S * nitems;
   if (S > 1 && need_partial > ctx->cap_small_partial) {

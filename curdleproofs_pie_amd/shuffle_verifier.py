@@ -194,6 +194,22 @@ class ShuffleBatchVerifier:
     def close(self) -> None:
         """Stop the two GPU threads (after what is queued has drained) and release the buffer slots and the MSM context.
         The verifier must not be used afterwards.  Idempotent; also run by __del__ and on cache eviction."""
+        self._release_lanes()
+        for kid in (getattr(self, "_kids", None) or []):
+            kid.close()
+        self._kids = None
+        if getattr(self, "_ctx_blocking", False) and self._ctx is not None and self._ctx.handle:
+            self._ctx.set_param("blocking_sync", 0)
+            self._ctx_blocking = False
+        if getattr(self, "_own_ctx", False) and self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+            self._own_ctx = False
+
+    def _release_lanes(self) -> None:
+        """Give back what this verifier's OWN lanes hold -- GPU threads, buffer slots, the MSM context, the front-end contexts -- and
+        with them their hardware queues (a process has 24: a verifier whose pipelines run on child verifiers must not keep lanes of its
+        own alive beside them).  They are rebuilt on demand."""
         for lane in range(len(self._gpu_threads)):
             t, q = self._gpu_threads[lane], self._gpu_jobs[lane]
             if t is not None:
@@ -211,9 +227,6 @@ class ShuffleBatchVerifier:
         if self._ctx_msm is not None:
             self._ctx_msm.close()
             self._ctx_msm = None
-        for kid in (getattr(self, "_kids", None) or []):
-            kid.close()
-        self._kids = None
         for k, pair in enumerate(getattr(self, "_fe", [])):
             if pair is not None:
                 cx, fe, aux_h, aux_d = pair
@@ -221,13 +234,6 @@ class ShuffleBatchVerifier:
                 aux_h.free(); aux_d.free()
                 cx.close()
                 self._fe[k] = None
-        if getattr(self, "_ctx_blocking", False) and self._ctx is not None and self._ctx.handle:
-            self._ctx.set_param("blocking_sync", 0)
-            self._ctx_blocking = False
-        if getattr(self, "_own_ctx", False) and self._ctx is not None:
-            self._ctx.close()
-            self._ctx = None
-            self._own_ctx = False
 
     def __del__(self):
         try:
@@ -607,6 +613,7 @@ class ShuffleBatchVerifier:
         from collections import deque
 
         if self._kids is None:
+            self._release_lanes()                             # (lanes a single batch may have built on this verifier itself)
             dev = self.ctx.device
             self._kids = [ShuffleBatchVerifier(self.crs, N.Context(dev), threads=self.threads, chunk=self.chunk, device_rows=self.device_rows,
                                                blocking_sync=self.blocking_sync, device_front_end=True, fe_lanes=self.fe_lanes, fe_prio=self.fe_prio, pipelines=1)
@@ -679,9 +686,16 @@ class ShuffleBatchVerifier:
 
         # several pipelines pay off on a STREAM of batches; one batch alone (is_valid_whisk_shuffle_proof, verify_many) runs on this
         # verifier's own lanes: no child verifiers, contexts or threads are made for it
-        if self.pipelines > 1 and not (isinstance(batches, (list, tuple)) and len(batches) <= 1):
-            yield from self._verify_stream_pipelines(batches, mode, rng)
-            return
+        if self.pipelines > 1:
+            if not (isinstance(batches, (list, tuple)) and len(batches) <= 1):
+                yield from self._verify_stream_pipelines(batches, mode, rng)
+                return
+            if self._kids:                                    # the pipelines exist already: the batch rides the first one, in this thread
+                kid = self._kids[0]
+                for st in kid._verify_stream_device(batches, mode, rng):
+                    self.last_status, self.last_stats = st, dict(kid.last_stats)
+                    yield st
+                return
 
         inflight = deque()
         depth = self.fe_lanes + 2
