@@ -66,6 +66,23 @@ int main() {
   cg1_merlin_challenge(st, (const uint8_t*)"c", 1, out, 400);
   cg1_merlin_challenge(st, (const uint8_t*)"c", 1, out, 0);
   cg1_merlin_challenge_scalar(st, (const uint8_t*)"s", 1, sc);
+  // the dedicated squaring (fe_mul_x86.h fe_sqr_adx) against the product, random and edge operands below p
+  {
+    static const uint64_t P[6] = {0xb9feffffffffaaabull, 0x1eabfffeb153ffffull, 0x6730d2a0f6b0f624ull, 0x64774b84f38512bfull, 0x4b1ba7b6434bacd7ull, 0x1a0111ea397fe69aull};
+    auto same = [](const fe& a) { fe s = fe_sqr(a), m = fe_mul(a, a); return memcmp(s.l, m.l, 48) == 0; };
+    fe a;
+    for (int i = 0; i < 200000; ++i) {
+      for (int j = 0; j < 6; ++j) a.l[j] = (i % 5 == 0 && (rnd() & 1)) ? ((rnd() & 1) ? ~0ull : 0ull) : rnd();
+      a.l[5] %= P[5];
+      if (!same(a)) { printf("fe_sqr differs from fe_mul at case %d\n", i); return 1; }
+    }
+    memset(a.l, 0, 48); if (!same(a)) return 1;
+    memcpy(a.l, P, 48); a.l[0] -= 1; if (!same(a)) return 1;
+    for (int k = 0; k < 380; ++k) {
+      memset(a.l, 0, 48); a.l[k / 64] = 1ull << (k % 64); if (!same(a)) return 1;
+      a.l[k / 64] -= 1; for (int j = 0; j < k / 64; ++j) a.l[j] = ~0ull; if (!same(a)) return 1;
+    }
+  }
   printf("sanitize ok %02x%02x\n", out[0], sc[0]);
   return 0;
 }
