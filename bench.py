@@ -202,6 +202,32 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
     return out
 
 
+def opening_measure(ctx, n=131072, reps=3):
+    """Whisk tracker-opening proofs verified/s (IsValidWhiskOpeningProof, whisk_interface.py:147-169): n proofs handed over as
+    packed wire bytes, verdicts back -- the device front-end (cg1_opening_prepare_device) and the host one.  The reference's valid goldens, cycled."""
+    from curdleproofs_pie_amd.shuffle_verifier import OpeningBatchVerifier
+
+    with open(os.path.join(ROOT, "tests", "golden", "opening_vectors.json")) as f:
+        cases = json.load(f)["cases"]
+    one = [(bytes.fromhex(c["r_G"]) + bytes.fromhex(c["k_r_G"]), bytes.fromhex(c["k_commitment"]), bytes.fromhex(c["proof"])) for c in cases]
+    reps_n = (n + len(one) - 1) // len(one)
+    trk = (b"".join(t for t, _, _ in one) * reps_n)[: 96 * n]
+    kcs = (b"".join(k for _, k, _ in one) * reps_n)[: 48 * n]
+    pfs = (b"".join(p for _, _, p in one) * reps_n)[: 128 * n]
+    out = {"unit": "opening proofs/s", "n": n, "data": "the reference's %d valid golden proofs cycled; wire bytes in host memory -> verdicts" % len(one)}
+    for key, dev in (("device_front_end", True), ("host_front_end", False)):
+        v = OpeningBatchVerifier(ctx, device_front_end=dev)
+        assert all(v.verify_packed(trk, kcs, pfs))
+        best = 1e9
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            ok = v.verify_packed(trk, kcs, pfs)
+            best = min(best, time.perf_counter() - t0)
+            assert all(ok)
+        out[key] = {"value": n / best, "ms_per_batch": best * 1e3}
+    return out
+
+
 def open_comm(args, rank, world, ctx):
     """The rank's communicator (None at N = 1): TCP control channel + RCCL for the data exchange unless the ranks share one GPU.
     If RCCL cannot be attached on some rank (library missing, ncclCommInitRank error) EVERY rank keeps the socket transport and the
@@ -257,6 +283,8 @@ def verify_mode(args, rank, local_rank, world):
     fe = max_over_ranks(out["phases_ms_per_step"][FE_KEY], comm)
     el = max(per_rank)
     if rank == 0:
+        if world == 1:
+            out["opening_proofs"] = opening_measure(ctx)
         out.update({"value": world * args.batch * args.steps / el, "ms_per_step": el / args.steps * 1e3, "n_gpus": world, "scaling": "weak",
                     "vs_baseline": None, "dtype": "u32",
                     "per_rank": {"ms_per_step": [x / args.steps * 1e3 for x in per_rank], "front_end_ms_per_step": fe,
@@ -714,6 +742,7 @@ def main():
             # ... and with 2048 proofs per batch: BASELINE config 5's share of one GPU (16 384 proofs over 8)
             dv2 = verify_measure(ctx, 2, max(10, args.verify_steps // 2), 1, 2 * args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
             out["secondary"]["device_front_end_on_2_host_threads_batches_of_%d" % (2 * args.batch)] = {k: dv2[k] for k in keys if k != "phases_ms_per_step"}
+            out["secondary"]["opening_proofs"] = opening_measure(ctx)
         if world == 1 and not args.no_python_face:
             # the drop-in itself: compute_MSM / MSMAccumulator through the reference's signature (lists of G1Point / Scalar objects), and
             # the reference's own backend-call sequence for one proof replayed through this backend.  (After the secondary metric: these

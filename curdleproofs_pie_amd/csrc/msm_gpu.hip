@@ -61,6 +61,7 @@ int pick_window(size_t n);
 #include "kernels_rows.h"
 #include "kernels_merlin.h"
 #include "kernels_frontend.h"
+#include "kernels_opening.h"
 namespace cg1 {
 
 // ------------------------------------------------------------------ host-side context
@@ -147,6 +148,7 @@ struct Ctx {
   int fe_rows = 1;                      // "fe_rows": 1 = the front-end's block-program kernel (k_shuffle_front_end_rows), 0 = the byte machine
   int fe_prio = 0;                      // "fe_prio": wave priority of k_shuffle_front_end (s_setprio 0 .. 3)
   int decompress_waves = 3;             // "decompress_waves": waves per SIMD k_batch_decompress<false> is compiled for (2: table in registers, 3: half of it in scratch)
+  void* d_opening = nullptr; size_t cap_opening = 0;              // cg1_opening_prepare_device's scratch (940 B per proof)
   int merlin_last_kernel = 0;           // which kernel served the last cg1_merlin_batch_device call: 2 block program, 1 byte machine, 0 one lane at a time
   int merlin_rows = 1;                  // "merlin_rows": 1 = cg1_merlin_batch_device hashes whole rate blocks (k_merlin_batch_rows) when the program fits, 0 = byte machine
   void* d_merlin_rows = nullptr; size_t merlin_rows_cap = 0;      // the rows of the last such call (kept: 134 KB per shuffle-shaped transcript)
@@ -1280,6 +1282,7 @@ void cg1_ctx_destroy(cg1_ctx* ctx) {
   if (ctx->ev_acc) (void)hipEventDestroy(ctx->ev_acc);
   cg1::free_bufs(ctx);
   if (ctx->d_merlin_rows) (void)hipFree(ctx->d_merlin_rows);
+  if (ctx->d_opening) (void)hipFree(ctx->d_opening);
   if (ctx->d_small_partial) (void)hipFree(ctx->d_small_partial);
   if (ctx->d_small_ctr) (void)hipFree(ctx->d_small_ctr);
   if (ctx->d_small_pts) (void)hipFree(ctx->d_small_pts);
@@ -1869,6 +1872,74 @@ int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg
                      (const uint8_t*)dst.p, (const cg1merlin::Op*)dops.p, (uint32_t)nops, (const uint8_t*)d_data, data_stride,
                      (uint8_t*)d_out, out_stride, (uint8_t*)d_states_out, (uint32_t)n);
   HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  return CG1_OK;
+}
+// Opening proofs, the batch verifier's front-end on the device (kernels_opening.h): the wire bytes of n proofs go up as they are, the
+// five own points of each are gathered in MSM order and decompressed WITH the subgroup test (both equalities are asserted exactly by the
+// reference, opening.py:73-74, on points it decodes unchecked: a random combination is sound only inside G1), the six-append transcript
+// runs through the block program, and the scalars of the merged check are written behind one another: what the caller hands to
+// cg1_msm_device is d_points96 / d_scalars32 with 5 n + 1 terms (the last one the generator with the summed scalar).  weights64 == NULL:
+// the weights are derived on the device from seed32 (kernels_opening.h weights_from_seed; cg1_opening_weights_from_seed is the host's copy).  status[i] and
+// point_status[5 i ..] come back exactly as cg1_opening_prepare + cg1_shuffle_apply_point_status leave them on the host path.
+int cg1_opening_prepare_device(cg1_ctx* ctx, size_t n, const uint8_t* trackers96, const uint8_t* k_commitments48, const uint8_t* proofs128,
+                               const uint8_t* weights64, const uint8_t* seed32, void* d_points96, void* d_scalars32, int32_t* status,
+                               uint8_t* point_status, uint8_t* out_g_scalars32) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) return CG1_OK;
+  if (!trackers96 || !k_commitments48 || !proofs128 || (!weights64 && !seed32) || !d_points96 || !d_scalars32 || !status || !point_status || n >= (1ull << 26))
+    return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  // scratch: trackers 96 | k_commitments 48 | proofs 128 | weights 64 | wire 240 | rows 288 | challenges 32 | g scalars 32 | status 4 | point status 5 (+3)
+  const size_t per = 96 + 48 + 128 + 64 + 240 + cg1open::ROW_BYTES + 32 + 32 + 4 + 8, need = per * n;
+  if (need > ctx->cap_opening) {
+    if (ctx->d_opening) (void)hipFree(ctx->d_opening);
+    ctx->d_opening = nullptr; ctx->cap_opening = 0;
+    HIPCHK(hipMalloc(&ctx->d_opening, need));
+    ctx->cap_opening = need;
+  }
+  uint8_t* base = (uint8_t*)ctx->d_opening;
+  uint8_t *d_trk = base, *d_kc = d_trk + 96 * n, *d_pf = d_kc + 48 * n, *d_w = d_pf + 128 * n, *d_wire = d_w + 64 * n, *d_rows = d_wire + 240 * n,
+          *d_ch = d_rows + (size_t)cg1open::ROW_BYTES * n, *d_gs = d_ch + 32 * n, *d_st = d_gs + 32 * n, *d_ps = d_st + 4 * n;
+  hipStream_t st = ctx->stream;
+  HIPCHK(hipMemcpyAsync(d_trk, trackers96, 96 * n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_kc, k_commitments48, 48 * n, hipMemcpyHostToDevice, st));
+  HIPCHK(hipMemcpyAsync(d_pf, proofs128, 128 * n, hipMemcpyHostToDevice, st));
+  if (weights64) HIPCHK(hipMemcpyAsync(d_w, weights64, 64 * n, hipMemcpyHostToDevice, st));
+  cg1open::Seed32 seed{};
+  if (!weights64) memcpy(seed.w, seed32, 32);
+  uint8_t gblob[CG1_POINT_BYTES], g48[48], g96[96];
+  cg1_generator(gblob);
+  cg1_compress(g48, gblob);
+  cg1_to_affine96(g96, gblob);
+  cg1open::Enc48 genc;
+  memcpy(genc.w, g48, 48);
+  const uint32_t n32 = (uint32_t)n;
+  hipLaunchKernelGGL(cg1open::k_opening_gather, dim3((unsigned)((6 * n + 255) / 256)), dim3(256), 0, st, (const uint32_t*)d_trk, (const uint32_t*)d_kc,
+                     (const uint32_t*)d_pf, genc, n32, (uint32_t*)d_wire, (uint32_t*)d_rows);
+  launch_decompress(ctx, d_wire, d_points96, d_ps, 5 * n, 1);
+  HIPCHK(hipMemcpyAsync((uint8_t*)d_points96 + 96 * 5 * n, g96, 96, hipMemcpyHostToDevice, st));
+  uint8_t init[CG1_MERLIN_STATE_BYTES];
+  cg1_merlin_init(init, (const uint8_t*)"whisk_opening_proof", 19);                      // opening.py:60
+  cg1_merlin_op ops[7];
+  memset(ops, 0, sizeof ops);
+  static const uint32_t off[6] = {0, 240, 48, 96, 144, 192};                              // k_G G k_r_G r_G A B (opening.py:61-66) inside a row
+  for (int k = 0; k < 6; ++k) {
+    ops[k].kind = 0; ops[k].label_len = 21; memcpy(ops[k].label, "tracker_opening_proof", 21);
+    ops[k].len = 48; ops[k].data_off = off[k];
+  }
+  ops[6].kind = 2; ops[6].label_len = 31; memcpy(ops[6].label, "tracker_opening_proof_challenge", 31);
+  { int rc = cg1_merlin_batch_device(ctx, init, ops, 7, d_rows, cg1open::ROW_BYTES, d_ch, 32, nullptr, n); if (rc) return rc; }
+  hipLaunchKernelGGL(cg1open::k_opening_scalars, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, (const uint8_t*)d_ch, (const uint8_t*)d_pf,
+                     weights64 ? (const uint8_t*)d_w : (const uint8_t*)nullptr, seed, (const uint8_t*)d_ps, n32, (int32_t)CG1_SHUFFLE_BAD_SCALAR, (int32_t)CG1_SHUFFLE_BAD_WEIGHT, (int32_t)CG1_SHUFFLE_BAD_POINT,
+                     (uint8_t*)d_scalars32, d_gs, (int32_t*)d_st);
+  const unsigned sum_blocks = (unsigned)std::min<size_t>(256, (n + 1023) / 1024);          // the challenges are spent: their buffer takes the partial sums
+  hipLaunchKernelGGL(cg1open::k_fr_sum, dim3(sum_blocks), dim3(256), 0, st, (const uint64_t*)d_gs, n32, (uint64_t*)d_ch);
+  hipLaunchKernelGGL(cg1open::k_fr_sum, dim3(1), dim3(256), 0, st, (const uint64_t*)d_ch, sum_blocks, (uint64_t*)((uint8_t*)d_scalars32 + 32 * 5 * n));
+  HIPCHK(hipMemcpyAsync(status, d_st, 4 * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(point_status, d_ps, 5 * n, hipMemcpyDeviceToHost, st));
+  if (out_g_scalars32) HIPCHK(hipMemcpyAsync(out_g_scalars32, d_gs, 32 * n, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
   HIPCHK(hipGetLastError());
   return CG1_OK;
 }

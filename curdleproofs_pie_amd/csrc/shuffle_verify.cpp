@@ -1048,6 +1048,27 @@ int cg1_opening_prepare(size_t n, const uint8_t* trackers, const uint8_t* k_comm
   return CG1_OK;
 }
 
+// rho1 | rho2 of proof i from a per-batch seed: the first 32 bytes of SHAKE256(seed || le64(i)), 16 bytes each (the device's
+// weights_from_seed, csrc/kernels_opening.h, computes the very same)
+int cg1_opening_weights_from_seed(const uint8_t seed32[32], size_t first, size_t n, uint8_t* out_weights64) {
+  if (!seed32 || (n && !out_weights64)) return CG1_ERR_ARG;
+  for (size_t k = 0; k < n; ++k) {
+    uint8_t st[200];
+    memset(st, 0, sizeof st);
+    memcpy(st, seed32, 32);
+    const uint64_t i = (uint64_t)(first + k);
+    for (int b = 0; b < 8; ++b) st[32 + b] = (uint8_t)(i >> (8 * b));
+    st[40] ^= 0x1F;
+    st[135] ^= 0x80;
+    cg1_keccak_f1600(st);
+    uint8_t* o = out_weights64 + 64 * k;
+    memset(o, 0, 64);
+    memcpy(o, st, 16);
+    memcpy(o + 32, st + 16, 16);
+  }
+  return CG1_OK;
+}
+
 // The equalities the reference asserts directly, evaluated EXACTLY (no random weights) with host group arithmetic, for
 // proofs that carry a point outside G1: random weights are only sound inside the prime-order subgroup (E(Fp) has points of
 // order 3, 11, ...), and the reference's own verdict on such a proof is the exact one.

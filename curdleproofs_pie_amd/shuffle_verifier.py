@@ -909,18 +909,24 @@ def are_valid_whisk_shuffle_proofs(crs, items, ctx=None) -> List[bool]:
 class OpeningBatchVerifier:
     """Many `IsValidWhiskOpeningProof(tracker, k_commitment, proof)` calls (whisk_interface.py:147-169) as one GPU MSM of
     5 n + 1 terms: both equalities of every proof (opening.py:74-77) under fresh random weights, points decompressed on
-    the GPU.  If the merged check fails, one 5-term MSM per proof (plus its generator term on the host) names the culprits."""
+    the GPU.  If the merged check fails, one 5-term MSM per proof (plus its generator term on the host) names the culprits.
+
+    `device_front_end` (default): the transcripts and the scalars of the merged check are produced on the GPU too
+    (`cg1_opening_prepare_device`, csrc/kernels_opening.h): the host only hands the wire bytes over.  False = the host front-end
+    (`cg1_opening_prepare` on the native worker pool); both give the same verdicts and status codes (tests/test_opening_batch.py)."""
 
     PROOF_BYTES = 128                       # A | B | s   (opening.py:94-99)
 
-    def __init__(self, ctx: Optional["N.Context"] = None):
+    def __init__(self, ctx: Optional["N.Context"] = None, device_front_end: bool = True):
         self._ctx = ctx
+        self.device_front_end = bool(device_front_end)
         g = ctypes.create_string_buffer(N.POINT_BYTES)
         N.cg1_generator(g)
         aff = ctypes.create_string_buffer(96)
         N.cg1_to_affine96(aff, g.raw)
         self._g_blob, self._g96 = g.raw, aff.raw
         self.last_status: List[int] = []
+        self._dev = None                      # (capacity, d_pts, d_sc) kept between calls
 
     @property
     def ctx(self) -> "N.Context":
@@ -928,8 +934,20 @@ class OpeningBatchVerifier:
             self._ctx = N.default_context()
         return self._ctx
 
-    def prepare(self, items, rng=None):
-        """items: (tracker, k_commitment, proof_bytes); tracker = WhiskTracker-like or (r_G, k_r_G).  Host half only."""
+    @staticmethod
+    def _weights(n, rng, seed=None):
+        """rng given (tests): 2 n weights from it.  Otherwise both front-ends derive them from `seed` (32 fresh bytes from the OS per batch):
+        SHAKE256(seed || le64(i)) -> two 128-bit weights per proof (cg1_opening_weights_from_seed; on the device inside k_opening_scalars)."""
+        if rng is not None:
+            return b"".join(rng.randint(1, FR_MODULUS - 1).to_bytes(32, "little") for _ in range(2 * n))
+        out = ctypes.create_string_buffer(max(1, 64 * n))
+        rc = N.cg1_opening_weights_from_seed(seed, 0, n, out)
+        if rc:
+            raise N.NativeError(f"cg1_opening_weights_from_seed failed ({rc})")
+        return out.raw[: 64 * n]
+
+    def _pack(self, items):
+        """items: (tracker, k_commitment, proof_bytes); tracker = WhiskTracker-like or (r_G, k_r_G) -> packed wire arrays + length verdicts"""
         items = list(items)
         n = len(items)
         trk = [it[0] for it in items]
@@ -942,71 +960,107 @@ class OpeningBatchVerifier:
         except TypeError:
             uniform = False
         if uniform:                                   # the common case: everything well-formed, packed without a per-item loop
-            trackers = b"".join(x for pair in zip(rs, krs) for x in pair)
-            kcs, pfs, pre = b"".join(ks), b"".join(ps), [0] * n
-        else:
-            tr, kc, pf, pre = [], [], [], []
-            for r, kr, k, p in zip(rs, krs, ks, ps):
-                r, kr, k, p = bytes(r), bytes(kr), bytes(k), bytes(p)
-                ok = len(r) == len(kr) == len(k) == 48 and len(p) >= self.PROOF_BYTES       # BufReader ignores trailing bytes
-                tr.append(r + kr if ok else bytes(96)); kc.append(k if ok else bytes(48)); pf.append(p[:128] if ok else bytes(128))
-                pre.append(0 if ok else REJECT_LENGTH)
-            trackers, kcs, pfs = b"".join(tr), b"".join(kc), b"".join(pf)
-        if rng is None:
-            raw = bytearray(secrets.token_bytes(64 * n))
-            raw[31::32] = raw[31::32].translate(_CLEAR_TOP2)
-            weights = bytes(raw)
-        else:
-            weights = b"".join(rng.randint(1, FR_MODULUS - 1).to_bytes(32, "little") for _ in range(2 * n))
-        out = {"n": n, "proof_s": b"".join(pfs[128 * i + 96: 128 * i + 128] for i in range(n)), "points48": ctypes.create_string_buffer(max(1, 240 * n)), "scalars32": ctypes.create_string_buffer(max(1, 160 * n)),
+            return n, b"".join(x for pair in zip(rs, krs) for x in pair), b"".join(ks), b"".join(ps), None
+        tr, kc, pf, pre = [], [], [], []
+        for r, kr, k, p in zip(rs, krs, ks, ps):
+            r, kr, k, p = bytes(r), bytes(kr), bytes(k), bytes(p)
+            ok = len(r) == len(kr) == len(k) == 48 and len(p) >= self.PROOF_BYTES       # BufReader ignores trailing bytes
+            tr.append(r + kr if ok else bytes(96)); kc.append(k if ok else bytes(48)); pf.append(p[:128] if ok else bytes(128))
+            pre.append(0 if ok else REJECT_LENGTH)
+        return n, b"".join(tr), b"".join(kc), b"".join(pf), pre
+
+    def prepare(self, items, rng=None):
+        """Host front-end only (no GPU): points in MSM order, scalars, generator scalars and status per proof."""
+        n, trackers, kcs, pfs, pre = self._pack(items)
+        return self._prepare_host(n, trackers, kcs, pfs, pre, self._weights(n, rng, secrets.token_bytes(32)))
+
+    def _prepare_host(self, n, trackers, kcs, pfs, pre, weights):
+        out = {"n": n, "points48": ctypes.create_string_buffer(max(1, 240 * n)), "scalars32": ctypes.create_string_buffer(max(1, 160 * n)),
                "g_scalars32": ctypes.create_string_buffer(max(1, 32 * n)), "status": (ctypes.c_int32 * max(1, n))()}
         rc = N.cg1_opening_prepare(n, trackers, kcs, pfs, weights, out["points48"], out["scalars32"],
                                    out["g_scalars32"], out["status"])
         if rc:
             raise N.NativeError(f"cg1_opening_prepare failed ({rc})")
-        for i, s in enumerate(pre):
+        for i, s in enumerate(pre or ()):
             if s:
                 out["status"][i] = s
                 ctypes.memset(ctypes.addressof(out["scalars32"]) + 160 * i, 0, 160)
                 ctypes.memset(ctypes.addressof(out["g_scalars32"]) + 32 * i, 0, 32)
         return out
 
-    def verify_many(self, items, rng=None) -> List[bool]:
-        prep = self.prepare(items, rng)
-        n = prep["n"]
+    def _buffers(self, n):
+        if self._dev is None or self._dev[0] < n:
+            ctx = self.ctx
+            cap = max(n, 1024)
+            self._dev = (cap, ctx.alloc(96 * (5 * cap + 1)), ctx.alloc(32 * (5 * cap + 1)))
+        return self._dev[1], self._dev[2]
+
+    def verify_many(self, items, rng=None, seed: Optional[bytes] = None) -> List[bool]:
+        n, trackers, kcs, pfs, pre = self._pack(items)
+        return self._verify(n, trackers, kcs, pfs, pre, rng, seed)
+
+    def verify_packed(self, trackers96: bytes, k_commitments48: bytes, proofs128: bytes, rng=None, seed: Optional[bytes] = None) -> List[bool]:
+        """The same verdicts for n proofs already laid out back to back: n x (r_G | k_r_G), n x k_commitment, n x (A | B | s)."""
+        n = len(proofs128) // self.PROOF_BYTES
+        if len(proofs128) != 128 * n or len(trackers96) != 96 * n or len(k_commitments48) != 48 * n:
+            raise ValueError("verify_packed: expected n x 96, n x 48 and n x 128 bytes")
+        return self._verify(n, trackers96, k_commitments48, proofs128, None, rng, seed)
+
+    def _verify(self, n, trackers, kcs, pfs, pre, rng, seed=None) -> List[bool]:
         if n == 0:
+            self.last_status = []
             return []
         ctx = self.ctx
-        d_wire, d_pts, d_stat, d_sc = ctx.alloc(240 * n), ctx.alloc(96 * (5 * n + 1)), ctx.alloc(5 * n), ctx.alloc(32 * (5 * n + 1))
-        d_wire.upload(prep["points48"].raw[: 240 * n])
+        if seed is None:
+            seed = secrets.token_bytes(32)
+        elif len(seed) != 32:
+            raise ValueError("seed: 32 bytes")
+        d_pts, d_sc = self._buffers(n)
         # Both equalities of an opening proof are asserted EXACTLY by the reference (opening.py:74-77) on points it decodes
         # unchecked: weighting them randomly is sound only inside G1, so every point is decoded with the subgroup test.  A
         # proof with a point outside G1 leaves the batch (its scalars are zeroed) and is decided by the exact host check.
-        ctx.check(N.cg1_batch_decompress_device(ctx.handle, d_wire.ptr, d_pts.ptr, d_stat.ptr, 5 * n, 1))
-        d_pts.upload(self._g96, 96 * 5 * n)
-        pstat = bytearray(d_stat.download(5 * n))
-        outside = [i for i in range(n) if N.ERR_NOT_IN_SUBGROUP in pstat[5 * i: 5 * i + 5]
-                   and not any(x not in (0, N.ERR_NOT_IN_SUBGROUP) for x in pstat[5 * i: 5 * i + 5])] if N.ERR_NOT_IN_SUBGROUP in pstat else []
-        ctx.check(N.cg1_shuffle_apply_point_status(prep["status"], bytes(pstat), n, 5, prep["scalars32"], prep["g_scalars32"], 1))
-        g_sum = ctypes.create_string_buffer(32)
-        ctx.check(N.cg1_shuffle_sum_crs_scalars(prep["g_scalars32"], prep["status"], n, 1, g_sum))
-        d_sc.upload(prep["scalars32"].raw[: 160 * n] + g_sum.raw)
-        status = [int(prep["status"][i]) for i in range(n)]
-        live = [i for i in range(n) if status[i] == 0]
-        if live and not N.cg1_is_identity(ctx.msm_device(d_pts, d_sc, 5 * n + 1)):
+        if self.device_front_end:
+            st_arr = (ctypes.c_int32 * n)()
+            ps_buf = ctypes.create_string_buffer(5 * n)
+            g_scalars = ctypes.create_string_buffer(32 * n)
+            ctx.check(N.cg1_opening_prepare_device(ctx.handle, n, trackers, kcs, pfs, self._weights(n, rng) if rng is not None else None, seed,
+                                                   d_pts.ptr, d_sc.ptr, st_arr, ps_buf, g_scalars))
+            pstat = ps_buf.raw
+            status = memoryview(st_arr).cast("B").cast("i").tolist()
+        else:
+            prep = self._prepare_host(n, trackers, kcs, pfs, pre, self._weights(n, rng, seed))
+            d_wire, d_stat = ctx.alloc(240 * n), ctx.alloc(5 * n)
+            d_wire.upload(prep["points48"].raw[: 240 * n])
+            ctx.check(N.cg1_batch_decompress_device(ctx.handle, d_wire.ptr, d_pts.ptr, d_stat.ptr, 5 * n, 1))
+            d_pts.upload(self._g96, 96 * 5 * n)
+            pstat = d_stat.download(5 * n)
+            ctx.check(N.cg1_shuffle_apply_point_status(prep["status"], pstat, n, 5, prep["scalars32"], prep["g_scalars32"], 1))
+            g_sum = ctypes.create_string_buffer(32)
+            ctx.check(N.cg1_shuffle_sum_crs_scalars(prep["g_scalars32"], prep["status"], n, 1, g_sum))
+            d_sc.upload(prep["scalars32"].raw[: 160 * n] + g_sum.raw)
+            g_scalars = prep["g_scalars32"]
+            status = [int(prep["status"][i]) for i in range(n)]
+        if pre:
+            status = [p or s for p, s in zip(pre, status)]
+        if N.ERR_NOT_IN_SUBGROUP in pstat:
+            outside = [i for i in range(n) if N.ERR_NOT_IN_SUBGROUP in pstat[5 * i: 5 * i + 5]
+                       and not any(x not in (0, N.ERR_NOT_IN_SUBGROUP) for x in pstat[5 * i: 5 * i + 5])]
+        else:
+            outside = []
+        if any(s == 0 for s in status) and not N.cg1_is_identity(ctx.msm_device(d_pts, d_sc, 5 * n + 1)):
             own = ctx.msm_batched_device(d_pts, d_sc, [5 * i for i in range(n + 1)])
             tmp = ctypes.create_string_buffer(N.POINT_BYTES)
-            for i in live:
-                N.cg1_mul(tmp, self._g_blob, prep["g_scalars32"].raw[32 * i: 32 * i + 32])
+            for i in range(n):
+                if status[i]:
+                    continue
+                N.cg1_mul(tmp, self._g_blob, g_scalars.raw[32 * i: 32 * i + 32])
                 N.cg1_add(tmp, tmp.raw, own[i])
                 if not N.cg1_is_identity(tmp.raw):
                     status[i] = REJECT_EQUATION
         ok = ctypes.c_int(0)
         for i in outside:
             if status[i] == 2:                       # rejected only for the subgroup flag: the exact equalities decide
-                trk = prep["points48"].raw[240 * i + 96: 240 * i + 144] + prep["points48"].raw[240 * i + 48: 240 * i + 96]
-                ctx.check(N.cg1_opening_exact(trk, prep["points48"].raw[240 * i: 240 * i + 48],
-                                              prep["points48"].raw[240 * i + 144: 240 * i + 240] + prep["proof_s"][32 * i: 32 * i + 32], ctypes.byref(ok)))
+                ctx.check(N.cg1_opening_exact(trackers[96 * i: 96 * i + 96], kcs[48 * i: 48 * i + 48], pfs[128 * i: 128 * i + 128], ctypes.byref(ok)))
                 status[i] = 0 if ok.value else REJECT_EQUATION
         self.last_status = status
         return [s == 0 for s in status]

@@ -399,6 +399,20 @@ int cg1_opening_prepare(size_t n, const uint8_t* trackers96 /* r_G | k_r_G */, c
                         const uint8_t* weights /* n x 2 x scalar32 */, uint8_t* out_points48, uint8_t* out_scalars32,
                         uint8_t* out_g_scalars32, int32_t* status);
 
+/* The same front-end on the device (csrc/kernels_opening.h; replaces the per-proof host work of opening.py:60-71 -- the transcript --
+ * and of opening.py:73-74 as one random combination): host wire bytes in, d_points96 ((5 n + 1) x 96 B: the own points decoded WITH the
+ * subgroup test, then the generator) and d_scalars32 ((5 n + 1) x 32 B, the last one the summed generator scalar) left on the device for
+ * cg1_msm_device.  status[n]: 0 or CG1_SHUFFLE_BAD_SCALAR / _BAD_WEIGHT / _BAD_POINT (scalars of such a proof are zero); point_status[5 n]:
+ * k_batch_decompress's codes (CG1_ERR_NOT_IN_SUBGROUP marks the proofs the exact check cg1_opening_exact decides);
+ * out_g_scalars32 (n x 32 B, may be NULL): each proof's own generator scalar, for the culprit search.  No weight in the reference: it
+ * asserts both equalities per proof; the random combination is the batch verifier's own. */
+int cg1_opening_prepare_device(cg1_ctx* ctx, size_t n, const uint8_t* trackers96 /* r_G | k_r_G */, const uint8_t* k_commitments48,
+                               const uint8_t* proofs128, const uint8_t* weights /* n x 2 x scalar32, or NULL */, const uint8_t* seed32 /* used when weights == NULL */,
+                               void* d_points96, void* d_scalars32, int32_t* status, uint8_t* point_status, uint8_t* out_g_scalars32);
+/* The weights both front-ends use when the caller supplies none: proof i gets rho1 | rho2 = two 128-bit values (as scalar32) from the first
+ * 32 bytes of SHAKE256(seed32 || le64(i)); seed32 = 32 fresh bytes from the OS per batch.  Writes proofs first .. first + n - 1. */
+int cg1_opening_weights_from_seed(const uint8_t seed32[32], size_t first, size_t n, uint8_t* out_weights64);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,18 +1,37 @@
 #!/usr/bin/env python3
-"""Throughput of batched Whisk tracker-opening verification (golden fixture cycled)."""
-import json, os, sys, time
+"""Throughput of batched Whisk tracker-opening verification (golden fixture cycled): the device front-end (cg1_opening_prepare_device)
+against the host one, through the item list of the reference's signature and through the packed entry.
+
+    python tools/gpu_opening_timing.py        -> profiles/r04_opening_fe.txt
+"""
+import json
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from curdleproofs_pie_amd.shuffle_verifier import OpeningBatchVerifier
+from curdleproofs_pie_amd import _native as N  # noqa: E402
+from curdleproofs_pie_amd.shuffle_verifier import OpeningBatchVerifier  # noqa: E402
+
 g = json.load(open(os.path.join(ROOT, "tests", "golden", "opening_vectors.json")))
 items = [((bytes.fromhex(c["r_G"]), bytes.fromhex(c["k_r_G"])), bytes.fromhex(c["k_commitment"]), bytes.fromhex(c["proof"])) for c in g["cases"]]
-v = OpeningBatchVerifier()
-for n in (1024, 16384, 131072):
+ctx = N.default_context()
+print(f"host threads of the native pool: {N.cg1_shuffle_default_threads()}")
+for n in (1024, 16384, 131072, 1048576):
     batch = [items[i % len(items)] for i in range(n)]
-    assert all(v.verify_many(batch))
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter(); ok = v.verify_many(batch); ts.append(time.perf_counter() - t0)
-        assert all(ok)
-    t0 = time.perf_counter(); prep = v.prepare(batch); tp = time.perf_counter() - t0
-    print(f"n={n}: {1e3 * min(ts):.1f} ms -> {n / min(ts):.0f} opening proofs/s (host front-end, one thread + Python packing: {1e3 * tp:.1f} ms)", flush=True)
+    trk = b"".join(t[0] + t[1] for t, _, _ in batch)
+    kcs = b"".join(k for _, k, _ in batch)
+    pfs = b"".join(p for _, _, p in batch)
+    line = [f"n={n}:"]
+    for name, dev in (("device front-end", True), ("host front-end", False)):
+        v = OpeningBatchVerifier(ctx, device_front_end=dev)
+        assert all(v.verify_many(batch))
+        t_items, t_packed = [], []
+        for _ in range(3):
+            t0 = time.perf_counter(); ok = v.verify_many(batch); t_items.append(time.perf_counter() - t0)
+            assert all(ok)
+            t0 = time.perf_counter(); ok = v.verify_packed(trk, kcs, pfs); t_packed.append(time.perf_counter() - t0)
+            assert all(ok)
+        line.append(f"{name}: items {1e3 * min(t_items):.2f} ms = {n / min(t_items) / 1e6:.2f} M proofs/s, packed {1e3 * min(t_packed):.2f} ms = {n / min(t_packed) / 1e6:.2f} M proofs/s;")
+    print(" ".join(line), flush=True)
