@@ -202,6 +202,21 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
     return out
 
 
+def pmc_traffic(logn):
+    """`roofline.traffic`: fabric-side bytes per k_accumulate launch from the last committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
+    their own runs, the gfx950 correction applied: tools/summarize_profiles.py -> profiles/pmc_traffic.json).  Counters cannot be read inside
+    this run, so the figure is the collection's, and only for the workload it was taken on (2^20 terms, one launch per step)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        if logn != 20 or "2^20" not in t.get("workload", ""):
+            raise ValueError("other workload")
+        return {"traffic": t["k_accumulate_hbm_bytes_per_launch"], "traffic_unit": "bytes per launch",
+                "traffic_source": "profiles/pmc_traffic.json <- " + t.get("source", "?").split(" (")[0] + "; " + t.get("note", "")}
+    except (OSError, ValueError, KeyError):
+        return {"traffic": None, "traffic_note": "PMC counters cannot be read inside this run; see profiles/pmc_traffic.json"}
+
+
 def opening_measure(ctx, n=131072, reps=3):
     """Whisk tracker-opening proofs verified/s (IsValidWhiskOpeningProof, whisk_interface.py:147-169): n proofs handed over as
     packed wire bytes, verdicts back -- the device front-end (cg1_opening_prepare_device) and the host one.  The reference's valid goldens, cycled."""
@@ -673,9 +688,7 @@ def main():
                        "result_equals_closed_form": r["closed_form_ok"],
                        "bit_exact_vs_oracle": "tests/test_msm_gpu.py"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
-                         "traffic_note": "PMC counters cannot be read inside this run; the per-launch HBM bytes of k_accumulate from separate "
-                                         "rocprofv3 --pmc passes are kept in profiles/pmc_traffic.json",
+                         "frac": achieved / 8000.0, **pmc_traffic(args.logn if world == 1 else 0),
                          "kernel": "k_accumulate", "kernel_ms": acc_ms / launches, "launches_per_step": launches, "kernel_ms_per_step": acc_ms,
                          "launch_note": ("a call of this size runs as TWO launch chains (high / low half of the windows, two streams): each "
                                          "k_accumulate launch takes every term through half of the windows, i.e. 64 B of the term's 128 algorithmic "

@@ -1,8 +1,9 @@
 """The shuffle verifier's front-end ON THE DEVICE (csrc/kernels_frontend.h: transcript, grand-product scalar, D, A', inner_prod,
 challenge inverses -- one proof per lane) against the host front-end (cg1_shuffle_prepare_inputs, whose challenges are the
 reference verifier's, tests/test_shuffle_verifier.py): row-input blocks byte for byte and front-end codes, on every golden proof and
-every tampered variant (tests/golden/shuffle_vectors.json: reference prover / verifier over the oracle), and the challenges inside
-the blocks against the ones the REFERENCE recorded."""
+every tampered variant (tests/golden/shuffle_vectors.json: reference prover / verifier over the oracle), the challenges inside
+the blocks against the ones the REFERENCE recorded, and the derived scalars of the untampered proof's block (beta^-1, inner_prod, the
+challenge inverses, the proof's Fr fields) against the oracle's restatement of the verifier (oracle/shuffle_rows.py)."""
 import ctypes
 import json
 import os
@@ -84,6 +85,24 @@ def test_device_front_end_equals_host_front_end(native_lib, gold, fe_rows):
         got = [slot(8 + 2 * lg + i) for i in range(ell)] + [slot(0), slot(1), slot(2), slot(3), slot(4), slot(5)] + \
               [slot(8 + j) for j in range(lg)] + [slot(6), slot(7)] + [slot(8 + lg + j) for j in range(lg)]
         assert got == [c[1] for c in ref], case["ell"]
+        # ... and everything else in that block is what the ORACLE's restatement of the verifier computes from those challenges
+        # (oracle/shuffle_rows.py: beta^-1 grand_prod.py:148, inner_prod grand_prod.py:164-166, the round challenges' inverses
+        # ipa.py:178 / same_msm.py:175, the proof's Fr fields, the weights) -- not only what the host front-end wrote
+        from oracle import shuffle_rows as SR
+
+        Rin = lambda name: {"head": 0, "gam": 8, "gm": 8 + lg, "a": 8 + 2 * lg, "beta_inv": 8 + 2 * lg + ell, "inner_prod": 9 + 2 * lg + ell,
+                            "gam_inv": 10 + 2 * lg + ell, "gm_inv": 10 + 3 * lg + ell, "fields": 10 + 4 * lg + ell, "rho": 16 + 4 * lg + ell}[name]
+        assert K == Rin("rho") + 12
+        val = lambda k: int.from_bytes(blk[32 * k: 32 * k + 32], "little")
+        rho = [int.from_bytes(w[32 * j: 32 * j + 32], "little") for j in range(12)]
+        ch = [(lab, int.from_bytes(bytes.fromhex(x), "little")) for lab, x in ref]
+        fields = SR.proof_fields(bytes.fromhex(case["proof"]), ell)
+        _, _, aux = SR.statement_rows(ell, fields, ch, rho)
+        assert val(Rin("beta_inv")) == aux["beta_inv"] and val(Rin("inner_prod")) == aux["inner_prod"]
+        for j in range(lg):
+            assert val(Rin("gam_inv") + j) == SR.inv(val(Rin("gam") + j)) and val(Rin("gm_inv") + j) == SR.inv(val(Rin("gm") + j))
+        assert [val(Rin("fields") + j) for j in range(6)] == [fields[k] for k in ("c_final", "d_final", "z_k", "z_t", "z_u", "x_final")]
+        assert [val(Rin("rho") + j) for j in range(12)] == rho
         v.close()
 
 
