@@ -177,31 +177,7 @@ __global__ void __launch_bounds__(256) k_batch_compress(const uint32_t* __restri
   o[0] |= (uint8_t)(0x80 | (is_large ? 0x20 : 0));
 }
 
-// P = (x, y) on the curve (Montgomery limbs, N-form) is in the prime-order subgroup G1  <=>  [z^2] P == phi(P) + P with
-// phi(x, y) = (beta x, y)  (the endomorphism acts on G1 as multiplication by z^2 - 1; on no other point of E(Fp) does it).
-// [z^2] P = [|z|] [|z|] P with |z| = 0xd201000000010000 (six set bits): 2 x (63 doublings + 5 additions) instead of the
-// 128 doublings + ~22 additions of a plain ladder over z^2.
-__device__ __forceinline__ bool g1_in_subgroup(const fp& x, const fp& y) {
-  constexpr uint64_t ZABS = 0xd201000000010000ull;
-  constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
-  fp beta; for (int k = 0; k < NL; ++k) beta.l[k] = bt[k];
-  xyzz q = xyzz_from_affine(x, y);                 // top bit of |z|
-#pragma unroll 1
-  for (int bit = 62; bit >= 0; --bit) {
-    q = xyzz_dbl(q);
-    if ((ZABS >> bit) & 1ull) q = xyzz_madd(q, x, y);
-  }
-  xyzz acc = q;
-#pragma unroll 1
-  for (int bit = 62; bit >= 0; --bit) {
-    acc = xyzz_dbl(acc);
-    if ((ZABS >> bit) & 1ull) acc = xyzz_add(acc, q);
-  }
-  const fp yneg = fp_neg<3>(y);
-  acc = xyzz_madd(acc, x, yneg);                   // - P
-  acc = xyzz_madd(acc, fp_mul(x, beta), yneg);     // - phi(P)
-  return acc.inf != 0;
-}
+// (g1_in_subgroup: g1_xyzz.h -- [z^2] P == phi(P) + P on Jacobian doublings)
 
 // Subgroup flags for SELECTED points of each proof of a batch (affine96 standard-form words as k_batch_decompress wrote
 // them; `stride_pts` points per proof; the k = so.k points at offsets so.off[] of every proof): flags[proof * k + j] = 1 if

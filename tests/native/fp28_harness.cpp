@@ -44,7 +44,11 @@ int t_worst_case_bounds() {
   fp r2 = fp_sqr(lazy);                  // P^2, R^2, M^2
   fp r3 = fp_mul2(lazy, lazy, norm, neg);  // fused Y3
   fp r4 = fp_mul(neg, norm);             // lazily negated y times ZZZ
-  return (int)((r1.l[0] ^ r2.l[0] ^ r3.l[0] ^ r4.l[0]) & 1u) | 2;
+  // jacp_dbl: E = 3A times (D - X3); 2 Y1 (Y1 in its lazy post-doubling form) times Z1; X1 times 4B
+  fp e3, y2, b4;
+  for (int i = 0; i < NL; ++i) { e3.l[i] = 3u * norm.l[i]; y2.l[i] = 2u * lazy.l[i]; b4.l[i] = 4u * norm.l[i]; }
+  fp r5 = fp_mul(e3, lazy), r6 = fp_mul(y2, norm), r7 = fp_mul(norm, b4), r8 = fp_sqr(e3);
+  return (int)((r1.l[0] ^ r2.l[0] ^ r3.l[0] ^ r4.l[0] ^ r5.l[0] ^ r6.l[0] ^ r7.l[0] ^ r8.l[0]) & 1u) | 2;
 }
 
 static void export_xyzz(const xyzz& a, uint8_t* out /* 4*48 + 4 */) {
@@ -126,5 +130,41 @@ void t_running_sum(const uint8_t* pts96, int n, uint8_t* out) {
   }
   export_xyzz(tot, out);
 }
+
+// ---- Jacobian coordinates (the subgroup test's doublings): k * P by double-and-add (jacp_dbl + jacp_madd), exported through XYZZ
+static void export_jacp(const jacp& a, uint8_t* out) {
+  xyzz t;
+  t.inf = a.inf;
+  if (!a.inf) { t.X = a.X; t.Y = fp_mul(a.Y, fp_one()); t.ZZ = fp_sqr(a.Z); t.ZZZ = fp_mul(t.ZZ, a.Z); }
+  else { t.X = t.Y = t.ZZ = t.ZZZ = fp_zero(); }
+  export_xyzz(t, out);
+}
+void t_scalar_mul_jac(const uint8_t* pt96, const uint8_t* k32, uint8_t* out) {
+  fp x = load_mont(pt96), y = load_mont(pt96 + 48);
+  jacp acc = jacp_identity();
+  for (int bit = 255; bit >= 0; --bit) {
+    acc = jacp_dbl(acc);
+    if ((k32[bit >> 3] >> (bit & 7)) & 1) acc = jacp_madd(acc, x, y);
+  }
+  export_jacp(acc, out);
+}
+// sum of n affine points as a balanced tree of jacp_add (incl. P + P, P - P, identity operands); neg[i] negates y lazily
+void t_add_tree_jac(const uint8_t* pts96, const uint8_t* neg, int n, uint8_t* out) {
+  jacp* v = new jacp[n + 1];
+  for (int i = 0; i < n; ++i) {
+    fp x = load_mont(pts96 + 96 * i), y = load_mont(pts96 + 96 * i + 48);
+    v[i] = jacp_dbl(jacp_from_affine(x, neg[i] ? fp_neg<3>(y) : y));      // doubled first: Z != 1 and Y in its lazy post-doubling form
+  }
+  int m = n;
+  if (m == 0) { export_jacp(jacp_identity(), out); delete[] v; return; }
+  while (m > 1) {
+    for (int i = 0; i < m / 2; ++i) v[i] = jacp_add(v[i], v[m - 1 - i]);
+    m = (m + 1) / 2;
+  }
+  export_jacp(v[0], out);
+  delete[] v;
+}
+// the checked decompression's subgroup test on a curve point given as affine96 (x || y, standard form)
+int t_in_subgroup(const uint8_t* pt96) { return g1_in_subgroup(load_mont(pt96), load_mont(pt96 + 48)) ? 1 : 0; }
 
 }  // extern "C"

@@ -89,3 +89,72 @@ def test_group_law_with_exceptional_cases(fp28_harness):
     for i, p in enumerate(seq):
         want = O.g1_add(want, O.g1_mul(p, i + 1))
     assert parse_xyzz(o) == want
+
+
+def test_jacobian_ops_and_subgroup_test(fp28_harness):
+    """jacp_dbl / jacp_madd / jacp_add (the subgroup test's arithmetic) against the oracle's group law, and g1_in_subgroup against
+    r * P == identity on points of G1, random curve points, points of order 3 / 11 / 10177 and sums of those with points of G1."""
+    L = fp28_harness
+    rng = random.Random(9)
+    o = ctypes.create_string_buffer(196)
+    t3 = (0, 2)                                                          # order 3 (tests/golden/torsion_vectors.json "t3")
+    assert O.g1_is_on_curve(t3) and O.g1_add(O.g1_add(t3, t3), t3) is None
+
+    def curve_point():
+        while True:
+            x = rng.randrange(P)
+            y = O.fp_sqrt((x * x * x + 4) % P)
+            if y is not None:
+                return (x, y if rng.randrange(2) else P - y)
+
+    def mul_any(pt, k):                                                  # k * pt WITHOUT reducing k mod r (pt may lie outside G1)
+        acc, base = O.JAC_INF, O.jac_from_affine(pt)
+        for bit in bin(k)[2:] if k else "":
+            acc = O.jac_double(acc)
+            if bit == "1":
+                acc = O.jac_add(acc, base)
+        return O.jac_to_affine(acc)
+
+    g1 = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(6)]
+    wild = [curve_point() for _ in range(6)]
+    for base in (O.G1_GEN, g1[0], wild[0], t3):
+        for k in [0, 1, 2, 3, 4, 5, 6, 7, 99, O.R - 1, O.R, O.R + 1, (1 << 255) - 1, rng.randrange(1 << 255)]:
+            L.t_scalar_mul_jac(raw96(base), k.to_bytes(32, "little"), o)
+            assert parse_xyzz(o) == mul_any(base, k), (base == t3, k)
+
+    def tree(seq, negs):
+        want = None
+        for p, s in zip(seq, negs):
+            want = O.g1_add(want, O.g1_mul(O.g1_neg(p) if s else p, 2))
+        L.t_add_tree_jac(b"".join(raw96(p) for p in seq), bytes(negs), len(seq), o)
+        assert parse_xyzz(o) == want
+
+    tree(g1 + wild, [rng.randrange(2) for _ in range(12)])
+    tree([], [])
+    tree([g1[0]], [1])
+    tree([g1[0], g1[0]], [0, 0])                                         # doubling branch of jacp_add
+    tree([g1[0], g1[0]], [0, 1])                                         # cancellation
+    tree([g1[0], g1[0], g1[1]], [0, 1, 0])                               # identity operand
+    tree([t3, t3], [0, 0])
+    tree([t3, t3, t3], [0, 0, 0])
+    tree([g1[0], g1[1], g1[0], g1[1]], [0, 0, 1, 1])
+
+    # the cofactor's prime factors: (z - 1)^2 = 3 h, z - 1 = -(3 * 11 * 10177 * 859267 * 52437899)
+    zm1 = 0xd201000000010001
+    assert zm1 == 3 * 11 * 10177 * 859267 * 52437899
+    h = zm1 * zm1 // 3
+    small = [t3]
+    for ell in (11, 10177):
+        while True:
+            t = mul_any(curve_point(), O.R * (h // (ell * ell)))          # the cofactor group is Z/((z-1)/3) x Z/(z-1): exponent ell, order ell^2
+            if t is not None:
+                break
+        assert mul_any(t, ell) is None
+        small.append(t)
+    cases = g1 + wild + small + [O.g1_add(t, g) for t, g in zip(small, g1)] + [O.g1_add(small[0], small[1]), mul_any(wild[1], O.R), mul_any(wild[2], h)]
+    for pt in cases:
+        if pt is None:
+            continue
+        assert O.g1_is_on_curve(pt)
+        assert bool(L.t_in_subgroup(raw96(pt))) == O.g1_in_subgroup(pt), pt
+    assert [bool(L.t_in_subgroup(raw96(p))) for p in g1] == [True] * 6 and not any(L.t_in_subgroup(raw96(p)) for p in wild + small)

@@ -35,3 +35,31 @@ for n in (1024, 16384, 131072, 1048576):
             assert all(ok)
         line.append(f"{name}: items {1e3 * min(t_items):.2f} ms = {n / min(t_items) / 1e6:.2f} M proofs/s, packed {1e3 * min(t_packed):.2f} ms = {n / min(t_packed) / 1e6:.2f} M proofs/s;")
     print(" ".join(line), flush=True)
+
+# where a batch of 131 072 goes on the device path: the C call (copies up, gather, checked decompression, transcripts, scalars, copies
+# back), the merged MSM, and the Python around them
+import ctypes  # noqa: E402
+import secrets  # noqa: E402
+
+n = 131072
+batch = [items[i % len(items)] for i in range(n)]
+trk = b"".join(t[0] + t[1] for t, _, _ in batch)
+kcs = b"".join(k for _, k, _ in batch)
+pfs = b"".join(p for _, _, p in batch)
+v = OpeningBatchVerifier(ctx)
+v.verify_packed(trk, kcs, pfs)
+for _ in range(3):
+    d_pts, d_sc = v._buffers(n)
+    t0 = time.perf_counter()
+    st = (ctypes.c_int32 * n)(); ps = ctypes.create_string_buffer(5 * n); gs = ctypes.create_string_buffer(32 * n)
+    t1 = time.perf_counter()
+    ctx.check(N.cg1_opening_prepare_device(ctx.handle, n, trk, kcs, pfs, None, secrets.token_bytes(32), d_pts.ptr, d_sc.ptr, st, ps, gs))
+    t2 = time.perf_counter()
+    status = memoryview(st).cast("B").cast("i").tolist(); pstat = ps.raw; x = N.ERR_NOT_IN_SUBGROUP in pstat; a = any(s == 0 for s in status)
+    t3 = time.perf_counter()
+    r = ctx.msm_device(d_pts, d_sc, 5 * n + 1)
+    t4 = time.perf_counter()
+    out = [s == 0 for s in status]
+    t5 = time.perf_counter()
+    print(f"split of n={n}: buffers {1e3 * (t1 - t0):.2f}  cg1_opening_prepare_device {1e3 * (t2 - t1):.2f}  status lists {1e3 * (t3 - t2):.2f}  "
+          f"merged MSM {1e3 * (t4 - t3):.2f}  verdict list {1e3 * (t5 - t4):.2f} ms", flush=True)
