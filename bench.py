@@ -32,6 +32,10 @@ import statistics
 import sys
 import time
 
+# The application's choice, made before anything initialises HIP (curdleproofs_pie_amd._native.tune_runtime does the same): the verifier's
+# three pipelines keep a dozen streams busy and the runtime's default is 4 hardware queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

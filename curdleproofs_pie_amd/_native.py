@@ -30,12 +30,32 @@ if not os.path.exists(LIB_PATH):
         "(hipcc --offload-arch=gfx950).  There is no pure-Python fallback."
     )
 
-# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A verifier with the front-end
-# on the device keeps seven or more streams busy (decoding, MSM, copies, several front-end launches): with four queues only two of
-# its front-end launches ever ran side by side (profiles/r03_frontend_device_bench.txt), and with eight a 26 ms front-end launch still
-# shared a queue with the decoding or MSM stream behind it: 13.5 ms per batch of 1024 proofs, against 7.8 ms with 24 queues
-# (profiles/r03_verify_fe_ab.txt; the MSM benchmark itself is indifferent: 3.03 ms either way).  Read by the runtime at its first call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; read at its first call).  A verifier
+# with the front-end on the device keeps seven or more streams busy (decoding, MSM, copies, several front-end launches): with four queues
+# only two of its front-end launches ever ran side by side (profiles/r03_frontend_device_bench.txt), and with eight a 26 ms front-end
+# launch still shared a queue with the decoding or MSM stream behind it: 13.5 ms per batch of 1024 proofs, against 7.8 ms with 24 queues
+# (profiles/r03_verify_fe_ab.txt; the MSM benchmark itself is indifferent: 3.03 ms either way).  The library does NOT touch the host
+# process's environment by itself: an application that wants the verifier's full throughput calls tune_runtime() (or exports the
+# variable) before anything initialises HIP; ShuffleBatchVerifier sizes its pipelines by hw_queues() either way.
+DEFAULT_HW_QUEUES = 4
+TUNED_HW_QUEUES = 24
+
+
+def hw_queues() -> int:
+    """The hardware queues the HIP runtime of this process will use (GPU_MAX_HW_QUEUES, else the runtime's default of 4)."""
+    try:
+        return max(1, int(os.environ.get("GPU_MAX_HW_QUEUES", DEFAULT_HW_QUEUES)))
+    except ValueError:
+        return DEFAULT_HW_QUEUES
+
+
+def tune_runtime(queues: int = TUNED_HW_QUEUES) -> int:
+    """Opt-in: export GPU_MAX_HW_QUEUES = `queues` unless the variable is already set.  Only effective BEFORE the first HIP call of the
+    process (creating a Context, torch.cuda, ...); bench.py, the tools and the test suite call it first thing.  Returns hw_queues()."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(int(queues)))
+    return hw_queues()
+
+
 lib = ctypes.CDLL(LIB_PATH)
 
 

@@ -148,16 +148,24 @@ class ShuffleBatchVerifier:
         if env in ("0", "1"):
             device_front_end = env == "1"
         if device_front_end is None:
-            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < 24
+            # ... with the runtime's default of 4 hardware queues (N.hw_queues(); the application did not call N.tune_runtime()) the device
+            # front-end is one pipeline at 13.5 ms per batch (76 K proofs/s): the host front-end is the better default from 8 threads up
+            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < (24 if N.hw_queues() >= 12 else 8)
         self.device_front_end = bool(device_front_end)
         # pipelines (device front-end only): that many complete pipelines -- decoding lane, front-end launches, MSM lane, each on contexts
         # of its own -- take the batches of a stream in turn.  One pipeline leaves the GPU idle between its dependent kernels (the
         # reduce chains of an MSM, the waits of a decoding lane): 7.0-7.8 ms per batch of 1024; two 6.4-6.6; three 6.16-6.33 (1.62-1.66e5
         # proofs/s); four are worse again (6.9-8.0: the process runs out of hardware queues) -- profiles/r03_verify_fe_ab.txt.  With the
         # host front-end a second pipeline only fights for the cores (11 ms), so it stays 1.
-        self.pipelines = max(1, int(pipelines if pipelines is not None else (3 if self.device_front_end else 1))) if self.device_front_end else 1
+        # The default follows the hardware queues the process has (N.hw_queues(): GPU_MAX_HW_QUEUES, 4 unless the application raised it
+        # -- N.tune_runtime()): a pipeline keeps 4 streams busy, so 3 pipelines from 20 queues, 2 from 12, else ONE pipeline with two
+        # front-end launches (streams beyond the queue count share queues and wait for each other's kernels).
+        if pipelines is None:
+            q = N.hw_queues()
+            pipelines = (3 if q >= 20 else 2 if q >= 12 else 1) if self.device_front_end else 1
+        self.pipelines = max(1, int(pipelines)) if self.device_front_end else 1
         if fe_lanes is None:
-            fe_lanes = 2 if self.pipelines > 1 else 3
+            fe_lanes = 2 if (self.pipelines > 1 or N.hw_queues() < 8) else 3
         self._kids = None
         self.fe_lanes = max(1, int(fe_lanes)) if self.device_front_end else 0
         # fe_cus > 0 (A/B switch, off): the front-end launches get that many compute units of their own (the last ones) and the

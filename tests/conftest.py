@@ -1,5 +1,7 @@
 import json
 import os
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # as an application would (N.tune_runtime()): before the first HIP call
 import subprocess
 import sys
 

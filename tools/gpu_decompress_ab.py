@@ -6,6 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from batch_fixture import ShuffleBatch
 from curdleproofs_pie_amd import _native as N
+N.tune_runtime()
 from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
 
 fx = ShuffleBatch()

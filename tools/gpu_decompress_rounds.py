@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 from batch_fixture import ShuffleBatch  # noqa: E402
 from curdleproofs_pie_amd import _native as N  # noqa: E402
+N.tune_runtime()
 from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier  # noqa: E402
 
 MADS_PER_POINT = 148862          # bench.py: 376 squarings x 301 + 85 + 7 products x 392 + the conversions of a decompression

@@ -9,6 +9,7 @@ os.makedirs(os.path.dirname(lib), exist_ok=True)
 B.build_variant(lib, ["-DCG1_FE_PROFILE"], verbose=False)
 os.environ["CURDLE_G1_LIB"] = lib
 from curdleproofs_pie_amd import _native as N
+N.tune_runtime()
 from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
 case = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "shuffle_vectors.json")))["cases"] if c["ell"] == 124][0]
 v = ShuffleBatchVerifier(bytes.fromhex(case["crs"]), threads=1)

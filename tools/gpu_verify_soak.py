@@ -4,6 +4,7 @@ import json, os, resource, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from curdleproofs_pie_amd import _native as N
+N.tune_runtime()
 from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
 from test_shuffle_verifier import apply_edits
 case = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "shuffle_vectors.json")))["cases"] if c["ell"] == 124][0]
