@@ -159,6 +159,7 @@ cg1_timer_end = _proto("cg1_timer_end", c_int, c_void_p, POINTER(c_float))
 cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
 cg1_batch_mul_add_device = _proto("cg1_batch_mul_add_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
 cg1_batch_mul_add = _proto("cg1_batch_mul_add", c_int, c_void_p, _u8p, c_size_t, _u8p, c_size_t, _u8p, _buf, c_size_t)
+cg1_batch_mul_add_pool = _proto("cg1_batch_mul_add_pool", c_int, _u8p, c_size_t, _u8p, c_size_t, _u8p, _buf, c_size_t, c_int)
 cg1_batch_decompress_device = _proto("cg1_batch_decompress_device", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int)
 cg1_batch_decompress_enqueue = _proto("cg1_batch_decompress_enqueue", c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int)
 cg1_subgroup_flags_enqueue = _proto("cg1_subgroup_flags_enqueue", c_int, c_void_p, c_void_p, c_size_t, c_size_t, POINTER(ctypes.c_uint32), c_size_t, c_void_p)
@@ -242,7 +243,7 @@ EXPORTED_SYMBOLS = [
     "cg1_is_identity", "cg1_compress", "cg1_decompress", "cg1_to_affine96", "cg1_from_affine96",
     "cg1_batch_to_affine96", "cg1_batch_decompress", "cg1_batch_compress", "cg1_device_count", "cg1_ctx_create",
     "cg1_ctx_destroy", "cg1_ctx_error", "cg1_dev_malloc", "cg1_dev_free", "cg1_h2d", "cg1_d2h", "cg1_d2h_2d", "cg1_h2d_async", "cg1_copy_fence", "cg1_stream_sync", "cg1_batch_decompress_enqueue", "cg1_host_alloc", "cg1_host_free", "cg1_ctx_sync", "cg1_ctx_set_param",
-    "cg1_msm", "cg1_msm_device", "cg1_msm_device_begin", "cg1_msm_device_end", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_get_last_counts", "cg1_timer_begin", "cg1_timer_end", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
+    "cg1_msm", "cg1_msm_device", "cg1_msm_device_begin", "cg1_msm_device_end", "cg1_msm_batched_device", "cg1_msm_batched", "cg1_get_timings", "cg1_get_host_timings", "cg1_get_last_counts", "cg1_timer_begin", "cg1_timer_end", "cg1_batch_mul_device", "cg1_batch_mul_add_device", "cg1_batch_mul_add", "cg1_batch_mul_add_pool", "cg1_batch_decompress_device", "cg1_batch_compress_device", "cg1_batch_decompress_gpu", "cg1_gen_scalars_device", "cg1_probe_madd",
     "cg1_ctx_create_cu_mask", "cg1_shuffle_fe_create", "cg1_shuffle_fe_destroy", "cg1_shuffle_fe_aux_bytes", "cg1_shuffle_gather_aux", "cg1_shuffle_fe_enqueue", "cg1_shuffle_fe_nodes", "cg1_shuffle_fe_last_passes", "cg1_shuffle_fe_last_split", "cg1_shuffle_fe_program_shape", "cg1_shuffle_fe_emulate_to_first_barrier",
     "cg1_merlin_last_passes", "cg1_merlin_last_kernel", "cg1_merlin_block_program_emulate", "cg1_probe_mad_rate", "cg1_batch_sum_device", "cg1_batch_sum", "cg1_ctx_device", "cg1_ctx_stream", "cg1_msm_multi_device",
     "cg1_comm_create", "cg1_comm_port", "cg1_comm_rank", "cg1_comm_connect", "cg1_comm_set_timeout", "cg1_comm_attach_rccl", "cg1_comm_transport",

@@ -154,6 +154,8 @@ struct Ctx {
   void* d_merlin_rows = nullptr; size_t merlin_rows_cap = 0;      // the rows of the last such call (kept: 134 KB per shuffle-shaped transcript)
   int merlin_lanes = 64;                // transcripts per wave of k_merlin_batch_sync ("merlin_lanes": 1 .. 64)
   uint32_t merlin_passes = 0;           // of the last cg1_merlin_batch_device call: Keccak passes of the slowest wave
+  int batch_mul_host_max = -1;          // cg1_batch_mul_add (host pointers): outputs up to which the host's pool does the work ("batch_mul_host_max"; -1 = 16 per pool thread, 0 = never)
+  int last_batch_mul_on_host = 0;
   int batch_mul_quad_max = 8192;        // k_batch_mul_quad up to this many outputs ("batch_mul_quad_max"; 0 = always one lane per output)
   int scan_one = 1;                     // the sort's two scans as one single-block launch each when they are small (A/B switch)
   int fold_pass = 1;                    // k_bucket_fold in front of k_rowcol / k_seg_reduce; 0 leaves multi-chunk buckets to their bucket_sum loops
@@ -1404,6 +1406,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "fold_pass")) { ctx->fold_pass = value != 0; return CG1_OK; }
   if (!strcmp(name, "scan_one")) { ctx->scan_one = value != 0; return CG1_OK; }
   if (!strcmp(name, "batched_host_horner_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batched_host_horner_max = value; return CG1_OK; }
+  if (!strcmp(name, "batch_mul_host_max")) { if (value < -1) return CG1_ERR_ARG; ctx->batch_mul_host_max = value; return CG1_OK; }
   if (!strcmp(name, "batch_mul_quad_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batch_mul_quad_max = value; return CG1_OK; }
   if (!strcmp(name, "merlin_sync")) { ctx->merlin_sync = value != 0; return CG1_OK; }
   if (!strcmp(name, "fe_timed")) { ctx->fe_timed = value != 0; return CG1_OK; }
@@ -1680,6 +1683,18 @@ int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases, size_t nbase, const ui
   if (!ctx) return CG1_ERR_HIP;
   if (n == 0) return CG1_OK;
   if (nbase == 0 || nscalars == 0) return CG1_ERR_ARG;
+  {
+    // Few outputs: the launch is 255 dependent doublings (~2.2 ms as quads, whatever n is) plus four copies, the host's pool does n
+    // scalar multiplications at ~80 us each on its threads -- take the host when that is the shorter way ("batch_mul_host_max": -1 =
+    // this rule, 0 = always the GPU, N = the host up to N outputs).
+    const size_t threads = cg1_shuffle_default_threads();
+    const size_t host_max = ctx->batch_mul_host_max >= 0 ? (size_t)ctx->batch_mul_host_max : threads * 16;
+    ctx->last_batch_mul_on_host = 0;
+    if (n <= host_max) {
+      ctx->last_batch_mul_on_host = 1;
+      return cg1_batch_mul_add_pool(bases, nbase, scalars, nscalars, addend, out, n, 0);
+    }
+  }
   HIPCHK(hipSetDevice(ctx->device));
   DevBuf db, ds, da, dout;
   HIPCHK(db.alloc(nbase * 96)); HIPCHK(ds.alloc(nscalars * 32)); HIPCHK(dout.alloc(n * 96));

@@ -1048,6 +1048,57 @@ int cg1_opening_prepare(size_t n, const uint8_t* trackers, const uint8_t* k_comm
   return CG1_OK;
 }
 
+// out[i] = addend[i] + scalars[i % nscalars] * bases[i % nbase] on the HOST's worker pool: the same contract as the device kernel behind
+// cg1_batch_mul_add (affine96 standard-form records in and out, zeros = identity, inputs not checked against the curve), for the calls
+// where a launch costs more than the arithmetic: a fold / map of a few hundred points is 255 dependent doublings on the GPU whatever
+// its size (~2.2 ms), and n scalar multiplications at ~80 us over the pool's threads here.  cg1_batch_mul_add (msm_gpu.hip) chooses.
+int cg1_batch_mul_add_pool(const uint8_t* bases, size_t nbase, const uint8_t* scalars, size_t nscalars, const uint8_t* addend, uint8_t* out,
+                           size_t n, int n_threads) {
+  if (n == 0) return CG1_OK;
+  if (!bases || !scalars || !out || nbase == 0 || nscalars == 0) return CG1_ERR_ARG;
+  using cg1h::fe; using cg1h::jac;
+  std::atomic<int> bad{0};
+  std::atomic<size_t> next{0};
+  const size_t slice = 16, items = (n + slice - 1) / slice;
+  auto load = [&](const uint8_t* rec, jac& o) {
+    bool zero = true;
+    for (int k = 0; k < 96 && zero; ++k) zero = rec[k] == 0;
+    if (zero) { o = cg1h::jac_identity(); return true; }
+    fe x, y;
+    if (!cg1h::fe_from_le48(rec, x) || !cg1h::fe_from_le48(rec + 48, y)) return false;
+    o = cg1h::jac_from_affine(x, y);
+    return true;
+  };
+  std::function<void()> work = [&]() {
+    jac acc[slice];
+    fe xs[slice], ys[slice];
+    uint8_t inf[slice];
+    for (;;) {
+      const size_t it = next.fetch_add(1);
+      if (it >= items) return;
+      const size_t lo = it * slice, cnt = std::min(slice, n - lo);
+      for (size_t k = 0; k < cnt; ++k) {
+        const size_t i = lo + k;
+        jac b, a = cg1h::jac_identity();
+        if (!load(bases + 96 * (i % nbase), b) || (addend && !load(addend + 96 * i, a))) { bad.store(1); acc[k] = cg1h::jac_identity(); continue; }
+        acc[k] = cg1h::jac_add(a, cg1h::jac_mul(b, scalars + 32 * (i % nscalars)));
+      }
+      cg1h::jac_batch_to_affine(acc, cnt, xs, ys, inf);                  // one inversion per slice
+      for (size_t k = 0; k < cnt; ++k) {
+        uint8_t* o = out + 96 * (lo + k);
+        if (inf[k]) { memset(o, 0, 96); continue; }
+        cg1h::fe_to_le48(xs[k], o);
+        cg1h::fe_to_le48(ys[k], o + 48);
+      }
+    }
+  };
+  Pool& pool = Pool::get();
+  size_t nt = n_threads > 0 ? (size_t)n_threads : pool.size() + 1;
+  nt = std::min(nt, items);
+  if (nt <= 1) work(); else pool.run(work, nt);
+  return bad.load() ? CG1_ERR_ENCODING : CG1_OK;
+}
+
 // rho1 | rho2 of proof i from a per-batch seed: the first 32 bytes of SHAKE256(seed || le64(i)), 16 bytes each (the device's
 // weights_from_seed, csrc/kernels_opening.h, computes the very same)
 int cg1_opening_weights_from_seed(const uint8_t seed32[32], size_t first, size_t n, uint8_t* out_weights64) {

@@ -93,7 +93,7 @@ void* cg1_ctx_stream(cg1_ctx* ctx);                                  /* the cont
 /* Tuning and A/B switches of a context (defaults are the measured best; DESIGN.md section 9 has the measurements):
  *   MSM plan / phases   "chunk_len" "seg_m" "auto_plan" "stage_sort" "partition_sort" "big_bins" "wave_agg" "quad" "reduce_2d" "rowcol_quad"
  *                       "rowcol_quad_max" "fold_pass" "tree_half" "scan_one" "host_split" "horner_threads" "zero_copy" "batched_host_horner_max"
- *                       "batch_mul_quad_max" "small_msm" (1: calls of <= 1024 terms run as ONE launch, k_msm_small; 0: the regime-A chain)
+ *                       "batch_mul_quad_max" "batch_mul_host_max" "small_msm" (1: calls of <= 1024 terms run as ONE launch, k_msm_small; 0: the regime-A chain)
  *                       "split" (A/B switch, default 0: a call of >= 2^"split_min_log2n" terms as two launch chains -- high and low half of its windows -- on
  *                       two streams; measured slower than the single chain, profiles/r04_split_ab.txt)
  *   waiting             "blocking_sync" (sleep instead of spinning on the stream), "profile" (0: no events, 1: around k_accumulate, 2: every phase)
@@ -219,7 +219,12 @@ int cg1_batch_mul_device(cg1_ctx* ctx, const void* d_bases_affine96, size_t nbas
  * per-index scalars:             G_i * beta^-i  (grand_prod.py:64-71). */
 int cg1_batch_mul_add_device(cg1_ctx* ctx, const void* d_bases_affine96, size_t nbase, const void* d_scalars32,
                              size_t nscalars, const void* d_addend_affine96, void* d_out_affine96, size_t n);
-/* same, all buffers in host memory (copied in and out by the call) */
+/* same, all buffers in host memory (copied in and out by the call).  Up to "batch_mul_host_max" outputs (cg1_set_param; -1 = 16 per
+ * host thread, the default; 0 = never) the host's worker pool does the work instead of a launch: a fold / map of a few hundred points is
+ * 255 dependent doublings on the GPU whatever its size (~2.2 ms), and n scalar multiplications of ~80 us over the pool's threads there
+ * (cg1_batch_mul_add_pool: the same records in and out, byte for byte). */
+int cg1_batch_mul_add_pool(const uint8_t* bases_affine96, size_t nbase, const uint8_t* scalars32, size_t nscalars,
+                           const uint8_t* addend_affine96, uint8_t* out_affine96, size_t n, int n_threads /* 0 = all */);
 int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t nbase, const uint8_t* scalars32, size_t nscalars,
                       const uint8_t* addend_affine96, uint8_t* out_affine96, size_t n);
 /* Batched 48-byte decompression on the GPU: from_compressed_bytes_unchecked

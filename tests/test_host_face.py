@@ -166,3 +166,46 @@ def test_decoded_points_keep_their_encoding(B):
     odd_inf = bytes([0xC0 | 0x20]) + bytes(46) + b"\x01"                      # infinity flag + stray bits: still the identity
     z = B.G1Point.from_compressed_bytes_unchecked(odd_inf)
     assert z._k is None and bytes(z.to_compressed_bytes()) == bytes([0xC0]) + bytes(47) and z == B.G1Point.identity()
+
+
+def test_batch_mul_add_pool_against_oracle():
+    """cg1_batch_mul_add_pool (the host pool's path of cg1_batch_mul_add: folds / maps of a few hundred points, ipa.py:142-146,
+    curdleproofs.py:310-311, grand_prod.py:64-71) against the oracle's group law: all three patterns, identities, 1 and 3 threads,
+    a coordinate >= p refused."""
+    import ctypes
+    import random
+
+    from conftest import raw96
+    from curdleproofs_pie_amd import _native as N
+    from oracle import bls12_381 as O
+
+    rng = random.Random(5)
+    n = 24
+    pts = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(n)]
+    pts[0] = None
+    add = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(n)]
+    add[1] = None
+    add[2] = O.g1_neg(pts[2])
+    sc = [rng.randint(0, O.R - 1) for _ in range(n)]
+    sc[2], sc[5], sc[6] = 1, 0, O.R - 1
+    b96, a96 = b"".join(raw96(p) for p in pts), b"".join(raw96(p) for p in add)
+    s32 = b"".join(s.to_bytes(32, "little") for s in sc)
+    out = ctypes.create_string_buffer(96 * n)
+    memo = {}
+
+    def mul(j, k):
+        if (j, k) not in memo:
+            memo[(j, k)] = O.g1_mul(pts[j], k)
+        return memo[(j, k)]
+
+    for threads in (1, 3):
+        for nbase, scal, nsc, addend in ((n, s32, n, None), (n, s32[64:96], 1, a96), (7, s32, n, a96), (1, s32[:32 * 9], 9, None)):
+            assert N.cg1_batch_mul_add_pool(b96, nbase, scal, nsc, addend, out, n, threads) == 0
+            for i in range(n):
+                sci = int.from_bytes(scal[32 * (i % nsc): 32 * (i % nsc) + 32], "little")
+                want = O.g1_add(None if addend is None else add[i], mul(i % nbase, sci))
+                assert out.raw[96 * i: 96 * i + 96] == raw96(want), (threads, nbase, nsc, i)
+    assert N.cg1_batch_mul_add_pool(b96, n, s32, n, None, out, 0, 0) == 0
+    bad = bytearray(b96)
+    bad[96 * 3: 96 * 3 + 48] = b"\xff" * 48                    # x >= p
+    assert N.cg1_batch_mul_add_pool(bytes(bad), n, s32, n, None, out, n, 2) != 0

@@ -228,6 +228,38 @@ def test_batch_mul_variable_base(native_lib, ctx):
         assert out[96 * i: 96 * i + 96] == raw96(O.g1_mul(bases[i % 6], sc[i])), i
 
 
+def test_batch_mul_add_pool_equals_device(native_lib, ctx):
+    """cg1_batch_mul_add with host pointers: the worker pool's path (few outputs) and the GPU kernel give the same records, byte for byte
+    (fold, same-scalar map and per-index patterns; identity bases / addends; scalar 0 and r - 1)."""
+    import ctypes
+
+    N = native_lib
+    rng = random.Random(77)
+    n = 41
+    pts = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(n)]
+    pts[4] = None
+    add = [O.g1_mul(O.G1_GEN, rng.randint(1, O.R - 1)) for _ in range(n)]
+    add[9] = None
+    add[11] = O.g1_neg(pts[11])
+    sc = [rng.randint(0, O.R - 1) for _ in range(n)]
+    sc[3], sc[11], sc[12] = 0, 1, O.R - 1
+    b96, a96 = b"".join(raw96(p) for p in pts), b"".join(raw96(p) for p in add)
+    s32 = b"".join(s.to_bytes(32, "little") for s in sc)
+    for nbase, scal, nsc, addend in ((n, s32, n, None), (n, s32[:32 * 5], 5, a96), (n, s32[32 * 20: 32 * 21], 1, a96), (1, s32, n, None), (6, s32, n, a96)):
+        outs = []
+        for host_max in (0, 1 << 20):
+            ctx.set_param("batch_mul_host_max", host_max)
+            try:
+                outs.append(ctx.batch_mul_add_host(b96, nbase, scal, nsc, addend, n))
+            finally:
+                ctx.set_param("batch_mul_host_max", -1)
+        assert outs[0] == outs[1]
+        for i in range(n):
+            sci = int.from_bytes(scal[32 * (i % nsc): 32 * (i % nsc) + 32], "little")
+            want = O.g1_add(None if addend is None else add[i], O.g1_mul(pts[i % nbase], sci))
+            assert outs[0][96 * i: 96 * i + 96] == raw96(want), i
+
+
 def test_batched_small_msms_ragged(native_lib, ctx):
     """Regime B: independent MSMs of ragged sizes (incl. empty) in one launch chain, each vs the naive oracle."""
     N = native_lib

@@ -111,12 +111,20 @@ def test_batch_mul_patterns(api):
     sc = [U.random_scalar() for _ in range(n)]
     sc[3] = A.Scalar(0)
     gamma = U.random_scalar()
-    assert batch_mul(Rr, sc) == [r * s for r, s in zip(Rr, sc)]                       # grand_prod.py:64-71
-    assert batch_mul_same_scalar(Rr, gamma) == [r * gamma for r in Rr]                # curdleproofs.py:310-311
-    assert batch_fold(L, Rr, gamma) == [l + r * gamma for l, r in zip(L, Rr)]         # ipa.py:142-146
-    assert batch_fold(L, L, A.Scalar(A.CURVE_ORDER - 1)) == [U.Z1] * n                # l + (-1) l == identity
-    assert batch_fold(L, L, A.Scalar(1)) == [l + l for l in L]                        # doubling through the add
-    assert batch_mul([], []) == []
+    from curdleproofs_pie_amd import _native as N
+
+    ctx = N.default_context()
+    for host_max in (0, -1):                       # 0: the GPU kernel; -1 (default): a call this small goes to the host's worker pool
+        ctx.set_param("batch_mul_host_max", host_max)
+        try:
+            assert batch_mul(Rr, sc) == [r * s for r, s in zip(Rr, sc)]                       # grand_prod.py:64-71
+            assert batch_mul_same_scalar(Rr, gamma) == [r * gamma for r in Rr]                # curdleproofs.py:310-311
+            assert batch_fold(L, Rr, gamma) == [l + r * gamma for l, r in zip(L, Rr)]         # ipa.py:142-146
+            assert batch_fold(L, L, A.Scalar(A.CURVE_ORDER - 1)) == [U.Z1] * n                # l + (-1) l == identity
+            assert batch_fold(L, L, A.Scalar(1)) == [l + l for l in L]                        # doubling through the add
+            assert batch_mul([], []) == []
+        finally:
+            ctx.set_param("batch_mul_host_max", -1)
 
 
 def test_batch_to_compressed(api):
