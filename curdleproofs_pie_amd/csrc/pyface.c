@@ -57,6 +57,14 @@ static inline PyObject* slot_get(PyObject* o, Py_ssize_t off) { return *(PyObjec
 /* pack_points(seq, dst_addr, capacity_points) -> (n, all_normalised)
  * Copies the 144-byte blob of every G1Point of `seq` (list or tuple) to dst_addr + 144 i.  all_normalised: every blob has
  * Z == 1 (Montgomery) or Z == 0 (identity), i.e. X, Y already are the affine coordinates and the device needs no inversion. */
+/* The walks below chase two pointers per element (list item -> object -> bytes / int): with a million objects every hop is a cache
+ * miss.  Each loop therefore touches element i + PF_FAR's object header and element i + PF_NEAR's payload ahead of time (the object of
+ * i + PF_NEAR was fetched PF_FAR - PF_NEAR iterations earlier, so reading its slot is cheap).  Prefetches of wrong addresses are harmless;
+ * the type of a look-ahead element is checked before its slot is read. */
+#define PF_FAR 24
+#define PF_NEAR 8
+static inline void pf_touch(const void* p) { __builtin_prefetch(p, 0, 1); }
+
 static PyObject* pf_pack_points(PyObject* self, PyObject* args) {
   PyObject* seq; unsigned long long addr; Py_ssize_t cap;
   if (!PyArg_ParseTuple(args, "OKn", &seq, &addr, &cap)) return NULL;
@@ -69,6 +77,11 @@ static PyObject* pf_pack_points(PyObject* self, PyObject* args) {
   uint8_t* dst = (uint8_t*)(uintptr_t)addr;
   int normalised = 1;
   for (Py_ssize_t i = 0; i < n; ++i) {
+    if (i + PF_FAR < n) pf_touch(items[i + PF_FAR]);
+    if (i + PF_NEAR < n && Py_TYPE(items[i + PF_NEAR]) == g_point_type) {
+      const char* nb = (const char*)slot_get(items[i + PF_NEAR], g_point_off);
+      if (nb) { pf_touch(nb); pf_touch(nb + 64); pf_touch(nb + 128); }
+    }
     PyObject* o = items[i];
     if (Py_TYPE(o) != g_point_type) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd is not a G1Point", i); return NULL; }
     PyObject* b = slot_get(o, g_point_off);
@@ -99,6 +112,11 @@ static PyObject* pf_pack_affine(PyObject* self, PyObject* args) {
   PyObject** items = PySequence_Fast_ITEMS(fast);
   uint8_t* dst = (uint8_t*)(uintptr_t)addr;
   for (Py_ssize_t i = 0; i < n; ++i) {
+    if (i + PF_FAR < n) pf_touch(items[i + PF_FAR]);
+    if (i + PF_NEAR < n && Py_TYPE(items[i + PF_NEAR]) == g_point_type) {
+      const char* nb = (const char*)slot_get(items[i + PF_NEAR], g_cache_off[0]);
+      if (nb) { pf_touch(nb); pf_touch(nb + 64); }
+    }
     PyObject* o = items[i];
     if (Py_TYPE(o) != g_point_type) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd is not a G1Point", i); return NULL; }
     PyObject* b = slot_get(o, g_cache_off[0]);
@@ -107,6 +125,30 @@ static PyObject* pf_pack_affine(PyObject* self, PyObject* args) {
   }
   Py_DECREF(fast);
   return PyLong_FromSsize_t(n);
+}
+
+/* A non-negative Python int below 2^256 as 32 little-endian bytes, read straight from its 30-bit digits (CPython's own
+ * _PyLong_AsByteArray walks the digits a byte at a time: 25 of the 33 ns an element costs).  Returns 0 when the value does not qualify
+ * (negative, too long, other digit width, big-endian host): the caller then lets _PyLong_AsByteArray decide and raise. */
+static inline int long_to_le32(PyObject* v, uint8_t* out) {
+#if PYLONG_BITS_IN_DIGIT == 30 && defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+  const PyLongObject* l = (const PyLongObject*)v;
+  const Py_ssize_t sz = Py_SIZE(l);
+  if (sz < 0 || sz > 9) return 0;
+  uint64_t w[6] = {0, 0, 0, 0, 0, 0};
+  for (Py_ssize_t k = 0; k < sz; ++k) {
+    const uint64_t d = (uint64_t)l->ob_digit[k];
+    const unsigned bit = 30u * (unsigned)k, sh = bit & 63u;
+    w[bit >> 6] |= d << sh;
+    if (sh > 34u) w[(bit >> 6) + 1] |= d >> (64u - sh);
+  }
+  if (w[4] | w[5]) return 0;
+  memcpy(out, w, 32);
+  return 1;
+#else
+  (void)v; (void)out;
+  return 0;
+#endif
 }
 
 /* pack_scalars(seq, dst_addr, capacity) -> n
@@ -122,13 +164,19 @@ static PyObject* pf_pack_scalars(PyObject* self, PyObject* args) {
   PyObject** items = PySequence_Fast_ITEMS(fast);
   uint8_t* dst = (uint8_t*)(uintptr_t)addr;
   for (Py_ssize_t i = 0; i < n; ++i) {
+    if (i + PF_FAR < n) pf_touch(items[i + PF_FAR]);
+    if (i + PF_NEAR < n && Py_TYPE(items[i + PF_NEAR]) == g_scalar_type) {
+      const void* nv = slot_get(items[i + PF_NEAR], g_scalar_off);
+      if (nv) pf_touch(nv);
+    }
     PyObject* o = items[i];
     PyObject* v;
     if (Py_TYPE(o) == g_scalar_type) v = slot_get(o, g_scalar_off);
     else if (PyLong_CheckExact(o)) v = o;                       /* plain ints are accepted: the accumulator keeps merged scalars as ints */
     else { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd is not a Scalar", i); return NULL; }
     if (!v || !PyLong_Check(v)) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd holds no integer", i); return NULL; }
-    if (_PyLong_AsByteArray((PyLongObject*)v, dst + 32 * (size_t)i, 32, 1, 0) < 0) { Py_DECREF(fast); return NULL; }   /* OverflowError: negative or >= 2^256 */
+    if (!long_to_le32(v, dst + 32 * (size_t)i) &&
+        _PyLong_AsByteArray((PyLongObject*)v, dst + 32 * (size_t)i, 32, 1, 0) < 0) { Py_DECREF(fast); return NULL; }   /* OverflowError: negative or >= 2^256 */
   }
   Py_DECREF(fast);
   return PyLong_FromSsize_t(n);

@@ -69,6 +69,14 @@ def test_pack_and_unpack(B, monkeypatch, use_helper):
         B.pack_scalars([2 ** 256], ctypes.addressof(sb), 4)
     with pytest.raises((TypeError, AttributeError)):
         B.pack_scalars([B.G1Point()], ctypes.addressof(sb), 4)
+    # every bit length 0 .. 256 (the C helper reads the 30-bit digits of the int itself): 2^k - 1, 2^k, a random k-bit value
+    edge = [0] + [v for k in range(1, 257) for v in ((1 << k) - 1, (1 << (k - 1)), rng.getrandbits(k) | (1 << (k - 1)))]
+    eb = ctypes.create_string_buffer(32 * len(edge))
+    assert B.pack_scalars(edge, ctypes.addressof(eb), len(edge)) == len(edge)
+    assert eb.raw == b"".join(v.to_bytes(32, "little") for v in edge)
+    for too_big in (2 ** 256, 2 ** 256 + 1, 2 ** 269, 2 ** 270, 2 ** 300, -(2 ** 40)):
+        with pytest.raises(OverflowError):
+            B.pack_scalars([1, too_big], ctypes.addressof(eb), 4)
 
     n1, f1 = B.ident(pts)
     assert n1 == n and B.ident(list(pts)) == (n1, f1) and B.ident(tuple(pts)) == (n1, f1)
