@@ -924,6 +924,7 @@ class OpeningBatchVerifier:
     (`cg1_opening_prepare` on the native worker pool); both give the same verdicts and status codes (tests/test_opening_batch.py)."""
 
     PROOF_BYTES = 128                       # A | B | s   (opening.py:94-99)
+    CULPRIT_SLICE = 32768                   # per-proof MSMs of one regime-B call when the merged check fails
 
     def __init__(self, ctx: Optional["N.Context"] = None, device_front_end: bool = True):
         self._ctx = ctx
@@ -1056,15 +1057,20 @@ class OpeningBatchVerifier:
         else:
             outside = []
         if any(s == 0 for s in status) and not N.cg1_is_identity(ctx.msm_device(d_pts, d_sc, 5 * n + 1)):
-            own = ctx.msm_batched_device(d_pts, d_sc, [5 * i for i in range(n + 1)])
+            # the merged check failed: one 5-term MSM per proof names the culprits (a regime-B call takes at most 65 535 MSMs: slices)
             tmp = ctypes.create_string_buffer(N.POINT_BYTES)
-            for i in range(n):
-                if status[i]:
-                    continue
-                N.cg1_mul(tmp, self._g_blob, g_scalars.raw[32 * i: 32 * i + 32])
-                N.cg1_add(tmp, tmp.raw, own[i])
-                if not N.cg1_is_identity(tmp.raw):
-                    status[i] = REJECT_EQUATION
+            gs_raw = g_scalars.raw
+            for lo in range(0, n, self.CULPRIT_SLICE):
+                cnt = min(self.CULPRIT_SLICE, n - lo)
+                own = ctx.msm_batched_device(d_pts.ptr + 96 * 5 * lo, d_sc.ptr + 32 * 5 * lo, [5 * i for i in range(cnt + 1)])
+                for k in range(cnt):
+                    i = lo + k
+                    if status[i]:
+                        continue
+                    N.cg1_mul(tmp, self._g_blob, gs_raw[32 * i: 32 * i + 32])
+                    N.cg1_add(tmp, tmp.raw, own[k])
+                    if not N.cg1_is_identity(tmp.raw):
+                        status[i] = REJECT_EQUATION
         ok = ctypes.c_int(0)
         for i in outside:
             if status[i] == 2:                       # rejected only for the subgroup flag: the exact equalities decide

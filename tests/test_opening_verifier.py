@@ -157,6 +157,17 @@ def test_device_front_end_equals_host_front_end(gold):
 
 
 @pytest.mark.gpu
+def test_culprit_search_in_slices(gold, monkeypatch):
+    """a failing batch larger than one culprit slice: every bad proof is named, nothing else (slices of 64 here; 32 768 in production)"""
+    items, want = items_of(gold)
+    monkeypatch.setattr(OpeningBatchVerifier, "CULPRIT_SLICE", 64)
+    v = OpeningBatchVerifier()
+    batch, expect = items * 13, want * 13
+    assert len(batch) > 3 * 64 and False in expect
+    assert v.verify_many(batch, rng=random.Random(6)) == expect
+
+
+@pytest.mark.gpu
 def test_verify_packed(gold):
     items, want = items_of(gold)
     shaped = [k for k, ((r, kr), kc, pf) in enumerate(items) if len(r) == len(kr) == len(kc) == 48 and len(pf) == 128]
