@@ -13,18 +13,19 @@
 //   fold        ... that a pairwise tree per bucket joins in log2(chunks) levels
 //   row / col   2-D bucket reduction (kernels_reduce.h): 2^hb row sums + 2^lb column sums, 4 quads each
 //   items       1 + hb + lb masked sums per window, 8 quads each -- the points whose power-of-two weights the host Horner applies
-//   combine     with several slices per window the last workgroup to arrive (ticket) adds their items; the last window to finish
+//   combine     with several slices per window the last workgroup to arrive (ticket) adds their items (a tree over pairs of slices); the last window to finish
 //               publishes the status words and the call's sequence number into mapped host memory (zero-copy export)
 // All EC additions of all phases go through ONE quad_add call site inside a phase state machine: the kernel has to stay inside the
 // instruction cache and under 256 registers.
 #pragma once
 
-constexpr uint32_t SM_MAX_N = 1024;       // terms per call
+constexpr uint32_t SM_MAX_N = 2048;       // terms per call (the combine step is a tree over up to 8 pairs of slices: S <= 16)
 constexpr uint32_t SM_SLICE = 256;        // terms per workgroup
 constexpr uint32_t SM_L = 4;              // entries per chunk
 constexpr uint32_t SM_QUADS = 128;
 
 constexpr uint32_t SM_MAX_MSMS = 16;      // independent MSMs one launch may carry (grid.z)
+constexpr uint32_t SM_ONE_ROUND = 256;    // workgroups of ONE MSM: windows x slices within one round of the chip's CUs (a workgroup fills a CU)
 constexpr uint32_t SM_MAX_GROUPS = 512;   // ... as long as windows x slices x MSMs stays a few workgroups per CU
 
 struct SmallArgs {
@@ -151,6 +152,10 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
   const uint32_t nchunks = s_choff[256], rounds = (nchunks + SM_QUADS - 1) / SM_QUADS, maxnch = s_misc[0];
   const uint32_t SR = ((R > Cn ? R : Cn) + 3u) / 4u;              // serial steps of a row / column sum on 4 quads
   const uint32_t ST = ((R > Cn ? R : Cn) + 7u) / 8u;              // serial steps of an item's masked sum on 8 quads
+  uint32_t comb_dq0 = 1, comb_levels = 0;                         // combine: pairs of slices, then log2 levels over the pairs
+  while (comb_dq0 < (S + 1u) / 2u) comb_dq0 <<= 1;
+  comb_dq0 >>= 1;
+  for (uint32_t d = comb_dq0; d; d >>= 1) ++comb_levels;
   xyzz acc = xyzz_identity();
   uint32_t phase = rounds ? PH_ACC : PH_ROWCOL, i0 = 0, i1 = 0, fold_st = 1;
   bool exp_live = false;
@@ -208,11 +213,20 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
         go = live && part < dq;
       }
     } else if (phase == PH_COMBINE) {
-      const bool live = Q < nitems;
-      const uint32_t item = live ? Q : 0u;
-      if (i1 == 0) acc = load_sum(a.partial + ((size_t)wslot * S) * nitems + item);
-      lp = a.partial + ((size_t)wslot * S + i1 + 1u) * nitems + item;
-      go = live;
+      // eight quads per item: quad `part` adds slices 2 part and 2 part + 1, then a shuffle tree over the pairs (S <= 16)
+      const uint32_t item = Q >> 3, part = Q & 7u;
+      const bool live = item < nitems;
+      if (i1 == 0) {
+        const PointSum* b = a.partial + ((size_t)wslot * S) * nitems + (live ? item : 0u);
+        const uint32_t s0 = 2u * part, s1 = s0 + 1u;
+        acc = (live && s0 < S) ? load_sum(b + (size_t)s0 * nitems) : xyzz_identity();
+        go = live && s1 < S;
+        lp = b + (size_t)(go ? s1 : 0u) * nitems;
+      } else {
+        const uint32_t dq = comb_dq0 >> (i1 - 1u);
+        shdelta = 4u * dq;
+        go = live && part < dq;
+      }
     }
     if (from_pts) {
       fp x, y; uint32_t fl;
@@ -266,7 +280,7 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
         i1 = 0; phase = PH_COMBINE;
       }
     } else {  // PH_COMBINE
-      if (++i1 == S - 1u) { exp_live = Q < nitems; exp_item = Q; phase = PH_EXPORT; break; }
+      if (++i1 == 1u + comb_levels) { exp_live = (Q >> 3) < nitems && (Q & 7u) == 0u; exp_item = Q >> 3; phase = PH_EXPORT; break; }
     }
   }
 

@@ -185,7 +185,7 @@ struct Ctx {
   hipEvent_t ev_prep = nullptr, ev_acc = nullptr;
   bool pend_split = false;
   int last_acc_launches = 0;            // k_accumulate launches of the last MSM call: 2 (split), 1, or 0 (k_msm_small)
-  int small_msm = 1;                    // "small_msm": MSMs of <= SM_MAX_N terms as ONE launch (k_msm_small); 0 = the regime-A chain (A/B switch)
+  int small_msm = 1;                    // "small_msm": MSMs of <= SM_MAX_N = 2048 terms as ONE launch (k_msm_small); 0 = the regime-A chain (A/B switch)
   PointSum* d_small_partial = nullptr; size_t cap_small_partial = 0;
   uint32_t* d_small_ctr = nullptr;
   PreparedPoint* d_small_pts = nullptr; uint8_t* d_small_flags = nullptr; size_t cap_small_pts = 0;      // k_prepare_blobs<true> output for un-normalised blob input
@@ -736,10 +736,14 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
 // a handful of entries into a bucket: every EC addition of the kernel is a ~10 us step of a dependent chain, and the reduction costs
 // ~log2(buckets) + 4 of them per window whatever n is, so few buckets (64 at c = 7) beat the wider windows the entry count alone
 // would suggest (measured, profiles/r04_small_msm.txt: n = 627 at c = 9 waits 232 us for the GPU, at c = 7 ...).
+// (windows x slices must stay within ONE round of workgroups for a single MSM -- SM_ONE_ROUND = the chip's 256 CUs, a workgroup of
+// k_msm_small fills one: 1 391 terms at c = 7 are 222 workgroups and take 0.35 ms, 2 048 are 296 = two rounds and take 0.47, more than
+// the launch chain's 0.40 (profiles/r04_small_msm.txt) -- so from 1 537 terms on the plan is c = 8: 32 windows x 8 slices = 256)
 static int pick_small_c(size_t n) {
   if (n <= 24) return 4;
   if (n <= 96) return 6;
-  return 7;
+  if (n <= 6 * SM_SLICE) return 7;
+  return 8;
 }
 
 // One launch (two when un-normalised blobs have to be inverted first) for an MSM of n <= SM_MAX_N terms -- or for M <= SM_MAX_MSMS
@@ -891,7 +895,8 @@ int msm_begin(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "n too large"); return CG1_ERR_ARG; }
   if (world < 1 || world > 255 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
-  if (ctx->small_msm && n <= SM_MAX_N && world == 1 && (c == 0 || (c >= 4 && c <= 9 && c != 5))) {
+  if (ctx->small_msm && n <= SM_MAX_N && world == 1 && (c == 0 || (c >= 4 && c <= 9 && c != 5)) &&
+      (size_t)(255 / (c ? c : pick_small_c(n)) + 1) * ((n + SM_SLICE - 1) / SM_SLICE) <= SM_ONE_ROUND) {
     if (c == 0) c = pick_small_c(n);
     ctx->pend_c = c;
     return msm_enqueue_small(ctx, src, d_scalars32, n, c);

@@ -1,5 +1,5 @@
 """k_msm_small -- the single-launch MSM of the protocol's own sizes (4 ... 627 terms: ipa.py:223,232; same_msm.py:219-226;
-msm_accumulator.py:64; anything up to 1024) -- against the CPU oracle, bit for bit, through the C ABI.  Needs an MI355X.
+msm_accumulator.py:64; anything up to 2048) -- against the CPU oracle, bit for bit, through the C ABI.  Needs an MI355X.
 
 Covers every size 1 ... 1024, every window width the kernel runs (4, 6, 7, 8, 9), all four point sources (affine96, normalised
 blobs, projective blobs, resident prepared records), the callers' skewed scalar patterns (all-equal, sigma = 0..n-1, r - 1,
@@ -48,6 +48,38 @@ def test_every_size_1_to_1024(native_lib, ctx, pool):
         want = C.compress(C.msm_bucket(p96, s32, n))
         assert compress_blob(N, ctx.msm_host(p96, s32, n)) == want, n
     assert ctx.timings()["window_c"] == 7                       # the last call (n = 1024) ran the small kernel (its plan for n > 96)
+
+
+def test_sizes_up_to_2048_tree_combine(native_lib, ctx, pool):
+    """5 ... 8 slices per window: the last workgroup of a window adds the slices' items as a tree over pairs (every slice count, sizes on
+    both sides of every slice edge; c = 7 up to 1 536 terms, c = 8 up to 2 048 = one round of workgroups; 2 049 takes the launch chain)."""
+    N = native_lib
+    ks, pts = pool
+    rng = random.Random(415)
+    sizes = [1025, 1279, 1280, 1281] + [256 * s + d for s in range(5, 8) for d in (0, 1)] + [1391, 1535, 1536, 1537, 2000, 2047, 2048]
+    for n in sorted(set(sizes)):
+        idx = [rng.randrange(len(pts)) for _ in range(n)]
+        sc = [rng.randint(0, O.R - 1) for _ in range(n)]
+        p96 = b"".join(bytes(96) if rng.random() < 0.01 else raw96(pts[i]) for i in idx)
+        s32 = b"".join(v.to_bytes(32, "little") for v in sc)
+        want = C.compress(C.msm_bucket(p96, s32, n))
+        assert compress_blob(N, ctx.msm_host(p96, s32, n)) == want, n
+        assert ctx.last_counts()["accumulate_launches"] == 0, n          # k_msm_small served it
+        assert ctx.timings()["window_c"] == (7 if n <= 1536 else 8), n
+        if n in (1281, 1536, 2048):
+            dp, ds = ctx.alloc(96 * n), ctx.alloc(32 * n)
+            dp.upload(p96); ds.upload(s32)
+            for c in (6, 7, 8, 9):                                     # other widths: other numbers of items per window in the tree
+                assert compress_blob(N, ctx.msm_device(dp, ds, n, window_c=c)) == want, (n, c)
+            dp.free(); ds.free()
+            s_eq = (sc[0].to_bytes(32, "little")) * n                   # every term in ONE bucket per window and slice
+            assert compress_blob(N, ctx.msm_host(p96, s_eq, n)) == C.compress(C.msm_bucket(p96, s_eq, n)), n
+    n = 2049
+    idx = [rng.randrange(len(pts)) for _ in range(n)]
+    p96 = b"".join(raw96(pts[i]) for i in idx)
+    s32 = b"".join(rng.randint(0, O.R - 1).to_bytes(32, "little") for _ in range(n))
+    assert compress_blob(N, ctx.msm_host(p96, s32, n)) == C.compress(C.msm_bucket(p96, s32, n))
+    assert ctx.last_counts()["accumulate_launches"] == 1
 
 
 @pytest.mark.parametrize("c", [4, 6, 7, 8, 9])
@@ -168,7 +200,7 @@ def test_golden_vectors_through_the_small_kernel(native_lib, ctx, golden):
     for case in golden:
         pts = [O.g1_decompress(bytes.fromhex(h)) for h in case["points"]]
         n = len(pts)
-        if n == 0 or n > 1024:
+        if n == 0 or n > 2048:
             continue
         p96 = b"".join(raw96(p) for p in pts)
         s32 = b"".join(bytes.fromhex(h) for h in case["scalars"])
@@ -186,7 +218,7 @@ def test_several_msms_in_one_launch(native_lib, ctx, pool):
     N = native_lib
     ks, pts = pool
     rng = random.Random(409)
-    for sizes in ([5], [3, 0, 7], [64, 65, 64, 64], [128, 129, 1, 128, 0, 127], [257, 300, 2], [1024, 1], [33] * 16, [20] * 17, [0, 0, 9]):
+    for sizes in ([5], [3, 0, 7], [64, 65, 64, 64], [128, 129, 1, 128, 0, 127], [257, 300, 2], [1024, 1], [1500, 700], [2048], [33] * 16, [20] * 17, [0, 0, 9]):
         idx = [[rng.randrange(len(pts)) for _ in range(n)] for n in sizes]
         sc = [[rng.randint(0, O.R - 1) for _ in range(n)] for n in sizes]
         p96 = b"".join(raw96(pts[i]) for row in idx for i in row)
@@ -199,7 +231,7 @@ def test_several_msms_in_one_launch(native_lib, ctx, pool):
         for j, n in enumerate(sizes):
             tot = sum(ks[i] * s for i, s in zip(idx[j], sc[j])) % O.R
             assert compress_blob(N, blobs[j]) == O.g1_compress(O.g1_mul(O.G1_GEN, tot)), (sizes, j)
-        if len(sizes) <= 16 and max(sizes) <= 1024:
+        if len(sizes) <= 16 and max(sizes) <= 2048:
             assert ctx.last_counts()["accumulate_launches"] == 0              # k_msm_small served it
     # an out-of-range scalar in one of the MSMs rejects the call and leaves the counters clean
     bad = bytearray(s32); bad[31] |= 0x80

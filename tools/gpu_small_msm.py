@@ -19,7 +19,7 @@ R = 5243587517512619047944774050818596583769055250052763782260365869993858118451
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=200)
-    ap.add_argument("--sizes", default="4,7,32,64,124,128,256,307,512,627,1024")
+    ap.add_argument("--sizes", default="4,7,32,64,124,128,256,307,512,627,1024,1391,1536,1792,2048")
     ap.add_argument("--sweep-c", default="", help="also time k_msm_small at these window widths (device-resident inputs), e.g. 4,6,7,8,9")
     a = ap.parse_args()
     from curdleproofs_pie_amd import _native as N
@@ -27,7 +27,7 @@ def main():
     ctx = N.Context(0)
     ctx.set_param("profile", 0)
     rng = random.Random(9)
-    nmax = 1024
+    nmax = 2048
     dk, dg, dp = ctx.alloc(32 * nmax), ctx.alloc(96), ctx.alloc(96 * nmax)
     dk.upload(b"".join(rng.randint(1, R - 1).to_bytes(32, "little") for _ in range(nmax)))
     import ctypes
