@@ -3,7 +3,10 @@
 // This is the product's *host logic*, not a fallback for the GPU path: it backs the single-element
 // G1Point operators (one kernel launch per `P + Q` would be absurd), the 48-byte wire codec of single
 // points, input marshalling (batch projective->affine), and the O(255)-doubling Horner tail that
-// finishes a GPU MSM.  Every batched / data-parallel entry point (MSM, batch mul, ...) is HIP-only.
+// finishes a GPU MSM.  The MSM entry points are HIP-only at every size.  One data-parallel entry point may take the host's worker pool
+// instead of a launch: cg1_batch_mul_add with a few hundred outputs (a fold / map of the prover), where the launch is 255 dependent
+// doublings (~2.2 ms) whatever it computes -- the same records come back, byte for byte (cg1_batch_mul_add_pool, shuffle_verify.cpp;
+// "batch_mul_host_max" = 0 keeps every such call on the GPU).
 #pragma once
 #include <cstdint>
 #include <cstddef>
