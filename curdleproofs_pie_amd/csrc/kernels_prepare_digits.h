@@ -184,12 +184,15 @@ struct WinWalk {
 struct DigitIter {
   uint32_t s[8];
   uint32_t carry;
-  __device__ __forceinline__ int next(const WinPlan& pl, int w) {         // must be called for w = 0,1,2,... in order
-    const int bit = pl.off(w), c = pl.width(w);
-    uint32_t wi = bit >> 5, sh = bit & 31;
-    uint64_t v = (wi < 8) ? s[wi] : 0u;
-    if (wi + 1 < 8) v |= (uint64_t)s[wi + 1] << 32;
-    uint32_t raw = (uint32_t)(v >> sh) & ((1u << c) - 1u);
+  // must be called for w = 0, 1, 2, ... in order: the window's bits are the low c bits of s, which is then shifted down by c as a
+  // whole (eight v_alignbit with a wave-uniform count).  Picking the words by the window's bit offset instead indexes a register array
+  // with a run-time index: k_digits took 31 us for 2^16 scalars of a 20-window plan that way, 3x what the shifts need.
+  __device__ __forceinline__ int next(const WinPlan& pl, int w) {
+    const int c = pl.width(w);                                             // 1 <= c <= 16
+    const uint32_t raw = s[0] & ((1u << c) - 1u);
+#pragma unroll
+    for (int k = 0; k < 7; ++k) s[k] = __builtin_amdgcn_alignbit(s[k + 1], s[k], (uint32_t)c);
+    s[7] >>= c;
     uint32_t d = raw + carry;
     if (d > (1u << (c - 1))) { carry = 1; return (int)d - (1 << c); }
     carry = 0;
