@@ -154,6 +154,7 @@ struct Ctx {
   void* d_merlin_rows = nullptr; size_t merlin_rows_cap = 0;      // the rows of the last such call (kept: 134 KB per shuffle-shaped transcript)
   int merlin_lanes = 64;                // transcripts per wave of k_merlin_batch_sync ("merlin_lanes": 1 .. 64)
   uint32_t merlin_passes = 0;           // of the last cg1_merlin_batch_device call: Keccak passes of the slowest wave
+  int sort_sub_bits = 0;                // partition sort: sub-bucket bits a k_bin_sort workgroup sorts by ("sort_sub_bits": 4 .. 8; 0 = 7 up to 2^16 terms, else 8)
   int batch_mul_host_max = -1;          // cg1_batch_mul_add (host pointers): outputs up to which the host's pool does the work ("batch_mul_host_max"; -1 = 16 per pool thread, 0 = never)
   int last_batch_mul_on_host = 0;
   int batch_mul_quad_max = 8192;        // k_batch_mul_quad up to this many outputs ("batch_mul_quad_max"; 0 = always one lane per output)
@@ -506,7 +507,12 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   if (ctx->use_partition_sort && n <= PART_MAX_N) {
     // ---- two-level partition sort: no global atomics
-    const uint32_t sub_bits = bb < 8u ? bb : 8u, nbins = 1u << (bb - sub_bits);
+    // bins per window = 2^(bb - sub_bits) <= 128 (the partition kernels' LDS tables); a bin is ONE workgroup of k_bin_sort, so mid sizes
+    // want many small bins ("sort_sub_bits": the sub-bucket width, 8 at most; A/B in profiles/r04_sort_bins_ab.txt)
+    const uint32_t want_sub = ctx->sort_sub_bits ? (uint32_t)ctx->sort_sub_bits : (n <= ((size_t)1 << 16) ? 7u : 8u);   // 0 = by size: measured
+    uint32_t sub_bits = bb < want_sub ? bb : want_sub;
+    while (bb - sub_bits > 7u) ++sub_bits;
+    const uint32_t nbins = 1u << (bb - sub_bits);
     const uint32_t nslices = (n32 + PART_TILE - 1) / PART_TILE;
     const uint32_t nbc = (uint32_t)nlw * nbins * nslices;
     hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_digits, n32, plan, rank, world, bad_flag);
@@ -1434,6 +1440,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "fold_pass")) { ctx->fold_pass = value != 0; return CG1_OK; }
   if (!strcmp(name, "scan_one")) { ctx->scan_one = value != 0; return CG1_OK; }
   if (!strcmp(name, "batched_host_horner_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batched_host_horner_max = value; return CG1_OK; }
+  if (!strcmp(name, "sort_sub_bits")) { if (value != 0 && (value < 4 || value > 8)) return CG1_ERR_ARG; ctx->sort_sub_bits = value; return CG1_OK; }
   if (!strcmp(name, "batch_mul_host_max")) { if (value < -1) return CG1_ERR_ARG; ctx->batch_mul_host_max = value; return CG1_OK; }
   if (!strcmp(name, "batch_mul_quad_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batch_mul_quad_max = value; return CG1_OK; }
   if (!strcmp(name, "merlin_sync")) { ctx->merlin_sync = value != 0; return CG1_OK; }
