@@ -168,41 +168,51 @@ __global__ void __launch_bounds__(256, 2) k_bucket_fold_quad(const uint32_t* __r
 
 // Quad-lane variant of k_rowcol for SMALL bucket counts (balanced plans of mid-size inputs: <= 2^18 buckets), where the
 // reduction is bound by its chain of dependent EC additions (~26 us each in one lane of a lone wave), not by throughput:
-// ONE WAVE per row / column, its 16 DPP quads take the elements p, p + 16, ... (each addition shared by the 4 lanes of a
-// quad, g1_quad.h: ~2.6x shorter), then four quad-shuffle levels.  Same results as k_rowcol.
+// 2^lgq DPP quads per row / column (16, 8 or 4: a wave carries 1, 2 or 4 rows), quad p takes the elements p, p + 2^lgq, ... (each
+// addition shared by the 4 lanes of a quad, g1_quad.h: ~2.6x shorter), then lgq quad-shuffle levels.  Same results as k_rowcol.
+// The host picks lgq so that (rounds of resident waves) x (steps per wave) is smallest: the kernel keeps 2 waves per SIMD = 2 048 on
+// the chip, and a 2^16-term call has 2 560 rows + columns -- one wave each was 1.25 rounds of 8 steps (144 us), half a wave each is one
+// round of 11 (profiles/r04_gap_trace.txt).
 __global__ void __launch_bounds__(256, 2) k_rowcol_quad(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
                                                         PointSum* __restrict__ rowsum, PointSum* __restrict__ colsum,
-                                                        uint32_t nlw, uint32_t hb, uint32_t lb) {
-  const uint32_t R = 1u << hb, Cn = 1u << lb;
-  const uint32_t gw = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u, q = lane & 3u, p = lane >> 2;
+                                                        uint32_t nlw, uint32_t hb, uint32_t lb, uint32_t lgq) {
+  const uint32_t R = 1u << hb, Cn = 1u << lb, G = 1u << lgq, per_wave = 16u >> lgq;
+  const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u, q = lane & 3u, quad = lane >> 2;
+  const uint32_t gw = wave * per_wave + (quad >> lgq), p = quad & (G - 1u);     // this quad's row / column, its place among the row's quads
   const uint32_t nrows = nlw * R, ncols = nlw * Cn;
-  if (gw >= nrows + ncols) return;                          // whole waves leave together
-  // element i of this row / column is bucket first + i * stride, i < len
-  uint32_t first, stride, len;
-  if (gw < nrows) { first = gw * Cn; stride = 1u; len = Cn; }
-  else { const uint32_t gc = gw - nrows, lw = gc / Cn, l = gc % Cn; first = lw * R * Cn + l; stride = Cn; len = R; }
-  const uint32_t nser = (len + 15u) >> 4;                   // serial elements per quad (wave-uniform)
+  if (wave * per_wave >= nrows + ncols) return;                                 // whole waves leave together
+  const bool live_row = gw < nrows + ncols;
+  // element i of this row / column is bucket first + i * stride, i < len (a wave may carry rows AND columns: the step count below is
+  // the longer one's, the bounds are each quad's own)
+  const bool is_row = gw < nrows;
+  uint32_t first = 0, stride = 1u;
+  const uint32_t len = is_row ? Cn : R;
+  if (live_row) {
+    if (is_row) { first = gw * Cn; stride = 1u; }
+    else { const uint32_t gc = gw - nrows, lw = gc / Cn, l = gc % Cn; first = lw * R * Cn + l; stride = Cn; }
+  }
+  const uint32_t nser = ((R > Cn ? R : Cn) + G - 1u) >> lgq;   // serial steps per quad (wave-uniform)
   xyzz acc = xyzz_identity();
-  // ONE quad_add call site for the serial steps and the four shuffle levels (the kernel must stay inside the instruction
+  // ONE quad_add call site for the serial steps and the shuffle levels (the kernel must stay inside the instruction
   // cache and under 256 registers).  k_bucket_fold / k_heavy_combine ran before: a non-empty bucket's sum is its first slot.
 #pragma unroll 1
-  for (uint32_t step = 0; step < nser + 4u; ++step) {
+  for (uint32_t step = 0; step < nser + lgq; ++step) {
     xyzz o;
     bool go;
     if (step < nser) {
-      const uint32_t i = p + 16u * step;
+      const uint32_t i = p + G * step;
       const uint32_t b = first + (i < len ? i : 0u) * stride;
       const uint32_t c0 = choff[b];
-      go = i < len && choff[b + 1] > c0;
+      go = live_row && i < len && choff[b + 1] > c0;
       o = load_sum(sums + c0);                               // (a valid address even for an empty bucket: the next bucket's slot or the pad)
     } else {
-      const uint32_t dq = 8u >> (step - nser);
+      const uint32_t dq = (G >> 1) >> (step - nser);
       o = shfl_down_xyzz(acc, (int)(4u * dq));
       go = p < dq;
     }
     if (go) acc = quad_add(acc, o, q);
   }
-  if (lane == 0) store_sum(gw < nrows ? rowsum + gw : colsum + (gw - nrows), acc);
+  if (live_row && p == 0u && q == 0u) store_sum(is_row ? rowsum + gw : colsum + (gw - nrows), acc);
 }
 
 // grid = (1 + hb + lb, nlw), 256 threads.  item 0: T0 = sum_h A_h; item 1+k (k < hb): sum of A_h with bit k of h set;

@@ -140,6 +140,7 @@ struct Ctx {
   int stage_sort = 1;                   // LDS-staged, line-coalesced writes in k_part_scatter / k_bin_sort (A/B switch)
   int host_split = 1;                   // host Horner tail on two threads (A/B switch)
   int rowcol_quad = 1;                  // k_rowcol_quad for small bucket counts (A/B switch)
+  int rowcol_lgq = 0;                   // "rowcol_lgq": log2 of the quads per row / column of k_rowcol_quad (2, 3, 4; 0 = by cost)
   int rowcol_quad_max = 1 << 18;        // ... up to this many buckets ("rowcol_quad_max")
   int tree_half = 1;                    // k_small_tree_quad: 2 lanes per element (a quad takes two elements) instead of 4 (A/B switch)
   int merlin_sync = 1;                  // k_merlin_batch_sync (lanes permute together) instead of k_merlin_batch (A/B switch)
@@ -584,9 +585,17 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
     const uint32_t ncol_blocks = ((uint32_t)nlw * Cn + (256u / lpc) - 1u) / (256u / lpc);
     PointSum* rowsum = ctx->d_segrun;                     // reuse the segment buffers (>= nb_total records each)
     PointSum* colsum = ctx->d_segtot;
-    if (small_quad)
-      hipLaunchKernelGGL(k_rowcol_quad, dim3(((uint32_t)nlw * (R + Cn) + 3u) / 4u), dim3(256), 0, st, ctx->d_choff, ctx->d_sums,
-                         rowsum, colsum, (uint32_t)nlw, hb2, lb2);
+    if (small_quad) {
+      // quads per row / column: 16, 8 or 4 (a wave carries 1, 2 or 4 rows).  Measured (profiles/r04_rowcol_ab.txt, fold + row / column
+      // sums at 2^12 .. 2^16 terms): a serial element costs a quad ~8 us, a shuffle level ~23 us (56 words through ds_bpermute), and
+      // 2 560 one-wave rows are 1.25 rounds of the 2 048 resident waves -- so FEW quads per row win: 4 where rows and columns are equally
+      // long (119 / 104 / 97 us at 2^12, 248 / 229 / 216 at 2^16 for 16 / 8 / 4 quads), 8 where they are not (2^14: 158 / 150 / 167).
+      uint32_t lgq = (R == Cn) ? 2u : 3u;
+      if (ctx->rowcol_lgq >= 2 && ctx->rowcol_lgq <= 4) lgq = (uint32_t)ctx->rowcol_lgq;
+      const uint32_t rc_waves = ((uint32_t)nlw * (R + Cn) + (16u >> lgq) - 1u) / (16u >> lgq);
+      hipLaunchKernelGGL(k_rowcol_quad, dim3((rc_waves + 3u) / 4u), dim3(256), 0, st, ctx->d_choff, ctx->d_sums,
+                         rowsum, colsum, (uint32_t)nlw, hb2, lb2, lgq);
+    }
     else
       hipLaunchKernelGGL(k_rowcol, dim3(nrow_blocks + ncol_blocks), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
                          rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks, ctx->quad);
@@ -1440,6 +1449,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "fold_pass")) { ctx->fold_pass = value != 0; return CG1_OK; }
   if (!strcmp(name, "scan_one")) { ctx->scan_one = value != 0; return CG1_OK; }
   if (!strcmp(name, "batched_host_horner_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batched_host_horner_max = value; return CG1_OK; }
+  if (!strcmp(name, "rowcol_lgq")) { if (value != 0 && (value < 2 || value > 4)) return CG1_ERR_ARG; ctx->rowcol_lgq = value; return CG1_OK; }
   if (!strcmp(name, "sort_sub_bits")) { if (value != 0 && (value < 4 || value > 8)) return CG1_ERR_ARG; ctx->sort_sub_bits = value; return CG1_OK; }
   if (!strcmp(name, "batch_mul_host_max")) { if (value < -1) return CG1_ERR_ARG; ctx->batch_mul_host_max = value; return CG1_OK; }
   if (!strcmp(name, "batch_mul_quad_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batch_mul_quad_max = value; return CG1_OK; }
