@@ -567,13 +567,16 @@ def main():
         # ... and let the step time settle (untimed, reported as settle_steps): blocks of five further steps until a block is within 1.5 %
         # of the one before -- the first steps of a process also pay for host threads and pages that are touched for the first time
         # (profiles/r03_v4_bench.json: 3.24 ms for the first 20 timed steps of a process, 2.98 / 3.00 ms for the next two runs)
-        settle, prev = 0, None
-        while settle < 40:
+        # (two agreeing comparisons in a row, i.e. three blocks at one level: a single pair has been seen to agree on the way down --
+        # profiles/r04_v6_bench.json's second run: 3.14 ms timed after 20 settling steps, 2.98 / 3.00 ms for the next two runs)
+        settle, prev, calm = 0, None, 0
+        while settle < 60:
             ts = time.perf_counter()
             results += stream(5)
             settle += 5
             blk = (time.perf_counter() - ts) / 5
-            done = prev is not None and abs(blk - prev) <= 0.015 * prev
+            calm = calm + 1 if (prev is not None and abs(blk - prev) <= 0.015 * prev) else 0
+            done = calm >= 2
             prev = blk
             if comm:                                          # every rank takes the same number of steps: stop when all have settled
                 done = max(max_over_ranks(0.0 if done else 1.0, comm)) < 0.5
