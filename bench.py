@@ -568,7 +568,7 @@ def main():
         # of the one before -- the first steps of a process also pay for host threads and pages that are touched for the first time
         # (profiles/r03_v4_bench.json: 3.24 ms for the first 20 timed steps of a process, 2.98 / 3.00 ms for the next two runs)
         # (two agreeing comparisons in a row, i.e. three blocks at one level: a single pair has been seen to agree on the way down --
-        # profiles/r04_v6_bench.json's second run: 3.14 ms timed after 20 settling steps, 2.98 / 3.00 ms for the next two runs)
+        # one round-4 run timed 3.14 ms after 20 settling steps and 2.98 / 3.00 ms in its next two runs)
         settle, prev, calm = 0, None, 0
         while settle < 60:
             ts = time.perf_counter()
