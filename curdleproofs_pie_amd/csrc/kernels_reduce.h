@@ -151,7 +151,8 @@ __global__ void __launch_bounds__(256, 2) k_rowcol(const uint32_t* __restrict__ 
 
 // Quad-lane k_bucket_fold for small bucket counts (same regime as k_rowcol_quad): one DPP quad per bucket adds the bucket's
 // 2..16 chunk sums into its first slot (balanced plans of mid-size inputs cut every bucket into a few short chunks so that
-// the madd chains of k_accumulate stay short; a lone lane needs ~26 us per addition, a quad ~10).
+// the madd chains of k_accumulate stay short; a lone lane needs ~26 us per addition, a quad ~10).  (Several buckets per quad, one after
+// the other, to have fewer resident waves -- what helped k_rowcol_quad -- was measured a loss here at every size: 0.223 -> 0.249 ms at 2^16.)
 __global__ void __launch_bounds__(256, 2) k_bucket_fold_quad(const uint32_t* __restrict__ choff, PointSum* __restrict__ sums,
                                                              uint8_t* __restrict__ combined, uint32_t nb_total,
                                                              const uint32_t* __restrict__ any_multi) {

@@ -142,6 +142,8 @@ struct Ctx {
   int rowcol_quad = 1;                  // k_rowcol_quad for small bucket counts (A/B switch)
   int rowcol_lgq = 0;                   // "rowcol_lgq": log2 of the quads per row / column of k_rowcol_quad (2, 3, 4; 0 = by cost)
   int rowcol_quad_max = 1 << 18;        // ... up to this many buckets ("rowcol_quad_max")
+  int tree_shift = 2;                   // "tree_shift": k_small_tree_quad's block = 4 lanes per element >> this (0 .. 4; -1 = tree_half's 0 / 1).  Measured
+                                        // (profiles/r04_tree_ab.txt, tree + export at 2^16 / 2^18 / 2^20): 0: 111 / 112 / 119 us, 1: 90 / 112 / 121, 2: 79 / 100 / 110, 4: 78 / 161 / 177
   int tree_half = 1;                    // k_small_tree_quad: 2 lanes per element (a quad takes two elements) instead of 4 (A/B switch)
   int merlin_sync = 1;                  // k_merlin_batch_sync (lanes permute together) instead of k_merlin_batch (A/B switch)
   uint32_t merlin_clk[2] = {0, 0};
@@ -601,7 +603,7 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
                          rowsum, colsum, (uint32_t)nlw, hb2, lb2, nrow_blocks, ctx->quad);
     if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
     // 4 lanes per element of the longer of the two sums (2^hb rows, 2^lb columns), at most 512 threads: no idle quads in the block
-    const uint32_t tree_threads = std::min<uint32_t>(512u, std::max<uint32_t>(64u, 4u << std::max(hb2, lb2)) >> (ctx->tree_half ? 1 : 0));
+    const uint32_t tree_threads = std::min<uint32_t>(512u, std::max<uint32_t>(64u, 4u << std::max(hb2, lb2)) >> (ctx->tree_shift >= 0 ? ctx->tree_shift : (ctx->tree_half ? 1 : 0)));
     if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(std::max<uint32_t>(64u, tree_threads)), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
     else hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
   } else {
@@ -1175,7 +1177,7 @@ static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, 
   }
   Ctx* ch = child_of(ctx);
   ch->profile = ctx->profile; ch->L0 = ctx->L0; ch->seg_m = ctx->seg_m; ch->quad = ctx->quad; ch->reduce_2d = ctx->reduce_2d;
-  ch->rowcol_quad = ctx->rowcol_quad; ch->rowcol_quad_max = ctx->rowcol_quad_max; ch->fold_pass = ctx->fold_pass; ch->tree_half = ctx->tree_half;
+  ch->rowcol_quad = ctx->rowcol_quad; ch->rowcol_quad_max = ctx->rowcol_quad_max; ch->fold_pass = ctx->fold_pass; ch->tree_half = ctx->tree_half; ch->tree_shift = ctx->tree_shift; ch->rowcol_lgq = ctx->rowcol_lgq; ch->sort_sub_bits = ctx->sort_sub_bits;
   ch->scan_one = ctx->scan_one; ch->zero_copy = ctx->zero_copy; ch->horner_threads = ctx->horner_threads; ch->host_split = ctx->host_split;
   ch->blocking_sync = ctx->blocking_sync; ch->stage_sort = ctx->stage_sort; ch->use_partition_sort = ctx->use_partition_sort; ch->big_bins = ctx->big_bins;
   const int n_own = win_count(plan.nwin, rank, world), n_lo = n_own / 2, n_hi = n_own - n_lo;      // this rank's windows: the upper ones here, the lower ones on the child
@@ -1449,6 +1451,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "fold_pass")) { ctx->fold_pass = value != 0; return CG1_OK; }
   if (!strcmp(name, "scan_one")) { ctx->scan_one = value != 0; return CG1_OK; }
   if (!strcmp(name, "batched_host_horner_max")) { if (value < 0) return CG1_ERR_ARG; ctx->batched_host_horner_max = value; return CG1_OK; }
+  if (!strcmp(name, "tree_shift")) { if (value < -1 || value > 4) return CG1_ERR_ARG; ctx->tree_shift = value; return CG1_OK; }
   if (!strcmp(name, "rowcol_lgq")) { if (value != 0 && (value < 2 || value > 4)) return CG1_ERR_ARG; ctx->rowcol_lgq = value; return CG1_OK; }
   if (!strcmp(name, "sort_sub_bits")) { if (value != 0 && (value < 4 || value > 8)) return CG1_ERR_ARG; ctx->sort_sub_bits = value; return CG1_OK; }
   if (!strcmp(name, "batch_mul_host_max")) { if (value < -1) return CG1_ERR_ARG; ctx->batch_mul_host_max = value; return CG1_OK; }
