@@ -592,8 +592,11 @@ __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__
       for (uint32_t k = 0; k < nch; ++k) {
         uint32_t s = k * L, len = (cnt - s < L) ? (cnt - s) : L;
         desc[o + k] = make_uint2(start + s, len);
-        atomicAdd(&sh[len_key(len)], 1u);
       }
+      // the histogram of chunk lengths: nch - 1 full chunks and the last one -- two LDS atomics per bucket, not one per chunk (most
+      // lanes of a block hit the same key: the atomics serialise)
+      if (nch > 1u) atomicAdd(&sh[len_key(L)], nch - 1u);
+      atomicAdd(&sh[len_key(cnt - (nch - 1u) * L)], 1u);
       if (nch >= HEAVY_MIN_CHUNKS) {
         uint32_t slot = atomicAdd(&heavy[0], 1u);
         if (slot < heavy_cap) heavy[1 + slot] = b;
@@ -637,7 +640,22 @@ __global__ void __launch_bounds__(256) k_order(const uint2* __restrict__ desc, c
   uint32_t t = blockIdx.x * 256 + threadIdx.x;
   bool live = t < *total_chunks;
   uint32_t key = 0, local = 0;
-  if (live) { key = len_key(desc[t].y); local = atomicAdd(&cnt[key], 1u); }
+  // the chunks of a call mostly share ONE length key (every chunk but the last of its bucket): the lanes that carry the first live
+  // lane's key take their slots from one atomic, the others from their own (64 same-address LDS atomics serialise)
+  if (live) key = len_key(desc[t].y);
+  {
+    const unsigned long long amask = __ballot(live);
+    if (amask) {
+      const int leader = __ffsll((long long)amask) - 1;
+      const uint32_t k0 = __shfl(key, leader, 64);
+      const unsigned long long same = __ballot(live && key == k0);
+      const uint32_t lane = threadIdx.x & 63u;
+      uint32_t b0 = 0;
+      if ((int)lane == leader) b0 = atomicAdd(&cnt[k0], (uint32_t)__popcll(same));
+      b0 = __shfl(b0, leader, 64);
+      if (live) local = (key == k0) ? b0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull)) : atomicAdd(&cnt[key], 1u);
+    }
+  }
   __syncthreads();
   uint32_t c = cnt[threadIdx.x];
   if (c) base[threadIdx.x] = atomicAdd(&len_cursor[threadIdx.x], c);
