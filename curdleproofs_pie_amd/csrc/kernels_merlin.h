@@ -506,27 +506,28 @@ __device__ __forceinline__ size_t row_word_index(uint32_t proof, uint32_t node, 
 
 // data: n rows of `stride` bytes (the FE: a proof's L wire points).  canon48: the rows are arrays of 48-byte point encodings and one
 // flagged as infinity is hashed as the wheel re-serialises it, C0 00 .. 00 (util.py:27-32).
+// grid = (ceil(nodes * 48 / 256), min(n, 65535)): x walks the words of ONE transcript's rows, y the transcripts (no 64-bit division per
+// word: the flat index of round 3 spent most of its ~100 instructions on t / (nodes * 48)).
 __global__ void __launch_bounds__(256) k_fill_rows(const RowDesc* __restrict__ desc, uint32_t nodes, const uint8_t* __restrict__ data, size_t stride,
                                                    uint32_t canon48, uint32_t n, uint32_t lanes_used, uint32_t* __restrict__ rows) {
-  const size_t per = (size_t)nodes * ROW_WORDS;
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= per * n) return;
-  const size_t proof = t / per, k = t - proof * per;
+  const uint32_t per = nodes * ROW_WORDS;
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k >= per) return;
   const RowDesc d = desc[k];
-  uint32_t v = d.tword;
-  if (d.src) {
-    const uint32_t lo = (d.src >> 1) & 3u, cnt = ((d.src >> 3) & 3u) + 1u, off = d.src >> 5;
-    const uint8_t* src = data + proof * stride + off;
-    bool inf = false;
-    uint32_t k0 = 0;
-    if (canon48) { k0 = off % 48u; inf = (src[-(int)k0] & 0xC0u) == 0xC0u; }
-    for (uint32_t b = 0; b < cnt; ++b) {
-      const uint32_t byte = inf ? (k0 + b == 0u ? 0xC0u : 0u) : (uint32_t)src[b];
-      v ^= byte << (8u * (lo + b));
+  const uint32_t node = k / ROW_WORDS, word = k - node * ROW_WORDS;
+  const uint32_t lo = (d.src >> 1) & 3u, cnt = ((d.src >> 3) & 3u) + 1u, off = d.src >> 5, k0 = canon48 ? off % 48u : 0u;
+  for (uint32_t proof = blockIdx.y; proof < n; proof += gridDim.y) {
+    uint32_t v = d.tword;
+    if (d.src) {
+      const uint8_t* src = data + (size_t)proof * stride + off;
+      const bool inf = canon48 && (src[-(int)k0] & 0xC0u) == 0xC0u;
+      for (uint32_t b = 0; b < cnt; ++b) {
+        const uint32_t byte = inf ? (k0 + b == 0u ? 0xC0u : 0u) : (uint32_t)src[b];
+        v ^= byte << (8u * (lo + b));
+      }
     }
+    rows[row_word_index(proof, node, nodes, lanes_used) + word] = v;
   }
-  const uint32_t node = (uint32_t)(k / ROW_WORDS), word = (uint32_t)(k - (size_t)node * ROW_WORDS);
-  rows[row_word_index((uint32_t)proof, node, nodes, lanes_used) + word] = v;
 }
 
 // One late piece: `len` <= 48 bytes from the challenge just drawn (LDS, word j at drawn[j * LANES], 9 words) or from the lane's out row

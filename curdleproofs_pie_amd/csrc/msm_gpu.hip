@@ -1888,8 +1888,7 @@ int cg1_merlin_batch_device(cg1_ctx* ctx, const uint8_t* init_state208, const cg
         HIPCHK(ddesc.alloc(desc.size() * sizeof(cg1merlin::RowDesc)));
         HIPCHK(dpass.alloc(4 * (size_t)nb));
         HIPCHK(hipMemcpyAsync(ddesc.p, desc.data(), desc.size() * sizeof(cg1merlin::RowDesc), hipMemcpyHostToDevice, ctx->stream));
-        const size_t total = n * (size_t)nn * cg1merlin::ROW_WORDS;
-        hipLaunchKernelGGL(cg1merlin::k_fill_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const cg1merlin::RowDesc*)ddesc.p, nn,
+        hipLaunchKernelGGL(cg1merlin::k_fill_rows, dim3((nn * cg1merlin::ROW_WORDS + 255u) / 256u, (unsigned)std::min<size_t>(n, 65535)), dim3(256), 0, ctx->stream, (const cg1merlin::RowDesc*)ddesc.p, nn,
                            (const uint8_t*)d_data, data_stride, 0u, (uint32_t)n, lanes_used, (uint32_t*)ctx->d_merlin_rows);
         hipLaunchKernelGGL(cg1merlin::k_merlin_batch_rows, dim3(nb), dim3(cg1merlin::LANES), 0, ctx->stream, (const uint8_t*)dst.p, (const uint32_t*)ctx->d_merlin_rows, nn,
                            (uint8_t*)d_out, out_stride, (uint8_t*)d_states_out, (uint32_t)n, lanes_used, (uint32_t*)dpass.p);
@@ -2517,8 +2516,7 @@ int cg1_shuffle_fe_enqueue(cg1_shuffle_fe* fe, cg1_ctx* ctx, size_t n, const voi
       fe->cap_rows = need; fe->cap_blocks = nblk;
     }
     fe->last_blocks = nblk;
-    const size_t total = n * row_words;
-    hipLaunchKernelGGL(cg1merlin::k_fill_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const cg1fe::RowDesc*)fe->d_desc, fe->n_nodes,
+    hipLaunchKernelGGL(cg1merlin::k_fill_rows, dim3((unsigned)((row_words + 255) / 256), (unsigned)std::min<size_t>(n, 65535)), dim3(256), 0, ctx->stream, (const cg1fe::RowDesc*)fe->d_desc, fe->n_nodes,
                        (const uint8_t*)d_wire48, (size_t)fe->pr.L * 48, 1u, (uint32_t)n, (uint32_t)lanes_per_wave, (uint32_t*)fe->d_rows);
     hipLaunchKernelGGL(ctx->fe_timed ? cg1fe::k_shuffle_front_end_rows<true> : cg1fe::k_shuffle_front_end_rows<false>, dim3(nblk), dim3(cg1merlin::LANES), 0, ctx->stream, (const uint8_t*)fe->d_init, (const uint32_t*)fe->d_rows,
                        fe->n_nodes, (const uint8_t*)d_wire48, (const uint8_t*)d_aux, (const cg1::PreparedPoint*)fe->d_four, (const cg1::PreparedPoint*)fe->d_tabG,
