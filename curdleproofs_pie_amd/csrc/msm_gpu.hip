@@ -75,12 +75,22 @@ struct Helper {
   std::mutex mu;
   std::condition_variable cv;
   std::function<void()> job;
-  bool has = false, done = true, quit = false;
+  bool has = false, done = true, quit = false, armed = false;
+  std::atomic<bool> posted{false};       // mirrors `has` for a helper that is spinning (arm())
+  void start_locked() { if (!th.joinable()) th = std::thread([this]() { loop(); }); }
   void run(std::function<void()> f) {
     std::unique_lock<std::mutex> lk(mu);
-    if (!th.joinable()) th = std::thread([this]() { loop(); });
+    start_locked();
     job = std::move(f); has = true; done = false;
+    posted.store(true, std::memory_order_release);
     cv.notify_all();
+  }
+  // A job is about to come (the caller starts polling for a GPU result a fraction of a millisecond away): wake the thread now and
+  // let it SPIN for the job (at most ~2 ms) instead of paying the futex wake-up -- 20-40 us -- inside a 100 us host tail.
+  void arm() {
+    std::unique_lock<std::mutex> lk(mu);
+    start_locked();
+    if (!has && done) { armed = true; cv.notify_all(); }
   }
   void wait() {
     std::unique_lock<std::mutex> lk(mu);
@@ -89,10 +99,23 @@ struct Helper {
   void loop() {
     std::unique_lock<std::mutex> lk(mu);
     for (;;) {
-      cv.wait(lk, [this]() { return has || quit; });
+      cv.wait(lk, [this]() { return has || quit || armed; });
       if (quit) return;
+      if (!has) {                                              // armed: spin for the job outside the lock
+        armed = false;
+        lk.unlock();
+        const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
+        for (uint32_t k = 0; !posted.load(std::memory_order_acquire); ++k) {
+          if ((k & 0xffu) == 0xffu && std::chrono::steady_clock::now() > until) break;
+          __builtin_ia32_pause();
+        }
+        lk.lock();
+        if (!has) continue;
+      }
+      armed = false;
       std::function<void()> f = std::move(job);
       has = false;
+      posted.store(false, std::memory_order_relaxed);
       lk.unlock();
       f();
       lk.lock();
@@ -173,6 +196,7 @@ struct Ctx {
     bool use2d = true;
     int profile = 0;                    // the level the events of THIS call were recorded under (may change before msm_finish)
     bool zero_copy = false; uint32_t seq = 0;
+    bool arm_helpers = false;           // the host tail is a large share of this call: its helper threads spin for their part while the GPU result is polled
     size_t nout_words = 0;
     const PointWords* hout = nullptr;   // where the exported items land (ctx->h_out, or h_small_out for k_msm_small)
     std::chrono::steady_clock::time_point h0, h1;
@@ -211,6 +235,7 @@ struct Ctx {
   uint32_t* h_flag_dev = nullptr;
   uint32_t seq = 0;
   int zero_copy = 1;                    // 1: export kernel + flag polling instead of a D2H copy + stream wait (A/B switch)
+  int arm_helpers = 1;                  // "arm_helpers": the Horner's helper threads spin for their part while a small / mid-size call's result is polled (A/B switch)
   int horner_threads = 4;               // host threads of the Horner tail: 1, 2 or 4 (A/B switch; host_split = 0 forces 1)
   // staging for host-pointer entry points
   void* d_stage_pts = nullptr; void* d_stage_sc = nullptr; size_t cap_stage_pts = 0, cap_stage_sc = 0;      // bytes
@@ -631,6 +656,7 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   pd.zero_copy = zc; pd.seq = ctx->seq; pd.hout = ctx->h_out;
   pd.active = true; pd.c = c; pd.plan = plan; pd.rank = rank; pd.world = world; pd.nlw = nlw; pd.nbits = nbits; pd.m = m; pd.lb2 = lb2; pd.hb2 = hb2;
   pd.nitems = nitems; pd.use2d = use2d; pd.profile = profile; pd.nout_words = nout_words; pd.h0 = h0; pd.h1 = h1;
+  pd.arm_helpers = ctx->arm_helpers && ctx->host_split && ctx->horner_threads > 1 && n <= ((size_t)1 << 18);
   return CG1_OK;
 }
 
@@ -648,6 +674,7 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   const auto h0 = pd.h0, h1 = pd.h1;
   HIPCHK(hipSetDevice(ctx->device));
   if (pd.zero_copy && !ctx->blocking_sync && pd.profile < 2) {
+    if (pd.arm_helpers) for (int j = 0; j < 3 && j + 1 < ctx->horner_threads; ++j) ctx->helper[j].arm();
     // poll the flag word k_export_host writes last; look at the stream now and then so that a failed launch cannot hang us
     volatile uint32_t* flag = ctx->h_flag;
     for (uint32_t spins = 0; *flag != pd.seq; ++spins) {
@@ -842,6 +869,7 @@ static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32
   pd.zero_copy = true; pd.seq = ctx->seq; pd.hout = ctx->h_small_out;
   pd.active = true; pd.c = c; pd.plan = plan; pd.rank = 0; pd.world = 1; pd.nlw = (int)nwin; pd.nbits = 0; pd.m = 1; pd.lb2 = lb2; pd.hb2 = hb2;
   pd.nitems = nitems; pd.use2d = true; pd.profile = 0; pd.nout_words = (size_t)M * nwin * nitems; pd.h0 = h0; pd.h1 = h1;
+  pd.arm_helpers = ctx->arm_helpers && ctx->host_split && ctx->horner_threads > 1 && M == 1;
   return CG1_OK;
 }
 
@@ -1443,6 +1471,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "blocking_sync")) { ctx->blocking_sync = value != 0; return CG1_OK; }
   if (!strcmp(name, "big_bins")) { ctx->big_bins = value != 0; return CG1_OK; }
   if (!strcmp(name, "host_split")) { ctx->host_split = value != 0; return CG1_OK; }
+  if (!strcmp(name, "arm_helpers")) { ctx->arm_helpers = value != 0; return CG1_OK; }
   if (!strcmp(name, "horner_threads")) { if (value != 1 && value != 2 && value != 4) return CG1_ERR_ARG; ctx->horner_threads = value; return CG1_OK; }
   if (!strcmp(name, "zero_copy")) { ctx->zero_copy = value != 0; return CG1_OK; }
   if (!strcmp(name, "auto_plan")) { ctx->auto_plan = value != 0; return CG1_OK; }
