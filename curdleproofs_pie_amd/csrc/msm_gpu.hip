@@ -32,6 +32,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <vector>
 #include <string>
 #include <algorithm>
@@ -248,6 +249,7 @@ struct Ctx {
   uint32_t last_chunks = 0, last_entries = 0;   // of the last MSM call: non-zero digits sorted into buckets; chunks k_accumulate ran
   hipEvent_t tm_ev[2] = {nullptr, nullptr};     // cg1_timer_begin / cg1_timer_end
   int last_c = 0, pend_c = 0;
+  int chunk_rule = 1;                   // "chunk_rule": whole-bucket chunks at 2^17 .. 2^19 terms (A/B switch)
   uint32_t L0 = 8;                      // MINIMUM chunk length; the per-call length grows with the entry count
   uint32_t seg_m = 4;
 };
@@ -514,6 +516,19 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   // (window-sharded ranks, skew, thin top windows) are re-joined by k_bucket_fold (<= 16 chunks) / k_heavy_combine.
   uint32_t L0 = ctx->L0;
   while (L0 < 65536u && ((uint64_t)n * (uint64_t)nlw >> 18) > (uint64_t)L0) L0 <<= 1;
+  // Between 2^17 and 2^19 terms k_accumulate is already bound by throughput, not by the chain of one chunk, and the lane-per-bucket tail
+  // runs (more than 2^18 buckets): there a chunk should hold a WHOLE bucket -- mean load m plus eight standard deviations of its Poisson
+  // spread -- so that no bucket is cut, k_bucket_fold finds nothing to do and k_rowcol reads one sum per bucket (profiles/r04_chunk_ab.txt:
+  // 2^18 terms 1.22 -> 1.11 ms).  Below 2^22 entries the chain still shows: 20 at most (2^17 terms: 0.94 -> 0.91 ms).
+  if (ctx->chunk_rule && world == 1) {
+    const uint64_t entries = (uint64_t)n * (uint64_t)nlw;
+    if (entries >= (1ull << 21) && entries < (1ull << 24) && nb_total > (size_t)ctx->rowcol_quad_max) {
+      const double mload = (double)n / (double)(1u << bb);
+      uint32_t want = (uint32_t)(mload + 8.0 * std::sqrt(mload) + 1.0);
+      if (entries < (1ull << 22) && want > 20u) want = 20u;
+      if (want > L0) L0 = want;
+    }
+  }
   int rc = ensure(ctx, n, nb_total, nlw, nitems, L0, src.kind != PtSrc::PREPARED);
   if (rc) return rc;
   hipStream_t st = ctx->stream;
@@ -1460,6 +1475,7 @@ int cg1_ctx_device(const cg1_ctx* ctx) { return ctx ? ctx->device : -1; }
 void* cg1_ctx_stream(cg1_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return CG1_ERR_ARG;
+  if (!strcmp(name, "chunk_rule")) { ctx->chunk_rule = value != 0; return CG1_OK; }
   if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "stage_sort")) { ctx->stage_sort = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "quad")) { ctx->quad = value ? 1 : 0; return CG1_OK; }
