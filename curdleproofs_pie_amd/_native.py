@@ -230,13 +230,14 @@ cg1_shuffle_exact_same_scalar = _proto("cg1_shuffle_exact_same_scalar", c_int, c
 cg1_opening_prepare_device = _proto("cg1_opening_prepare_device", c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p)
 cg1_opening_weights_from_seed = _proto("cg1_opening_weights_from_seed", c_int, c_void_p, c_size_t, c_size_t, c_void_p)
 cg1_opening_exact = _proto("cg1_opening_exact", c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int))
+cg1_opening_exact_status = _proto("cg1_opening_exact_status", c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int))
 cg1_shuffle_gather_points = _proto("cg1_shuffle_gather_points", c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p)
 cg1_shuffle_apply_point_status = _proto("cg1_shuffle_apply_point_status", c_int, _buf, _u8p, c_size_t, c_size_t, _buf, _buf, c_size_t)
 cg1_shuffle_sum_crs_scalars = _proto("cg1_shuffle_sum_crs_scalars", c_int, _buf, _buf, c_size_t, c_size_t, _buf)
 
 EXPORTED_SYMBOLS = [
     "cg1_shuffle_crs_create", "cg1_shuffle_crs_destroy", "cg1_shuffle_proof_bytes", "cg1_shuffle_points_per_proof",
-    "cg1_shuffle_crs_points", "cg1_shuffle_challenges_per_proof", "cg1_opening_prepare", "cg1_shuffle_prepare", "cg1_shuffle_set_grouped", "cg1_shuffle_default_threads", "cg1_shuffle_gather_points", "cg1_shuffle_rowin_scalars", "cg1_shuffle_prepare_inputs", "cg1_shuffle_rows_device", "cg1_shuffle_exact_same_scalar", "cg1_opening_exact", "cg1_opening_prepare_device", "cg1_opening_weights_from_seed", "cg1_subgroup_flags_enqueue", "cg1_side_sync", "cg1_shuffle_apply_point_status", "cg1_shuffle_sum_crs_scalars",
+    "cg1_shuffle_crs_points", "cg1_shuffle_challenges_per_proof", "cg1_opening_prepare", "cg1_shuffle_prepare", "cg1_shuffle_set_grouped", "cg1_shuffle_default_threads", "cg1_shuffle_gather_points", "cg1_shuffle_rowin_scalars", "cg1_shuffle_prepare_inputs", "cg1_shuffle_rows_device", "cg1_shuffle_exact_same_scalar", "cg1_opening_exact", "cg1_opening_exact_status", "cg1_opening_prepare_device", "cg1_opening_weights_from_seed", "cg1_subgroup_flags_enqueue", "cg1_side_sync", "cg1_shuffle_apply_point_status", "cg1_shuffle_sum_crs_scalars",
     "cg1_keccak_f1600", "cg1_keccak_f1600_x8", "cg1_keccak_f1600_x8_states", "cg1_strobe_new", "cg1_strobe_meta_ad", "cg1_strobe_ad", "cg1_strobe_prf", "cg1_strobe_key", "cg1_merlin_init",
     "cg1_merlin_append", "cg1_merlin_append_list", "cg1_merlin_challenge", "cg1_merlin_challenge_scalar", "cg1_merlin_batch_device",
     "cg1_identity", "cg1_generator", "cg1_add", "cg1_sub", "cg1_neg", "cg1_double", "cg1_mul", "cg1_eq",

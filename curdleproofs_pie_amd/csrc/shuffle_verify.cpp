@@ -1156,16 +1156,30 @@ int cg1_shuffle_exact_same_scalar(const cg1_shuffle_crs* crs_, const uint8_t* in
   return CG1_OK;
 }
 
+// status: 0 accepted, CG1_SHUFFLE_BAD_SCALAR (s >= r), CG1_SHUFFLE_BAD_POINT (a point does not decode), 6 (an equality fails) -- the codes
+// the batch path reports (OpeningBatchVerifier.last_status), in its order of checks
+int cg1_opening_exact_status(const uint8_t* tracker96, const uint8_t* k_commitment48, const uint8_t* proof128, int* status);
 int cg1_opening_exact(const uint8_t* tracker96, const uint8_t* k_commitment48, const uint8_t* proof128, int* ok) {
-  if (!tracker96 || !k_commitment48 || !proof128 || !ok) return CG1_ERR_ARG;
-  *ok = 0;
+  if (!ok) return CG1_ERR_ARG;
+  int st = 0;
+  const int rc = cg1_opening_exact_status(tracker96, k_commitment48, proof128, &st);
+  *ok = (rc == CG1_OK && st == 0) ? 1 : 0;
+  return rc;
+}
+int cg1_opening_exact_status(const uint8_t* tracker96, const uint8_t* k_commitment48, const uint8_t* proof128, int* status) {
+  if (!tracker96 || !k_commitment48 || !proof128 || !status) return CG1_ERR_ARG;
+  int st_ok = 0;
+  int* ok = &st_ok;
+  *status = 6;
   const uint8_t *rG = tracker96, *krG = tracker96 + 48, *kG = k_commitment48, *A = proof128, *B = proof128 + 48;
   fr s_;
-  if (!fr_from_le32(proof128 + 96, s_)) return CG1_OK;
+  if (!fr_from_le32(proof128 + 96, s_)) { *status = CG1_SHUFFLE_BAD_SCALAR; return CG1_OK; }
   jac jrG, jkrG, jkG, jA, jB;
   if (cg1h::g1_decompress(rG, false, jrG) || cg1h::g1_decompress(krG, false, jkrG) || cg1h::g1_decompress(kG, false, jkG) ||
-      cg1h::g1_decompress(A, false, jA) || cg1h::g1_decompress(B, false, jB))
+      cg1h::g1_decompress(A, false, jA) || cg1h::g1_decompress(B, false, jB)) {
+    *status = CG1_SHUFFLE_BAD_POINT;
     return CG1_OK;
+  }
   uint8_t G48[48], own[5 * 48];
   cg1h::g1_compress(cg1h::jac_generator(), G48);
   memcpy(own, kG, 48); memcpy(own + 48, krG, 48); memcpy(own + 96, rG, 48); memcpy(own + 144, A, 48); memcpy(own + 192, B, 48);
@@ -1180,6 +1194,7 @@ int cg1_opening_exact(const uint8_t* tracker96, const uint8_t* k_commitment48, c
   const bool e1 = jac_eq(jac_add(jac_mul(cg1h::jac_generator(), s32), jac_mul(jkG, c32)), jA);      // opening.py:73
   const bool e2 = jac_eq(jac_add(jac_mul(jrG, s32), jac_mul(jkrG, c32)), jB);                       // opening.py:74
   *ok = (e1 && e2) ? 1 : 0;
+  *status = *ok ? 0 : 6;
   return CG1_OK;
 }
 

@@ -925,6 +925,8 @@ class OpeningBatchVerifier:
 
     PROOF_BYTES = 128                       # A | B | s   (opening.py:94-99)
     CULPRIT_SLICE = 32768                   # per-proof MSMs of one regime-B call when the merged check fails
+    SMALL_EXACT = 4                         # up to this many proofs are checked one by one on the host (cg1_opening_exact_status: ~0.4 ms each;
+                                            # the GPU path is ~2.4 ms of dependent launches whatever the batch: IsValidWhiskOpeningProof is a batch of one)
 
     def __init__(self, ctx: Optional["N.Context"] = None, device_front_end: bool = True):
         self._ctx = ctx
@@ -1019,6 +1021,17 @@ class OpeningBatchVerifier:
         if n == 0:
             self.last_status = []
             return []
+        if n <= self.SMALL_EXACT:
+            # the reference's own two equalities (opening.py:73-74), asserted exactly, proof by proof: no weights, no GPU round trips
+            st = ctypes.c_int(0)
+            status = []
+            for i in range(n):
+                rc = N.cg1_opening_exact_status(trackers[96 * i: 96 * i + 96], kcs[48 * i: 48 * i + 48], pfs[128 * i: 128 * i + 128], ctypes.byref(st))
+                if rc:
+                    raise N.NativeError(f"cg1_opening_exact_status failed ({rc})")
+                status.append((pre[i] if pre else 0) or int(st.value))
+            self.last_status = status
+            return [s == 0 for s in status]
         ctx = self.ctx
         if seed is None:
             seed = secrets.token_bytes(32)

@@ -385,6 +385,10 @@ int cg1_shuffle_fe_enqueue(cg1_shuffle_fe* fe, cg1_ctx* ctx, size_t n, const voi
                            void* d_rowin, void* d_status, int lanes_per_wave /* 1..64 transcripts per wave; 0 = 64 */);
 int cg1_shuffle_exact_same_scalar(const cg1_shuffle_crs* crs, const uint8_t* instance, const uint8_t* proof, int* ok);
 int cg1_opening_exact(const uint8_t* tracker96 /* r_G | k_r_G */, const uint8_t* k_commitment48, const uint8_t* proof128, int* ok);
+/* the same check with the batch path's status code: 0 accepted, CG1_SHUFFLE_BAD_SCALAR, CG1_SHUFFLE_BAD_POINT, 6 = an equality fails.  What
+ * OpeningBatchVerifier uses for a handful of proofs -- IsValidWhiskOpeningProof itself (whisk_interface.py:147-169) is a batch of ONE: five
+ * single decompressions and four scalar multiplications on the host (~0.4 ms) against ~2.4 ms of dependent GPU launches. */
+int cg1_opening_exact_status(const uint8_t* tracker96, const uint8_t* k_commitment48, const uint8_t* proof128, int* status);
 /* just the gather step: every proof's own points (instance, then the proof's points in wire order) */
 int cg1_shuffle_gather_points(const cg1_shuffle_crs* crs, size_t n_proofs, const uint8_t* instances, const uint8_t* proofs,
                               uint8_t* out_points48);

@@ -69,6 +69,28 @@ def test_challenge_matches_reference(gold):
         assert k_g_scalar * pow(rho1, -1, R) % R == int.from_bytes(bytes.fromhex(c["challenge"]), "little")
 
 
+def test_exact_check_with_status_codes(gold):
+    """cg1_opening_exact_status (what OpeningBatchVerifier runs for a handful of proofs -- IsValidWhiskOpeningProof is a batch of one):
+    the reference's verdict on every golden variant, and the batch path's status codes (1 bad scalar, 2 bad point, 6 equality)."""
+    items, want = items_of(gold)
+    st = ctypes.c_int(0)
+    R = 0x73EDA753299D7D483339D80809A1D80553BDA402FFFE5BFEFFFFFFFF00000001
+    seen = set()
+    for ((r_g, kr_g), kc, pf), acc in zip(items, want):
+        if not (len(r_g) == len(kr_g) == len(kc) == 48 and len(pf) == 128):
+            continue
+        assert N.cg1_opening_exact_status(r_g + kr_g, kc, pf, ctypes.byref(st)) == 0
+        assert (st.value == 0) == acc
+        seen.add(st.value)
+    (r_g, kr_g), kc, pf = items[0]
+    assert N.cg1_opening_exact_status(r_g + kr_g, kc, pf[:96] + R.to_bytes(32, "little"), ctypes.byref(st)) == 0 and st.value == 1
+    assert N.cg1_opening_exact_status(bytes(48) + kr_g, kc, pf, ctypes.byref(st)) == 0 and st.value == 2
+    assert N.cg1_opening_exact_status(r_g + kr_g, kc, pf[:96] + (R - 1).to_bytes(32, "little"), ctypes.byref(st)) == 0 and st.value == 6
+    assert 0 in seen and 6 in seen
+    ok = ctypes.c_int(0)
+    assert N.cg1_opening_exact(r_g + kr_g, kc, pf, ctypes.byref(ok)) == 0 and ok.value == 1
+
+
 def test_seed_weights_are_shake256():
     """cg1_opening_weights_from_seed: rho1 | rho2 of proof i = SHAKE256(seed || le64(i))[:32], 16 bytes each, zero-extended to scalar32"""
     import hashlib
