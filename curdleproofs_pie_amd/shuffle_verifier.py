@@ -147,6 +147,8 @@ class ShuffleBatchVerifier:
         env = os.environ.get("CURDLE_G1_DEVICE_FRONT_END")
         if env in ("0", "1"):
             device_front_end = env == "1"
+        self._fe_by_default = device_front_end is None      # nobody asked for one of the two: an ISOLATED batch may take the other (verify_packed)
+        self._host_twin = None
         if device_front_end is None:
             # ... with the runtime's default of 4 hardware queues (N.hw_queues(); the application did not call N.tune_runtime()) the device
             # front-end is one pipeline at 13.5 ms per batch (76 K proofs/s): the host front-end is the better default from 8 threads up
@@ -203,6 +205,9 @@ class ShuffleBatchVerifier:
         """Stop the two GPU threads (after what is queued has drained) and release the buffer slots and the MSM context.
         The verifier must not be used afterwards.  Idempotent; also run by __del__ and on cache eviction."""
         self._release_lanes()
+        if getattr(self, "_host_twin", None) is not None:
+            self._host_twin.close()
+            self._host_twin = None
         for kid in (getattr(self, "_kids", None) or []):
             kid.close()
         self._kids = None
@@ -814,6 +819,9 @@ class ShuffleBatchVerifier:
         the GPU finishes the MSM of batch k-1 and already decompresses batch k+1.
         `batches` yields (instances, proofs, n[, pre_status[, weights]]); yields one status list (0 = valid) per batch."""
         if self.device_front_end:
+            if self._host_twin is not None:            # (its lanes would keep hardware queues the pipelines need)
+                self._host_twin.close()
+                self._host_twin = None
             yield from self._verify_stream_device(batches, mode, rng)
             return
         it = iter(batches)
@@ -874,6 +882,21 @@ class ShuffleBatchVerifier:
                         total[k] = total.get(k, 0) + v
             self.last_status, self.last_stats = out, total
             return out
+        if self.device_front_end and self._fe_by_default:
+            # ONE batch on its own is a matter of latency, not of throughput: the device front-end answers in ~12.5 ms + 30 us per proof
+            # whatever the batch (a transcript is ~800 dependent Keccak passes), the host front-end in ~1.4 ms + 1 ms per proof over the
+            # host's threads (profiles/r04_single_proof_latency.txt: one proof 1.4 against 12.7 ms, 256 proofs 5.2 against 14.2 on 16
+            # threads).  IsValidWhiskShuffleProof is a batch of one.  Streams of batches (verify_stream) keep the device front-end.
+            threads = self.threads or int(N.cg1_shuffle_default_threads())
+            host_ms = 1.4 + 1.05 * n / max(1, min(threads, n))
+            if host_ms < 12.5 + 0.03 * n:
+                if self._host_twin is None:
+                    self._host_twin = ShuffleBatchVerifier(self.crs, self._ctx if not getattr(self, "_own_ctx", False) else None, threads=self.threads,
+                                                           chunk=self.chunk, device_rows=self.device_rows, blocking_sync=self.blocking_sync, device_front_end=False)
+                tw = self._host_twin
+                out = tw.verify_packed(instances, proofs, n, mode=mode, rng=rng, weights=weights, pre_status=pre_status)
+                self.last_status, self.last_stats = tw.last_status, tw.last_stats
+                return out
         return next(self.verify_stream([(instances, proofs, n, pre_status, weights)], mode=mode, rng=rng))
 
     def verify_many(self, items, mode: str = "merged", rng=None) -> List[bool]:
