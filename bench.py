@@ -206,6 +206,37 @@ def verify_measure(ctx, threads, steps, warmup, batch, verify_mode="merged", cpu
     return out
 
 
+def single_proof_measure(ctx, reps=9):
+    """Latency of ONE proof through the batch verifiers -- what the reference's IsValidWhiskShuffleProof / IsValidWhiskOpeningProof calls are
+    (whisk_interface.py:72-87, 147-169): wire bytes in host memory -> verdict, median of `reps`."""
+    from curdleproofs_pie_amd.shuffle_verifier import OpeningBatchVerifier, ShuffleBatchVerifier
+
+    fx = load_batch_fixture()
+    v = ShuffleBatchVerifier(fx.crs, ctx)
+    inst, proofs, _ = fx.tiled(1)
+    assert v.verify_packed(inst, proofs, 1) == [0]
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        st = v.verify_packed(inst, proofs, 1)
+        ts.append((time.perf_counter() - t0) * 1e3)
+        assert st == [0]
+    v.close()
+    with open(os.path.join(ROOT, "tests", "golden", "opening_vectors.json")) as f:
+        c = json.load(f)["cases"][0]
+    ov = OpeningBatchVerifier(ctx)
+    item = ((bytes.fromhex(c["r_G"]), bytes.fromhex(c["k_r_G"])), bytes.fromhex(c["k_commitment"]), bytes.fromhex(c["proof"]))
+    to = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        ok = ov.verify_many([item])
+        to.append((time.perf_counter() - t0) * 1e3)
+        assert ok == [True]
+    return {"shuffle_proof_ell124_ms": statistics.median(ts), "opening_proof_ms": statistics.median(to),
+            "what": "ONE proof, wire bytes -> verdict, through ShuffleBatchVerifier / OpeningBatchVerifier with their defaults (an isolated small "
+                    "batch takes the host front-end; an opening proof the exact host check)"}
+
+
 def pmc_traffic(logn):
     """`roofline.traffic`: fabric-side bytes per k_accumulate launch from the last committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in
     their own runs, the gfx950 correction applied: tools/summarize_profiles.py -> profiles/pmc_traffic.json).  Counters cannot be read inside
@@ -304,6 +335,7 @@ def verify_mode(args, rank, local_rank, world):
     if rank == 0:
         if world == 1:
             out["opening_proofs"] = opening_measure(ctx)
+            out["single_proof"] = single_proof_measure(ctx)
         out.update({"value": world * args.batch * args.steps / el, "ms_per_step": el / args.steps * 1e3, "n_gpus": world, "scaling": "weak",
                     "vs_baseline": None, "dtype": "u32",
                     "per_rank": {"ms_per_step": [x / args.steps * 1e3 for x in per_rank], "front_end_ms_per_step": fe,
@@ -763,6 +795,7 @@ def main():
             dv2 = verify_measure(ctx, 2, max(10, args.verify_steps // 2), 1, 2 * args.batch, args.verify_mode, cpu_leg=False, peak_T=peak["peak_T"], front_end="device")
             out["secondary"]["device_front_end_on_2_host_threads_batches_of_%d" % (2 * args.batch)] = {k: dv2[k] for k in keys if k != "phases_ms_per_step"}
             out["secondary"]["opening_proofs"] = opening_measure(ctx)
+            out["secondary"]["single_proof"] = single_proof_measure(ctx)
         if world == 1 and not args.no_python_face:
             # the drop-in itself: compute_MSM / MSMAccumulator through the reference's signature (lists of G1Point / Scalar objects), and
             # the reference's own backend-call sequence for one proof replayed through this backend.  (After the secondary metric: these
