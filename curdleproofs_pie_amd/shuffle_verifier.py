@@ -121,6 +121,7 @@ class Prepared:
 
 class ShuffleBatchVerifier:
     SPLIT = 2048                            # verify_packed cuts calls of more than 2 * SPLIT proofs into pieces of this many
+    FE_FIRST_MAX = 8                        # host front-end: batches up to this size run it BESIDE the GPU's decoding (it decodes its own four points)
 
     def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True,
                  blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: Optional[int] = None, fe_cus: int = 0, fe_prio: int = 0,
@@ -368,6 +369,7 @@ class ShuffleBatchVerifier:
                 "hstat": N.PinnedBuffer(ctx, 4 * n),
                 "pstat": N.PinnedBuffer(ctx, n * L),
                 "decoded": N.PinnedBuffer(ctx, n * 768),
+                "fe_wire": N.PinnedBuffer(ctx, min(n, self.FE_FIRST_MAX) * L * 48),   # the front-end's own copy of a tiny batch's points
             },
         }
 
@@ -437,6 +439,11 @@ class ShuffleBatchVerifier:
         step = max(self.chunk, (n + 1) // 2) if (prefetched and self.prefetch_big) else self.chunk
         tk["bounds"] = [(lo, min(lo + step, n)) for lo in range(0, n, step)]
         b["busy"] = tk["done"]
+        # a handful of proofs (IsValidWhiskShuffleProof is a batch of one): the front-end does not wait for the GPU's decoding -- it decodes
+        # the four points it needs itself (4 x 14 us per proof) and runs BESIDE the decompression launch instead of behind it
+        tk["fe_first"] = n <= self.FE_FIRST_MAX and not self.device_front_end
+        if tk["fe_first"] and tk["weights"] is None:
+            tk["weights"] = self.draw_weights(n, rng)
 
         def gpu_stage(tk=tk, b=b):
             try:
@@ -489,15 +496,24 @@ class ShuffleBatchVerifier:
         prep = None if dev else Prepared(crs, n, False, host)
         tk["prep"] = prep
         hstat = (ctypes.c_int32 * n).from_address(host["hstat"].ptr)
-        for _ in tk["bounds"]:
-            r = tk["chunks"].get()
+        fe_first = tk.get("fe_first", False)
+        if fe_first:
+            todo = [(0, n)]                                   # the whole batch at once, before the GPU has decoded anything
+        else:
+            todo = tk["bounds"]
+        for item in todo:
+            if fe_first:
+                r = item
+            else:
+                r = tk["chunks"].get()
             if isinstance(r, BaseException):
                 tk["error"] = r
                 tk["done"].set()
                 raise r
             lo, hi = r
             args = (crs.handle, hi - lo, _addr(tk["instances"]) + lo * 4 * crs.ell * 48, _addr(tk["proofs"]) + lo * crs.proof_bytes,
-                    _addr(tk["weights"]) + lo * N_WEIGHTS * 32, host["decoded"].ptr + lo * 768, 768, host["wire"].ptr + lo * L * 48)
+                    _addr(tk["weights"]) + lo * N_WEIGHTS * 32, None if fe_first else host["decoded"].ptr + lo * 768, 768,
+                    host["fe_wire"].ptr + lo * L * 48 if fe_first else host["wire"].ptr + lo * L * 48)
             if dev:
                 rc = N.cg1_shuffle_prepare_inputs(*args, host["rowin"].ptr + lo * K * 32, host["hstat"].ptr + lo * 4, self.threads)
             else:
@@ -506,6 +522,13 @@ class ShuffleBatchVerifier:
             if rc:
                 tk["done"].set()
                 raise N.NativeError(f"cg1_shuffle_prepare failed ({rc})")
+        if fe_first:                                          # now the decoding must have finished (point verdicts, decoded points for the MSM)
+            for _ in tk["bounds"]:
+                r = tk["chunks"].get()
+                if isinstance(r, BaseException):
+                    tk["error"] = r
+                    tk["done"].set()
+                    raise r
         if dev:
             for i, s in enumerate(tk["pre_status"] or ()):
                 if s:
