@@ -577,6 +577,7 @@ __global__ void __launch_bounds__(1024) k_scan_one(const uint32_t* __restrict__ 
   if (threadIdx.x == 1023) { off[nb_total] = sh[1023].x; choff[nb_total] = sh[1023].y; }
 }
 
+constexpr uint32_t CHUNK_DESC_BLOCKS = 320;
 __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__ off, const uint32_t* __restrict__ choff,
                                                     uint2* __restrict__ desc, uint32_t* __restrict__ len_hist,
                                                     uint32_t* __restrict__ heavy /* [0] = count, then bucket ids */,
@@ -584,7 +585,10 @@ __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__
   __shared__ uint32_t sh[LEN_BINS];
   sh[threadIdx.x] = 0;
   __syncthreads();
-  uint32_t b = blockIdx.x * 256 + threadIdx.x;
+  // Several tiles of 256 buckets per block when there are many: every block ends with one global atomic per length key it met, and with whole-bucket chunks a block
+  // meets ~30 keys -- 2 048 blocks x 30 atomics on 30 addresses were most of this kernel's 30 us at 2^20 terms
+#pragma unroll 1
+  for (uint32_t b = blockIdx.x * 256 + threadIdx.x; b - threadIdx.x < nb_total; b += gridDim.x * 256) {      // grid-stride: at most CHUNK_DESC_BLOCKS blocks
   if (b < nb_total) {
     uint32_t start = off[b], cnt = off[b + 1] - start;
     if (cnt) {
@@ -604,6 +608,7 @@ __global__ void __launch_bounds__(256) k_chunk_desc(const uint32_t* __restrict__
         *any_multi = 1u;                 // k_bucket_fold has work (benign race: every writer stores 1)
       }
     }
+  }
   }
   __syncthreads();
   uint32_t v = sh[threadIdx.x];
@@ -631,35 +636,44 @@ __global__ void __launch_bounds__(256) k_len_scan(const uint32_t* __restrict__ l
 }
 
 // order[] = chunk ids sorted by descending length key (stable enough: order inside a key is arbitrary)
+// ORDER_PER tiles of 256 chunks per block share ONE LDS histogram and therefore one global atomic per length key: with whole-bucket
+// chunks a tile meets ~30 keys, and 2 048 tiles x 30 atomics on 30 addresses were most of this kernel's 31 us at 2^20 terms.
+constexpr uint32_t ORDER_PER = 8;
 __global__ void __launch_bounds__(256) k_order(const uint2* __restrict__ desc, const uint32_t* __restrict__ total_chunks,
                                                uint32_t* __restrict__ len_cursor, uint32_t* __restrict__ order) {
   __shared__ uint32_t cnt[LEN_BINS];
   __shared__ uint32_t base[LEN_BINS];
   cnt[threadIdx.x] = 0;
   __syncthreads();
-  uint32_t t = blockIdx.x * 256 + threadIdx.x;
-  bool live = t < *total_chunks;
-  uint32_t key = 0, local = 0;
-  // the chunks of a call mostly share ONE length key (every chunk but the last of its bucket): the lanes that carry the first live
-  // lane's key take their slots from one atomic, the others from their own (64 same-address LDS atomics serialise)
-  if (live) key = len_key(desc[t].y);
-  {
+  const uint32_t total = *total_chunks;
+  uint32_t key[ORDER_PER], local[ORDER_PER];
+#pragma unroll
+  for (uint32_t rep = 0; rep < ORDER_PER; ++rep) {
+    const uint32_t t = (blockIdx.x * ORDER_PER + rep) * 256 + threadIdx.x;
+    const bool live = t < total;
+    key[rep] = live ? len_key(desc[t].y) : 0u;
+    local[rep] = 0;
+    // the lanes that carry the first live lane's key take their slots from one LDS atomic, the others from their own
     const unsigned long long amask = __ballot(live);
     if (amask) {
       const int leader = __ffsll((long long)amask) - 1;
-      const uint32_t k0 = __shfl(key, leader, 64);
-      const unsigned long long same = __ballot(live && key == k0);
+      const uint32_t k0 = __shfl(key[rep], leader, 64);
+      const unsigned long long same = __ballot(live && key[rep] == k0);
       const uint32_t lane = threadIdx.x & 63u;
       uint32_t b0 = 0;
       if ((int)lane == leader) b0 = atomicAdd(&cnt[k0], (uint32_t)__popcll(same));
       b0 = __shfl(b0, leader, 64);
-      if (live) local = (key == k0) ? b0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull)) : atomicAdd(&cnt[key], 1u);
+      if (live) local[rep] = (key[rep] == k0) ? b0 + (uint32_t)__popcll(same & ((1ull << lane) - 1ull)) : atomicAdd(&cnt[key[rep]], 1u);
     }
   }
   __syncthreads();
-  uint32_t c = cnt[threadIdx.x];
+  const uint32_t c = cnt[threadIdx.x];
   if (c) base[threadIdx.x] = atomicAdd(&len_cursor[threadIdx.x], c);
   __syncthreads();
-  if (live) order[base[key] + local] = t;
+#pragma unroll
+  for (uint32_t rep = 0; rep < ORDER_PER; ++rep) {
+    const uint32_t t = (blockIdx.x * ORDER_PER + rep) * 256 + threadIdx.x;
+    if (t < total) order[base[key[rep]] + local[rep]] = t;
+  }
 }
 

@@ -601,11 +601,11 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   }
   // one memset: chunk-length histogram, the any_multi flag, combined[] and the heavy-bucket count (ensure() laid them out together)
   HIPCHK(hipMemsetAsync(ctx->d_zblock, 0, zblock_clear_bytes(ctx), st));
-  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0, ctx->d_any_multi);
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)std::min<size_t>(CHUNK_DESC_BLOCKS, (nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0, ctx->d_any_multi);
   const size_t max_chunks = nb_total + (n * (size_t)nlw) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
-  hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
+  hipLaunchKernelGGL(k_order, dim3((gchunks + ORDER_PER - 1) / ORDER_PER), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
   if (hooks.before_accumulate) HIPCHK(hipStreamWaitEvent(st, hooks.before_accumulate, 0));
   if (profile >= 1) HIPCHK(hipEventRecord(ctx->ev[4], st));
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, pts, ctx->d_sums);
@@ -1124,11 +1124,11 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   hipLaunchKernelGGL(k_group_scatter, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_off, ctx->d_sorted, N32, NB, nwin);
   if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
   HIPCHK(hipMemsetAsync(ctx->d_zblock, 0, zblock_clear_bytes(ctx), st));
-  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0, ctx->d_any_multi);
+  hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)std::min<size_t>(CHUNK_DESC_BLOCKS, (nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0, ctx->d_any_multi);
   const size_t max_chunks = nb_total + (N * (size_t)nwin) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
-  hipLaunchKernelGGL(k_order, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
+  hipLaunchKernelGGL(k_order, dim3((gchunks + ORDER_PER - 1) / ORDER_PER), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
   if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[4], st));
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
   if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[5], st));
