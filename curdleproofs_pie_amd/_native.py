@@ -171,6 +171,13 @@ cg1_probe_madd = _proto("cg1_probe_madd", c_int, c_void_p, c_void_p, c_size_t, c
 cg1_probe_mad_rate = _proto("cg1_probe_mad_rate", c_int, c_void_p, c_int, c_int, POINTER(ctypes.c_double))
 cg1_batch_sum_device = _proto("cg1_batch_sum_device", c_int, c_void_p, c_void_p, POINTER(ctypes.c_uint32), c_size_t, c_void_p)
 cg1_batch_sum = _proto("cg1_batch_sum", c_int, c_void_p, _u8p, POINTER(ctypes.c_uint32), c_size_t, _buf)
+# deferred evaluation of the G1Point operators (csrc/lazy_host.cpp, msm_gpu.hip)
+cg1_validate_compressed = _proto("cg1_validate_compressed", c_int, _u8p, POINTER(c_int))
+cg1_fp_jacobi = _proto("cg1_fp_jacobi", c_int, _u8p)
+cg1_batch_decompress_pool = _proto("cg1_batch_decompress_pool", c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, POINTER(c_size_t))
+cg1_batch_subgroup_pool = _proto("cg1_batch_subgroup_pool", c_int, c_void_p, c_size_t, c_void_p, c_int)
+cg1_lincomb_batch = _proto("cg1_lincomb_batch", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int))
+cg1_lincomb_batch_pool = _proto("cg1_lincomb_batch_pool", c_int, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int)
 
 # native Merlin transcript (host)
 MERLIN_STATE_BYTES = 208
@@ -249,6 +256,7 @@ EXPORTED_SYMBOLS = [
     "cg1_merlin_last_passes", "cg1_merlin_last_kernel", "cg1_merlin_block_program_emulate", "cg1_probe_mad_rate", "cg1_batch_sum_device", "cg1_batch_sum", "cg1_ctx_device", "cg1_ctx_stream", "cg1_msm_multi_device",
     "cg1_comm_create", "cg1_comm_port", "cg1_comm_rank", "cg1_comm_connect", "cg1_comm_set_timeout", "cg1_comm_attach_rccl", "cg1_comm_transport",
     "cg1_comm_world_seen", "cg1_comm_error", "cg1_comm_allgather", "cg1_comm_allgather_host", "cg1_comm_barrier", "cg1_comm_allreduce_g1", "cg1_comm_destroy",
+    "cg1_validate_compressed", "cg1_fp_jacobi", "cg1_batch_decompress_pool", "cg1_batch_subgroup_pool", "cg1_lincomb_batch", "cg1_lincomb_batch_pool",
     "cg1_msm_blobs", "cg1_vec_create", "cg1_vec_destroy", "cg1_vec_len", "cg1_msm_vec", "cg1_batch_normalize", "cg1_batch_from_affine96", "cg1_get_last_launches",
 ]
 
@@ -629,9 +637,21 @@ _default_ctx = None
 _default_lock = threading.Lock()
 
 
+_close_hooks: list = []
+
+
+def on_close_default_context(fn) -> None:
+    """Register `fn()` to run before the default context is closed (modules holding device / page-locked memory on it free it there)."""
+    if fn not in _close_hooks:
+        _close_hooks.append(fn)
+
+
 def close_default_context() -> None:
     """Release the process-wide context (its stream, scratch and staging buffers); the next default_context() makes a new one."""
     global _default_ctx
+    if _default_ctx is not None:
+        for fn in list(_close_hooks):
+            fn()
     with _default_lock:
         if _default_ctx is not None:
             _default_ctx.close()
@@ -644,7 +664,13 @@ def default_context() -> Context:
     with _default_lock:
         if _default_ctx is None:
             dev = int(os.environ.get("CURDLE_G1_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-            if dev >= max(cg1_device_count(), 1):
-                dev = 0
+            count = cg1_device_count()
+            if count > 0 and dev >= count and os.environ.get("CURDLE_G1_SHARE_DEVICE", "0") != "1":
+                # a rank that silently lands on GPU 0 turns a scaling run into N processes on one card: say so instead
+                # (CURDLE_G1_SHARE_DEVICE=1: rehearsals of several ranks on one GPU map rank r to device r mod count)
+                raise NativeError(f"CURDLE_G1_DEVICE / LOCAL_RANK = {dev} but only {count} GPU(s) are visible "
+                                  "(set CURDLE_G1_SHARE_DEVICE=1 to let ranks share devices)")
+            if count > 0:
+                dev %= count
             _default_ctx = Context(dev)
         return _default_ctx

@@ -14,9 +14,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcurdle_g1.so")
-SOURCES = [os.path.join(CSRC, "msm_gpu.hip"), os.path.join(CSRC, "host_g1.cpp"), os.path.join(CSRC, "merlin.cpp"), os.path.join(CSRC, "shuffle_verify.cpp"), os.path.join(CSRC, "comm.cpp")]
+SOURCES = [os.path.join(CSRC, "msm_gpu.hip"), os.path.join(CSRC, "host_g1.cpp"), os.path.join(CSRC, "merlin.cpp"), os.path.join(CSRC, "shuffle_verify.cpp"), os.path.join(CSRC, "comm.cpp"), os.path.join(CSRC, "lazy_host.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("kernels_opening.h", "fp28.h", "g1_xyzz.h", "g1_quad.h", "host_g1.h", "fe_mul_x86.h", "fr.h", "merlin_group.h", "bls_consts.h", "kernels_records.h", "kernels_prepare_digits.h",
-                                                    "kernels_sort.h", "kernels_accumulate.h", "kernels_reduce.h", "kernels_small.h", "kernels_batch.h", "kernels_rows.h", "kernels_merlin.h", "kernels_frontend.h")] + [
+                                                    "kernels_sort.h", "kernels_accumulate.h", "kernels_reduce.h", "kernels_small.h", "kernels_batch.h", "kernels_rows.h", "kernels_merlin.h", "kernels_frontend.h", "pool.h", "lazy_host.h")] + [
     os.path.join(HERE, "..", "include", "curdle_g1.h")
 ]
 
@@ -38,7 +38,7 @@ def _source_hash() -> str:
 
 
 HASH_FILE = LIB + ".srchash"
-HOST_ONLY = ("host_g1.cpp", "merlin.cpp", "shuffle_verify.cpp", "comm.cpp", "merlin_group.h", "fe_mul_x86.h")
+HOST_ONLY = ("host_g1.cpp", "merlin.cpp", "shuffle_verify.cpp", "comm.cpp", "lazy_host.cpp", "merlin_group.h", "fe_mul_x86.h", "pool.h", "lazy_host.h")
 
 
 def _hip_unit_hash(extra_flags=()) -> str:

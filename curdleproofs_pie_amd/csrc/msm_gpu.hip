@@ -240,6 +240,7 @@ struct Ctx {
   int horner_threads = 4;               // host threads of the Horner tail: 1, 2 or 4 (A/B switch; host_split = 0 forces 1)
   // staging for host-pointer entry points
   void* d_stage_pts = nullptr; void* d_stage_sc = nullptr; size_t cap_stage_pts = 0, cap_stage_sc = 0;      // bytes
+  uint8_t* h_lin = nullptr; size_t cap_h_lin = 0;   // page-locked gather buffer of cg1_lincomb_batch (terms' points | scalars)
   // timing
   hipEvent_t ev[CG1_NPHASE + 1];
   float phase_ms[CG1_NPHASE] = {0};
@@ -263,6 +264,7 @@ static void free_bufs(Ctx* c) {
   F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot); F(c->d_boffs); F(c->d_gsum); F(c->d_bout);
   F(c->d_slice_base); F(c->d_slicehist); F(c->d_subbase); F(c->d_bigflag); c->cap_bigflag = 0; c->cap_slices = 0;
   if (c->h_bout) { (void)hipHostFree(c->h_bout); c->h_bout = nullptr; }
+  if (c->h_lin) { (void)hipHostFree(c->h_lin); c->h_lin = nullptr; c->cap_h_lin = 0; }
   if (c->d_gout) { (void)hipFree(c->d_gout); c->d_gout = nullptr; }
   if (c->h_gout) { (void)hipHostFree(c->h_gout); c->h_gout = nullptr; }
   c->cap_gout = 0;
@@ -1707,6 +1709,96 @@ int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars,
   HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
   return cg1_msm_batched_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, offsets, n_msm, 0, out_blobs);
+}
+
+// A batch of linear combinations over shared bases -- what a flush of deferred G1Point operators is (py_arkworks_bls12381.py):
+// out_j = sum_{t in [offsets[j], offsets[j+1])} scalars[t] * (+/-) bases[term_base[t] & 0x7fffffff]   (bit 31: the negated base).
+// path 0 = choose, 1 = the host's worker pool (cg1_lincomb_batch_pool: one interleaved-NAF evaluation per output), 2 = the GPU (the terms
+// gathered into one concatenated input of cg1_msm_batched_device: ONE k_msm_small launch for up to 16 outputs, regime B beyond).  The choice
+// depends on the batch alone, not on the machine: an estimate of the pool's time at a nominal 8 threads against ~0.35 ms for a GPU round trip.
+// Outputs are normalised: blobs with Z = 1 (or the identity), affine96, compressed48 (each may be NULL).
+int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_bases, const uint32_t* offsets, size_t n_out, const uint32_t* term_base,
+                      const uint8_t* term_scalars32, int path, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48, int* path_used) {
+  if (path_used) *path_used = 0;
+  if (n_out == 0) return CG1_OK;
+  if (!offsets || offsets[0] != 0 || path < 0 || path > 2) return CG1_ERR_ARG;
+  const size_t T = offsets[n_out];
+  if (T && (!bases_affine96 || !term_base || !term_scalars32)) return CG1_ERR_ARG;
+  if (path == 0) {
+    // pool estimate in group operations: 255 doublings per output that has a non-unit term, ~52 per non-unit term, 1 per unit term
+    double ops = 0;
+    for (size_t j = 0; j < n_out; ++j) {
+      size_t heavy = 0, unit = 0;
+      for (size_t t = offsets[j]; t < offsets[j + 1]; ++t) {
+        const uint8_t* sc = term_scalars32 + 32 * t;
+        bool small = sc[0] <= 1;
+        for (int b = 1; b < 32 && small; ++b) small = sc[b] == 0;
+        if (small) ++unit; else ++heavy;
+      }
+      ops += (heavy ? 255.0 : 0.0) + 52.0 * (double)heavy + (double)unit;
+    }
+    const double est_us = 0.25 * ops / (double)std::min<size_t>(n_out, 8);
+    path = (!ctx || est_us < 300.0) ? 1 : 2;
+  }
+  if (path_used) *path_used = path;
+  if (path == 1) return cg1_lincomb_batch_pool(bases_affine96, n_bases, offsets, n_out, term_base, term_scalars32, out_blobs144, out_affine96, out_comp48, 0);
+  if (!ctx) return CG1_ERR_HIP;
+  if (T == 0) {
+    for (size_t j = 0; j < n_out; ++j) {
+      if (out_blobs144) blob_out(out_blobs144 + CG1_POINT_BYTES * j, cg1h::jac_identity());
+      if (out_affine96) memset(out_affine96 + 96 * j, 0, 96);
+      if (out_comp48) { memset(out_comp48 + 48 * j, 0, 48); out_comp48[48 * j] = 0xC0; }
+    }
+    return CG1_OK;
+  }
+  // gather the terms (a negated base: y -> p - y on the standard-form record) into page-locked staging, upload, one batched MSM
+  HIPCHK(hipSetDevice(ctx->device));
+  if (T * 128 > ctx->cap_h_lin) {
+    if (ctx->h_lin) (void)hipHostFree(ctx->h_lin);
+    ctx->h_lin = nullptr; ctx->cap_h_lin = 0;
+    const size_t want = T * 128 + T * 32 + 4096;
+    HIPCHK(hipHostMalloc((void**)&ctx->h_lin, want, hipHostMallocDefault));
+    ctx->cap_h_lin = want;
+  }
+  uint8_t* hp = ctx->h_lin;
+  uint8_t* hs = ctx->h_lin + T * 96;
+  for (size_t t = 0; t < T; ++t) {
+    const uint32_t b = term_base[t] & 0x7fffffffu;
+    if (b >= n_bases) { snprintf(ctx->err, sizeof ctx->err, "lincomb: base index out of range"); return CG1_ERR_ARG; }
+    const uint8_t* src = bases_affine96 + 96 * (size_t)b;
+    uint8_t* dst = hp + 96 * t;
+    memcpy(dst, src, 96);
+    if (term_base[t] >> 31) {
+      uint64_t y[6], any = 0;
+      memcpy(y, src + 48, 48);
+      for (int i = 0; i < 6; ++i) any |= y[i];
+      if (any) {                                         // (the identity record stays all-zero)
+        unsigned __int128 br = 0;
+        for (int i = 0; i < 6; ++i) { const unsigned __int128 d = (unsigned __int128)cg1::H_P[i] - y[i] - br; y[i] = (uint64_t)d; br = (d >> 64) & 1; }
+        memcpy(dst + 48, y, 48);
+      }
+    }
+  }
+  memcpy(hs, term_scalars32, T * 32);
+  { int src = ensure_stage(ctx, T * 96, T * 32); if (src) return src; }
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, hp, T * 96, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, hs, T * 32, hipMemcpyHostToDevice, ctx->stream));
+  std::vector<cg1h::jac> res;
+  int rc = cg1::msm_batched_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, offsets, n_out, 0, res);
+  if (rc != CG1_OK) return rc;
+  std::vector<cg1h::fe> xs(n_out), ys(n_out);
+  std::vector<uint8_t> inf(n_out);
+  cg1h::jac_batch_to_affine(res.data(), n_out, xs.data(), ys.data(), inf.data());
+  for (size_t j = 0; j < n_out; ++j) {
+    if (out_blobs144) blob_out(out_blobs144 + CG1_POINT_BYTES * j, inf[j] ? cg1h::jac_identity() : cg1h::jac_from_affine(xs[j], ys[j]));
+    if (out_affine96) {
+      uint8_t* o = out_affine96 + 96 * j;
+      if (inf[j]) memset(o, 0, 96);
+      else { cg1h::fe_to_le48(xs[j], o); cg1h::fe_to_le48(ys[j], o + 48); }
+    }
+    if (out_comp48) cg1h::g1_compress_affine(xs[j], ys[j], inf[j] != 0, out_comp48 + 48 * j);
+  }
+  return CG1_OK;
 }
 
 int cg1_get_timings(const cg1_ctx* ctx, float* phase_ms, float* host_tail_ms, int* window_c) {

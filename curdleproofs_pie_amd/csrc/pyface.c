@@ -19,10 +19,20 @@
 
 #define POINT_BYTES 144
 
-static PyTypeObject* g_point_type = NULL;   /* G1Point: slot `_b` = bytes(144)  (host Jacobian X | Y | Z, Montgomery 2^384) */
+static PyTypeObject* g_point_type = NULL;   /* G1Point: slot `_blob` = bytes(144) (host Jacobian X | Y | Z, Montgomery 2^384) or None while the value is deferred */
 static PyTypeObject* g_scalar_type = NULL;  /* Scalar:  slot `_v` = int in [0, r) */
 static Py_ssize_t g_point_off = -1, g_scalar_off = -1;
 static Py_ssize_t g_cache_off[2] = {-1, -1};   /* G1Point slots `_a`, `_k` (normal-form caches; None until filled) */
+/* the remaining G1Point slots (`_t` deferred terms, `_sg` subgroup certainty, `_seq` creation number), set to None by points_from_blobs */
+#define PF_MAX_EXTRA 6
+static Py_ssize_t g_extra_off[PF_MAX_EXTRA];
+static int g_n_extra = 0;
+static Py_ssize_t g_t_off = -1, g_sg_off = -1, g_seq_off = -1;
+static PyObject* g_unforced = NULL;         /* exception: a point of the sequence has no blob yet (the caller evaluates it and retries) */
+static PyObject* g_pending = NULL;          /* the Python face's list of weak references to unevaluated values (bind) */
+static PyObject* g_identity_blob = NULL;
+typedef int (*validate_fn)(const unsigned char*, int*);
+static validate_fn g_validate = NULL;       /* cg1_validate_compressed of libcurdle_g1.so (set_native) */
 
 /* Montgomery form of 1 (csrc/bls_consts.h H_R1): Z of a normalised point */
 static const uint64_t MONT_ONE[6] = {0x760900000002fffdull, 0xebf4000bc40c0002ull, 0x5f48985753c758baull,
@@ -36,19 +46,40 @@ static Py_ssize_t slot_offset(PyTypeObject* tp, const char* name) {
   return m->offset;
 }
 
-/* bind(G1Point, Scalar): remember the two classes and where their single slot lives */
+/* bind(G1Point, Scalar[, pending_list, identity_blob]): remember the two classes and where their slots live */
 static PyObject* pf_bind(PyObject* self, PyObject* args) {
-  PyObject *pt, *sc;
-  if (!PyArg_ParseTuple(args, "OO", &pt, &sc)) return NULL;
+  PyObject *pt, *sc, *pending = NULL, *idb = NULL;
+  if (!PyArg_ParseTuple(args, "OO|OO", &pt, &sc, &pending, &idb)) return NULL;
   if (!PyType_Check(pt) || !PyType_Check(sc)) { PyErr_SetString(PyExc_TypeError, "bind(G1Point, Scalar) expects two classes"); return NULL; }
-  Py_ssize_t po = slot_offset((PyTypeObject*)pt, "_b"), so = slot_offset((PyTypeObject*)sc, "_v");
-  if (po < 0 || so < 0) { PyErr_SetString(PyExc_TypeError, "G1Point._b / Scalar._v are not __slots__ members"); return NULL; }
+  Py_ssize_t po = slot_offset((PyTypeObject*)pt, "_blob"), so = slot_offset((PyTypeObject*)sc, "_v");
+  if (po < 0 || so < 0) { PyErr_SetString(PyExc_TypeError, "G1Point._blob / Scalar._v are not __slots__ members"); return NULL; }
+  if (pending && pending != Py_None && !PyList_CheckExact(pending)) { PyErr_SetString(PyExc_TypeError, "pending must be a list"); return NULL; }
+  if (idb && idb != Py_None && (!PyBytes_CheckExact(idb) || PyBytes_GET_SIZE(idb) != 144)) { PyErr_SetString(PyExc_TypeError, "identity blob must be 144 bytes"); return NULL; }
   Py_INCREF(pt); Py_INCREF(sc);
   Py_XDECREF(g_point_type); Py_XDECREF(g_scalar_type);
   g_point_type = (PyTypeObject*)pt; g_scalar_type = (PyTypeObject*)sc;
   g_point_off = po; g_scalar_off = so;
   g_cache_off[0] = slot_offset((PyTypeObject*)pt, "_a");
   g_cache_off[1] = slot_offset((PyTypeObject*)pt, "_k");
+  g_t_off = slot_offset((PyTypeObject*)pt, "_t");
+  g_sg_off = slot_offset((PyTypeObject*)pt, "_sg");
+  g_seq_off = slot_offset((PyTypeObject*)pt, "_seq");
+  g_n_extra = 0;
+  if (g_t_off >= 0) g_extra_off[g_n_extra++] = g_t_off;
+  if (g_sg_off >= 0) g_extra_off[g_n_extra++] = g_sg_off;
+  if (g_seq_off >= 0) g_extra_off[g_n_extra++] = g_seq_off;
+  Py_XDECREF(g_pending); g_pending = NULL;
+  if (pending && pending != Py_None) { Py_INCREF(pending); g_pending = pending; }
+  Py_XDECREF(g_identity_blob); g_identity_blob = NULL;
+  if (idb && idb != Py_None) { Py_INCREF(idb); g_identity_blob = idb; }
+  Py_RETURN_NONE;
+}
+
+/* set_native(addr of cg1_validate_compressed) */
+static PyObject* pf_set_native(PyObject* self, PyObject* args) {
+  unsigned long long a;
+  if (!PyArg_ParseTuple(args, "K", &a)) return NULL;
+  g_validate = (validate_fn)(uintptr_t)a;
   Py_RETURN_NONE;
 }
 
@@ -85,6 +116,7 @@ static PyObject* pf_pack_points(PyObject* self, PyObject* args) {
     PyObject* o = items[i];
     if (Py_TYPE(o) != g_point_type) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd is not a G1Point", i); return NULL; }
     PyObject* b = slot_get(o, g_point_off);
+    if (b == Py_None) { Py_DECREF(fast); PyErr_Format(g_unforced, "element %zd is a deferred value", i); return NULL; }
     if (!b || !PyBytes_CheckExact(b) || PyBytes_GET_SIZE(b) != POINT_BYTES) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd holds no 144-byte blob", i); return NULL; }
     const char* src = PyBytes_AS_STRING(b);
     memcpy(dst + (size_t)POINT_BYTES * (size_t)i, src, POINT_BYTES);
@@ -131,7 +163,7 @@ static PyObject* pf_pack_affine(PyObject* self, PyObject* args) {
  * _PyLong_AsByteArray walks the digits a byte at a time: 25 of the 33 ns an element costs).  Returns 0 when the value does not qualify
  * (negative, too long, other digit width, big-endian host): the caller then lets _PyLong_AsByteArray decide and raise. */
 static inline int long_to_le32(PyObject* v, uint8_t* out) {
-#if PYLONG_BITS_IN_DIGIT == 30 && defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+#if PY_VERSION_HEX < 0x030C0000 && PYLONG_BITS_IN_DIGIT == 30 && defined(__BYTE_ORDER__) && __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__   /* (3.12 moved the digit count into lv_tag) */
   const PyLongObject* l = (const PyLongObject*)v;
   const Py_ssize_t sz = Py_SIZE(l);
   if (sz < 0 || sz > 9) return 0;
@@ -148,6 +180,15 @@ static inline int long_to_le32(PyObject* v, uint8_t* out) {
 #else
   (void)v; (void)out;
   return 0;
+#endif
+}
+
+/* the interpreter's own conversion (any digit layout); -1 with OverflowError set for a negative value or one of 2^256 and more */
+static inline int pf_long_as_le32(PyObject* v, uint8_t* out) {
+#if PY_VERSION_HEX >= 0x030D0000
+  return _PyLong_AsByteArray((PyLongObject*)v, out, 32, 1, 0, 1);
+#else
+  return _PyLong_AsByteArray((PyLongObject*)v, out, 32, 1, 0);
 #endif
 }
 
@@ -175,8 +216,7 @@ static PyObject* pf_pack_scalars(PyObject* self, PyObject* args) {
     else if (PyLong_CheckExact(o)) v = o;                       /* plain ints are accepted: the accumulator keeps merged scalars as ints */
     else { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd is not a Scalar", i); return NULL; }
     if (!v || !PyLong_Check(v)) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd holds no integer", i); return NULL; }
-    if (!long_to_le32(v, dst + 32 * (size_t)i) &&
-        _PyLong_AsByteArray((PyLongObject*)v, dst + 32 * (size_t)i, 32, 1, 0) < 0) { Py_DECREF(fast); return NULL; }   /* OverflowError: negative or >= 2^256 */
+    if (!long_to_le32(v, dst + 32 * (size_t)i) && pf_long_as_le32(v, dst + 32 * (size_t)i) < 0) { Py_DECREF(fast); return NULL; }   /* OverflowError: negative or >= 2^256 */
   }
   Py_DECREF(fast);
   return PyLong_FromSsize_t(n);
@@ -198,6 +238,7 @@ static PyObject* pf_points_from_blobs(PyObject* self, PyObject* args) {
     *(PyObject**)((char*)o + g_point_off) = b;
     for (int c = 0; c < 2; ++c)
       if (g_cache_off[c] >= 0) { Py_INCREF(Py_None); *(PyObject**)((char*)o + g_cache_off[c]) = Py_None; }
+    for (int c = 0; c < g_n_extra; ++c) { Py_INCREF(Py_None); *(PyObject**)((char*)o + g_extra_off[c]) = Py_None; }
     PyList_SET_ITEM(out, i, o);
   }
   PyBuffer_Release(&view);
@@ -239,7 +280,63 @@ static PyObject* pf_same_items(PyObject* self, PyObject* args) {
   Py_RETURN_FALSE;
 }
 
+static inline void slot_put(PyObject* o, Py_ssize_t off, PyObject* v) {
+  if (off < 0) return;
+  Py_INCREF(v);
+  *(PyObject**)((char*)o + off) = v;
+}
+
+/* mk(blob, a, k, t, sg, seq) -> G1Point with exactly these slot values; a value with terms (t is not None) is entered in the pending list */
+static PyObject* pf_mk(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 6) { PyErr_SetString(PyExc_TypeError, "mk(blob, a, k, t, sg, seq)"); return NULL; }
+  if (!g_point_type || g_t_off < 0 || g_sg_off < 0 || g_seq_off < 0) { PyErr_SetString(PyExc_RuntimeError, "_pyface.bind() has not run"); return NULL; }
+  PyObject* o = g_point_type->tp_alloc(g_point_type, 0);
+  if (!o) return NULL;
+  slot_put(o, g_point_off, args[0]);
+  slot_put(o, g_cache_off[0], args[1]);
+  slot_put(o, g_cache_off[1], args[2]);
+  slot_put(o, g_t_off, args[3]);
+  slot_put(o, g_sg_off, args[4]);
+  slot_put(o, g_seq_off, args[5]);
+  if (args[3] != Py_None && g_pending) {
+    PyObject* r = PyWeakref_NewRef(o, NULL);
+    if (!r || PyList_Append(g_pending, r) < 0) { Py_XDECREF(r); Py_DECREF(o); return NULL; }
+    Py_DECREF(r);
+  }
+  return o;
+}
+
+/* decode_lazy(data: bytes of 48) -> G1Point: the encoding validated now (flags, x < p, on the curve: libcurdle_g1's cg1_validate_compressed,
+ * a Jacobi symbol instead of the square root), y left for later: the object holds the 48 bytes as its `_k` and no blob.  ValueError as
+ * G1Point.from_compressed_bytes_unchecked raises it. */
+static PyObject* pf_decode_lazy(PyObject* self, PyObject* data) {
+  if (!g_point_type || !g_validate || !g_identity_blob || g_t_off < 0) { PyErr_SetString(PyExc_RuntimeError, "_pyface.bind() / set_native() have not run"); return NULL; }
+  PyObject* owned = NULL;
+  if (!PyBytes_CheckExact(data)) {
+    owned = PyObject_Bytes(data);
+    if (!owned) return NULL;
+    data = owned;
+  }
+  if (PyBytes_GET_SIZE(data) != 48) { Py_XDECREF(owned); PyErr_SetString(PyExc_ValueError, "Err From Rust: serialised data seems to be invalid (need 48 bytes)"); return NULL; }
+  int inf = 0;
+  const int rc = g_validate((const unsigned char*)PyBytes_AS_STRING(data), &inf);
+  if (rc != 0) { Py_XDECREF(owned); PyErr_Format(PyExc_ValueError, "Err From Rust: serialised data seems to be invalid (code %d)", rc); return NULL; }
+  PyObject* o = g_point_type->tp_alloc(g_point_type, 0);
+  if (!o) { Py_XDECREF(owned); return NULL; }
+  slot_put(o, g_point_off, inf ? g_identity_blob : Py_None);
+  slot_put(o, g_cache_off[0], Py_None);
+  slot_put(o, g_cache_off[1], inf ? Py_None : data);       /* a finite point decodes from exactly one encoding: these bytes ARE its compression */
+  slot_put(o, g_t_off, Py_None);
+  slot_put(o, g_sg_off, inf ? Py_True : Py_None);
+  slot_put(o, g_seq_off, Py_None);
+  Py_XDECREF(owned);
+  return o;
+}
+
 static PyMethodDef methods[] = {
+    {"mk", (PyCFunction)(void (*)(void))pf_mk, METH_FASTCALL, "mk(blob, a, k, t, sg, seq) -> G1Point"},
+    {"decode_lazy", pf_decode_lazy, METH_O, "decode_lazy(data48) -> G1Point (validated, y deferred)"},
+    {"set_native", pf_set_native, METH_VARARGS, "set_native(address of cg1_validate_compressed)"},
     {"ident", pf_ident, METH_VARARGS, "ident(seq) -> (n, fingerprint of the element identities)"},
     {"same_items", pf_same_items, METH_VARARGS, "same_items(a, b) -> bool"},
     {"bind", pf_bind, METH_VARARGS, "bind(G1Point, Scalar)"},
@@ -251,4 +348,12 @@ static PyMethodDef methods[] = {
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_pyface", "marshalling helper of the curdleproofs_pie_amd Python face", -1, methods};
 
-PyMODINIT_FUNC PyInit__pyface(void) { return PyModule_Create(&moddef); }
+PyMODINIT_FUNC PyInit__pyface(void) {
+  PyObject* m = PyModule_Create(&moddef);
+  if (!m) return NULL;
+  g_unforced = PyErr_NewException("_pyface.Unforced", PyExc_LookupError, NULL);
+  if (!g_unforced) { Py_DECREF(m); return NULL; }
+  Py_INCREF(g_unforced);
+  if (PyModule_AddObject(m, "Unforced", g_unforced) < 0) { Py_DECREF(g_unforced); Py_DECREF(m); return NULL; }
+  return m;
+}

@@ -39,6 +39,7 @@
 #include "fr.h"
 #include "host_g1.h"
 #include "merlin_group.h"
+#include "pool.h"
 
 using namespace cg1fr;
 using cg1h::jac;
@@ -198,87 +199,7 @@ void fold_scalars(const std::vector<fr>& gamma, std::vector<fr>& s) {
   }
 }
 
-// Persistent worker pool (spawning a thread per core per call costs more than a sub-batch of proofs).  Leaked on
-// purpose: its threads sleep on a condition variable until the process exits.
-class Pool {
- public:
-  static Pool& get() {
-    static Pool* p = new Pool;
-    return *p;
-  }
-  size_t size() const { return threads_.size(); }
-  // run `job` on `nt` of the pool's threads (the caller's thread also takes part) and wait for all of them
-  void run(const std::function<void()>& job, size_t nt) {
-    std::lock_guard<std::mutex> serial(run_mutex_);
-    if (nt > threads_.size() + 1) nt = threads_.size() + 1;
-    {
-      std::lock_guard<std::mutex> lk(m_);
-      job_ = &job;
-      want_ = nt - 1;
-      pending_ = nt - 1;
-      ++generation_;
-    }
-    cv_work_.notify_all();
-    job();
-    std::unique_lock<std::mutex> lk(m_);
-    cv_done_.wait(lk, [&] { return pending_ == 0; });
-    job_ = nullptr;
-  }
-
- private:
-  // CPUs this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one (a
-  // container that sees 256 cores but owns 16 cores' worth of quota gets throttled, not faster, with 256 threads)
-  static size_t usable_cpus() {
-    size_t n = 0;
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) n = (size_t)CPU_COUNT(&set);
-    if (n == 0) n = std::thread::hardware_concurrency();
-    if (n == 0) n = 1;
-    long long quota = -1, period = 0;
-    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                         // cgroup v2: "<quota|max> <period>"
-      char q[32] = {0};
-      if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
-      fclose(f);
-    } else {
-      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
-      if (FILE* g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
-    }
-    if (quota > 0 && period > 0) {
-      size_t q = (size_t)((quota + period - 1) / period);
-      if (q >= 1 && q < n) n = q;
-    }
-    return n;
-  }
-  Pool() {
-    size_t n = usable_cpus();
-    if (const char* e = getenv("CURDLE_G1_THREADS")) { long v = atol(e); if (v >= 1) n = (size_t)v; }
-    if (n > 256) n = 256;
-    for (size_t i = 0; i + 1 < n; ++i) threads_.emplace_back([this, i] { loop(i); });
-    for (auto& t : threads_) t.detach();
-  }
-  void loop(size_t index) {
-    size_t seen = 0;
-    for (;;) {
-      const std::function<void()>* job = nullptr;
-      {
-        std::unique_lock<std::mutex> lk(m_);
-        cv_work_.wait(lk, [&] { return generation_ != seen; });
-        seen = generation_;
-        if (index < want_) job = job_;
-      }
-      if (job) {
-        (*job)();
-        std::lock_guard<std::mutex> lk(m_);
-        if (--pending_ == 0) cv_done_.notify_all();
-      }
-    }
-  }
-  std::vector<std::thread> threads_;
-  std::mutex m_, run_mutex_;
-  std::condition_variable cv_work_, cv_done_;
-  const std::function<void()>* job_ = nullptr;
-  size_t want_ = 0, pending_ = 0, generation_ = 0;
-};
+using cg1::Pool;   // csrc/pool.h: the persistent worker pool (shared with lazy_host.cpp)
 
 // The per-proof block the DEVICE row builder (csrc/kernels_rows.h, k_shuffle_rows) works from, instead of the rows themselves:
 // every challenge the transcript produced plus the handful of scalars derived from them on the host, 32-byte little-endian

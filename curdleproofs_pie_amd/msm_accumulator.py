@@ -11,9 +11,27 @@ from collections import OrderedDict
 from typing import Dict, Iterable, List, Tuple
 
 from . import _native as N
+from . import py_arkworks_bls12381 as B
 from .py_arkworks_bls12381 import (CURVE_ORDER, G1Point, Scalar, ensure_normalised, ident, pack_affine, pack_points, pack_scalars, points_from_blobs,
                                    points_to_affine96, points_to_compressed, same_items)
 from .util import random_scalar
+
+# Every entry point below that touches the default context -- its staging buffers, its stream, the resident-vector cache -- runs under the
+# Python face's one re-entrant lock (py_arkworks_bls12381._LOCK, the lock deferred evaluation uses too): the wheel's values may be
+# used from any thread, so may these; calls are serialised per process, which is what one GPU stream does to them anyway.
+_LOCK = B._LOCK
+
+
+def _locked(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*a, **kw):
+        with _LOCK:
+            return fn(*a, **kw)
+
+    return wrapper
+LAZY_MSM_MAX = 2048                      # compute_MSM of up to this many terms returns a deferred value when deferred evaluation is on (= k_msm_small's reach)
 
 _ZERO96 = bytes(96)
 
@@ -39,6 +57,19 @@ def _staging(ctx) -> "N.Staging":
     return st
 
 
+def _drop_stale(ctx) -> None:
+    """Entries made on a context that is gone (N.close_default_context() without release()): free what can be freed, forget the rest."""
+    global _vec_cache_points
+    for fp in [fp for fp, (_, v) in _vec_cache.items() if v.ctx is not ctx or not v.handle]:
+        _, v = _vec_cache.pop(fp)
+        _vec_cache_points -= v.n
+        if v.ctx.handle:
+            v.free()
+    for key in [k for k, st in _stagings.items() if st.ctx is not ctx]:
+        del _stagings[key]
+
+
+@_locked
 def clear_vec_cache() -> None:
     global _vec_cache_points
     for _, v in _vec_cache.values():
@@ -48,6 +79,7 @@ def clear_vec_cache() -> None:
     _vec_cache_points = 0
 
 
+@_locked
 def release() -> None:
     """Free what this module keeps on the default context: the resident vectors and the page-locked staging (before the context is
     closed: N.close_default_context())."""
@@ -59,6 +91,9 @@ def release() -> None:
     _stagings.clear()
 
 
+N.on_close_default_context(release)      # N.close_default_context() frees this module's device / page-locked memory first
+
+
 def _resident(ctx, bases, n: int):
     """The device-resident form of `bases[:n]` if this very sequence of objects was met before; None the first time."""
     global _vec_cache_points
@@ -67,10 +102,14 @@ def _resident(ctx, bases, n: int):
     _, fp = ident(bases)
     hit = _vec_cache.get(fp)
     if hit is not None:
-        if hit[1].ctx is ctx and hit[1].handle and same_items(bases, hit[0]):
+        if hit[1].ctx is not ctx or not hit[1].handle:
+            _drop_stale(ctx)                 # made on a context that was closed since: evict, and treat this sighting as the first
+            hit = None
+        elif same_items(bases, hit[0]):
             _vec_cache.move_to_end(fp)
             return hit[1]
-        return None
+        else:
+            return None
     if fp not in _vec_seen:
         _vec_seen[fp] = None
         if len(_vec_seen) > 4 * _VEC_CACHE_MAX_ENTRIES:
@@ -96,11 +135,15 @@ def compute_MSM(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> G1Point:
     """sum_i scalars[i] * bases[i]  (msm_accumulator.py:6-12).
 
     `zip` semantics like the reference: any iterables, truncated to the shorter (the reference's tests pass a
-    `map` object, test_curdleproofs.py:432).  Neither argument is retained or mutated.
+    `map` object, test_curdleproofs.py:432).  The arguments are not mutated; a base list met twice is kept (as a tuple of its
+    objects) by the resident-vector cache until it is evicted.
 
-    Host side of a call: two C walks over the lists straight into page-locked staging (csrc/pyface.c), no field arithmetic --
-    the point blobs go up as the objects hold them and are normalised on the device (k_prepare_blobs); a base list met before
-    (same objects) is already resident there and only the scalars move.
+    With deferred evaluation on (the default), a call of the protocol's own sizes (<= LAZY_MSM_MAX terms) returns a deferred value:
+    the coefficients of deferred bases -- a prover's folded `G_L[i] + G_R[i] * gamma` (ipa.py:142-146) -- are folded into the scalars,
+    and the MSM runs on the GPU, together with the other values of its group (the four L / R points of a halving round: one launch),
+    when its bytes are needed.  Larger calls run at once: two C walks over the lists straight into page-locked staging (csrc/pyface.c),
+    no field arithmetic on the host -- the point blobs go up as the objects hold them and are normalised on the device
+    (k_prepare_blobs); a base list met before (same objects) is already resident there and only the scalars move.
     """
     global last_path
     if not (isinstance(bases, (list, tuple)) and isinstance(scalars, (list, tuple))):
@@ -114,26 +157,31 @@ def compute_MSM(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> G1Point:
         bases = bases[:n]
     if len(scalars) != n:
         scalars = scalars[:n]
-    ctx = N.default_context()
-    st = _staging(ctx)
-    sc_addr = st.scalars(n)
-    pack_scalars(scalars, sc_addr, st.cap_sc)
-    vec = _resident(ctx, bases, n)
-    if vec is not None:
-        last_path = "resident"
-        return G1Point._from_blob(ctx.msm_vec(vec, sc_addr, n))
-    pt_addr = st.points(n)
-    if n <= _HOST_NORMALISE_MAX:
-        # the protocol's own sizes (4 ... 627 terms): the device inversion (one Fermat chain per lane, ~0.45 ms whatever n) costs more
-        # than the call; these few points are normalised on the host, once per OBJECT (CRS points come back call after call)
-        pack_affine(bases, pt_addr, (st.cap_pts * 3) // 2)
-        last_path = "affine"
-        return G1Point._from_blob(ctx.msm_affine(pt_addr, sc_addr, n))
-    _, normalised = pack_points(bases, pt_addr, st.cap_pts)
-    last_path = "blobs_normalised" if normalised else "blobs"
-    return G1Point._from_blob(ctx.msm_blobs(pt_addr, sc_addr, n, bool(normalised)))
+    with _LOCK:
+        ctx = N.default_context()              # no GPU: NativeError here, deferred or not
+        if B._LAZY and n <= LAZY_MSM_MAX:
+            last_path = "deferred"
+            return B.msm_node(bases, scalars, n)
+        st = _staging(ctx)
+        sc_addr = st.scalars(n)
+        pack_scalars(scalars, sc_addr, st.cap_sc)
+        vec = _resident(ctx, bases, n)
+        if vec is not None:
+            last_path = "resident"
+            return G1Point._from_blob(ctx.msm_vec(vec, sc_addr, n))
+        pt_addr = st.points(n)
+        if n <= _HOST_NORMALISE_MAX:
+            # the protocol's own sizes (4 ... 627 terms): the device inversion (one Fermat chain per lane, ~0.45 ms whatever n) costs more
+            # than the call; these few points are normalised on the host, once per OBJECT (CRS points come back call after call)
+            pack_affine(bases, pt_addr, (st.cap_pts * 3) // 2)
+            last_path = "affine"
+            return G1Point._from_blob(ctx.msm_affine(pt_addr, sc_addr, n))
+        _, normalised = pack_points(bases, pt_addr, st.cap_pts)
+        last_path = "blobs_normalised" if normalised else "blobs"
+        return G1Point._from_blob(ctx.msm_blobs(pt_addr, sc_addr, n, bool(normalised)))
 
 
+@_locked
 def compute_MSM_batch(jobs: Iterable[Tuple[Iterable[G1Point], Iterable[Scalar]]]) -> List[G1Point]:
     """[compute_MSM(bases, scalars) for (bases, scalars) in jobs] as ONE GPU launch chain (regime B).
 
@@ -174,6 +222,7 @@ def _blobs_from_affine96(raw: bytes, n: int) -> List[G1Point]:
     return points_from_blobs(blobs, n)
 
 
+@_locked
 def batch_mul(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> List[G1Point]:
     """[b * s for b, s in zip(bases, scalars)] on the GPU (e.g. G_i * beta^-i, grand_prod.py:64-71)."""
     pairs = list(zip(bases, scalars))
@@ -185,6 +234,7 @@ def batch_mul(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> List[G1Poi
     return _blobs_from_affine96(raw, n)
 
 
+@_locked
 def batch_mul_same_scalar(bases: Iterable[G1Point], scalar: Scalar) -> List[G1Point]:
     """[b * scalar for b in bases] on the GPU (e.g. vec_T = [R * k ...], curdleproofs.py:310-311)."""
     bases = list(bases)
@@ -195,6 +245,7 @@ def batch_mul_same_scalar(bases: Iterable[G1Point], scalar: Scalar) -> List[G1Po
     return _blobs_from_affine96(raw, n)
 
 
+@_locked
 def batch_fold(left: Iterable[G1Point], right: Iterable[G1Point], scalar: Scalar) -> List[G1Point]:
     """[l + r * scalar for l, r in zip(left, right)] on the GPU (the IPA / same-MSM folding step,
     ipa.py:142-146, same_msm.py:122-126)."""
@@ -207,6 +258,7 @@ def batch_fold(left: Iterable[G1Point], right: Iterable[G1Point], scalar: Scalar
     return _blobs_from_affine96(raw, n)
 
 
+@_locked
 def batch_fold_scalars(left: Iterable[G1Point], right: Iterable[G1Point], scalars: Iterable[Scalar]) -> List[G1Point]:
     """[l + r * s for l, r, s in zip(left, right, scalars)] as one launch: the folds of several provers' rounds (each with its
     own challenge) side by side."""
@@ -219,6 +271,7 @@ def batch_fold_scalars(left: Iterable[G1Point], right: Iterable[G1Point], scalar
     return _blobs_from_affine96(raw, n)
 
 
+@_locked
 def batch_sum(groups: Iterable[Iterable[G1Point]]) -> List[G1Point]:
     """[reduce(lambda a, b: a + b, g, Z1) for g in groups] on the GPU -- the linear point sums G_sum / H_sum of the CRS
     (crs.py:64-65: over vec_G and vec_H), one wave per group (k_batch_sum)."""
@@ -233,6 +286,7 @@ def batch_sum(groups: Iterable[Iterable[G1Point]]) -> List[G1Point]:
     return _blobs_from_affine96(raw, len(groups))
 
 
+@_locked
 def batch_from_compressed(encodings: Iterable[bytes], checked: bool = False) -> List[G1Point]:
     """[G1Point.from_compressed_bytes[_unchecked](e) for e in encodings] with the square roots (and subgroup
     checks) on the GPU -- e.g. the 4*ell tracker points + every proof element of IsValidWhiskShuffleProof
@@ -246,6 +300,7 @@ def batch_from_compressed(encodings: Iterable[bytes], checked: bool = False) -> 
     return _blobs_from_affine96(raw, len(enc))
 
 
+@_locked
 def batch_to_compressed(points: Iterable[G1Point]) -> List[bytes]:
     """[p.to_compressed_bytes() for p in points] (util.py:27-28, points_projective_to_bytes util.py:31-32): ONE batched
     normalisation on the host (a single field inversion) and the encoding itself on the GPU (k_batch_compress)."""
@@ -267,49 +322,83 @@ class MSMAccumulator:
     Same observable behaviour: one `random_scalar()` draw per `accumulate_check` (so seeded runs draw in the
     same order, :43), identity bases skipped (:49-50), equal bases merged by their 48-byte compression (:54-58),
     `verify()` raises AssertionError on mismatch (:68) and ValueError when nothing was accumulated (:63).
-    Internals differ where the reference wastes work (its own TODO at :52-53): keys come from ONE batched
-    normalisation per call, the affine form is kept next to the key so nothing is decompressed again (:65),
+    Internals differ where the reference wastes work (its own TODO at :52-53): a call only records its arguments (the points may
+    still be deferred values or undecoded encodings); the keys of ALL calls come from ONE evaluation + ONE batched normalisation when
+    the map is first needed, the affine form is kept next to the key so nothing is decompressed again (:65),
     and the left-hand sides `rho_i * C_i` join the final GPU MSM instead of costing a scalar-mul each (:45):
         sum_j s_j B_j - sum_i rho_i C_i == 0.
     """
 
     def __init__(self) -> None:
-        self._lhs: List[Tuple[bytes, int]] = []           # (affine96 of C_i, rho_i)
-        self.base_scalar_map: Dict[bytes, List] = {}       # compressed48 -> [scalar int, affine96]
+        self._calls: List[tuple] = []                      # (C, [bases], [scalar ints], rho) not merged yet
+        self._lhs_done: List[Tuple[bytes, int]] = []       # (affine96 of C_i, rho_i)
+        self._map: Dict[bytes, List] = {}                  # compressed48 -> [scalar int, affine96]
+
+    def _settle(self) -> None:
+        """Merge the recorded calls into the map: every point of every call evaluated / decoded / normalised in one go."""
+        if not self._calls:
+            return
+        with _LOCK:
+            calls, self._calls = self._calls, []
+            pts = []
+            for C, bases, _, _ in calls:
+                pts.append(C)
+                pts.extend(bases)
+            ensure_normalised(pts)             # ONE flush + ONE decoding + ONE inversion for the points not met before; CRS points keep their normal form
+            m = self._map
+            for C, bases, svals, rho in calls:
+                self._lhs_done.append((C._a, rho))
+                for base, sv in zip(bases, svals):
+                    a = base._a
+                    if a == _ZERO96:  # :49-50 zero bases contribute nothing
+                        continue
+                    ent = m.get(base._k)  # :54 the 48-byte compression is the key
+                    if ent is None:
+                        m[base._k] = [rho * sv % CURVE_ORDER, a]
+                    else:
+                        ent[0] = (ent[0] + rho * sv) % CURVE_ORDER  # :58
+
+    @property
+    def base_scalar_map(self) -> Dict[bytes, List]:
+        self._settle()
+        return self._map
+
+    @property
+    def _lhs(self) -> List[Tuple[bytes, int]]:
+        self._settle()
+        return self._lhs_done
 
     @property
     def A_c(self) -> G1Point:  # the reference's running left-hand side (:45); computed on demand
-        n = len(self._lhs)
+        lhs = self._lhs
+        n = len(lhs)
         if n == 0:
             return G1Point.identity()
-        out = N.default_context().msm_host(b"".join(a for a, _ in self._lhs),
-                                           _scalars32([r for _, r in self._lhs]), n)
+        with _LOCK:
+            out = N.default_context().msm_host(b"".join(a for a, _ in lhs), _scalars32([r for _, r in lhs]), n)
         return G1Point._from_blob(out)
 
     def accumulate_check(self, C: G1Point, bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> None:
         random_factor = random_scalar()  # :43  (exactly one draw per call)
         rho = random_factor._v
-        pairs = list(zip(bases, scalars))  # :47
-        pts = [C]
-        pts.extend(b for b, _ in pairs)
-        ensure_normalised(pts)             # ONE inversion for the points not met before; CRS points keep their normal form
-        self._lhs.append((C._a, rho))
-        m = self.base_scalar_map
-        for base, scalar in pairs:
-            a = base._a
-            if a == _ZERO96:  # :49-50 zero bases contribute nothing
-                continue
-            ent = m.get(base._k)  # :54 the 48-byte compression is the key
-            if ent is None:
-                m[base._k] = [rho * scalar._v % CURVE_ORDER, a]
-            else:
-                ent[0] = (ent[0] + rho * scalar._v) % CURVE_ORDER  # :58
+        if type(C) is not G1Point:
+            raise TypeError("accumulate_check: C must be a G1Point")
+        bl, sl = [], []
+        for b, s in zip(bases, scalars):  # :47
+            if type(b) is not G1Point or type(s) is not Scalar:
+                raise TypeError("accumulate_check: bases must be G1Point, scalars must be Scalar")
+            bl.append(b)
+            sl.append(s._v)
+        self._calls.append((C, bl, sl, rho))
+        if not B._LAZY:
+            self._settle()
 
     def _final_msm_terms(self) -> Tuple[bytes, bytes, int]:
         ents = list(self.base_scalar_map.values())
-        pts = b"".join(e[1] for e in ents) + b"".join(a for a, _ in self._lhs)
-        sc = _scalars32([e[0] for e in ents] + [(-r) % CURVE_ORDER for _, r in self._lhs])
-        return pts, sc, len(ents) + len(self._lhs)
+        lhs = self._lhs_done
+        pts = b"".join(e[1] for e in ents) + b"".join(a for a, _ in lhs)
+        sc = _scalars32([e[0] for e in ents] + [(-r) % CURVE_ORDER for _, r in lhs])
+        return pts, sc, len(ents) + len(lhs)
 
     @staticmethod
     def verify_many(accumulators: List["MSMAccumulator"]) -> List[bool]:
@@ -324,16 +413,15 @@ class MSMAccumulator:
         for a in accumulators:
             p, s, n = a._final_msm_terms()
             pts.append(p); sc.append(s); offsets.append(offsets[-1] + n)
-        blobs = N.default_context().msm_batched_host(b"".join(pts), b"".join(sc), offsets)
+        with _LOCK:
+            blobs = N.default_context().msm_batched_host(b"".join(pts), b"".join(sc), offsets)
         return [N.cg1_is_identity(b) == 1 for b in blobs]
 
     def verify(self) -> None:
         if not self.base_scalar_map:
             # the reference unpacks `zip(*{}.items())` into two names (:63)
             raise ValueError("not enough values to unpack (expected 2, got 0)")
-        ents = list(self.base_scalar_map.values())
-        pts = b"".join(e[1] for e in ents) + b"".join(a for a, _ in self._lhs)
-        sc = _scalars32([e[0] for e in ents] + [(-r) % CURVE_ORDER for _, r in self._lhs])
-        n = len(ents) + len(self._lhs)
-        out = N.default_context().msm_host(pts, sc, n)
+        pts, sc, n = self._final_msm_terms()
+        with _LOCK:
+            out = N.default_context().msm_host(pts, sc, n)
         assert N.cg1_is_identity(out) == 1  # computed == self.A_c  (:68)

@@ -252,6 +252,33 @@ int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out_scalars32, size_t n, uint64
  * returns elapsed ms in *ms */
 int cg1_probe_madd(cg1_ctx* ctx, const void* d_points_affine96, size_t npts, size_t lanes, int iters, float* ms);
 
+/* ---------------- deferred evaluation of the G1Point operators (north_star: "the prover/verifier keep their Python control flow
+ * unchanged") -----------------------------------------------------------------------------------------------------------
+ * The reference's loops call the operators one at a time: 585 x from_compressed_bytes_unchecked per verification
+ * (whisk_interface.py:96-106 -> util.py:35-36), G_L[i] + G_R[i] * gamma (ipa.py:142-146, same_msm.py:122-126), R * k
+ * (curdleproofs.py:310-311), G_i * beta^-i (grand_prod.py:64-71).  The Python face (py_arkworks_bls12381.py) answers them with
+ * deferred values and evaluates whole batches through the entry points below when bytes or a comparison are asked for.
+ *
+ * cg1_validate_compressed: what from_compressed_bytes_unchecked must decide AT THE CALL (util.py:35-36 raises there;
+ * test_curdleproofs.py:170-176,211-213): compression flag, x < p, and x^3 + 4 a square -- by its Jacobi symbol, no square root.
+ * CG1_OK (is_identity: the infinity flag was set), CG1_ERR_ENCODING, CG1_ERR_NOT_ON_CURVE. */
+int cg1_validate_compressed(const uint8_t in48[48], int* is_identity);
+int cg1_fp_jacobi(const uint8_t le48[48]);               /* Jacobi symbol (a / p) of a 48-byte little-endian a < p: 1, -1, 0; 2 = a >= p */
+/* n encodings (already validated, or not: the first failing index / status come back) -> blobs and / or affine96, on the worker pool */
+int cg1_batch_decompress_pool(const uint8_t* in48, size_t n, uint8_t* out_blobs144, uint8_t* out_affine96, int n_threads, size_t* bad_index);
+/* out_flags[i] = 1 iff affine96 point i (on the curve; zeros = identity) lies in the prime-order subgroup G1: [z^2]P == phi(P) + P.
+ * Only for such bases may the coefficient of a deferred product be reduced mod r (`(P * a) * b` == P * (a b mod r)). */
+int cg1_batch_subgroup_pool(const uint8_t* affine96, size_t n, uint8_t* out_flags, int n_threads);
+/* out_j = sum_{t in [offsets[j], offsets[j+1])} scalars32[t] * (+/-) bases[term_base[t] & 0x7fffffff]  (bit 31 of term_base: the negated
+ * base); offsets: n_out + 1 host entries, offsets[0] == 0.  path 0 = choose from the batch (never from the machine), 1 = the host's worker
+ * pool, 2 = the GPU (cg1_msm_batched_device over the gathered terms).  ctx may be NULL for paths 0 / 1 (then always the pool).  Outputs
+ * (each may be NULL) are normalised: point blobs with Z = 1, affine96, compressed48.  *path_used: which path ran. */
+int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_bases, const uint32_t* offsets, size_t n_out,
+                      const uint32_t* term_base, const uint8_t* term_scalars32, int path, uint8_t* out_blobs144, uint8_t* out_affine96,
+                      uint8_t* out_comp48, int* path_used);
+int cg1_lincomb_batch_pool(const uint8_t* bases_affine96, size_t n_bases, const uint32_t* offsets, size_t n_out, const uint32_t* term_base,
+                           const uint8_t* term_scalars32, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48, int n_threads);
+
 /* ---------------- native Merlin transcript (host C++) ------------------------
  * Stands behind merlin_transcripts/merlin_transcripts/{merlin_transcript.py:6-24, strobe.py:16-107,
  * keccak.py:16-66} and curdleproofs/curdleproofs/curdleproofs_transcript.py:7-28.

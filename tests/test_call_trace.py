@@ -66,12 +66,23 @@ def test_trace_replays_on_the_host_face(trace):
 
 
 @pytest.mark.gpu
-def test_trace_replays_through_the_gpu_backend(trace):
+@pytest.mark.parametrize("lazy", [True, False], ids=["deferred", "eager"])
+def test_trace_replays_through_the_gpu_backend(trace, lazy):
     RT, doc, blob = trace
     import curdleproofs_pie_amd.msm_accumulator as M
+    import curdleproofs_pie_amd.py_arkworks_bls12381 as B
 
+    prev = B.set_lazy(lazy)
+    try:
+        _replay_on_gpu(RT, doc, blob, M, B, lazy)
+    finally:
+        B.set_lazy(prev)
+
+
+def _replay_on_gpu(RT, doc, blob, M, B, lazy):
     M.clear_vec_cache()
     paths = {}
+    before = dict(B.stats)
     for rep in range(2):                                         # twice: the second time CRS vectors are resident on the device
         rp = RT.product_replayer(doc, blob)
         orig = rp.compute_MSM
@@ -86,5 +97,12 @@ def test_trace_replays_through_the_gpu_backend(trace):
             rp.prepare(doc[ph])
             rp.run(doc[ph])
         assert rp.mismatches == [], rp.mismatches[:3]
-    assert paths.get("resident", 0) > 0 and paths.get("affine", 0) > 0       # both ways into the small-MSM kernel were taken
+    if lazy:
+        # every compute_MSM of the protocol's sizes was deferred and evaluated on the GPU in groups (the L / R points of a halving round
+        # together); the 585 + 248 + 133 decodings were validated one by one and their square roots taken in a few batches
+        assert set(paths) == {"deferred"} and B.stats["flush_device"] > before["flush_device"]
+        assert B.stats["flushed_values"] - before["flushed_values"] > 4 * (B.stats["flushes"] - before["flushes"])
+        assert B.stats["decoded"] - before["decoded"] >= 2 * 700 and B.stats["decode_batches"] - before["decode_batches"] < 60
+    else:
+        assert paths.get("resident", 0) > 0 and paths.get("affine", 0) > 0       # both ways into the small-MSM kernel were taken
     M.clear_vec_cache()

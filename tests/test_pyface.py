@@ -18,7 +18,11 @@ def B(native_lib):
 
 def _points(B, rng, n):
     G = B.G1Point()
-    pts = [G * B.Scalar(rng.randint(1, O.R - 1)) for _ in range(n)]      # projective blobs (Z != 1), like util.get_random_point
+    prev = B.set_lazy(False)             # computed at once on the host library: projective blobs (Z != 1), like util.get_random_point over the wheel
+    try:
+        pts = [G * B.Scalar(rng.randint(1, O.R - 1)) for _ in range(n)]
+    finally:
+        B.set_lazy(prev)
     return pts
 
 
@@ -105,8 +109,17 @@ def test_normal_form_cache(B, native_lib):
     assert B.points_to_affine96(pts) == b"".join(p._a for p in pts)
     assert B.points_to_compressed(pts) == want_k
     # to_compressed_bytes alone fills only the key
+    p = _points(B, rng, 1)[0]
+    k77 = O.g1_compress(O.g1_decompress(bytes(p.to_compressed_bytes())))
+    p = B.G1Point._from_blob(p._b)
+    assert p._k is None and bytes(p.to_compressed_bytes()) == k77 and p._k is not None and p._a is None
+    B.ensure_normalised([p])
+    assert p._a == b"".join(c.to_bytes(48, "little") for c in O.g1_decompress(k77))
+    # a deferred value leaves its evaluation with blob (Z = 1), affine96 record and encoding
     p = B.G1Point() * B.Scalar(77)
-    assert p._k is None and bytes(p.to_compressed_bytes()) == O.g1_compress(O.g1_mul(O.G1_GEN, 77)) and p._k is not None and p._a is None
+    if B.lazy_enabled():
+        assert p._blob is None and p._t is not None
+    assert bytes(p.to_compressed_bytes()) == O.g1_compress(O.g1_mul(O.G1_GEN, 77)) and p._k is not None and p._t is None
     B.ensure_normalised([p])
     assert p._a == b"".join(c.to_bytes(48, "little") for c in O.g1_mul(O.G1_GEN, 77))
     # values stay immutable from the outside

@@ -9,12 +9,17 @@ from oracle import bls12_381 as O
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def api(native_lib):
+@pytest.fixture(scope="module", params=["deferred", "eager"])
+def api(native_lib, request):
+    """Every test of this module runs with the operators deferred (the default: values evaluated in batches when bytes / comparisons are
+    asked for) and computing at once (CURDLE_G1_LAZY=0): the same results either way."""
     import curdleproofs_pie_amd as A
+    import curdleproofs_pie_amd.py_arkworks_bls12381 as B
     from curdleproofs_pie_amd import util as U
 
-    return A, U
+    prev = B.set_lazy(request.param == "deferred")
+    yield A, U
+    B.set_lazy(prev)
 
 
 def naive(bases, scalars, A):
