@@ -302,6 +302,12 @@ def open_comm(args, rank, world, ctx):
         errs = [x.rstrip(b"\0") for x in comm.allgather(err.ljust(200, b"\0"), host_only=True)]
         if any(errs):
             bad = [(r, x.decode(errors="replace")) for r, x in enumerate(errs) if x]
+            if not args.same_device and not args.allow_socket:
+                # every rank has its own GPU and was asked for RCCL: north_star's exchange is RCCL over xGMI -- a line measured over the
+                # TCP star would not be that measurement.  Every rank sees the same `errs`, so every rank leaves here.
+                comm.barrier()
+                comm.close()
+                sys.exit("bench.py: RCCL could not be attached (rank %d: %s); re-run with --allow-socket to measure over the TCP transport instead" % bad[0])
             comm.barrier()
             comm.close()                                       # some ranks may hold a half-made RCCL communicator: every rank starts over
             comm = init_comm(rank, world, timeout_s=900.0)     # (rank 0 removed the rendezvous file after the first connect and writes it anew)
@@ -505,12 +511,16 @@ def main():
                     help="transport of the N>1 partial-sum exchange: rccl (ncclAllGather over xGMI, one GPU per rank) or socket (the TCP "
                          "control channel alone: ranks rehearsing on one GPU); nccl / gloo are accepted as aliases")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (implies --backend socket)")
+    ap.add_argument("--allow-socket", action="store_true", help="N > 1 with one GPU per rank: keep going on the TCP transport when RCCL cannot be attached "
+                                                                 "(default: exit non-zero -- a scaling run must not silently stop being an RCCL run)")
     args = ap.parse_args()
 
     if args.batch is None:
         args.batch = 2048 if (args.mode == "verify" and args.gpus > 1) else 1024
     if args.backend in ("nccl", "gloo"):                      # the names torch gives the same two transports
         args.backend = {"nccl": "rccl", "gloo": "socket"}[args.backend]
+    if args.same_device:
+        os.environ["CURDLE_G1_SHARE_DEVICE"] = "1"            # ranks beyond the device count are meant to share GPU 0 here (N.default_context() refuses otherwise)
     if args.same_device and not os.environ.get("CG1_BENCH_TRY_RCCL_ON_ONE_DEVICE"):
         args.backend = "socket"                               # RCCL refuses two ranks on one device (the env switch lets a test see that refusal handled)
     if args.gpus > 1 and "RANK" not in os.environ:

@@ -143,6 +143,8 @@ cg1_msm_device = _proto("cg1_msm_device", c_int, c_void_p, c_void_p, c_void_p, c
 cg1_msm_device_begin = _proto("cg1_msm_device_begin", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, c_int, c_int)
 cg1_msm_device_end = _proto("cg1_msm_device_end", c_int, c_void_p, _buf)
 cg1_msm_blobs = _proto("cg1_msm_blobs", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, _buf)
+cg1_stage_reserve = _proto("cg1_stage_reserve", c_int, c_void_p, c_size_t, c_size_t, POINTER(c_void_p), POINTER(c_void_p))
+cg1_msm_blobs_device = _proto("cg1_msm_blobs_device", c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_int, _buf)
 cg1_vec_create = _proto("cg1_vec_create", c_void_p, c_void_p, c_void_p, c_size_t, c_int)
 cg1_vec_destroy = _proto("cg1_vec_destroy", None, c_void_p)
 cg1_vec_len = _proto("cg1_vec_len", c_size_t, c_void_p)
@@ -257,7 +259,7 @@ EXPORTED_SYMBOLS = [
     "cg1_comm_create", "cg1_comm_port", "cg1_comm_rank", "cg1_comm_connect", "cg1_comm_set_timeout", "cg1_comm_attach_rccl", "cg1_comm_transport",
     "cg1_comm_world_seen", "cg1_comm_error", "cg1_comm_allgather", "cg1_comm_allgather_host", "cg1_comm_barrier", "cg1_comm_allreduce_g1", "cg1_comm_destroy",
     "cg1_validate_compressed", "cg1_fp_jacobi", "cg1_batch_decompress_pool", "cg1_batch_subgroup_pool", "cg1_lincomb_batch", "cg1_lincomb_batch_pool",
-    "cg1_msm_blobs", "cg1_vec_create", "cg1_vec_destroy", "cg1_vec_len", "cg1_msm_vec", "cg1_batch_normalize", "cg1_batch_from_affine96", "cg1_get_last_launches",
+    "cg1_msm_blobs", "cg1_stage_reserve", "cg1_msm_blobs_device", "cg1_vec_create", "cg1_vec_destroy", "cg1_vec_len", "cg1_msm_vec", "cg1_batch_normalize", "cg1_batch_from_affine96", "cg1_get_last_launches",
 ]
 
 
@@ -368,6 +370,23 @@ class Context:
         """compute_MSM over n host point blobs (bytes / ctypes buffer / raw address of page-locked memory) as G1Point objects hold them."""
         out = ctypes.create_string_buffer(POINT_BYTES)
         self.check(cg1_msm_blobs(self.handle, blobs144, scalars32, n, 1 if all_normalised else 0, out))
+        return out.raw
+
+    def stage_reserve(self, pts_bytes: int, sc_bytes: int):
+        """(device address of the point staging, of the scalar staging) with room for that many bytes."""
+        dp, ds = c_void_p(), c_void_p()
+        self.check(cg1_stage_reserve(self.handle, pts_bytes, sc_bytes, ctypes.byref(dp), ctypes.byref(ds)))
+        return dp.value, ds.value
+
+    def h2d_async(self, dst_dev: int, src_host: int, nbytes: int) -> None:
+        self.check(cg1_h2d_async(self.handle, dst_dev, src_host, nbytes))
+
+    def copy_fence(self) -> None:
+        self.check(cg1_copy_fence(self.handle))
+
+    def msm_blobs_device(self, d_blobs144: int, d_scalars32: int, n: int, all_normalised: bool = False) -> bytes:
+        out = ctypes.create_string_buffer(POINT_BYTES)
+        self.check(cg1_msm_blobs_device(self.handle, d_blobs144, d_scalars32, n, 1 if all_normalised else 0, out))
         return out.raw
 
     def vec(self, blobs144, n: int, all_normalised: bool = False) -> "Vec":

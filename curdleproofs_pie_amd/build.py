@@ -234,10 +234,11 @@ def build_pyface(force: bool = False, verbose: bool = True) -> str:
     if not os.path.exists(os.path.join(inc, "Python.h")):
         raise RuntimeError(f"Python.h not found under {inc}")
     tmp = f"{out}.tmp.{os.getpid()}"
-    _run(["gcc", "-O2", "-fPIC", "-shared", "-Wall", f"-I{inc}", PYFACE_SRC, "-o", tmp], verbose)
+    _run(["gcc", "-O2", "-fPIC", "-shared", "-pthread", "-Wall", f"-I{inc}", PYFACE_SRC, "-o", tmp], verbose)
     os.replace(tmp, out)
-    with open(stamp, "w") as f:
+    with open(f"{stamp}.tmp.{os.getpid()}", "w") as f:      # ranks may build side by side: the stamp appears whole or not at all
         f.write(want)
+    os.replace(f"{stamp}.tmp.{os.getpid()}", stamp)
     return out
 
 

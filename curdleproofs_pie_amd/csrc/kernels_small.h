@@ -24,9 +24,9 @@ constexpr uint32_t SM_SLICE = 256;        // terms per workgroup
 constexpr uint32_t SM_L = 4;              // entries per chunk
 constexpr uint32_t SM_QUADS = 128;
 
-constexpr uint32_t SM_MAX_MSMS = 16;      // independent MSMs one launch may carry (grid.z)
+constexpr uint32_t SM_MAX_MSMS = 64;      // independent MSMs one launch may carry (grid.z)
 constexpr uint32_t SM_ONE_ROUND = 256;    // workgroups of ONE MSM: windows x slices within one round of the chip's CUs (a workgroup fills a CU)
-constexpr uint32_t SM_MAX_GROUPS = 512;   // ... as long as windows x slices x MSMs stays a few workgroups per CU
+constexpr uint32_t SM_MAX_GROUPS = 2560;  // ... as long as windows x slices x MSMs stays a few rounds of workgroups (no workgroup waits for another: any number is safe)
 
 struct SmallArgs {
   const void* src;                        // SRC 0: n x affine96; 1: n x point blob with Z in {0, 1}; 2: PreparedPoint records

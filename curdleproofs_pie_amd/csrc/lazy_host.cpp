@@ -237,29 +237,65 @@ jac lincomb_one(const aff* pts, const uint32_t* idx, const uint8_t* neg, const u
   return jac_add(acc, units);
 }
 
-}  // namespace cg1h
-
-// ------------------------------------------------------------------ C ABI (host-only entry points of the deferred evaluation)
-namespace {
-
-using cg1h::aff; using cg1h::fe; using cg1h::jac;
-
-inline bool load_affine96(const uint8_t* rec, aff& o) {
+static inline bool load_affine96(const uint8_t* rec, aff& o) {
   bool zero = true;
   for (int k = 0; k < 96 && zero; ++k) zero = rec[k] == 0;
-  if (zero) { o.inf = true; o.x = cg1h::fe_zero(); o.y = cg1h::fe_zero(); return true; }
+  if (zero) { o.inf = true; o.x = fe_zero(); o.y = fe_zero(); return true; }
   o.inf = false;
-  return cg1h::fe_from_le48(rec, o.x) && cg1h::fe_from_le48(rec + 48, o.y);
+  return fe_from_le48(rec, o.x) && fe_from_le48(rec + 48, o.y);
 }
 
-inline void run_pool(const std::function<void()>& work, size_t items, int n_threads) {
+static inline void run_pool(const std::function<void()>& work, size_t items, int n_threads) {
   cg1::Pool& pool = cg1::Pool::get();
   size_t nt = n_threads > 0 ? (size_t)n_threads : pool.size() + 1;
   nt = std::min(nt, items);
   if (nt <= 1) work(); else pool.run(work, nt);
 }
 
+int lincomb_pool_jac(const uint8_t* bases_affine96, size_t n_bases, const uint32_t* offsets, const uint32_t* term_base, const uint8_t* term_scalars32,
+                     const uint32_t* sel, size_t n_sel, jac* results, int n_threads) {
+  if (n_sel == 0) return 0;
+  // only the bases the selected combinations use are converted (a base costs one Montgomery product per coordinate)
+  std::vector<aff> pts(n_bases);
+  std::vector<uint8_t> loaded(n_bases, 0);
+  size_t max_k = 0;
+  for (size_t q = 0; q < n_sel; ++q) {
+    const size_t j = sel ? sel[q] : q;
+    max_k = std::max<size_t>(max_k, offsets[j + 1] - offsets[j]);
+    for (size_t t = offsets[j]; t < offsets[j + 1]; ++t) {
+      const uint32_t b = term_base[t] & 0x7fffffffu;
+      if (b >= n_bases) return 1;
+      if (!loaded[b]) { if (!load_affine96(bases_affine96 + 96 * (size_t)b, pts[b])) return 3; loaded[b] = 1; }
+    }
+  }
+  std::atomic<size_t> next{0};
+  std::function<void()> work = [&]() {
+    std::vector<uint32_t> idx(max_k);
+    std::vector<uint8_t> neg(max_k);
+    for (;;) {
+      const size_t q = next.fetch_add(1);
+      if (q >= n_sel) return;
+      const size_t j = sel ? sel[q] : q;
+      const size_t lo = offsets[j], k = offsets[j + 1] - lo;
+      for (size_t t = 0; t < k; ++t) { idx[t] = term_base[lo + t] & 0x7fffffffu; neg[t] = (uint8_t)(term_base[lo + t] >> 31); }
+      results[j] = lincomb_one(pts.data(), idx.data(), neg.data(), term_scalars32 + 32 * lo, k);
+    }
+  };
+  run_pool(work, n_sel, n_threads);
+  return 0;
+}
+
+}  // namespace cg1h
+
+// ------------------------------------------------------------------ C ABI (host-only entry points of the deferred evaluation)
+namespace {
+
+using cg1h::aff; using cg1h::fe; using cg1h::jac;
+using cg1h::load_affine96; using cg1h::run_pool;
+
 }  // namespace
+
+extern "C" void cg1_lincomb_write_outputs(const void* jac_results, size_t n_out, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48);
 
 extern "C" {
 
@@ -340,29 +376,19 @@ int cg1_lincomb_batch_pool(const uint8_t* bases_affine96, size_t n_bases, const 
   const size_t T = offsets[n_out];
   if (T && (!bases_affine96 || !term_base || !term_scalars32)) return CG1_ERR_ARG;
   for (size_t j = 0; j < n_out; ++j) if (offsets[j] > offsets[j + 1]) return CG1_ERR_ARG;
-  std::vector<aff> pts(n_bases);
-  for (size_t i = 0; i < n_bases; ++i) if (!load_affine96(bases_affine96 + 96 * i, pts[i])) return CG1_ERR_ENCODING;
-  std::vector<uint32_t> idx(T);
-  std::vector<uint8_t> neg(T);
-  for (size_t t = 0; t < T; ++t) {
-    idx[t] = term_base[t] & 0x7fffffffu;
-    neg[t] = (uint8_t)(term_base[t] >> 31);
-    if (idx[t] >= n_bases) return CG1_ERR_ARG;
-  }
   std::vector<jac> res(n_out);
-  std::atomic<size_t> next{0};
-  std::function<void()> work = [&]() {
-    for (;;) {
-      const size_t j = next.fetch_add(1);
-      if (j >= n_out) return;
-      const size_t lo = offsets[j], k = offsets[j + 1] - lo;
-      res[j] = cg1h::lincomb_one(pts.data(), idx.data() + lo, neg.data() + lo, term_scalars32 + 32 * lo, k);
-    }
-  };
-  run_pool(work, n_out, n_threads);
+  const int rc = cg1h::lincomb_pool_jac(bases_affine96, n_bases, offsets, term_base, term_scalars32, nullptr, n_out, res.data(), n_threads);
+  if (rc) return rc == 3 ? CG1_ERR_ENCODING : CG1_ERR_ARG;
+  cg1_lincomb_write_outputs(res.data(), n_out, out_blobs144, out_affine96, out_comp48);
+  return CG1_OK;
+}
+
+// n results -> normalised blobs (Z = 1) / affine96 / compressed48 (each may be NULL) with ONE shared inversion
+void cg1_lincomb_write_outputs(const void* jac_results, size_t n_out, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48) {
+  const jac* res = static_cast<const jac*>(jac_results);
   std::vector<fe> xs(n_out), ys(n_out);
   std::vector<uint8_t> inf(n_out);
-  cg1h::jac_batch_to_affine(res.data(), n_out, xs.data(), ys.data(), inf.data());
+  cg1h::jac_batch_to_affine(res, n_out, xs.data(), ys.data(), inf.data());
   for (size_t j = 0; j < n_out; ++j) {
     if (out_blobs144) {
       const jac p = inf[j] ? cg1h::jac_identity() : cg1h::jac_from_affine(xs[j], ys[j]);
@@ -375,7 +401,6 @@ int cg1_lincomb_batch_pool(const uint8_t* bases_affine96, size_t n_bases, const 
     }
     if (out_comp48) cg1h::g1_compress_affine(xs[j], ys[j], inf[j] != 0, out_comp48 + 48 * j);
   }
-  return CG1_OK;
 }
 
 }  // extern "C"

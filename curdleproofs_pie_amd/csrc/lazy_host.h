@@ -31,4 +31,9 @@ struct aff { fe x, y; bool inf; };
 // value below 2^256; used as plain integers, as `G1Point * Scalar` does)
 jac lincomb_one(const aff* pts, const uint32_t* idx, const uint8_t* neg, const uint8_t* scalars32, size_t k);
 
+// results[j] = combination j (terms [offsets[j], offsets[j+1])) for every j of `sel` (n_sel indices; sel == nullptr: j = 0 .. n_sel - 1),
+// on the process's worker pool, one combination at a time per thread.  0 ok, 1 bad argument, 3 a base is not a canonical record.
+int lincomb_pool_jac(const uint8_t* bases_affine96, size_t n_bases, const uint32_t* offsets, const uint32_t* term_base, const uint8_t* term_scalars32,
+                     const uint32_t* sel, size_t n_sel, jac* results, int n_threads);
+
 }  // namespace cg1h

@@ -45,6 +45,8 @@
 #include "g1_xyzz.h"
 #include "g1_quad.h"
 #include "host_g1.h"
+#include "lazy_host.h"
+#include "pool.h"
 #include "../../include/curdle_g1.h"
 
 namespace cg1 {
@@ -952,10 +954,17 @@ static int msm_small_batched_finish(Ctx* ctx, uint32_t M, std::vector<cg1h::jac>
   auto t0 = std::chrono::steady_clock::now();
   const size_t per = (size_t)pd.plan.nwin * pd.nitems;
   auto one = [&](size_t j) { results[j] = horner_2d_items(pd.hout + j * per, pd.plan, pd.nitems, pd.hb2, pd.lb2); };
-  const size_t nth = std::min<size_t>(4, M);
-  for (size_t t = 1; t < nth; ++t) ctx->helper[t - 1].run([&, t]() { for (size_t j = t; j < M; j += nth) one(j); });
-  for (size_t j = 0; j < M; j += nth) one(j);
-  for (size_t t = 1; t < nth; ++t) ctx->helper[t - 1].wait();
+  if (M <= 4) {
+    const size_t nth = std::min<size_t>(4, M);
+    for (size_t t = 1; t < nth; ++t) ctx->helper[t - 1].run([&, t]() { for (size_t j = t; j < M; j += nth) one(j); });
+    for (size_t j = 0; j < M; j += nth) one(j);
+    for (size_t t = 1; t < nth; ++t) ctx->helper[t - 1].wait();
+  } else {                                             // more Horners than the context's own helpers: the process's worker pool, one Horner at a time per thread
+    std::atomic<size_t> next{0};
+    std::function<void()> work = [&]() { for (;;) { const size_t j = next.fetch_add(1); if (j >= M) return; one(j); } };
+    Pool& pool = Pool::get();
+    pool.run(work, std::min<size_t>(M, pool.size() + 1));
+  }
   auto t1 = std::chrono::steady_clock::now();
   ctx->host_ms[0] = std::chrono::duration<float, std::milli>(pd.h1 - pd.h0).count();
   ctx->host_ms[1] = std::chrono::duration<float, std::milli>(t0 - pd.h1).count();
@@ -1041,8 +1050,15 @@ int pick_window_batched(size_t n_avg) {
 }
 
 // M independent MSMs over one concatenated (points, scalars) input resident on the device.
+// async_small (may be NULL): when the call fits ONE k_msm_small launch it is only ENQUEUED and *async_small set; the caller does other
+// work and collects the results with msm_batched_small_end.  Calls that take the regime-B chain complete before returning.
+static int msm_batched_small_end(Ctx* ctx, size_t M, std::vector<cg1h::jac>& results) {
+  if (M == 1) { cg1h::jac r; int rc = msm_finish(ctx, r); ctx->last_acc_launches = 0; if (rc == CG1_OK) results[0] = r; return rc; }
+  return msm_small_batched_finish(ctx, (uint32_t)M, results);
+}
 int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, const uint32_t* h_offsets, size_t M,
-                       int c, std::vector<cg1h::jac>& results) {
+                       int c, std::vector<cg1h::jac>& results, bool* async_small = nullptr) {
+  if (async_small) *async_small = false;
   results.assign(M, cg1h::jac_identity());
   if (M == 0) return CG1_OK;
   const size_t N = h_offsets[M];
@@ -1068,8 +1084,8 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
       HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
       int rc = msm_enqueue_small(ctx, PtSrc(d_points96), d_scalars32, N, cs, (uint32_t)M, ctx->d_boffs, max_n);
       if (rc) return rc;
-      if (M == 1) { cg1h::jac r; rc = msm_finish(ctx, r); ctx->last_acc_launches = 0; if (rc == CG1_OK) results[0] = r; return rc; }
-      return msm_small_batched_finish(ctx, (uint32_t)M, results);
+      if (async_small) { *async_small = true; return CG1_OK; }
+      return msm_batched_small_end(ctx, M, results);
     }
   }
   if (c <= 0) c = pick_window_batched((N + M - 1) / M);
@@ -1616,6 +1632,29 @@ int cg1_msm_blobs(cg1_ctx* ctx, const uint8_t* blobs144, const uint8_t* scalars3
   if (rc == CG1_OK) blob_out(out, r);
   return rc;
 }
+// The two halves of cg1_msm_blobs for a caller that uploads in slices while it is still gathering (msm_accumulator.compute_MSM over 2^20
+// objects: each 64 K-element slice is copied by cg1_h2d_async while the next one is packed): cg1_stage_reserve hands out the context's
+// device staging (valid until the next call that stages more), cg1_msm_blobs_device runs the MSM over blobs already there.
+int cg1_stage_reserve(cg1_ctx* ctx, size_t pts_bytes, size_t sc_bytes, void** d_pts, void** d_sc) {
+  if (!ctx) return CG1_ERR_HIP;
+  HIPCHK(hipSetDevice(ctx->device));
+  { int src = ensure_stage(ctx, pts_bytes, sc_bytes); if (src) return src; }
+  if (d_pts) *d_pts = ctx->d_stage_pts;
+  if (d_sc) *d_sc = ctx->d_stage_sc;
+  return CG1_OK;
+}
+int cg1_msm_blobs_device(cg1_ctx* ctx, const void* d_blobs144, const void* d_scalars32, size_t n, int all_normalised, uint8_t* out) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) { blob_out(out, cg1h::jac_identity()); return CG1_OK; }
+  if (!d_blobs144 || !d_scalars32) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  cg1::PtSrc src;
+  src.kind = cg1::PtSrc::BLOBS; src.p = d_blobs144; src.normalised = all_normalised != 0;
+  cg1h::jac r;
+  int rc = cg1::msm_device(ctx, src, d_scalars32, n, 0, 0, 1, r);
+  if (rc == CG1_OK) blob_out(out, r);
+  return rc;
+}
 }  // extern "C"
 
 // A vector of points kept on the device in the accumulation kernels' own record format (128 B per point + a flag byte): made once
@@ -1713,10 +1752,74 @@ int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars,
 
 // A batch of linear combinations over shared bases -- what a flush of deferred G1Point operators is (py_arkworks_bls12381.py):
 // out_j = sum_{t in [offsets[j], offsets[j+1])} scalars[t] * (+/-) bases[term_base[t] & 0x7fffffff]   (bit 31: the negated base).
-// path 0 = choose, 1 = the host's worker pool (cg1_lincomb_batch_pool: one interleaved-NAF evaluation per output), 2 = the GPU (the terms
-// gathered into one concatenated input of cg1_msm_batched_device: ONE k_msm_small launch for up to 16 outputs, regime B beyond).  The choice
-// depends on the batch alone, not on the machine: an estimate of the pool's time at a nominal 8 threads against ~0.35 ms for a GPU round trip.
-// Outputs are normalised: blobs with Z = 1 (or the identity), affine96, compressed48 (each may be NULL).
+//
+// Two engines.  The host's worker pool evaluates one combination per thread (interleaved width-5 NAF: 255 doublings + ~52 additions per
+// term, ~0.25 us each); the GPU evaluates many terms at once but every output ends in a host Horner of 255 dependent doublings, so a
+// combination of one to three terms gains nothing from the trip.  path 0 chooses from the BATCH alone (never from the machine: the pool is
+// priced at a nominal 8 threads, a k_msm_small launch at 0.25 ms + 20 us per output, the regime-B chain at 1.9 ms -- the round-5
+// measurements, profiles/r05_lazy_profile.txt):
+//     all on the pool  |  combinations of >= 4 weighted terms on the GPU with the small ones on the pool MEANWHILE (path_used 3)  |  all on the GPU
+// path 1 = pool, 2 = GPU (everything gathered into one cg1_msm_batched_device input).  Outputs are normalised: blobs with Z = 1 (or the
+// identity), affine96, compressed48 (each may be NULL).
+extern "C" void cg1_lincomb_write_outputs(const void* jac_results, size_t n_out, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48);
+}  // extern "C"
+
+// results[sel[q]] = s * B (+ A) for the selected outputs, each one weighted term and at most one unit term: one k_batch_mul launch
+static void negate_affine96_y(uint8_t* rec) {
+  uint64_t y[6], any = 0;
+  memcpy(y, rec + 48, 48);
+  for (int i = 0; i < 6; ++i) any |= y[i];
+  if (!any) return;                                      // the identity record stays all-zero
+  unsigned __int128 br = 0;
+  for (int i = 0; i < 6; ++i) { const unsigned __int128 d = (unsigned __int128)cg1::H_P[i] - y[i] - br; y[i] = (uint64_t)d; br = (d >> 64) & 1; }
+  memcpy(rec + 48, y, 48);
+}
+static int lincomb_shaped_device(cg1_ctx* ctx, const uint8_t* bases_affine96, const uint32_t* offsets, const uint32_t* term_base, const uint8_t* term_scalars32,
+                                 const std::vector<uint32_t>& sel, std::vector<cg1h::jac>& results) {
+  const size_t m = sel.size();
+  if (m == 0) return CG1_OK;
+  std::vector<uint8_t> hb(m * 96), hs(m * 32), ha(m * 96, 0), ho(m * 96);
+  bool any_addend = false;
+  for (size_t q = 0; q < m; ++q) {
+    const size_t j = sel[q];
+    for (size_t t = offsets[j]; t < offsets[j + 1]; ++t) {
+      const uint8_t* sc = term_scalars32 + 32 * t;
+      bool unit = sc[0] <= 1;
+      for (int b = 1; b < 32 && unit; ++b) unit = sc[b] == 0;
+      const uint8_t* src = bases_affine96 + 96 * (size_t)(term_base[t] & 0x7fffffffu);
+      if (!unit) {
+        memcpy(&hb[96 * q], src, 96);
+        if (term_base[t] >> 31) negate_affine96_y(&hb[96 * q]);
+        memcpy(&hs[32 * q], sc, 32);
+      } else if (sc[0] == 1) {
+        memcpy(&ha[96 * q], src, 96);
+        if (term_base[t] >> 31) negate_affine96_y(&ha[96 * q]);
+        any_addend = true;
+      }
+    }
+  }
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf db, ds, da, dout;
+  HIPCHK(db.alloc(m * 96)); HIPCHK(ds.alloc(m * 32)); HIPCHK(dout.alloc(m * 96));
+  HIPCHK(hipMemcpy(db.p, hb.data(), m * 96, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(ds.p, hs.data(), m * 32, hipMemcpyHostToDevice));
+  if (any_addend) { HIPCHK(da.alloc(m * 96)); HIPCHK(hipMemcpy(da.p, ha.data(), m * 96, hipMemcpyHostToDevice)); }
+  int rc = cg1_batch_mul_add_device(ctx, db.p, m, ds.p, m, da.p, dout.p, m);
+  if (rc != CG1_OK) return rc;
+  HIPCHK(hipMemcpy(ho.data(), dout.p, m * 96, hipMemcpyDeviceToHost));
+  for (size_t q = 0; q < m; ++q) {
+    const uint8_t* rec = &ho[96 * q];
+    bool zero = true;
+    for (int k = 0; k < 96 && zero; ++k) zero = rec[k] == 0;
+    if (zero) { results[sel[q]] = cg1h::jac_identity(); continue; }
+    cg1h::fe x, y;
+    if (!cg1h::fe_from_le48(rec, x) || !cg1h::fe_from_le48(rec + 48, y)) { snprintf(ctx->err, sizeof ctx->err, "k_batch_mul returned a non-canonical record"); return CG1_ERR_HIP; }
+    results[sel[q]] = cg1h::jac_from_affine(x, y);
+  }
+  return CG1_OK;
+}
+
+extern "C" {
 int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_bases, const uint32_t* offsets, size_t n_out, const uint32_t* term_base,
                       const uint8_t* term_scalars32, int path, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48, int* path_used) {
   if (path_used) *path_used = 0;
@@ -1724,9 +1827,21 @@ int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_base
   if (!offsets || offsets[0] != 0 || path < 0 || path > 2) return CG1_ERR_ARG;
   const size_t T = offsets[n_out];
   if (T && (!bases_affine96 || !term_base || !term_scalars32)) return CG1_ERR_ARG;
-  if (path == 0) {
-    // pool estimate in group operations: 255 doublings per output that has a non-unit term, ~52 per non-unit term, 1 per unit term
-    double ops = 0;
+  for (size_t j = 0; j < n_out; ++j) if (offsets[j] > offsets[j + 1]) return CG1_ERR_ARG;
+  for (size_t t = 0; t < T; ++t) if ((term_base[t] & 0x7fffffffu) >= n_bases) { if (ctx) snprintf(ctx->err, sizeof ctx->err, "lincomb: base index out of range"); return CG1_ERR_ARG; }
+  // ---- which outputs go where
+  std::vector<uint32_t> gsel, psel;                          // output indices for the GPU / for the pool
+  if (path == 1 || !ctx) {
+    if (path == 2) return CG1_ERR_HIP;
+    path = 1;
+  } else if (path == 0) {
+    auto gpu_est = [](size_t m, size_t max_terms) -> double {            // us
+      if (m == 0) return 0.0;
+      return (m <= cg1::SM_MAX_MSMS && max_terms <= cg1::SM_MAX_N) ? 250.0 + 20.0 * (double)m : 1900.0;
+    };
+    double ops_all = 0, ops_small = 0;
+    size_t n_big = 0, big_max = 0, all_max = 0, n_shaped = 0;
+    std::vector<uint8_t> big(n_out, 0);                    // 1: >= 4 weighted terms; 2: "s * B" or "A + s * B" (the callers' map / fold loops)
     for (size_t j = 0; j < n_out; ++j) {
       size_t heavy = 0, unit = 0;
       for (size_t t = offsets[j]; t < offsets[j + 1]; ++t) {
@@ -1735,69 +1850,121 @@ int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_base
         for (int b = 1; b < 32 && small; ++b) small = sc[b] == 0;
         if (small) ++unit; else ++heavy;
       }
-      ops += (heavy ? 255.0 : 0.0) + 52.0 * (double)heavy + (double)unit;
+      const double ops = (heavy ? 255.0 : 0.0) + 52.0 * (double)heavy + (double)unit;
+      ops_all += ops;
+      all_max = std::max(all_max, (size_t)(offsets[j + 1] - offsets[j]));
+      if (heavy >= 4) { big[j] = 1; ++n_big; big_max = std::max(big_max, (size_t)(offsets[j + 1] - offsets[j])); }
+      else {
+        ops_small += ops;
+        if (heavy == 1 && offsets[j + 1] - offsets[j] <= 2) { big[j] = 2; ++n_shaped; }
+      }
     }
-    const double est_us = 0.25 * ops / (double)std::min<size_t>(n_out, 8);
-    path = (!ctx || est_us < 300.0) ? 1 : 2;
+    if (n_shaped >= 2048) {
+      // thousands of independent scalar multiplications (get_random_point over a long vector, a map / fold of 2^16 points): the batched
+      // scalar-multiplication kernel (k_batch_mul: one lane per output, ~2.2 ms of dependent doublings whatever the count) takes them;
+      // what is left of the batch is decided as below, without them
+      std::vector<uint32_t> ssel;
+      for (size_t j = 0; j < n_out; ++j) if (big[j] == 2) ssel.push_back((uint32_t)j);
+      std::vector<cg1h::jac> all(n_out, cg1h::jac_identity());
+      int rc = lincomb_shaped_device(ctx, bases_affine96, offsets, term_base, term_scalars32, ssel, all);
+      if (rc != CG1_OK) return rc;
+      if (ssel.size() < n_out) {
+        // the rest as its own batch (recursion depth 1: no shaped outputs of this size are left in it)
+        std::vector<uint32_t> rsel, roffs(1, 0), rtb;
+        std::vector<uint8_t> rsc;
+        for (size_t j = 0; j < n_out; ++j) if (big[j] != 2) {
+          rsel.push_back((uint32_t)j);
+          for (size_t t = offsets[j]; t < offsets[j + 1]; ++t) { rtb.push_back(term_base[t]); rsc.insert(rsc.end(), term_scalars32 + 32 * t, term_scalars32 + 32 * t + 32); }
+          roffs.push_back((uint32_t)rtb.size());
+        }
+        std::vector<uint8_t> rblobs(rsel.size() * CG1_POINT_BYTES);
+        rc = cg1_lincomb_batch(ctx, bases_affine96, n_bases, roffs.data(), rsel.size(), rtb.empty() ? nullptr : rtb.data(), rsc.empty() ? nullptr : rsc.data(), 0,
+                               rblobs.data(), nullptr, nullptr, nullptr);
+        if (rc != CG1_OK) return rc;
+        for (size_t q = 0; q < rsel.size(); ++q) all[rsel[q]] = blob_in(rblobs.data() + CG1_POINT_BYTES * q);
+      }
+      if (path_used) *path_used = 2;
+      cg1_lincomb_write_outputs(all.data(), n_out, out_blobs144, out_affine96, out_comp48);
+      return CG1_OK;
+    }
+    const double pool_all = 0.25 * ops_all / (double)std::min<size_t>(n_out, 8);
+    const double pool_small = n_out > n_big ? 0.25 * ops_small / (double)std::min<size_t>(n_out - n_big, 8) : 0.0;
+    const double hybrid = std::max(gpu_est(n_big, big_max), pool_small) + (n_big && n_out > n_big ? 30.0 : 0.0);
+    const double gpu_all = gpu_est(n_out, all_max);
+    if (pool_all <= hybrid && pool_all <= gpu_all) path = 1;
+    else if (gpu_all < hybrid || n_big == n_out) path = 2;
+    else {
+      path = 3;
+      for (size_t j = 0; j < n_out; ++j) (big[j] == 1 ? gsel : psel).push_back((uint32_t)j);
+    }
   }
   if (path_used) *path_used = path;
   if (path == 1) return cg1_lincomb_batch_pool(bases_affine96, n_bases, offsets, n_out, term_base, term_scalars32, out_blobs144, out_affine96, out_comp48, 0);
-  if (!ctx) return CG1_ERR_HIP;
-  if (T == 0) {
-    for (size_t j = 0; j < n_out; ++j) {
-      if (out_blobs144) blob_out(out_blobs144 + CG1_POINT_BYTES * j, cg1h::jac_identity());
-      if (out_affine96) memset(out_affine96 + 96 * j, 0, 96);
-      if (out_comp48) { memset(out_comp48 + 48 * j, 0, 48); out_comp48[48 * j] = 0xC0; }
+  if (path == 2 && n_out > 32768) {
+    // the regime-B chain takes up to 65 535 MSMs per call: halves
+    const size_t h = n_out / 2;
+    std::vector<uint32_t> o2(n_out - h + 1);
+    for (size_t j = h; j <= n_out; ++j) o2[j - h] = offsets[j] - offsets[h];
+    int rc = cg1_lincomb_batch(ctx, bases_affine96, n_bases, offsets, h, term_base, term_scalars32, 2, out_blobs144, out_affine96, out_comp48, nullptr);
+    if (rc != CG1_OK) return rc;
+    return cg1_lincomb_batch(ctx, bases_affine96, n_bases, o2.data(), n_out - h, term_base + offsets[h], term_scalars32 + 32 * (size_t)offsets[h], 2,
+                             out_blobs144 ? out_blobs144 + CG1_POINT_BYTES * h : nullptr, out_affine96 ? out_affine96 + 96 * h : nullptr,
+                             out_comp48 ? out_comp48 + 48 * h : nullptr, nullptr);
+  }
+  if (path == 2) { gsel.resize(n_out); for (size_t j = 0; j < n_out; ++j) gsel[j] = (uint32_t)j; }
+  std::vector<cg1h::jac> res(n_out, cg1h::jac_identity());
+  // ---- the GPU's share: its terms gathered (a negated base: y -> p - y on the standard-form record) into page-locked staging, one batched MSM
+  const size_t G = gsel.size();
+  std::vector<uint32_t> goffs(G + 1, 0);
+  for (size_t q = 0; q < G; ++q) goffs[q + 1] = goffs[q] + (offsets[gsel[q] + 1] - offsets[gsel[q]]);
+  const size_t TG = goffs[G];
+  std::vector<cg1h::jac> gres;
+  bool pending = false;
+  if (TG) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (TG * 128 > ctx->cap_h_lin) {
+      if (ctx->h_lin) (void)hipHostFree(ctx->h_lin);
+      ctx->h_lin = nullptr; ctx->cap_h_lin = 0;
+      const size_t want = TG * 128 + TG * 32 + 4096;
+      HIPCHK(hipHostMalloc((void**)&ctx->h_lin, want, hipHostMallocDefault));
+      ctx->cap_h_lin = want;
     }
-    return CG1_OK;
-  }
-  // gather the terms (a negated base: y -> p - y on the standard-form record) into page-locked staging, upload, one batched MSM
-  HIPCHK(hipSetDevice(ctx->device));
-  if (T * 128 > ctx->cap_h_lin) {
-    if (ctx->h_lin) (void)hipHostFree(ctx->h_lin);
-    ctx->h_lin = nullptr; ctx->cap_h_lin = 0;
-    const size_t want = T * 128 + T * 32 + 4096;
-    HIPCHK(hipHostMalloc((void**)&ctx->h_lin, want, hipHostMallocDefault));
-    ctx->cap_h_lin = want;
-  }
-  uint8_t* hp = ctx->h_lin;
-  uint8_t* hs = ctx->h_lin + T * 96;
-  for (size_t t = 0; t < T; ++t) {
-    const uint32_t b = term_base[t] & 0x7fffffffu;
-    if (b >= n_bases) { snprintf(ctx->err, sizeof ctx->err, "lincomb: base index out of range"); return CG1_ERR_ARG; }
-    const uint8_t* src = bases_affine96 + 96 * (size_t)b;
-    uint8_t* dst = hp + 96 * t;
-    memcpy(dst, src, 96);
-    if (term_base[t] >> 31) {
-      uint64_t y[6], any = 0;
-      memcpy(y, src + 48, 48);
-      for (int i = 0; i < 6; ++i) any |= y[i];
-      if (any) {                                         // (the identity record stays all-zero)
-        unsigned __int128 br = 0;
-        for (int i = 0; i < 6; ++i) { const unsigned __int128 d = (unsigned __int128)cg1::H_P[i] - y[i] - br; y[i] = (uint64_t)d; br = (d >> 64) & 1; }
-        memcpy(dst + 48, y, 48);
+    uint8_t* hp = ctx->h_lin;
+    uint8_t* hs = ctx->h_lin + TG * 96;
+    size_t o = 0;
+    for (size_t q = 0; q < G; ++q) {
+      for (size_t t = offsets[gsel[q]]; t < offsets[gsel[q] + 1]; ++t, ++o) {
+        const uint8_t* src = bases_affine96 + 96 * (size_t)(term_base[t] & 0x7fffffffu);
+        uint8_t* dst = hp + 96 * o;
+        memcpy(dst, src, 96);
+        if (term_base[t] >> 31) {
+          uint64_t y[6], any = 0;
+          memcpy(y, src + 48, 48);
+          for (int i = 0; i < 6; ++i) any |= y[i];
+          if (any) {                                         // (the identity record stays all-zero)
+            unsigned __int128 br = 0;
+            for (int i = 0; i < 6; ++i) { const unsigned __int128 d = (unsigned __int128)cg1::H_P[i] - y[i] - br; y[i] = (uint64_t)d; br = (d >> 64) & 1; }
+            memcpy(dst + 48, y, 48);
+          }
+        }
+        memcpy(hs + 32 * o, term_scalars32 + 32 * t, 32);
       }
     }
+    { int src = ensure_stage(ctx, TG * 96, TG * 32); if (src) return src; }
+    HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, hp, TG * 96, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, hs, TG * 32, hipMemcpyHostToDevice, ctx->stream));
+    int rc = cg1::msm_batched_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, goffs.data(), G, 0, gres, &pending);
+    if (rc != CG1_OK) return rc;
+  } else {
+    gres.assign(G, cg1h::jac_identity());
   }
-  memcpy(hs, term_scalars32, T * 32);
-  { int src = ensure_stage(ctx, T * 96, T * 32); if (src) return src; }
-  HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, hp, T * 96, hipMemcpyHostToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, hs, T * 32, hipMemcpyHostToDevice, ctx->stream));
-  std::vector<cg1h::jac> res;
-  int rc = cg1::msm_batched_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, offsets, n_out, 0, res);
-  if (rc != CG1_OK) return rc;
-  std::vector<cg1h::fe> xs(n_out), ys(n_out);
-  std::vector<uint8_t> inf(n_out);
-  cg1h::jac_batch_to_affine(res.data(), n_out, xs.data(), ys.data(), inf.data());
-  for (size_t j = 0; j < n_out; ++j) {
-    if (out_blobs144) blob_out(out_blobs144 + CG1_POINT_BYTES * j, inf[j] ? cg1h::jac_identity() : cg1h::jac_from_affine(xs[j], ys[j]));
-    if (out_affine96) {
-      uint8_t* o = out_affine96 + 96 * j;
-      if (inf[j]) memset(o, 0, 96);
-      else { cg1h::fe_to_le48(xs[j], o); cg1h::fe_to_le48(ys[j], o + 48); }
-    }
-    if (out_comp48) cg1h::g1_compress_affine(xs[j], ys[j], inf[j] != 0, out_comp48 + 48 * j);
-  }
+  // ---- the pool's share, while the launch runs
+  int prc = 0;
+  if (!psel.empty()) prc = cg1h::lincomb_pool_jac(bases_affine96, n_bases, offsets, term_base, term_scalars32, psel.data(), psel.size(), res.data(), 0);
+  if (pending) { int rc = cg1::msm_batched_small_end(ctx, G, gres); if (rc != CG1_OK) return rc; }
+  if (prc) return prc == 3 ? CG1_ERR_ENCODING : CG1_ERR_ARG;
+  for (size_t q = 0; q < G; ++q) res[gsel[q]] = gres[q];
+  cg1_lincomb_write_outputs(res.data(), n_out, out_blobs144, out_affine96, out_comp48);
   return CG1_OK;
 }
 

@@ -16,6 +16,8 @@
 #include <structmember.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdlib.h>
+#include <unistd.h>
 
 #define POINT_BYTES 144
 
@@ -96,30 +98,24 @@ static inline PyObject* slot_get(PyObject* o, Py_ssize_t off) { return *(PyObjec
 #define PF_NEAR 8
 static inline void pf_touch(const void* p) { __builtin_prefetch(p, 0, 1); }
 
-static PyObject* pf_pack_points(PyObject* self, PyObject* args) {
-  PyObject* seq; unsigned long long addr; Py_ssize_t cap;
-  if (!PyArg_ParseTuple(args, "OKn", &seq, &addr, &cap)) return NULL;
-  if (!g_point_type) { PyErr_SetString(PyExc_RuntimeError, "_pyface.bind() has not run"); return NULL; }
-  PyObject* fast = PySequence_Fast(seq, "pack_points expects a sequence of G1Point");
-  if (!fast) return NULL;
-  const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
-  if (n > cap) { Py_DECREF(fast); PyErr_SetString(PyExc_ValueError, "staging buffer too small"); return NULL; }
-  PyObject** items = PySequence_Fast_ITEMS(fast);
-  uint8_t* dst = (uint8_t*)(uintptr_t)addr;
+/* ---- the walks, over a range of a sequence's items; no call into the interpreter, no reference count touched: a helper thread may run
+ * them while the calling thread holds the GIL (the objects are immutable and nobody else can run Python code meanwhile).
+ * Return -1 when done, else the index of the first element that cannot be handled here (wrong type, no blob, an int the digit reader does
+ * not take): the caller looks at that element again under the GIL and raises what it deserves. */
+static Py_ssize_t walk_points(PyObject** items, Py_ssize_t lo, Py_ssize_t hi, Py_ssize_t n, uint8_t* dst, int* all_normalised) {
   int normalised = 1;
-  for (Py_ssize_t i = 0; i < n; ++i) {
+  for (Py_ssize_t i = lo; i < hi; ++i) {
     if (i + PF_FAR < n) pf_touch(items[i + PF_FAR]);
     if (i + PF_NEAR < n && Py_TYPE(items[i + PF_NEAR]) == g_point_type) {
       const char* nb = (const char*)slot_get(items[i + PF_NEAR], g_point_off);
       if (nb) { pf_touch(nb); pf_touch(nb + 64); pf_touch(nb + 128); }
     }
     PyObject* o = items[i];
-    if (Py_TYPE(o) != g_point_type) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd is not a G1Point", i); return NULL; }
+    if (Py_TYPE(o) != g_point_type) { *all_normalised = 0; return i; }
     PyObject* b = slot_get(o, g_point_off);
-    if (b == Py_None) { Py_DECREF(fast); PyErr_Format(g_unforced, "element %zd is a deferred value", i); return NULL; }
-    if (!b || !PyBytes_CheckExact(b) || PyBytes_GET_SIZE(b) != POINT_BYTES) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd holds no 144-byte blob", i); return NULL; }
+    if (!b || !PyBytes_CheckExact(b) || PyBytes_GET_SIZE(b) != POINT_BYTES) { *all_normalised = 0; return i; }
     const char* src = PyBytes_AS_STRING(b);
-    memcpy(dst + (size_t)POINT_BYTES * (size_t)i, src, POINT_BYTES);
+    memcpy(dst + (size_t)POINT_BYTES * (size_t)(i - lo), src, POINT_BYTES);
     if (normalised) {
       uint64_t z[6];
       memcpy(z, src + 96, 48);
@@ -127,8 +123,171 @@ static PyObject* pf_pack_points(PyObject* self, PyObject* args) {
       if (nz && memcmp(z, MONT_ONE, 48) != 0) normalised = 0;
     }
   }
+  *all_normalised = normalised;
+  return -1;
+}
+
+static inline int long_to_le32(PyObject* v, uint8_t* out);
+
+static Py_ssize_t walk_scalars(PyObject** items, Py_ssize_t lo, Py_ssize_t hi, Py_ssize_t n, uint8_t* dst) {
+  for (Py_ssize_t i = lo; i < hi; ++i) {
+    if (i + PF_FAR < n) pf_touch(items[i + PF_FAR]);
+    if (i + PF_NEAR < n && Py_TYPE(items[i + PF_NEAR]) == g_scalar_type) {
+      const void* nv = slot_get(items[i + PF_NEAR], g_scalar_off);
+      if (nv) pf_touch(nv);
+    }
+    PyObject* o = items[i];
+    PyObject* v;
+    if (Py_TYPE(o) == g_scalar_type) v = slot_get(o, g_scalar_off);
+    else if (PyLong_CheckExact(o)) v = o;                       /* plain ints are accepted: the accumulator keeps merged scalars as ints */
+    else return i;
+    if (!v || !PyLong_Check(v)) return i;
+    if (!long_to_le32(v, dst + 32 * (size_t)(i - lo))) return i;
+  }
+  return -1;
+}
+
+/* ---- helper threads for the walks over long sequences (2^20 objects: two pointer chases per element, every hop a cache miss -- one
+ * thread spends ~11 ns per element waiting; several threads wait side by side).  A small persistent crew, started at the first long walk;
+ * the calling thread takes a share too. */
+#include <pthread.h>
+#define PF_MAX_THREADS 8
+#define PF_MT_MIN 16384                    /* shorter ranges are walked by the caller alone */
+typedef struct {
+  int kind;                                /* 0 points, 1 scalars */
+  PyObject** items; Py_ssize_t lo, hi, n; uint8_t* dst; size_t rec;
+  Py_ssize_t err[PF_MAX_THREADS]; int normalised[PF_MAX_THREADS];
+  int parts;
+} pf_job;
+static struct {
+  pthread_mutex_t m; pthread_cond_t work, done;
+  pthread_t th[PF_MAX_THREADS];
+  int started, parts, pending; unsigned long generation;
+  pf_job* job;
+} g_crew = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, {0}, 0, 0, 0, 0, NULL};
+
+static void pf_run_part(pf_job* j, int part) {
+  const Py_ssize_t len = j->hi - j->lo, per = (len + j->parts - 1) / j->parts;
+  Py_ssize_t a = j->lo + per * part, b = a + per;
+  if (a > j->hi) a = j->hi;
+  if (b > j->hi) b = j->hi;
+  uint8_t* dst = j->dst + j->rec * (size_t)(a - j->lo);
+  j->normalised[part] = 1;
+  if (a >= b) { j->err[part] = -1; return; }
+  j->err[part] = j->kind == 0 ? walk_points(j->items, a, b, j->n, dst, &j->normalised[part]) : walk_scalars(j->items, a, b, j->n, dst);
+}
+
+static void* pf_crew_main(void* arg) {
+  const int me = (int)(intptr_t)arg;       /* part me + 1 (the caller runs part 0) */
+  unsigned long seen = 0;
+  for (;;) {
+    /* a walk over 2^20 objects arrives as 2 x 16 slices back to back: look out for the next one for a few microseconds before going to sleep */
+    for (int spin = 0; spin < 4000 && __atomic_load_n(&g_crew.generation, __ATOMIC_ACQUIRE) == seen; ++spin) __builtin_ia32_pause();
+    pthread_mutex_lock(&g_crew.m);
+    while (g_crew.generation == seen) pthread_cond_wait(&g_crew.work, &g_crew.m);
+    seen = g_crew.generation;
+    pf_job* j = g_crew.job;
+    const int parts = g_crew.parts;        /* read under the lock: the job lives on the caller's stack only while its parts are pending */
+    pthread_mutex_unlock(&g_crew.m);
+    if (j && me + 1 < parts) {
+      pf_run_part(j, me + 1);
+      pthread_mutex_lock(&g_crew.m);
+      if (--g_crew.pending == 0) pthread_cond_signal(&g_crew.done);
+      pthread_mutex_unlock(&g_crew.m);
+    }
+  }
+  return NULL;
+}
+
+static int g_walk_threads = -1;            /* -1: not decided yet; set_threads(n) overrides (1 = never use helpers) */
+
+static int pf_crew_size(void) {
+  if (g_walk_threads < 0) {
+    long c = sysconf(_SC_NPROCESSORS_ONLN);
+    const char* e = getenv("CURDLE_G1_WALK_THREADS");
+    if (e && atol(e) >= 1) c = atol(e);
+    if (c > PF_MAX_THREADS) c = PF_MAX_THREADS;
+    if (c < 1) c = 1;
+    g_walk_threads = (int)c;
+  }
+  return g_walk_threads;
+}
+
+/* walk [lo, hi) with the crew; returns the lowest failing index or -1; *all_normalised as walk_points */
+static Py_ssize_t pf_walk(int kind, PyObject** items, Py_ssize_t lo, Py_ssize_t hi, Py_ssize_t n, uint8_t* dst, int* all_normalised) {
+  pf_job j;
+  j.kind = kind; j.items = items; j.lo = lo; j.hi = hi; j.n = n; j.dst = dst; j.rec = kind == 0 ? POINT_BYTES : 32;
+  int parts = pf_crew_size();
+  if (hi - lo < PF_MT_MIN) parts = 1;
+  if (parts > 1) {
+    pthread_mutex_lock(&g_crew.m);
+    while (g_crew.started < parts - 1) {
+      if (pthread_create(&g_crew.th[g_crew.started], NULL, pf_crew_main, (void*)(intptr_t)g_crew.started) != 0) break;
+      pthread_detach(g_crew.th[g_crew.started]);
+      ++g_crew.started;
+    }
+    if (parts > g_crew.started + 1) parts = g_crew.started + 1;
+    pthread_mutex_unlock(&g_crew.m);
+  }
+  j.parts = parts;
+  if (parts > 1) {
+    pthread_mutex_lock(&g_crew.m);
+    g_crew.job = &j; g_crew.parts = parts; g_crew.pending = parts - 1; ++g_crew.generation;
+    pthread_cond_broadcast(&g_crew.work);
+    pthread_mutex_unlock(&g_crew.m);
+  }
+  pf_run_part(&j, 0);
+  if (parts > 1) {
+    for (int spin = 0; spin < 20000 && __atomic_load_n(&g_crew.pending, __ATOMIC_ACQUIRE) != 0; ++spin) __builtin_ia32_pause();
+    pthread_mutex_lock(&g_crew.m);
+    while (g_crew.pending != 0) pthread_cond_wait(&g_crew.done, &g_crew.m);
+    g_crew.job = NULL; g_crew.parts = 0;
+    pthread_mutex_unlock(&g_crew.m);
+  }
+  Py_ssize_t err = -1;
+  int norm = 1;
+  for (int p = 0; p < parts; ++p) {
+    if (j.err[p] >= 0 && (err < 0 || j.err[p] < err)) err = j.err[p];
+    if (!j.normalised[p]) norm = 0;
+  }
+  if (all_normalised) *all_normalised = norm;
+  return err;
+}
+
+/* set_threads(n): helper threads of the long walks (1 = the calling thread alone); returns the previous setting */
+static PyObject* pf_set_threads(PyObject* self, PyObject* args) {
+  int nth;
+  if (!PyArg_ParseTuple(args, "i", &nth)) return NULL;
+  const int prev = pf_crew_size();
+  if (nth >= 1) g_walk_threads = nth > PF_MAX_THREADS ? PF_MAX_THREADS : nth;
+  return PyLong_FromLong(prev);
+}
+
+/* pack_points(seq, dst_addr, capacity_points[, start, count]) -> (n, all_normalised)
+ * Copies the 144-byte blobs of seq[start : start + count] (default: all of it) to dst_addr + 144 i, i counted from `start`. */
+static PyObject* pf_pack_points(PyObject* self, PyObject* args) {
+  PyObject* seq; unsigned long long addr; Py_ssize_t cap, start = 0, count = -1;
+  if (!PyArg_ParseTuple(args, "OKn|nn", &seq, &addr, &cap, &start, &count)) return NULL;
+  if (!g_point_type) { PyErr_SetString(PyExc_RuntimeError, "_pyface.bind() has not run"); return NULL; }
+  PyObject* fast = PySequence_Fast(seq, "pack_points expects a sequence of G1Point");
+  if (!fast) return NULL;
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+  if (count < 0) count = n - start;
+  if (start < 0 || start > n || count > n - start) { Py_DECREF(fast); PyErr_SetString(PyExc_ValueError, "range outside the sequence"); return NULL; }
+  if (count > cap) { Py_DECREF(fast); PyErr_SetString(PyExc_ValueError, "staging buffer too small"); return NULL; }
+  PyObject** items = PySequence_Fast_ITEMS(fast);
+  int normalised = 1;
+  const Py_ssize_t bad = pf_walk(0, items, start, start + count, n, (uint8_t*)(uintptr_t)addr, &normalised);
+  if (bad >= 0) {
+    PyObject* o = items[bad];
+    if (Py_TYPE(o) != g_point_type) PyErr_Format(PyExc_TypeError, "element %zd is not a G1Point", bad);
+    else if (slot_get(o, g_point_off) == Py_None) PyErr_Format(g_unforced, "element %zd is a deferred value", bad);
+    else PyErr_Format(PyExc_TypeError, "element %zd holds no 144-byte blob", bad);
+    Py_DECREF(fast);
+    return NULL;
+  }
   Py_DECREF(fast);
-  return Py_BuildValue("ni", n, normalised);
+  return Py_BuildValue("ni", count, normalised);
 }
 
 /* pack_affine(seq, dst_addr, capacity_points) -> n
@@ -192,34 +351,38 @@ static inline int pf_long_as_le32(PyObject* v, uint8_t* out) {
 #endif
 }
 
-/* pack_scalars(seq, dst_addr, capacity) -> n
- * Writes int(s) of every Scalar of `seq` as 32 little-endian bytes to dst_addr + 32 i (Scalar.to_le_bytes, one call). */
+/* pack_scalars(seq, dst_addr, capacity[, start, count]) -> n
+ * Writes int(s) of every Scalar of seq[start : start + count] as 32 little-endian bytes to dst_addr + 32 i (Scalar.to_le_bytes, one call). */
 static PyObject* pf_pack_scalars(PyObject* self, PyObject* args) {
-  PyObject* seq; unsigned long long addr; Py_ssize_t cap;
-  if (!PyArg_ParseTuple(args, "OKn", &seq, &addr, &cap)) return NULL;
+  PyObject* seq; unsigned long long addr; Py_ssize_t cap, start = 0, count = -1;
+  if (!PyArg_ParseTuple(args, "OKn|nn", &seq, &addr, &cap, &start, &count)) return NULL;
   if (!g_scalar_type) { PyErr_SetString(PyExc_RuntimeError, "_pyface.bind() has not run"); return NULL; }
   PyObject* fast = PySequence_Fast(seq, "pack_scalars expects a sequence of Scalar");
   if (!fast) return NULL;
   const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
-  if (n > cap) { Py_DECREF(fast); PyErr_SetString(PyExc_ValueError, "staging buffer too small"); return NULL; }
+  if (count < 0) count = n - start;
+  if (start < 0 || start > n || count > n - start) { Py_DECREF(fast); PyErr_SetString(PyExc_ValueError, "range outside the sequence"); return NULL; }
+  if (count > cap) { Py_DECREF(fast); PyErr_SetString(PyExc_ValueError, "staging buffer too small"); return NULL; }
   PyObject** items = PySequence_Fast_ITEMS(fast);
   uint8_t* dst = (uint8_t*)(uintptr_t)addr;
-  for (Py_ssize_t i = 0; i < n; ++i) {
-    if (i + PF_FAR < n) pf_touch(items[i + PF_FAR]);
-    if (i + PF_NEAR < n && Py_TYPE(items[i + PF_NEAR]) == g_scalar_type) {
-      const void* nv = slot_get(items[i + PF_NEAR], g_scalar_off);
-      if (nv) pf_touch(nv);
-    }
-    PyObject* o = items[i];
+  Py_ssize_t lo = start;
+  const Py_ssize_t hi = start + count;
+  while (lo < hi) {
+    const Py_ssize_t bad = pf_walk(1, items, lo, hi, n, dst + 32 * (size_t)(lo - start), NULL);
+    if (bad < 0) break;
+    /* an element the digit reader does not take: wrong type (raise), or an int that is negative / too long / of another digit layout --
+     * let the interpreter's own conversion decide (it raises OverflowError where it must), then go on behind it */
+    PyObject* o = items[bad];
     PyObject* v;
     if (Py_TYPE(o) == g_scalar_type) v = slot_get(o, g_scalar_off);
-    else if (PyLong_CheckExact(o)) v = o;                       /* plain ints are accepted: the accumulator keeps merged scalars as ints */
-    else { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd is not a Scalar", i); return NULL; }
-    if (!v || !PyLong_Check(v)) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd holds no integer", i); return NULL; }
-    if (!long_to_le32(v, dst + 32 * (size_t)i) && pf_long_as_le32(v, dst + 32 * (size_t)i) < 0) { Py_DECREF(fast); return NULL; }   /* OverflowError: negative or >= 2^256 */
+    else if (PyLong_CheckExact(o)) v = o;
+    else { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd is not a Scalar", bad); return NULL; }
+    if (!v || !PyLong_Check(v)) { Py_DECREF(fast); PyErr_Format(PyExc_TypeError, "element %zd holds no integer", bad); return NULL; }
+    if (pf_long_as_le32(v, dst + 32 * (size_t)(bad - start)) < 0) { Py_DECREF(fast); return NULL; }
+    lo = bad + 1;
   }
   Py_DECREF(fast);
-  return PyLong_FromSsize_t(n);
+  return PyLong_FromSsize_t(count);
 }
 
 /* points_from_blobs(data, n) -> [G1Point, ...]: n objects over consecutive 144-byte blobs of a bytes-like object */
@@ -337,12 +500,13 @@ static PyMethodDef methods[] = {
     {"mk", (PyCFunction)(void (*)(void))pf_mk, METH_FASTCALL, "mk(blob, a, k, t, sg, seq) -> G1Point"},
     {"decode_lazy", pf_decode_lazy, METH_O, "decode_lazy(data48) -> G1Point (validated, y deferred)"},
     {"set_native", pf_set_native, METH_VARARGS, "set_native(address of cg1_validate_compressed)"},
+    {"set_threads", pf_set_threads, METH_VARARGS, "set_threads(n) -> previous: threads of the long walks"},
     {"ident", pf_ident, METH_VARARGS, "ident(seq) -> (n, fingerprint of the element identities)"},
     {"same_items", pf_same_items, METH_VARARGS, "same_items(a, b) -> bool"},
     {"bind", pf_bind, METH_VARARGS, "bind(G1Point, Scalar)"},
-    {"pack_points", pf_pack_points, METH_VARARGS, "pack_points(seq, dst_addr, capacity) -> (n, all_normalised)"},
+    {"pack_points", pf_pack_points, METH_VARARGS, "pack_points(seq, dst_addr, capacity[, start, count]) -> (n, all_normalised)"},
     {"pack_affine", pf_pack_affine, METH_VARARGS, "pack_affine(seq, dst_addr, capacity) -> n"},
-    {"pack_scalars", pf_pack_scalars, METH_VARARGS, "pack_scalars(seq, dst_addr, capacity) -> n"},
+    {"pack_scalars", pf_pack_scalars, METH_VARARGS, "pack_scalars(seq, dst_addr, capacity[, start, count]) -> n"},
     {"points_from_blobs", pf_points_from_blobs, METH_VARARGS, "points_from_blobs(data, n) -> list of G1Point"},
     {NULL, NULL, 0, NULL}};
 

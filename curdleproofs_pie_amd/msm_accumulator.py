@@ -164,6 +164,13 @@ def compute_MSM(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> G1Point:
             return B.msm_node(bases, scalars, n)
         st = _staging(ctx)
         sc_addr = st.scalars(n)
+        if n >= _SLICED_UPLOAD_MIN and B._pyface is not None:
+            fp = ident(bases)[1]
+            if fp not in _vec_cache and (fp not in _vec_seen or n > _VEC_CACHE_MAX_POINTS):
+                _vec_seen[fp] = None             # first sighting of this list of objects (the second makes it resident: _resident)
+                if len(_vec_seen) > 4 * _VEC_CACHE_MAX_ENTRIES:
+                    _vec_seen.popitem(last=False)
+                return _msm_sliced(ctx, st, sc_addr, bases, scalars, n)
         pack_scalars(scalars, sc_addr, st.cap_sc)
         vec = _resident(ctx, bases, n)
         if vec is not None:
@@ -179,6 +186,44 @@ def compute_MSM(bases: Iterable[G1Point], scalars: Iterable[Scalar]) -> G1Point:
         _, normalised = pack_points(bases, pt_addr, st.cap_pts)
         last_path = "blobs_normalised" if normalised else "blobs"
         return G1Point._from_blob(ctx.msm_blobs(pt_addr, sc_addr, n, bool(normalised)))
+
+
+_SLICED_UPLOAD_MIN = 1 << 15
+last_pack_ms = (0.0, 0.0, 0.0)              # (scalars walk, points walk, device call) of the last sliced compute_MSM, for the bench's python_face object
+
+
+def _msm_sliced(ctx, st, sc_addr: int, bases, scalars, n: int) -> G1Point:
+    """compute_MSM over tens of thousands of objects and more: the two lists are gathered SLICE BY SLICE (threaded C walks, csrc/pyface.c)
+    into page-locked staging, and each slice's upload (cg1_h2d_async on the context's copy stream) runs while the next slice is gathered;
+    the MSM then starts on blobs that are already on the device.  (Taken at the FIRST sighting of a base list; the second makes it
+    resident on the device, _resident, and only scalars move from then on.)"""
+    global last_path, last_pack_ms
+    import time as _t
+
+    pt_addr = st.points(n)
+    d_pts, d_sc = ctx.stage_reserve(N.POINT_BYTES * n, 32 * n)
+    step = 1 << 15 if n < (1 << 18) else 1 << 16
+    normalised = True
+    t_sc = t_pt = 0.0
+    for off in range(0, n, step):
+        cnt = min(step, n - off)
+        t0 = _t.perf_counter()
+        pack_scalars(scalars, sc_addr + 32 * off, cnt, off, cnt)
+        t1 = _t.perf_counter()
+        ctx.h2d_async(d_sc + 32 * off, sc_addr + 32 * off, 32 * cnt)
+        t2 = _t.perf_counter()
+        _, nz = pack_points(bases, pt_addr + N.POINT_BYTES * off, cnt, off, cnt)
+        t3 = _t.perf_counter()
+        ctx.h2d_async(d_pts + N.POINT_BYTES * off, pt_addr + N.POINT_BYTES * off, N.POINT_BYTES * cnt)
+        normalised = normalised and bool(nz)
+        t_sc += t1 - t0
+        t_pt += t3 - t2
+    ctx.copy_fence()
+    t4 = _t.perf_counter()
+    out = ctx.msm_blobs_device(d_pts, d_sc, n, normalised)
+    last_pack_ms = (t_sc * 1e3, t_pt * 1e3, (_t.perf_counter() - t4) * 1e3)
+    last_path = "blobs_normalised" if normalised else "blobs"
+    return G1Point._from_blob(out)
 
 
 @_locked
@@ -330,24 +375,22 @@ class MSMAccumulator:
     """
 
     def __init__(self) -> None:
-        self._calls: List[tuple] = []                      # (C, [bases], [scalar ints], rho) not merged yet
-        self._lhs_done: List[Tuple[bytes, int]] = []       # (affine96 of C_i, rho_i)
+        self._calls: List[tuple] = []                      # ([bases], [scalar ints], rho) not merged yet
+        self._lhs_pts: List[Tuple[G1Point, int]] = []      # (C_i, rho_i), in call order; C_i may still be a deferred value
         self._map: Dict[bytes, List] = {}                  # compressed48 -> [scalar int, affine96]
 
     def _settle(self) -> None:
-        """Merge the recorded calls into the map: every point of every call evaluated / decoded / normalised in one go."""
+        """Merge the recorded calls into the map: every base of every call evaluated / decoded / normalised in one go."""
         if not self._calls:
             return
         with _LOCK:
             calls, self._calls = self._calls, []
             pts = []
-            for C, bases, _, _ in calls:
-                pts.append(C)
+            for bases, _, _ in calls:
                 pts.extend(bases)
-            ensure_normalised(pts)             # ONE flush + ONE decoding + ONE inversion for the points not met before; CRS points keep their normal form
+            ensure_normalised(pts)             # ONE decoding + ONE inversion for the points not met before; CRS points keep their normal form
             m = self._map
-            for C, bases, svals, rho in calls:
-                self._lhs_done.append((C._a, rho))
+            for bases, svals, rho in calls:
                 for base, sv in zip(bases, svals):
                     a = base._a
                     if a == _ZERO96:  # :49-50 zero bases contribute nothing
@@ -365,8 +408,10 @@ class MSMAccumulator:
 
     @property
     def _lhs(self) -> List[Tuple[bytes, int]]:
-        self._settle()
-        return self._lhs_done
+        """(affine96 of C_i, rho_i) per call (evaluates the C_i that are still deferred)."""
+        with _LOCK:
+            ensure_normalised([C for C, _ in self._lhs_pts])
+        return [(C._a, rho) for C, rho in self._lhs_pts]
 
     @property
     def A_c(self) -> G1Point:  # the reference's running left-hand side (:45); computed on demand
@@ -389,16 +434,44 @@ class MSMAccumulator:
                 raise TypeError("accumulate_check: bases must be G1Point, scalars must be Scalar")
             bl.append(b)
             sl.append(s._v)
-        self._calls.append((C, bl, sl, rho))
+        self._lhs_pts.append((C, rho))
+        self._calls.append((bl, sl, rho))
         if not B._LAZY:
             self._settle()
 
     def _final_msm_terms(self) -> Tuple[bytes, bytes, int]:
-        ents = list(self.base_scalar_map.values())
-        lhs = self._lhs_done
-        pts = b"".join(e[1] for e in ents) + b"".join(a for a, _ in lhs)
-        sc = _scalars32([e[0] for e in ents] + [(-r) % CURVE_ORDER for _, r in lhs])
-        return pts, sc, len(ents) + len(lhs)
+        """Points and scalars of  sum_j s_j B_j - sum_i rho_i C_i.  A left-hand side that is still a deferred value over bases of G1
+        (tested once per base, one pooled call) is not evaluated at all: its terms join the sum with rho_i folded into their
+        coefficients; over a base outside G1 it is evaluated first, as the reference computes it (:45)."""
+        with _LOCK:
+            ents = list(self.base_scalar_map.values())
+            pts = [e[1] for e in ents]
+            sc = [e[0] for e in ents]
+            deferred = [C for C, _ in self._lhs_pts if C._t is not None]
+            if deferred:
+                B.certify_all(deferred)
+                rest = [C for C in deferred if C._sg is not True]
+                if rest:
+                    B.materialise(rest)
+            need = []
+            for C, _ in self._lhs_pts:
+                t = C._t
+                if t is None:
+                    need.append(C)
+                else:
+                    need.extend(t[1])
+            ensure_normalised(need)
+            R = CURVE_ORDER
+            for C, rho in self._lhs_pts:
+                t = C._t
+                if t is None:
+                    pts.append(C._a)
+                    sc.append((-rho) % R)
+                else:
+                    for c, l in zip(t[0], t[1]):
+                        pts.append(l._a)
+                        sc.append((-rho * c) % R)
+            return b"".join(pts), _scalars32(sc), len(sc)
 
     @staticmethod
     def verify_many(accumulators: List["MSMAccumulator"]) -> List[bool]:

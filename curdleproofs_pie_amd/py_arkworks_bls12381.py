@@ -165,7 +165,7 @@ _SIBLING_LOOKBEHIND = 0          # a flush takes the asked-for value and every l
 _pending: list = []              # weak references to deferred values, in creation order
 _next_seq = itertools.count(1).__next__
 _ref = weakref.ref
-stats = {"flushes": 0, "flushed_values": 0, "flush_terms": 0, "flush_host": 0, "flush_device": 0, "decoded": 0, "decode_batches": 0, "subgroup_tests": 0}
+stats = {"flushes": 0, "flushed_values": 0, "flush_terms": 0, "flush_host": 0, "flush_device": 0, "flush_hybrid": 0, "decoded": 0, "decode_batches": 0, "subgroup_tests": 0}
 
 
 def set_lazy(on: bool) -> bool:
@@ -589,13 +589,12 @@ def _flush(nodes) -> None:
     out_a = ctypes.create_string_buffer(96 * n_out)
     out_k = ctypes.create_string_buffer(48 * n_out)
     used = ctypes.c_int(0)
-    if from_msm:
-        ctx = N.default_context()       # compute_MSM has no host path: no GPU, no result
-        handle, path = ctx.handle, 2
-    else:
-        ctx = _have_gpu()
-        handle, path = (ctx.handle if ctx is not None else None), 0
-    rc = N.cg1_lincomb_batch(handle, bases, len(leaf_list), offs, n_out, tba, scb, path, out_b, out_a, out_k, ctypes.byref(used))
+    # compute_MSM has no host path: a batch carrying its results needs the GPU context (NativeError without one); the native call then
+    # splits the batch by what each engine is good at (csrc/msm_gpu.hip cg1_lincomb_batch: combinations of >= 4 weighted terms on the GPU,
+    # the one- to three-term operator results on the host's worker pool meanwhile)
+    ctx = N.default_context() if from_msm else _have_gpu()
+    handle = ctx.handle if ctx is not None else None
+    rc = N.cg1_lincomb_batch(handle, bases, len(leaf_list), offs, n_out, tba, scb, 0, out_b, out_a, out_k, ctypes.byref(used))
     if rc != N.OK:
         if ctx is not None:
             ctx.check(rc)
@@ -615,7 +614,7 @@ def _flush(nodes) -> None:
     stats["flushes"] += 1
     stats["flushed_values"] += n_out
     stats["flush_terms"] += T
-    stats["flush_device" if used.value == 2 else "flush_host"] += 1
+    stats[("flush_host", "flush_host", "flush_device", "flush_hybrid")[used.value & 3]] += 1
 
 
 def msm_node(bases, scalars, n: int) -> G1Point:
@@ -652,15 +651,18 @@ def msm_node(bases, scalars, n: int) -> G1Point:
     return _mk(None, None, None, (coefs, leaves, True), True if sg else None, _next_seq())
 
 
-def pack_points(points, addr: int, capacity: int):
-    """Write the blobs of `points` (list / tuple of G1Point) to addr + 144 i; returns (n, every blob has Z in {0, 1}).  Deferred
-    values among them are evaluated first (one batch)."""
+def pack_points(points, addr: int, capacity: int, start: int = 0, count: int = -1):
+    """Write the blobs of points[start : start + count] (list / tuple of G1Point; default: all) to addr + 144 i; returns (n, every blob
+    has Z in {0, 1}).  Deferred values among them are evaluated first (one batch).  Long ranges are walked by several threads
+    (csrc/pyface.c: the objects are immutable and the caller holds the GIL)."""
     if _pyface is not None:
         try:
-            return _pyface.pack_points(points, addr, capacity)
+            return _pyface.pack_points(points, addr, capacity, start, count)
         except Unforced:
-            materialise(points)
-            return _pyface.pack_points(points, addr, capacity)
+            materialise(points if count < 0 else points[start: start + count])
+            return _pyface.pack_points(points, addr, capacity, start, count)
+    if count >= 0 or start:
+        points = points[start: start + count] if count >= 0 else points[start:]
     n = len(points)
     if n > capacity:
         raise ValueError("staging buffer too small")
@@ -683,10 +685,12 @@ def pack_affine(points, addr: int, capacity: int) -> int:
     return n
 
 
-def pack_scalars(scalars, addr: int, capacity: int) -> int:
-    """Write int(s) of every Scalar (or plain int) of `scalars` as 32 little-endian bytes to addr + 32 i."""
+def pack_scalars(scalars, addr: int, capacity: int, start: int = 0, count: int = -1) -> int:
+    """Write int(s) of every Scalar (or plain int) of scalars[start : start + count] (default: all) as 32 little-endian bytes to addr + 32 i."""
     if _pyface is not None:
-        return _pyface.pack_scalars(scalars, addr, capacity)
+        return _pyface.pack_scalars(scalars, addr, capacity, start, count)
+    if count >= 0 or start:
+        scalars = scalars[start: start + count] if count >= 0 else scalars[start:]
     n = len(scalars)
     if n > capacity:
         raise ValueError("staging buffer too small")

@@ -136,6 +136,12 @@ int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points_affine96, const uint8_t*
  * arithmetic per call.  all_normalised != 0: every blob has Z = 1 or Z = 0 (the caller checked): no inversion at all. */
 int cg1_msm_blobs(cg1_ctx* ctx, const uint8_t* blobs144, const uint8_t* scalars32, size_t n, int all_normalised,
                   uint8_t out[CG1_POINT_BYTES]);
+/* The same in two halves, for a caller that uploads slice by slice while it is still gathering the next one (cg1_h2d_async +
+ * cg1_copy_fence): cg1_stage_reserve hands out the context's device staging for n blobs / n scalars (valid until the next call that
+ * stages more), cg1_msm_blobs_device sums over blobs already resident there (or anywhere else on the device). */
+int cg1_stage_reserve(cg1_ctx* ctx, size_t pts_bytes, size_t sc_bytes, void** d_pts, void** d_sc);
+int cg1_msm_blobs_device(cg1_ctx* ctx, const void* d_blobs144, const void* d_scalars32, size_t n, int all_normalised,
+                         uint8_t out[CG1_POINT_BYTES]);
 /* A point vector resident on the device in the accumulation kernels' record format -- crs.vec_G / vec_H / vec_R ... are the
  * bases of dozens of compute_MSM calls of one prover (curdleproofs.py:77,94,95,319; grand_prod.py:54,90; ipa.py:97,98): made
  * once (upload + k_prepare_blobs), then each MSM uploads only its scalars.  cg1_msm_vec sums scalars[i] * vec[first + i], i < n. */
@@ -272,7 +278,8 @@ int cg1_batch_subgroup_pool(const uint8_t* affine96, size_t n, uint8_t* out_flag
 /* out_j = sum_{t in [offsets[j], offsets[j+1])} scalars32[t] * (+/-) bases[term_base[t] & 0x7fffffff]  (bit 31 of term_base: the negated
  * base); offsets: n_out + 1 host entries, offsets[0] == 0.  path 0 = choose from the batch (never from the machine), 1 = the host's worker
  * pool, 2 = the GPU (cg1_msm_batched_device over the gathered terms).  ctx may be NULL for paths 0 / 1 (then always the pool).  Outputs
- * (each may be NULL) are normalised: point blobs with Z = 1, affine96, compressed48.  *path_used: which path ran. */
+ * (each may be NULL) are normalised: point blobs with Z = 1, affine96, compressed48.  *path_used: 1 pool, 2 GPU, 3 = both at once
+ * (combinations of >= 4 weighted terms in one k_msm_small launch, the smaller ones on the pool while it runs). */
 int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_bases, const uint32_t* offsets, size_t n_out,
                       const uint32_t* term_base, const uint8_t* term_scalars32, int path, uint8_t* out_blobs144, uint8_t* out_affine96,
                       uint8_t* out_comp48, int* path_used);

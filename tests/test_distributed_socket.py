@@ -81,8 +81,10 @@ def test_two_rank_g1_all_reduce(native_lib, mode):
     assert got[0] == got[1] == want
 
 
-def test_four_rank_hybrid_all_reduce(native_lib):
-    """2 window groups x 2 point groups over 4 ranks: every rank ends with the single-process result."""
+@pytest.mark.parametrize("world", [4, 8])
+def test_hybrid_all_reduce_over_four_and_eight_ranks(native_lib, world):
+    """2 window groups x (world / 2) point groups: every rank ends with the single-process result.  world = 8 is the driver's SCALE shape
+    (a GPU rehearsal of it is not possible: the pool admits 6 processes per card), here over the TCP transport on CPU."""
     import random
 
     import multiprocessing as mp
@@ -96,10 +98,10 @@ def test_four_rank_hybrid_all_reduce(native_lib):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _rdzv()
-    procs = [ctx.Process(target=_worker, args=(r, 4, port, "hybrid", q)) for r in range(4)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "hybrid", q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = dict(q.get(timeout=240) for _ in range(4))
+    got = dict(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -108,7 +110,7 @@ def test_four_rank_hybrid_all_reduce(native_lib):
     ks = [rng.randint(1, 2 ** 200) for _ in range(n)]
     scalars = [rng.randint(0, 2 ** 255 - 20) for _ in range(n)]
     want = O.g1_compress(O.g1_mul(O.G1_GEN, sum(k * (s % O.R) for k, s in zip(ks, scalars)) % O.R)).hex()
-    assert got[0] == got[1] == got[2] == got[3] == want
+    assert len(got) == world and set(got.values()) == {want}
 
 
 def _worker_batch(rank, world, port, q):

@@ -301,3 +301,51 @@ def test_operators_from_several_threads(B):
     for th in ths:
         th.join()
     assert errors == []
+
+
+def _random_batch(rng, bases, shapes):
+    offsets, tb, sc = [0], [], []
+    for k in shapes:
+        for _ in range(k):
+            i = rng.randrange(len(bases))
+            tb.append(i | (0x80000000 if rng.random() < 0.3 else 0))
+            sc.append(rng.choice([0, 1, 1, 2, rng.randrange(O.R), rng.randrange(O.R), rng.randrange(O.R)]))
+        offsets.append(len(tb))
+    return offsets, tb, sc
+
+
+@pytest.mark.gpu
+def test_lincomb_batch_on_the_gpu_and_split_between_both(native_lib):
+    """cg1_lincomb_batch: the GPU path (one k_msm_small launch for up to 64 combinations, the regime-B chain beyond), the split path
+    (large combinations on the GPU while the pool does the small ones) and the pool give the same normalised outputs, byte for byte;
+    the pool's are pinned by the oracle above."""
+    N = native_lib
+    ctx = N.default_context()
+    rng = random.Random(15)
+    bases = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(40)] + [None, O.g1_add(O.g1_mul(O.G1_GEN, 5), T3)]
+    raw = b"".join(bytes(96) if p is None else p[0].to_bytes(48, "little") + p[1].to_bytes(48, "little") for p in bases)
+    seen = set()
+    for shapes in ([1, 2, 3, 1, 0, 2], [40, 17, 129, 64], [7] * 10 + [1, 2, 3] * 9 + [0], [1] * 56, [300, 5, 1, 1, 2, 0, 9], [3] * 70 + [20] * 3, [5] * 80,
+                   [1] * 2100 + [2] * 40 + [9] * 3 + [0]):      # thousands of s * B / A + s * B: the batched scalar-multiplication kernel
+        offsets, tb, sc = _random_batch(rng, bases, shapes)
+        n_out = len(shapes)
+        offs = (ctypes.c_uint32 * (n_out + 1))(*offsets)
+        tba = (ctypes.c_uint32 * max(1, len(tb)))(*tb)
+        scb = b"".join(s.to_bytes(32, "little") for s in sc) or bytes(32)
+        outs = {}
+        for path in (1, 2, 0):
+            ob, oa, ok = (ctypes.create_string_buffer(144 * n_out), ctypes.create_string_buffer(96 * n_out), ctypes.create_string_buffer(48 * n_out))
+            used = ctypes.c_int(0)
+            ctx.check(N.cg1_lincomb_batch(ctx.handle, raw, len(bases), offs, n_out, tba, scb, path, ob, oa, ok, ctypes.byref(used)))
+            assert used.value == path or path == 0
+            seen.add(used.value)
+            outs[path] = (ob.raw, oa.raw, ok.raw)
+        assert outs[1] == outs[2] == outs[0], shapes
+        # the oracle on a sample of the outputs
+        for j in rng.sample(range(n_out), min(n_out, 4)):
+            acc = None
+            for t in range(offsets[j], offsets[j + 1]):
+                b = bases[tb[t] & 0x7fffffff]
+                acc = O.g1_add(acc, _imul(O.g1_neg(b) if tb[t] >> 31 else b, sc[t]))
+            assert outs[0][2][48 * j: 48 * j + 48] == O.g1_compress(acc)
+    assert seen == {1, 2, 3}

@@ -262,8 +262,15 @@ def test_compute_msm_paths_blobs_and_resident_vectors(api):
     (second sighting of the same objects).  Every path gives the reference loop's result."""
     A, U = api
     import curdleproofs_pie_amd.msm_accumulator as M
+    import curdleproofs_pie_amd.py_arkworks_bls12381 as B
 
     want_of = lambda b, s: O.g1_compress(O.compute_MSM_fast([O.g1_decompress(bytes(x.to_compressed_bytes())) for x in b], [int(v) for v in s]))
+    if B.lazy_enabled():
+        # calls of the protocol's sizes are deferred values (evaluated by the GPU's batched MSM when their bytes are asked for); the
+        # three immediate ways in serve calls above M.LAZY_MSM_MAX terms (and everything when deferral is off: the other parameter)
+        deferred = True
+    else:
+        deferred = False
     for n, first_path in ((200, "affine"), (1500, "blobs")):
         M.clear_vec_cache()
         random.seed(21 + n)
@@ -276,17 +283,17 @@ def test_compute_msm_paths_blobs_and_resident_vectors(api):
             got = A.compute_MSM(bases, scalars)
             seen.append(M.last_path)
             assert bytes(got.to_compressed_bytes()) == want_of(bases, scalars)
-        assert seen == [first_path, "resident", "resident", "resident"]
+        assert seen == (["deferred"] * 4 if deferred else [first_path, "resident", "resident", "resident"])
         # a prefix of the resident list is another sequence of objects: its own entry
         scalars = [U.random_scalar() for _ in range(n - 9)]
         assert bytes(A.compute_MSM(bases[: n - 9], scalars).to_compressed_bytes()) == want_of(bases[: n - 9], scalars)
-        assert M.last_path == first_path
+        assert M.last_path == ("deferred" if deferred else first_path)
         # replacing an element of the caller's list must not hit the stale resident vector
         bases[5] = U.get_random_point()
         scalars = [U.random_scalar() for _ in range(n)]
         assert bytes(A.compute_MSM(bases, scalars).to_compressed_bytes()) == want_of(bases, scalars)
-        assert M.last_path == first_path
-        if n > 1024:
+        assert M.last_path == ("deferred" if deferred else first_path)
+        if n > 1024 and not deferred:
             # normal forms (decoded points) skip the device inversion
             dec = [A.G1Point.from_compressed_bytes_unchecked(b.to_compressed_bytes()) for b in bases]
             assert bytes(A.compute_MSM(dec, scalars).to_compressed_bytes()) == want_of(bases, scalars)
@@ -340,3 +347,80 @@ def test_msm_blobs_many_points_per_lane(native_lib):
     with pytest.raises(N.NativeError):
         ctx.msm_vec(vec, s32, n, 1)                                       # window past the end
     vec.free()
+
+
+def test_drop_in_from_four_threads(api):
+    """The wheel's values may be used from any thread; so may this backend: 4 Python threads, 1 000 iterations between them, each a
+    compute_MSM of a mixed size -- deferred (k_msm_small through the batched evaluation), immediate over host-normalised points, over
+    blobs, over a base list resident on the device -- or a whole MSMAccumulator sequence, every result checked against the oracle's
+    closed form (the bases are k_i G, so the sum is (sum k_i s_i) G).  One lock serialises the device calls (msm_accumulator._LOCK)."""
+    import threading
+
+    A, U = api
+    import curdleproofs_pie_amd.msm_accumulator as M
+    from curdleproofs_pie_amd.msm_accumulator import batch_mul
+
+    rng = random.Random(31)
+    n_max = 3000
+    ks = [rng.randint(1, O.R - 1) for _ in range(n_max)]
+    pts = batch_mul([A.G1Point()] * n_max, [A.Scalar(k) for k in ks])
+    shared = pts[:2500]                                       # one list object used by every thread: becomes resident on the device
+    errors = []
+    want_cache = {}
+    lock = threading.Lock()
+
+    def expect(tot):
+        with lock:
+            w = want_cache.get(tot)
+        if w is None:
+            w = O.g1_compress(O.g1_mul(O.G1_GEN, tot % O.R))
+            with lock:
+                want_cache[tot] = w
+        return w
+
+    def worker(t):
+        r = random.Random(100 + t)
+        try:
+            for it in range(250):
+                kind = r.choice(["small", "small", "mid", "blobs", "resident", "acc"])
+                if kind == "acc":
+                    acc = A.MSMAccumulator()
+                    for _ in range(3):
+                        m = r.choice([4, 17, 60])
+                        idx = [r.randrange(n_max) for _ in range(m)]
+                        sc = [r.randint(0, O.R - 1) for _ in range(m)]
+                        C = A.compute_MSM([pts[i] for i in idx], [A.Scalar(s) for s in sc])
+                        acc.accumulate_check(C, [pts[i] for i in idx], [A.Scalar(s) for s in sc])
+                    acc.verify()
+                    bad = A.MSMAccumulator()
+                    bad.accumulate_check(pts[0], [pts[1]], [A.Scalar(1)])
+                    try:
+                        bad.verify()
+                        errors.append((t, it, "a wrong check was accepted"))
+                    except AssertionError:
+                        pass
+                    continue
+                if kind == "resident":
+                    bases, idx = shared, range(2500)
+                else:
+                    m = {"small": r.choice([1, 5, 37, 300]), "mid": r.choice([1100, 1900]), "blobs": r.choice([2100, 2900])}[kind]
+                    lo = r.randrange(n_max - m + 1)
+                    idx = range(lo, lo + m)
+                    bases = pts[lo: lo + m]
+                sc = [r.randint(0, O.R - 1) for _ in idx]
+                got = A.compute_MSM(bases, [A.Scalar(s) for s in sc])
+                if bytes(got.to_compressed_bytes()) != expect(sum(ks[i] * s for i, s in zip(idx, sc))):
+                    errors.append((t, it, kind, len(sc)))
+        except Exception as e:           # noqa: BLE001 -- reported below
+            import traceback
+
+            errors.append((t, repr(e), traceback.format_exc()[-600:]))
+
+    M.clear_vec_cache()
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert errors == []
+    M.clear_vec_cache()

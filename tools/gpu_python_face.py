@@ -70,6 +70,8 @@ def time_compute_msm(n, projective, reps, seed=1, check=True):
         t = ctx.timings()
         dev.append(t["host_enqueue"] + t["host_wait"] + t["host_events"] + t["host_horner"])
     res["path"] = path0
+    if n >= M._SLICED_UPLOAD_MIN:
+        res["sliced_upload_ms"] = dict(zip(("scalar_walks", "point_walks", "msm_after_fence"), (round(v, 3) for v in M.last_pack_ms)))
     res["wall_ms"] = min(walls)
     res["wall_ms_median"] = sorted(walls)[len(walls) // 2]
     res["device_call_ms"] = min(dev)                           # enqueue + wait + Horner inside cg1_msm_blobs (H2D queued in front of it)

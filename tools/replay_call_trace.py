@@ -4,7 +4,7 @@ Python face.  Every output the reference's caller could observe -- compressed by
 must come back bit for bit; the wall time is what the reference's UNCHANGED control flow costs on this backend (its scalar
 arithmetic and transcript, which are the caller's own Python, are not in the trace).
 
-    python tools/replay_call_trace.py [--reps 5]            -> profiles/r04_call_trace_replay.txt
+    python tools/replay_call_trace.py [--reps 5]            -> profiles/r05_call_trace_replay.txt
 """
 import argparse
 import json
@@ -138,12 +138,7 @@ def product_replayer(doc, blob):
     return Replayer(doc, blob, A.G1Point, A.Scalar, A.compute_MSM, ReplayAccumulator, set_rho)
 
 
-def measure(reps=3):
-    """{"verify_ms", "prove_ms", by-kind splits, "parity"}: best of `reps` full replays (fresh value table each time; the normal-form and
-    resident-vector caches of the Python face behave as in a long-lived process: CRS points stay the same objects across proofs)."""
-    doc, blob = load()
-    out = {"what": "the reference's backend calls of one ell = 124 proof replayed through curdleproofs_pie_amd (G1Point ops on the host library, compute_MSM / MSMAccumulator on the GPU)",
-           "ops": {ph: sum(doc["counts"][ph].values()) for ph in ("setup", "prove", "verify")}}
+def _measure_mode(doc, blob, reps):
     best = {}
     parity = True
     for r in range(reps):
@@ -158,9 +153,37 @@ def measure(reps=3):
         for ph in ("prove", "verify"):
             if ph not in best or times[ph] < best[ph][0]:
                 best[ph] = (times[ph], kinds[ph])
-    for ph in ("prove", "verify"):
-        out[ph + "_ms"] = best[ph][0] * 1e3
-        out[ph + "_by_kind_ms"] = {k: {"calls": v[0], "ms": round(v[1] * 1e3, 3)} for k, v in sorted(best[ph][1].items(), key=lambda kv: -kv[1][1])}
+    return best, parity
+
+
+def measure(reps=3, ab=True):
+    """{"verify_ms", "prove_ms", by-kind splits, "parity"}: best of `reps` full replays (fresh value table each time; the normal-form and
+    resident-vector caches of the Python face behave as in a long-lived process: CRS points stay the same objects across proofs) with
+    the operators deferred (the default), and -- `ab` -- the same with every operator computing at once (CURDLE_G1_LAZY=0, round 4)."""
+    import curdleproofs_pie_amd.py_arkworks_bls12381 as B
+
+    doc, blob = load()
+    out = {"what": "the reference's backend calls of one ell = 124 proof replayed through curdleproofs_pie_amd, its control flow unchanged: the G1Point operators return "
+                   "deferred values, evaluated in batches (host worker pool for a handful of operator results, the GPU's batched MSM for the rest and for every compute_MSM) "
+                   "when bytes or a comparison are asked for; compute_MSM / MSMAccumulator on the GPU",
+           "ops": {ph: sum(doc["counts"][ph].values()) for ph in ("setup", "prove", "verify")}}
+    prev = B.set_lazy(True)
+    try:
+        s0 = dict(B.stats)
+        best, parity = _measure_mode(doc, blob, reps)
+        s1 = dict(B.stats)
+        out["deferred"] = True
+        for ph in ("prove", "verify"):
+            out[ph + "_ms"] = best[ph][0] * 1e3
+            out[ph + "_by_kind_ms"] = {k: {"calls": v[0], "ms": round(v[1] * 1e3, 3)} for k, v in sorted(best[ph][1].items(), key=lambda kv: -kv[1][1])}
+        out["per_replay"] = {k: round((s1[k] - s0[k]) / reps, 1) for k in s1}
+        if ab:
+            B.set_lazy(False)
+            eb, ep = _measure_mode(doc, blob, max(1, reps - 1))
+            out["eager"] = {"verify_ms": eb["verify"][0] * 1e3, "prove_ms": eb["prove"][0] * 1e3, "parity": ep}
+            parity = parity and ep
+    finally:
+        B.set_lazy(prev)
     out["parity"] = parity
     return out
 
