@@ -1764,6 +1764,8 @@ int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars,
 extern "C" void cg1_lincomb_write_outputs(const void* jac_results, size_t n_out, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48);
 }  // extern "C"
 
+constexpr size_t LINCOMB_MAX_REGIME_B = 2048;    // independent MSMs cg1_lincomb_batch hands the regime-B chain in one call (r04: 1 024 - 2 048 x 627 terms)
+
 // results[sel[q]] = s * B (+ A) for the selected outputs, each one weighted term and at most one unit term: one k_batch_mul launch
 static void negate_affine96_y(uint8_t* rec) {
   uint64_t y[6], any = 0;
@@ -1837,7 +1839,9 @@ int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_base
   } else if (path == 0) {
     auto gpu_est = [](size_t m, size_t max_terms) -> double {            // us
       if (m == 0) return 0.0;
-      return (m <= cg1::SM_MAX_MSMS && max_terms <= cg1::SM_MAX_N) ? 250.0 + 20.0 * (double)m : 1900.0;
+      if (m <= cg1::SM_MAX_MSMS && max_terms <= cg1::SM_MAX_N) return 250.0 + 20.0 * (double)m;
+      if (m <= LINCOMB_MAX_REGIME_B) return 1900.0 + 2.0 * (double)m;
+      return 1e18;           // more independent MSMs than the regime-B chain has ever been run with: the pool (or k_batch_mul above) takes them
     };
     double ops_all = 0, ops_small = 0;
     size_t n_big = 0, big_max = 0, all_max = 0, n_shaped = 0;
@@ -1900,8 +1904,8 @@ int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_base
   }
   if (path_used) *path_used = path;
   if (path == 1) return cg1_lincomb_batch_pool(bases_affine96, n_bases, offsets, n_out, term_base, term_scalars32, out_blobs144, out_affine96, out_comp48, 0);
-  if (path == 2 && n_out > 32768) {
-    // the regime-B chain takes up to 65 535 MSMs per call: halves
+  if (path == 2 && n_out > LINCOMB_MAX_REGIME_B) {
+    // the regime-B chain is run with at most LINCOMB_MAX_REGIME_B MSMs per call (what it has been measured with): halves
     const size_t h = n_out / 2;
     std::vector<uint32_t> o2(n_out - h + 1);
     for (size_t j = h; j <= n_out; ++j) o2[j - h] = offsets[j] - offsets[h];

@@ -184,15 +184,15 @@ static void* pf_crew_main(void* arg) {
     /* a walk over 2^20 objects arrives as 2 x 16 slices back to back: look out for the next one for a few microseconds before going to sleep */
     for (int spin = 0; spin < 4000 && __atomic_load_n(&g_crew.generation, __ATOMIC_ACQUIRE) == seen; ++spin) __builtin_ia32_pause();
     pthread_mutex_lock(&g_crew.m);
-    while (g_crew.generation == seen) pthread_cond_wait(&g_crew.work, &g_crew.m);
-    seen = g_crew.generation;
+    while (__atomic_load_n(&g_crew.generation, __ATOMIC_ACQUIRE) == seen) pthread_cond_wait(&g_crew.work, &g_crew.m);
+    seen = __atomic_load_n(&g_crew.generation, __ATOMIC_ACQUIRE);
     pf_job* j = g_crew.job;
     const int parts = g_crew.parts;        /* read under the lock: the job lives on the caller's stack only while its parts are pending */
     pthread_mutex_unlock(&g_crew.m);
     if (j && me + 1 < parts) {
       pf_run_part(j, me + 1);
       pthread_mutex_lock(&g_crew.m);
-      if (--g_crew.pending == 0) pthread_cond_signal(&g_crew.done);
+      if (__atomic_sub_fetch(&g_crew.pending, 1, __ATOMIC_ACQ_REL) == 0) pthread_cond_signal(&g_crew.done);
       pthread_mutex_unlock(&g_crew.m);
     }
   }
@@ -232,7 +232,9 @@ static Py_ssize_t pf_walk(int kind, PyObject** items, Py_ssize_t lo, Py_ssize_t 
   j.parts = parts;
   if (parts > 1) {
     pthread_mutex_lock(&g_crew.m);
-    g_crew.job = &j; g_crew.parts = parts; g_crew.pending = parts - 1; ++g_crew.generation;
+    g_crew.job = &j; g_crew.parts = parts;
+    __atomic_store_n(&g_crew.pending, parts - 1, __ATOMIC_RELEASE);
+    __atomic_add_fetch(&g_crew.generation, 1, __ATOMIC_RELEASE);      /* (the crew looks at these two without the lock while it spins) */
     pthread_cond_broadcast(&g_crew.work);
     pthread_mutex_unlock(&g_crew.m);
   }
@@ -240,7 +242,7 @@ static Py_ssize_t pf_walk(int kind, PyObject** items, Py_ssize_t lo, Py_ssize_t 
   if (parts > 1) {
     for (int spin = 0; spin < 20000 && __atomic_load_n(&g_crew.pending, __ATOMIC_ACQUIRE) != 0; ++spin) __builtin_ia32_pause();
     pthread_mutex_lock(&g_crew.m);
-    while (g_crew.pending != 0) pthread_cond_wait(&g_crew.done, &g_crew.m);
+    while (__atomic_load_n(&g_crew.pending, __ATOMIC_ACQUIRE) != 0) pthread_cond_wait(&g_crew.done, &g_crew.m);
     g_crew.job = NULL; g_crew.parts = 0;
     pthread_mutex_unlock(&g_crew.m);
   }

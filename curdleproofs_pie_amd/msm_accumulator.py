@@ -200,24 +200,35 @@ def _msm_sliced(ctx, st, sc_addr: int, bases, scalars, n: int) -> G1Point:
     global last_path, last_pack_ms
     import time as _t
 
-    pt_addr = st.points(n)
-    d_pts, d_sc = ctx.stage_reserve(N.POINT_BYTES * n, 32 * n)
     step = 1 << 15 if n < (1 << 18) else 1 << 16
-    normalised = True
-    t_sc = t_pt = 0.0
-    for off in range(0, n, step):
-        cnt = min(step, n - off)
-        t0 = _t.perf_counter()
-        pack_scalars(scalars, sc_addr + 32 * off, cnt, off, cnt)
-        t1 = _t.perf_counter()
-        ctx.h2d_async(d_sc + 32 * off, sc_addr + 32 * off, 32 * cnt)
-        t2 = _t.perf_counter()
-        _, nz = pack_points(bases, pt_addr + N.POINT_BYTES * off, cnt, off, cnt)
-        t3 = _t.perf_counter()
-        ctx.h2d_async(d_pts + N.POINT_BYTES * off, pt_addr + N.POINT_BYTES * off, N.POINT_BYTES * cnt)
-        normalised = normalised and bool(nz)
-        t_sc += t1 - t0
-        t_pt += t3 - t2
+    for attempt in (0, 1):
+        pt_addr = st.points(n)
+        d_pts, d_sc = ctx.stage_reserve(N.POINT_BYTES * n, 32 * n)
+        normalised = True
+        t_sc = t_pt = 0.0
+        try:
+            for off in range(0, n, step):
+                cnt = min(step, n - off)
+                t0 = _t.perf_counter()
+                pack_scalars(scalars, sc_addr + 32 * off, cnt, off, cnt)
+                t1 = _t.perf_counter()
+                ctx.h2d_async(d_sc + 32 * off, sc_addr + 32 * off, 32 * cnt)
+                t2 = _t.perf_counter()
+                _, nz = pack_points(bases, pt_addr + N.POINT_BYTES * off, cnt, off, cnt, raise_unforced=True)
+                t3 = _t.perf_counter()
+                ctx.h2d_async(d_pts + N.POINT_BYTES * off, pt_addr + N.POINT_BYTES * off, N.POINT_BYTES * cnt)
+                normalised = normalised and bool(nz)
+                t_sc += t1 - t0
+                t_pt += t3 - t2
+            break
+        except B.Unforced:
+            # a base is still a deferred value: evaluating it uses the very staging the slices are going up through -- let the copies
+            # land, evaluate every deferred base (one batch), and gather again from the first slice
+            if attempt:
+                raise
+            ctx.copy_fence()
+            ctx.check(N.cg1_stream_sync(ctx.handle))
+            B.materialise(bases)
     ctx.copy_fence()
     t4 = _t.perf_counter()
     out = ctx.msm_blobs_device(d_pts, d_sc, n, normalised)

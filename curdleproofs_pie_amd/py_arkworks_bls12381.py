@@ -651,7 +651,7 @@ def msm_node(bases, scalars, n: int) -> G1Point:
     return _mk(None, None, None, (coefs, leaves, True), True if sg else None, _next_seq())
 
 
-def pack_points(points, addr: int, capacity: int, start: int = 0, count: int = -1):
+def pack_points(points, addr: int, capacity: int, start: int = 0, count: int = -1, raise_unforced: bool = False):
     """Write the blobs of points[start : start + count] (list / tuple of G1Point; default: all) to addr + 144 i; returns (n, every blob
     has Z in {0, 1}).  Deferred values among them are evaluated first (one batch).  Long ranges are walked by several threads
     (csrc/pyface.c: the objects are immutable and the caller holds the GIL)."""
@@ -659,6 +659,8 @@ def pack_points(points, addr: int, capacity: int, start: int = 0, count: int = -
         try:
             return _pyface.pack_points(points, addr, capacity, start, count)
         except Unforced:
+            if raise_unforced:              # the caller has uploads in flight that an evaluation would disturb: it evaluates and starts over
+                raise
             materialise(points if count < 0 else points[start: start + count])
             return _pyface.pack_points(points, addr, capacity, start, count)
     if count >= 0 or start:

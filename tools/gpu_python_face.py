@@ -29,8 +29,14 @@ def make_points(n, seed, projective):
     ks = [rng.randint(1, R - 1) for _ in range(n)]
     pts = batch_mul([A.G1Point()] * n, [A.Scalar._raw(k) for k in ks])
     if projective:
-        Q = A.G1Point() * A.Scalar(12345)
-        pts = [(p + Q) - Q for p in pts]
+        import curdleproofs_pie_amd.py_arkworks_bls12381 as B
+
+        prev = B.set_lazy(False)           # computed at once on the host library: the blobs keep Z != 1 (a deferred value would leave its evaluation normalised)
+        try:
+            Q = A.G1Point() * A.Scalar(12345)
+            pts = [(p + Q) - Q for p in pts]
+        finally:
+            B.set_lazy(prev)
     return pts, ks
 
 
@@ -40,6 +46,8 @@ def time_compute_msm(n, projective, reps, seed=1, check=True):
     import curdleproofs_pie_amd.py_arkworks_bls12381 as B
     from curdleproofs_pie_amd import _native as N
 
+    note = lambda m: print("[gpu_python_face] n = %d %s: %s" % (n, "projective" if projective else "normal forms", m), file=sys.stderr, flush=True)
+    note("making the points")
     pts, ks = make_points(n, seed, projective)
     rng = random.Random(seed + 100)
     sc_ints = [rng.randint(0, R - 1) for _ in range(n)]
@@ -47,7 +55,9 @@ def time_compute_msm(n, projective, reps, seed=1, check=True):
     ctx = N.default_context()
     M.clear_vec_cache()
     res = {"n": n, "inputs": "projective blobs (Z != 1)" if projective else "normal forms (Z = 1)"}
+    note("warm-up call")
     A.compute_MSM(pts[:64], scalars[:64])                      # library warm-up (context, staging growth is part of 'first')
+    note("first call")
     t0 = time.perf_counter()
     first = A.compute_MSM(pts, scalars)
     res["first_call_ms"] = (time.perf_counter() - t0) * 1e3    # includes growing the page-locked staging
@@ -57,6 +67,7 @@ def time_compute_msm(n, projective, reps, seed=1, check=True):
         assert first == A.G1Point() * A.Scalar(tot), "compute_MSM differs from its closed form"
     # steady state, fresh lists every time so the identity cache never hits: the "blobs" path
     walls, dev = [], []
+    note("steady state (%s)" % path0)
     for _ in range(reps):
         b2 = list(pts)
         b2[0], b2[1] = b2[1], b2[0]
@@ -82,6 +93,7 @@ def time_compute_msm(n, projective, reps, seed=1, check=True):
     res["pack_points_ms"] = (t1 - t0) * 1e3
     res["pack_scalars_ms"] = (t2 - t1) * 1e3
     res["h2d_bytes"] = 176 * n
+    note("resident vector")
     # resident vector: the same list object again and again (only scalars move)
     A.compute_MSM(pts, scalars); A.compute_MSM(pts, scalars)
     walls = []
