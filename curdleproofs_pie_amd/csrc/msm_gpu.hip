@@ -60,6 +60,7 @@ int pick_window(size_t n);
 #include "kernels_reduce.h"
 #include "kernels_small.h"
 #include "kernels_batch.h"
+#include "fp_row.h"
 }  // namespace cg1
 #include "kernels_rows.h"
 #include "kernels_merlin.h"
@@ -229,6 +230,8 @@ struct Ctx {
   PointSum* d_gsum = nullptr; size_t cap_gsum = 0;
   PointWords* d_bout = nullptr; PointWords* h_bout = nullptr; size_t cap_bout = 0;
   PointWords* d_gout = nullptr; PointWords* h_gout = nullptr; size_t cap_gout = 0;       // regime B, few MSMs: window sums exported for the host Horner
+  int horner_row = 1;                   // "horner_row": regime B's device Horner with one wave per MSM, one limb per lane (A/B switch; 0: one quad per MSM)
+  int batch_mul_row = 1;                // "batch_mul_row": deferred map / fold batches of 96 .. 4096 results on k_batch_mul_row (A/B switch; 0: pool / k_batch_mul)
   int batched_host_horner_max = 24;     // regime B calls with at most this many MSMs run their Horner on the host ("batched_host_horner_max")
   PointSum *d_sums = nullptr, *d_segrun = nullptr, *d_segtot = nullptr;
   PointWords* d_out = nullptr;
@@ -1172,7 +1175,10 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
     HIPCHK(hipMemcpyAsync(ctx->h_gout, ctx->d_gout, G * sizeof(PointWords), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(ctx->h_bout + M, ctx->d_bout + M, sizeof(PointWords), hipMemcpyDeviceToHost, st));      // the status words
   } else {
-    if (ctx->quad) hipLaunchKernelGGL(k_msm_horner_quad, dim3((uint32_t)((M * 4 + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
+    // up to ~2 000 MSMs one WAVE each, one limb per lane (fp_row.h: a lone wave's doubling in ~1.5 us instead of a quad's ~5); beyond,
+    // a wave per MSM would be eight and more to a SIMD and the quads' throughput wins (profiles/r05_rowlane_ab.txt)
+    if (ctx->horner_row && M <= 2048) hipLaunchKernelGGL(k_msm_horner_row, dim3((uint32_t)M), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
+    else if (ctx->quad) hipLaunchKernelGGL(k_msm_horner_quad, dim3((uint32_t)((M * 4 + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
     else hipLaunchKernelGGL(k_msm_horner, dim3((uint32_t)((M + 63) / 64)), dim3(64), 0, st, ctx->d_gsum, ctx->d_bout, (uint32_t)M, nwin, (uint32_t)c);
     HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, (M + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   }
@@ -1498,6 +1504,8 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "stage_sort")) { ctx->stage_sort = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "quad")) { ctx->quad = value ? 1 : 0; return CG1_OK; }
+  if (!strcmp(name, "horner_row")) { ctx->horner_row = value ? 1 : 0; return CG1_OK; }
+  if (!strcmp(name, "batch_mul_row")) { ctx->batch_mul_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "small_msm")) { ctx->small_msm = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "split")) { ctx->split = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "split_min_log2n")) { if (value < 10 || value > 31) return CG1_ERR_ARG; ctx->split_min_n = (size_t)1 << value; return CG1_OK; }
@@ -1764,6 +1772,8 @@ int cg1_msm_batched(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars,
 extern "C" void cg1_lincomb_write_outputs(const void* jac_results, size_t n_out, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48);
 }  // extern "C"
 
+constexpr size_t LINCOMB_ROW_MAX = 4096;         // map / fold results k_batch_mul_row takes (one wave each); beyond: k_batch_mul, one lane each
+constexpr size_t LINCOMB_ROW_MIN = 96;           // fewer are quicker on the host's pool (~77 us each over its threads) than a ~0.7 ms launch
 constexpr size_t LINCOMB_MAX_REGIME_B = 2048;    // independent MSMs cg1_lincomb_batch hands the regime-B chain in one call (r04: 1 024 - 2 048 x 627 terms)
 
 // results[sel[q]] = s * B (+ A) for the selected outputs, each one weighted term and at most one unit term: one k_batch_mul launch
@@ -1802,10 +1812,24 @@ static int lincomb_shaped_device(cg1_ctx* ctx, const uint8_t* bases_affine96, co
   }
   HIPCHK(hipSetDevice(ctx->device));
   DevBuf db, ds, da, dout;
-  HIPCHK(db.alloc(m * 96)); HIPCHK(ds.alloc(m * 32)); HIPCHK(dout.alloc(m * 96));
-  HIPCHK(hipMemcpy(db.p, hb.data(), m * 96, hipMemcpyHostToDevice));
-  HIPCHK(hipMemcpy(ds.p, hs.data(), m * 32, hipMemcpyHostToDevice));
-  if (any_addend) { HIPCHK(da.alloc(m * 96)); HIPCHK(hipMemcpy(da.p, ha.data(), m * 96, hipMemcpyHostToDevice)); }
+  HIPCHK(db.alloc(m * 96)); HIPCHK(ds.alloc(m * 32));
+  HIPCHK(hipMemcpyAsync(db.p, hb.data(), m * 96, hipMemcpyHostToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(ds.p, hs.data(), m * 32, hipMemcpyHostToDevice, ctx->stream));
+  if (any_addend) { HIPCHK(da.alloc(m * 96)); HIPCHK(hipMemcpyAsync(da.p, ha.data(), m * 96, hipMemcpyHostToDevice, ctx->stream)); }
+  if (ctx->batch_mul_row && m <= LINCOMB_ROW_MAX) {
+    // one wave per result, one limb per lane; canonical XYZZ words come back (the host normalises all results of the batch together)
+    HIPCHK(dout.alloc(m * sizeof(cg1::PointWords)));
+    hipLaunchKernelGGL(cg1::k_batch_mul_row, dim3((unsigned)m), dim3(64), 0, ctx->stream, (const uint32_t*)db.p, (uint32_t)m, (const uint32_t*)ds.p, (uint32_t)m,
+                       (const uint32_t*)da.p, (cg1::PointWords*)dout.p, (uint32_t)m);
+    std::vector<cg1::PointWords> hw(m);
+    HIPCHK(hipMemcpyAsync(hw.data(), dout.p, m * sizeof(cg1::PointWords), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    for (size_t q = 0; q < m; ++q) results[sel[q]] = cg1::jac_from_words(hw[q]);
+    return CG1_OK;
+  }
+  HIPCHK(dout.alloc(m * 96));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
   int rc = cg1_batch_mul_add_device(ctx, db.p, m, ds.p, m, da.p, dout.p, m);
   if (rc != CG1_OK) return rc;
   HIPCHK(hipMemcpy(ho.data(), dout.p, m * 96, hipMemcpyDeviceToHost));
@@ -1863,7 +1887,7 @@ int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_base
         if (heavy == 1 && offsets[j + 1] - offsets[j] <= 2) { big[j] = 2; ++n_shaped; }
       }
     }
-    if (n_shaped >= 2048) {
+    if (n_shaped >= 2048 || (ctx->batch_mul_row && n_shaped >= LINCOMB_ROW_MIN)) {
       // thousands of independent scalar multiplications (get_random_point over a long vector, a map / fold of 2^16 points): the batched
       // scalar-multiplication kernel (k_batch_mul: one lane per output, ~2.2 ms of dependent doublings whatever the count) takes them;
       // what is left of the batch is decided as below, without them
@@ -2041,15 +2065,46 @@ int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases, size_t nbase, const ui
   if (n == 0) return CG1_OK;
   if (nbase == 0 || nscalars == 0) return CG1_ERR_ARG;
   {
-    // Few outputs: the launch is 255 dependent doublings (~2.2 ms as quads, whatever n is) plus four copies, the host's pool does n
-    // scalar multiplications at ~80 us each on its threads -- take the host when that is the shorter way ("batch_mul_host_max": -1 =
-    // this rule, 0 = always the GPU, N = the host up to N outputs).
-    const size_t threads = cg1_shuffle_default_threads();
-    const size_t host_max = ctx->batch_mul_host_max >= 0 ? (size_t)ctx->batch_mul_host_max : threads * 16;
+    // one error contract whichever engine serves the call: every coordinate a canonical field element (< p); the curve equation is not checked
+    auto canonical = [](const uint8_t* rec) {
+      for (int c = 0; c < 2; ++c) {
+        uint64_t w[6];
+        memcpy(w, rec + 48 * c, 48);
+        bool lt = false;
+        for (int i = 5; i >= 0; --i) { if (w[i] != cg1::H_P[i]) { lt = w[i] < cg1::H_P[i]; break; } }
+        if (!lt) return false;
+      }
+      return true;
+    };
+    for (size_t i = 0; i < nbase; ++i) if (!canonical(bases + 96 * i)) { snprintf(ctx->err, sizeof ctx->err, "base %zu: coordinate >= p", i); return CG1_ERR_ENCODING; }
+    if (addend) for (size_t i = 0; i < n; ++i) if (!canonical(addend + 96 * i)) { snprintf(ctx->err, sizeof ctx->err, "addend %zu: coordinate >= p", i); return CG1_ERR_ENCODING; }
+    // Which engine -- decided by the call alone, never by the machine ("batch_mul_host_max": -1 = this rule, 0 = never the host, N = the
+    // host up to N outputs):  up to 96 outputs the host's pool (~77 us each over its threads against a ~0.6 ms launch);  up to 4 096 one
+    // WAVE per output with one limb per lane (k_batch_mul_row: 255 doublings at a lone wave's ~1.5 us, ~0.55 ms whatever n is,
+    // "batch_mul_row" = 0 switches it off);  beyond, one quad / one lane per output (k_batch_mul_quad / k_batch_mul: ~2.2 ms up to 8 192).
+    const size_t host_max = ctx->batch_mul_host_max >= 0 ? (size_t)ctx->batch_mul_host_max : LINCOMB_ROW_MIN;
     ctx->last_batch_mul_on_host = 0;
     if (n <= host_max) {
       ctx->last_batch_mul_on_host = 1;
       return cg1_batch_mul_add_pool(bases, nbase, scalars, nscalars, addend, out, n, 0);
+    }
+    if (ctx->batch_mul_row && n <= LINCOMB_ROW_MAX) {
+      HIPCHK(hipSetDevice(ctx->device));
+      DevBuf db, ds, da, dout;
+      HIPCHK(db.alloc(nbase * 96)); HIPCHK(ds.alloc(nscalars * 32)); HIPCHK(dout.alloc(n * sizeof(cg1::PointWords)));
+      HIPCHK(hipMemcpyAsync(db.p, bases, nbase * 96, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ds.p, scalars, nscalars * 32, hipMemcpyHostToDevice, ctx->stream));
+      if (addend) { HIPCHK(da.alloc(n * 96)); HIPCHK(hipMemcpyAsync(da.p, addend, n * 96, hipMemcpyHostToDevice, ctx->stream)); }
+      hipLaunchKernelGGL(cg1::k_batch_mul_row, dim3((unsigned)n), dim3(64), 0, ctx->stream, (const uint32_t*)db.p, (uint32_t)nbase, (const uint32_t*)ds.p,
+                         (uint32_t)nscalars, (const uint32_t*)da.p, (cg1::PointWords*)dout.p, (uint32_t)n);
+      std::vector<cg1::PointWords> hw(n);
+      HIPCHK(hipMemcpyAsync(hw.data(), dout.p, n * sizeof(cg1::PointWords), hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      HIPCHK(hipGetLastError());
+      std::vector<cg1h::jac> res(n);
+      for (size_t i = 0; i < n; ++i) res[i] = cg1::jac_from_words(hw[i]);
+      cg1_lincomb_write_outputs(res.data(), n, nullptr, out, nullptr);      // ONE shared inversion on the host: affine96 records
+      return CG1_OK;
     }
   }
   HIPCHK(hipSetDevice(ctx->device));
@@ -2970,6 +3025,43 @@ int cg1_probe_madd(cg1_ctx* ctx, const void* d_points, size_t npts, size_t lanes
   HIPCHK(hipStreamSynchronize(ctx->stream));
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventElapsedTime(ms, ctx->ev[0], ctx->ev[1]));
+  return CG1_OK;
+}
+
+// `waves` waves each run `iters` dependent EC additions (k_probe_add_chain, fp_row.h): mode 0 = one lane per addition, 1 = a DPP quad,
+// 2 = one limb per lane.  *ms: device time of one launch (hipEvents, best of `reps`); out_blob: wave 0's result.
+int cg1_probe_add_chain(cg1_ctx* ctx, int mode, const uint8_t* two_points_affine96, size_t waves, int iters, int reps, uint8_t* out_blob, float* ms) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (mode < 0 || mode > 2 || !two_points_affine96 || waves == 0 || waves > (1u << 20) || iters < 0 || reps < 1 || !ms) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  DevBuf raw, prep, fl, out;
+  HIPCHK(raw.alloc(2 * 96)); HIPCHK(prep.alloc(2 * sizeof(cg1::PreparedPoint))); HIPCHK(fl.alloc(32)); HIPCHK(out.alloc(waves * sizeof(cg1::PointWords)));
+  HIPCHK(hipMemcpy(raw.p, two_points_affine96, 2 * 96, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(cg1::k_prepare_points, dim3(1), dim3(256), 0, ctx->stream, (const uint32_t*)raw.p, (cg1::PreparedPoint*)prep.p, (uint8_t*)fl.p, 2u, (uint32_t*)nullptr);
+  auto launch = [&](int it) {
+    const dim3 g((unsigned)waves), b(64);
+    if (mode == 0) hipLaunchKernelGGL((cg1::k_probe_add_chain<0>), g, b, 0, ctx->stream, (const cg1::PreparedPoint*)prep.p, (cg1::PointWords*)out.p, it);
+    else if (mode == 1) hipLaunchKernelGGL((cg1::k_probe_add_chain<1>), g, b, 0, ctx->stream, (const cg1::PreparedPoint*)prep.p, (cg1::PointWords*)out.p, it);
+    else hipLaunchKernelGGL((cg1::k_probe_add_chain<2>), g, b, 0, ctx->stream, (const cg1::PreparedPoint*)prep.p, (cg1::PointWords*)out.p, it);
+  };
+  launch(2);                                             // warm-up (code object load, instruction cache)
+  float best = 1e30f;
+  for (int r = 0; r < reps; ++r) {
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->stream));
+    launch(iters);
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipGetLastError());
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, ctx->ev[0], ctx->ev[1]));
+    if (t < best) best = t;
+  }
+  *ms = best;
+  if (out_blob) {
+    cg1::PointWords w;
+    HIPCHK(hipMemcpy(&w, out.p, sizeof w, hipMemcpyDeviceToHost));
+    blob_out(out_blob, cg1::jac_from_words(w));
+  }
   return CG1_OK;
 }
 

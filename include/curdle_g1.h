@@ -93,7 +93,7 @@ void* cg1_ctx_stream(cg1_ctx* ctx);                                  /* the cont
 /* Tuning and A/B switches of a context (defaults are the measured best; DESIGN.md section 9 has the measurements):
  *   MSM plan / phases   "chunk_len" "seg_m" "auto_plan" "stage_sort" "partition_sort" "big_bins" "wave_agg" "quad" "reduce_2d" "rowcol_quad"
  *                       "rowcol_quad_max" "fold_pass" "tree_half" "scan_one" "host_split" "horner_threads" "zero_copy" "batched_host_horner_max"
- *                       "batch_mul_quad_max" "batch_mul_host_max" "sort_sub_bits" "rowcol_lgq" "tree_shift" "arm_helpers" "small_msm" (1: calls of <= 2048 terms run as ONE launch, k_msm_small; 0: the regime-A chain)
+ *                       "batch_mul_quad_max" "batch_mul_host_max" "batch_mul_row" "horner_row" "sort_sub_bits" "rowcol_lgq" "tree_shift" "arm_helpers" "small_msm" (1: calls of <= 2048 terms run as ONE launch, k_msm_small; 0: the regime-A chain)
  *                       "split" (A/B switch, default 0: a call of >= 2^"split_min_log2n" terms as two launch chains -- high and low half of its windows -- on
  *                       two streams; measured slower than the single chain, profiles/r04_split_ab.txt)
  *   waiting             "blocking_sync" (sleep instead of spinning on the stream), "profile" (0: no events, 1: around k_accumulate, 2: every phase)
@@ -225,10 +225,11 @@ int cg1_batch_mul_device(cg1_ctx* ctx, const void* d_bases_affine96, size_t nbas
  * per-index scalars:             G_i * beta^-i  (grand_prod.py:64-71). */
 int cg1_batch_mul_add_device(cg1_ctx* ctx, const void* d_bases_affine96, size_t nbase, const void* d_scalars32,
                              size_t nscalars, const void* d_addend_affine96, void* d_out_affine96, size_t n);
-/* same, all buffers in host memory (copied in and out by the call).  Up to "batch_mul_host_max" outputs (cg1_set_param; -1 = 16 per
- * host thread, the default; 0 = never) the host's worker pool does the work instead of a launch: a fold / map of a few hundred points is
- * 255 dependent doublings on the GPU whatever its size (~2.2 ms), and n scalar multiplications of ~80 us over the pool's threads there
- * (cg1_batch_mul_add_pool: the same records in and out, byte for byte). */
+/* same, all buffers in host memory (copied in and out by the call).  Which engine serves a call depends on the call alone ("batch_mul_host_max":
+ * -1 = this rule, 0 = never the host, N = the host up to N outputs): up to 96 outputs the host's worker pool (cg1_batch_mul_add_pool: n scalar
+ * multiplications of ~77 us over its threads, against a ~0.6 ms launch); up to 4 096 one WAVE per output with one limb per lane (k_batch_mul_row,
+ * csrc/fp_row.h: ~0.55 ms whatever n is; "batch_mul_row" = 0 switches it off); beyond, one quad / one lane per output.  Every engine returns the
+ * same records, byte for byte, and refuses the same inputs: a coordinate >= p is CG1_ERR_ENCODING; the curve equation is not checked. */
 int cg1_batch_mul_add_pool(const uint8_t* bases_affine96, size_t nbase, const uint8_t* scalars32, size_t nscalars,
                            const uint8_t* addend_affine96, uint8_t* out_affine96, size_t n, int n_threads /* 0 = all */);
 int cg1_batch_mul_add(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t nbase, const uint8_t* scalars32, size_t nscalars,
@@ -285,6 +286,12 @@ int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_base
                       uint8_t* out_comp48, int* path_used);
 int cg1_lincomb_batch_pool(const uint8_t* bases_affine96, size_t n_bases, const uint32_t* offsets, size_t n_out, const uint32_t* term_base,
                            const uint8_t* term_scalars32, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48, int n_threads);
+
+/* The lone-wave addition probe (csrc/fp_row.h): `waves` waves each run `iters` DEPENDENT EC additions; mode 0 = one lane per addition (the
+ * formulas k_accumulate uses), 1 = one DPP quad per addition (g1_quad.h: the latency-bound kernels), 2 = one limb per lane, the four
+ * products of a stage on the four rows of the wave.  *ms = device time of one launch (best of reps); out_blob144 = wave 0's result. */
+int cg1_probe_add_chain(cg1_ctx* ctx, int mode, const uint8_t* two_points_affine96, size_t waves, int iters, int reps,
+                        uint8_t* out_blob144, float* ms);
 
 /* ---------------- native Merlin transcript (host C++) ------------------------
  * Stands behind merlin_transcripts/merlin_transcripts/{merlin_transcript.py:6-24, strobe.py:16-107,

@@ -1,0 +1,130 @@
+"""One limb per lane (csrc/fp_row.h): a chain of dependent EC additions run by the three device formulations -- one lane, a DPP quad,
+one limb per lane on the four rows of a wave -- ends in the point the host library's chain ends in, which is the oracle's
+(k0 + a k1 + b k0) G for the multiples of the generator the chain adds up; the exceptional additions (P + P, P - P, the identity)
+go through the same entry point."""
+import ctypes
+
+import pytest
+
+from oracle import bls12_381 as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _affine96(pt):
+    return bytes(96) if pt is None else pt[0].to_bytes(48, "little") + pt[1].to_bytes(48, "little")
+
+
+@pytest.mark.parametrize("iters", [0, 1, 2, 7, 64])
+def test_three_formulations_agree_with_the_oracle(native_lib, iters):
+    N = native_lib
+    ctx = N.default_context()
+    k0, k1 = 0x1234567, 0x7654321
+    p0, p1 = O.g1_mul(O.G1_GEN, k0), O.g1_mul(O.G1_GEN, k1)
+    # acc = P0; acc += (P1, P0, P1, ...)
+    tot = k0 + sum(k0 if (i & 1) else k1 for i in range(iters))
+    want = O.g1_compress(O.g1_mul(O.G1_GEN, tot % O.R))
+    for mode in (0, 1, 2):
+        out = ctypes.create_string_buffer(144)
+        ms = ctypes.c_float(0)
+        ctx.check(N.cg1_probe_add_chain(ctx.handle, mode, _affine96(p0) + _affine96(p1), 3, iters, 1, out, ctypes.byref(ms)))
+        c = ctypes.create_string_buffer(48)
+        N.cg1_compress(c, out.raw)
+        assert c.raw == want, (mode, iters)
+
+
+def test_exceptional_additions_on_rows(native_lib):
+    """P0 == P1 makes the first addition a doubling; P1 == -P0 makes the chain pass through the identity every other step."""
+    N = native_lib
+    ctx = N.default_context()
+    p0 = O.g1_mul(O.G1_GEN, 99)
+    for p1, coef in ((p0, 1), (O.g1_neg(p0), -1)):
+        for iters in (1, 2, 3, 6):
+            tot = 99 + sum(99 if (i & 1) else 99 * coef for i in range(iters))
+            want = O.g1_compress(O.g1_mul(O.G1_GEN, tot % O.R) if tot % O.R else None)
+            for mode in (0, 1, 2):
+                out = ctypes.create_string_buffer(144)
+                ms = ctypes.c_float(0)
+                ctx.check(N.cg1_probe_add_chain(ctx.handle, mode, _affine96(p0) + _affine96(p1), 2, iters, 1, out, ctypes.byref(ms)))
+                c = ctypes.create_string_buffer(48)
+                N.cg1_compress(c, out.raw)
+                assert c.raw == want, (mode, iters, coef)
+
+
+def test_regime_b_horner_one_wave_per_msm(native_lib):
+    """cg1_msm_batched with more MSMs than finish on the host (> 24): the per-MSM Horner on the device, one wave per MSM with one limb
+    per lane ("horner_row" = 1, the default) and one quad per MSM (= 0): the same points, and the oracle's on a sample."""
+    import random
+
+    N = native_lib
+    ctx = N.default_context()
+    rng = random.Random(41)
+    m_msm = 40
+    offsets, pts, sc, ks = [0], [], [], []
+    base_pts = [(k, O.g1_mul(O.G1_GEN, k)) for k in (rng.randrange(1, O.R) for _ in range(16))]
+    for j in range(m_msm):
+        n = rng.choice([1, 3, 17, 64])
+        for _ in range(n):
+            k, p = base_pts[rng.randrange(16)]
+            ks.append(k)
+            pts.append(_affine96(p))
+            sc.append(rng.randrange(O.R))
+        offsets.append(len(pts))
+    raw_p, raw_s = b"".join(pts), b"".join(s.to_bytes(32, "little") for s in sc)
+    got = {}
+    for flag in (1, 0):
+        ctx.set_param("horner_row", flag)
+        try:
+            got[flag] = ctx.msm_batched_host(raw_p, raw_s, offsets)
+        finally:
+            ctx.set_param("horner_row", 1)
+    for j in range(m_msm):
+        assert N.cg1_eq(got[0][j], got[1][j]) == 1, j
+    for j in rng.sample(range(m_msm), 6):
+        tot = sum(ks[t] * sc[t] for t in range(offsets[j], offsets[j + 1])) % O.R
+        c = ctypes.create_string_buffer(48)
+        N.cg1_compress(c, got[1][j])
+        assert c.raw == O.g1_compress(O.g1_mul(O.G1_GEN, tot) if tot else None)
+
+
+def test_map_and_fold_batches_on_one_wave_per_result(native_lib):
+    """A deferred batch of `s * B` / `A + s * B` results (the callers' map and fold loops) through cg1_lincomb_batch: k_batch_mul_row
+    (one wave per result) gives what the host's pool gives, byte for byte; points outside G1, the identity, zero and unit scalars
+    included."""
+    import random
+
+    N = native_lib
+    ctx = N.default_context()
+    rng = random.Random(42)
+    T3 = (0, 2)
+    bases = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(30)] + [None, O.g1_add(O.g1_mul(O.G1_GEN, 5), T3), T3]
+    raw = b"".join(_affine96(p) for p in bases)
+    offsets, tb, sc = [0], [], []
+    for j in range(300):
+        kind = j % 5
+        if kind in (0, 1, 2):                                    # s * B
+            tb.append(rng.randrange(len(bases)) | (0x80000000 if rng.random() < 0.3 else 0)); sc.append(rng.choice([rng.randrange(2, O.R), O.R - 1, 2, 3]))
+        elif kind == 3:                                          # A + s * B
+            tb.append(rng.randrange(len(bases))); sc.append(1)
+            tb.append(rng.randrange(len(bases)) | (0x80000000 if rng.random() < 0.3 else 0)); sc.append(rng.randrange(2, O.R))
+        else:                                                    # s * B + A with A = +-B (the addition is a doubling / cancels)
+            b = rng.randrange(30)
+            tb.append(b); sc.append(2)
+            tb.append(b | (0x80000000 if rng.random() < 0.5 else 0)); sc.append(1)
+        offsets.append(len(tb))
+    n_out = len(offsets) - 1
+    offs = (ctypes.c_uint32 * (n_out + 1))(*offsets)
+    tba = (ctypes.c_uint32 * len(tb))(*tb)
+    scb = b"".join(s.to_bytes(32, "little") for s in sc)
+    outs = {}
+    for label, path, row in (("pool", 1, 1), ("row_kernel", 0, 1), ("without_row_kernel", 0, 0)):
+        ctx.set_param("batch_mul_row", row)
+        try:
+            ob, oa, ok = (ctypes.create_string_buffer(144 * n_out), ctypes.create_string_buffer(96 * n_out), ctypes.create_string_buffer(48 * n_out))
+            used = ctypes.c_int(0)
+            ctx.check(N.cg1_lincomb_batch(ctx.handle, raw, len(bases), offs, n_out, tba, scb, path, ob, oa, ok, ctypes.byref(used)))
+            outs[label] = (ob.raw, oa.raw, ok.raw, used.value)
+        finally:
+            ctx.set_param("batch_mul_row", 1)
+    assert outs["row_kernel"][3] == 2 and outs["pool"][3] == 1
+    assert outs["pool"][:3] == outs["row_kernel"][:3] == outs["without_row_kernel"][:3]
