@@ -297,6 +297,47 @@ __global__ void __launch_bounds__(64) k_batch_mul_row(const uint32_t* __restrict
   row_export(acc, l, out + i);
 }
 
+// flags[i] = 1 iff affine96 point i (standard form, on the curve; zeros = identity) lies in the prime-order subgroup: [z^2] P == phi(P) + P
+// (g1_in_subgroup, g1_xyzz.h) with one WAVE per point: 126 doublings + 12 additions of a lone wave, ~0.25 ms for up to ~1 000 points --
+// what the deferred G1Point layer asks before it folds a product of products over bases decoded unchecked (py_arkworks_bls12381.py).
+__global__ void __launch_bounds__(64) k_subgroup_row(const uint32_t* __restrict__ raw, uint32_t n, uint8_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x;
+  if (i >= n) return;
+  const RowK k = row_constants();
+  const uint32_t l = k.lane16;
+  constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
+  uint32_t r2 = 0, beta = 0;
+#pragma unroll
+  for (int t = 0; t < NL; ++t) { r2 = l == (uint32_t)t ? fp_r2().l[t] : r2; beta = l == (uint32_t)t ? bt[t] : beta; }
+  uint32_t wd[24], any = 0;
+  for (int t = 0; t < 24; ++t) { wd[t] = raw[24ull * i + t]; any |= wd[t]; }
+  if (!any) { if ((threadIdx.x & 63u) == 0) flags[i] = 1; return; }
+  xyzz_row P;
+  P.X = row_mul(row_from_fp(fp_from_words(wd), l), r2, k);
+  P.Y = row_mul(row_from_fp(fp_from_words(wd + 12), l), r2, k);
+  P.ZZ = k.one; P.ZZZ = k.one; P.inf = 0;
+  constexpr uint64_t ZABS = 0xd201000000010000ull;
+  xyzz_row q = P;
+#pragma unroll 1
+  for (int bit = 62; bit >= 0; --bit) {
+    q = row_dbl(q, k);
+    if ((ZABS >> bit) & 1ull) q = row_add(q, P, k);
+  }
+  xyzz_row acc = q;
+#pragma unroll 1
+  for (int bit = 62; bit >= 0; --bit) {
+    acc = row_dbl(acc, k);
+    if ((ZABS >> bit) & 1ull) acc = row_add(acc, q, k);
+  }
+  xyzz_row N1 = P;                                                             // - P
+  N1.Y = row_norm_pass(row_norm_pass(k.kp3 - P.Y, l), l);
+  acc = row_add(acc, N1, k);
+  xyzz_row N2 = N1;                                                            // - phi(P) = (beta x, -y)
+  N2.X = row_mul(P.X, beta, k);
+  acc = row_add(acc, N2, k);
+  if ((threadIdx.x & 63u) == 0) flags[i] = acc.inf ? 1 : 0;
+}
+
 // ---- the measurement behind "does one limb per lane shorten a lone wave's chain of additions?": every wave of the launch runs `iters`
 // DEPENDENT additions acc += (P0, P1 alternating).  MODE 0: the one-lane formulas (all 64 lanes compute the same thing: a lone LANE's
 // latency); 1: a DPP quad per addition (g1_quad.h); 2: one limb per lane (row_add).  Wave w exports its result as canonical words.

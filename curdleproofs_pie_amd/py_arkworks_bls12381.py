@@ -165,7 +165,7 @@ _SIBLING_LOOKBEHIND = 0          # a flush takes the asked-for value and every l
 _pending: list = []              # weak references to deferred values, in creation order
 _next_seq = itertools.count(1).__next__
 _ref = weakref.ref
-stats = {"flushes": 0, "flushed_values": 0, "flush_terms": 0, "flush_host": 0, "flush_device": 0, "flush_hybrid": 0, "decoded": 0, "decode_batches": 0, "subgroup_tests": 0}
+stats = {"flushes": 0, "flushed_values": 0, "flush_terms": 0, "flush_host": 0, "flush_device": 0, "flush_hybrid": 0, "decoded": 0, "decode_batches": 0, "subgroup_tests": 0, "subgroup_device": 0, "subgroup_host": 0}
 
 
 def set_lazy(on: bool) -> bool:
@@ -485,6 +485,23 @@ def _decode_leaves(leaves) -> None:
     stats["decode_batches"] += 1
 
 
+def _subgroup_flags(todo) -> None:
+    """`_sg` for every point of `todo` (normalised first): one native call -- one wave per point on the GPU for 32 .. 4 096 points
+    (k_subgroup_row), the host's worker pool otherwise (or without a GPU)."""
+    ensure_normalised(todo)
+    n = len(todo)
+    flags = ctypes.create_string_buffer(n)
+    ctx = _have_gpu()
+    used = ctypes.c_int(0)
+    rc = N.cg1_batch_subgroup(ctx.handle if ctx is not None else None, b"".join([l._a for l in todo]), n, flags, ctypes.byref(used))
+    if rc != N.OK:
+        raise N.NativeError(f"cg1_batch_subgroup failed ({rc})")
+    for l, f in zip(todo, flags.raw):
+        _set(l, "_sg", bool(f))
+    stats["subgroup_tests"] += n
+    stats["subgroup_device" if used.value else "subgroup_host"] += 1
+
+
 def _certify(node: G1Point) -> bool:
     """True iff every leaf of the deferred value lies in the prime-order subgroup (then its coefficients may be reduced mod r).  Leaves
     not tested before are tested now, in one pooled call; the verdict stays with the leaf object."""
@@ -496,15 +513,7 @@ def _certify(node: G1Point) -> bool:
                 seen.add(id(l))
                 todo.append(l)
         if todo:
-            ensure_normalised(todo)
-            n = len(todo)
-            flags = ctypes.create_string_buffer(n)
-            rc = N.cg1_batch_subgroup_pool(b"".join([l._a for l in todo]), n, flags, 0)
-            if rc != N.OK:
-                raise N.NativeError(f"cg1_batch_subgroup_pool failed ({rc})")
-            for l, f in zip(todo, flags.raw):
-                _set(l, "_sg", bool(f))
-            stats["subgroup_tests"] += n
+            _subgroup_flags(todo)
         ok = all(l._sg is True for l in leaves)
         if ok:
             _set(node, "_sg", True)
@@ -522,15 +531,7 @@ def certify_all(points) -> None:
                     todo.append(l)
         if not todo:
             return
-        ensure_normalised(todo)
-        n = len(todo)
-        flags = ctypes.create_string_buffer(n)
-        rc = N.cg1_batch_subgroup_pool(b"".join([l._a for l in todo]), n, flags, 0)
-        if rc != N.OK:
-            raise N.NativeError(f"cg1_batch_subgroup_pool failed ({rc})")
-        for l, f in zip(todo, flags.raw):
-            _set(l, "_sg", bool(f))
-        stats["subgroup_tests"] += n
+        _subgroup_flags(todo)
         for p in points:
             if p._t is not None and p._sg is not True and all(l._sg is True for l in p._t[1]):
                 _set(p, "_sg", True)
@@ -590,7 +591,7 @@ def _flush(nodes) -> None:
     out_k = ctypes.create_string_buffer(48 * n_out)
     used = ctypes.c_int(0)
     # compute_MSM has no host path: a batch carrying its results needs the GPU context (NativeError without one); the native call then
-    # splits the batch by what each engine is good at (csrc/msm_gpu.hip cg1_lincomb_batch: combinations of >= 4 weighted terms on the GPU,
+    # splits the batch by what each engine is good at (csrc/capi_lincomb.h cg1_lincomb_batch: combinations of >= 4 weighted terms on the GPU,
     # the one- to three-term operator results on the host's worker pool meanwhile)
     ctx = N.default_context() if from_msm else _have_gpu()
     handle = ctx.handle if ctx is not None else None

@@ -125,7 +125,12 @@ class ShuffleBatchVerifier:
 
     def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True,
                  blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: Optional[int] = None, fe_cus: int = 0, fe_prio: int = 0,
-                 pipelines: Optional[int] = None):
+                 pipelines: Optional[int] = None, max_pinned_bytes: Optional[int] = None):
+        # max_pinned_bytes: budget for the page-locked staging of the batch slots of ONE pipeline (None = no limit).  A stream keeps
+        # 3 + fe_lanes + 1 slots rotating so that packing, decoding, front-end launches and the MSM of different batches overlap; under a
+        # budget the rotation shrinks towards the minimum of 3 (fewer batches in flight: throughput cost in profiles/r05_verify_footprint.txt).
+        # The other knob is `pipelines` (each is a complete set of contexts, threads and slots).  footprint() reports what is held.
+        self.max_pinned_bytes = max_pinned_bytes
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
@@ -373,10 +378,42 @@ class ShuffleBatchVerifier:
             },
         }
 
+    def _slot_pinned_bytes(self, n: int) -> int:
+        L, C = self.crs.points_per_proof, self.crs.ncrs
+        return n * L * 48 + (n * L + C) * 32 + n * self._rowin_scalars * 32 + 4 * n + n * L + n * 768 + min(n, self.FE_FIRST_MAX) * L * 48
+
+    def footprint(self) -> dict:
+        """Bytes this verifier holds for its batch slots and front-end lanes: {"pinned_bytes", "device_bytes", "slots", "pipelines": [...]}
+        (page-locked host staging / hipMalloc'd buffers; the contexts' own scratch -- MSM buckets, sort buffers -- is not counted here)."""
+        pinned = device = slots = 0
+        for b in self._slots:
+            if b is None:
+                continue
+            slots += 1
+            for v in b.values():
+                if isinstance(v, N.DeviceBuffer):
+                    device += v.nbytes
+            for v in b["host"].values():
+                if isinstance(v, N.PinnedBuffer):
+                    pinned += v.nbytes
+        for pair in self._fe:
+            if pair is not None:
+                pinned += pair[2].nbytes
+                device += pair[3].nbytes
+        kids = [k.footprint() for k in (self._kids or [])]
+        return {"pinned_bytes": pinned + sum(k["pinned_bytes"] for k in kids), "device_bytes": device + sum(k["device_bytes"] for k in kids),
+                "slots": slots, "pipelines": kids}
+
     def _slot(self, n: int) -> dict:
         """Buffers of one batch in flight (3 slots rotate: MSM of batch k-1, front-end of k, decompression of k+1).
         All three are allocated together the first time a batch size is seen (page-locking tens of MB takes
         milliseconds: not something to meet again in the middle of a stream)."""
+        if self.max_pinned_bytes is not None and all(x is None for x in self._slots):
+            fit = max(3, int(self.max_pinned_bytes) // max(1, self._slot_pinned_bytes(n)))
+            if fit < self._nslots:                            # (decided once, before the first slot exists)
+                self._nslots = fit
+                self._slots = [None] * fit
+                self._next_slot = 0
         idx = self._next_slot
         self._next_slot = (idx + 1) % self._nslots
         b = self._slots[idx]
@@ -652,7 +689,8 @@ class ShuffleBatchVerifier:
             self._release_lanes()                             # (lanes a single batch may have built on this verifier itself)
             dev = self.ctx.device
             self._kids = [ShuffleBatchVerifier(self.crs, N.Context(dev), threads=self.threads, chunk=self.chunk, device_rows=self.device_rows,
-                                               blocking_sync=self.blocking_sync, device_front_end=True, fe_lanes=self.fe_lanes, fe_prio=self.fe_prio, pipelines=1)
+                                               blocking_sync=self.blocking_sync, device_front_end=True, fe_lanes=self.fe_lanes, fe_prio=self.fe_prio, pipelines=1,
+                                               max_pinned_bytes=self.max_pinned_bytes)
                           for _ in range(self.pipelines)]
             for k in self._kids:
                 k._own_ctx = True
@@ -738,6 +776,7 @@ class ShuffleBatchVerifier:
         try:
             for batch in batches:
                 tk = self._begin(batch, mode, rng, prefetched=True)
+                depth = min(depth, max(1, self._nslots - 2))       # (a pinned-memory budget may have shrunk the slot rotation: fewer batches in flight)
                 self._front_end_device(tk)
                 self._enqueue_msm(tk)
                 inflight.append(tk)

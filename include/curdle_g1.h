@@ -276,6 +276,9 @@ int cg1_batch_decompress_pool(const uint8_t* in48, size_t n, uint8_t* out_blobs1
 /* out_flags[i] = 1 iff affine96 point i (on the curve; zeros = identity) lies in the prime-order subgroup G1: [z^2]P == phi(P) + P.
  * Only for such bases may the coefficient of a deferred product be reduced mod r (`(P * a) * b` == P * (a b mod r)). */
 int cg1_batch_subgroup_pool(const uint8_t* affine96, size_t n, uint8_t* out_flags, int n_threads);
+/* the same flags; 32 .. 4 096 points and a GPU context: one wave per point with one limb per lane (k_subgroup_row: ~0.25 ms whatever n is);
+ * otherwise the pool.  *on_device (may be NULL): 1 when the GPU served the call.  Coordinates >= p: CG1_ERR_ENCODING on both paths. */
+int cg1_batch_subgroup(cg1_ctx* ctx, const uint8_t* affine96, size_t n, uint8_t* out_flags, int* on_device);
 /* out_j = sum_{t in [offsets[j], offsets[j+1])} scalars32[t] * (+/-) bases[term_base[t] & 0x7fffffff]  (bit 31 of term_base: the negated
  * base); offsets: n_out + 1 host entries, offsets[0] == 0.  path 0 = choose from the batch (never from the machine), 1 = the host's worker
  * pool, 2 = the GPU (cg1_msm_batched_device over the gathered terms).  ctx may be NULL for paths 0 / 1 (then always the pool).  Outputs

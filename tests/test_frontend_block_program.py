@@ -1,5 +1,5 @@
 """The device front-end's BLOCK PROGRAM (csrc/kernels_frontend.h, second form) checked without a GPU: the host cuts the verifier's
-transcript into the rate blocks between two Keccak permutations (build_block_program in csrc/msm_gpu.hip) and k_fill_rows /
+transcript into the rate blocks between two Keccak permutations (build_block_program in csrc/capi_frontend.h) and k_fill_rows /
 k_shuffle_front_end_rows consume them.  `cg1_shuffle_fe_emulate_to_first_barrier` walks those very tables on the CPU for one proof
 -- rows, late pieces, first-draw and redo squeeze nodes -- up to the grand-product step; the challenges it draws must be the ones
 the REFERENCE verifier drew (tests/golden/shuffle_vectors.json: curdleproofs.py:176-180, same_perm.py:91-96 over

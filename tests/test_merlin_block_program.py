@@ -1,5 +1,5 @@
 """cg1_merlin_batch_device's BLOCK PROGRAM checked without a GPU: `cg1_merlin_block_program_emulate` (test support in the library) runs one transcript through
-the node tables the device kernels consume (build_block_program in csrc/msm_gpu.hip, walked on the CPU the way k_fill_rows /
+the node tables the device kernels consume (build_block_program in csrc/capi_frontend.h, walked on the CPU the way k_fill_rows /
 k_merlin_batch_rows walk them) -- random operation lists over merlin_transcript.py:11-24 / curdleproofs_transcript.py:15-25 against the
 host transcript (itself pinned by the reference's known answers and recorded sequences, tests/test_merlin.py), outputs AND the final
 208-byte state.  The kernels run the same tables on the GPU: tests/test_merlin_gpu.py."""
