@@ -281,8 +281,12 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   const size_t nout_words = pd.nout_words;
   const auto h0 = pd.h0, h1 = pd.h1;
   HIPCHK(hipSetDevice(ctx->device));
+  // helpers armed below spin for a job for up to 2 ms: on every way out of this function (a failed stream, a bad scalar, a tail that needs
+  // fewer threads) the ones still spinning are told to stand down
+  struct StandDown { Ctx* c; bool on; ~StandDown() { if (on) for (int j = 0; j < 3; ++j) c->helper[j].disarm(); } } stand_down{ctx, false};
   if (pd.zero_copy && !ctx->blocking_sync && pd.profile < 2) {
     if (pd.arm_helpers) for (int j = 0; j < 3 && j + 1 < ctx->horner_threads; ++j) ctx->helper[j].arm();
+    stand_down.on = pd.arm_helpers;
     // poll the flag word k_export_host writes last; look at the stream now and then so that a failed launch cannot hang us
     volatile uint32_t* flag = ctx->h_flag;
     for (uint32_t spins = 0; *flag != pd.seq; ++spins) {
@@ -394,10 +398,12 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
       part[j] = a;
     };
     for (int j = 0; j + 1 < nth; ++j) ctx->helper[j].run([&, j]() { run_part(j); });
+    if (pd.arm_helpers) for (int j = nth - 1 < 0 ? 0 : nth - 1; j < 3; ++j) ctx->helper[j].disarm();      // armed for a wider tail than this call has
     run_part(nth - 1);
     acc = part[nth - 1];
     for (int j = 0; j + 1 < nth; ++j) { ctx->helper[j].wait(); acc = cg1h::jac_add(acc, part[j]); }
   } else {
+    if (pd.arm_helpers) for (int j = 0; j < 3; ++j) ctx->helper[j].disarm();
     acc = horner(0, e_top);
   }
   result = acc;

@@ -17,6 +17,7 @@ struct Helper {
   std::function<void()> job;
   bool has = false, done = true, quit = false, armed = false;
   std::atomic<bool> posted{false};       // mirrors `has` for a helper that is spinning (arm())
+  std::atomic<bool> stand_down{false};   // disarm(): the spinning helper gives up at once
   void start_locked() { if (!th.joinable()) th = std::thread([this]() { loop(); }); }
   void run(std::function<void()> f) {
     std::unique_lock<std::mutex> lk(mu);
@@ -30,8 +31,10 @@ struct Helper {
   void arm() {
     std::unique_lock<std::mutex> lk(mu);
     start_locked();
-    if (!has && done) { armed = true; cv.notify_all(); }
+    if (!has && done) { stand_down.store(false, std::memory_order_relaxed); armed = true; cv.notify_all(); }
   }
+  // no job will come after all (the call failed, or its tail needs fewer threads than were armed): stop spinning, go back to sleep
+  void disarm() { stand_down.store(true, std::memory_order_release); }
   void wait() {
     std::unique_lock<std::mutex> lk(mu);
     cv.wait(lk, [this]() { return done; });
@@ -46,6 +49,7 @@ struct Helper {
         lk.unlock();
         const auto until = std::chrono::steady_clock::now() + std::chrono::milliseconds(2);
         for (uint32_t k = 0; !posted.load(std::memory_order_acquire); ++k) {
+          if (stand_down.load(std::memory_order_acquire)) break;
           if ((k & 0xffu) == 0xffu && std::chrono::steady_clock::now() > until) break;
           __builtin_ia32_pause();
         }

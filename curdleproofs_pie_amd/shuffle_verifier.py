@@ -1085,22 +1085,32 @@ class OpeningBatchVerifier:
         return out
 
     def _buffers(self, n):
+        """Device buffers for n proofs (grown geometrically; the old pair is freed first).  One verifier = one caller at a time: its buffers
+        and `last_status` are per-object state (use one OpeningBatchVerifier per thread)."""
         if self._dev is None or self._dev[0] < n:
             ctx = self.ctx
-            cap = max(n, 1024)
+            if self._dev is not None:
+                self._dev[1].free()
+                self._dev[2].free()
+                self._dev = None
+            cap = max(n, 1024, 2 * (self._dev_cap_seen if hasattr(self, "_dev_cap_seen") else 0))
+            self._dev_cap_seen = cap
             self._dev = (cap, ctx.alloc(96 * (5 * cap + 1)), ctx.alloc(32 * (5 * cap + 1)))
         return self._dev[1], self._dev[2]
 
-    def verify_many(self, items, rng=None, seed: Optional[bytes] = None) -> List[bool]:
+    def verify_many(self, items, rng=None, _seed: Optional[bytes] = None) -> List[bool]:
+        """One verdict per (tracker, k_commitment, proof).  The batch weights come from 32 fresh bytes of the OS per call; `_seed` replaces
+        them for TESTS that compare two front-ends on the same weights -- a seed that is reused or known to the prover makes every weight
+        predictable, and a forged batch can then pass: never pass it in production."""
         n, trackers, kcs, pfs, pre = self._pack(items)
-        return self._verify(n, trackers, kcs, pfs, pre, rng, seed)
+        return self._verify(n, trackers, kcs, pfs, pre, rng, _seed)
 
-    def verify_packed(self, trackers96: bytes, k_commitments48: bytes, proofs128: bytes, rng=None, seed: Optional[bytes] = None) -> List[bool]:
+    def verify_packed(self, trackers96: bytes, k_commitments48: bytes, proofs128: bytes, rng=None, _seed: Optional[bytes] = None) -> List[bool]:
         """The same verdicts for n proofs already laid out back to back: n x (r_G | k_r_G), n x k_commitment, n x (A | B | s)."""
         n = len(proofs128) // self.PROOF_BYTES
         if len(proofs128) != 128 * n or len(trackers96) != 96 * n or len(k_commitments48) != 48 * n:
             raise ValueError("verify_packed: expected n x 96, n x 48 and n x 128 bytes")
-        return self._verify(n, trackers96, k_commitments48, proofs128, None, rng, seed)
+        return self._verify(n, trackers96, k_commitments48, proofs128, None, rng, _seed)
 
     def _verify(self, n, trackers, kcs, pfs, pre, rng, seed=None) -> List[bool]:
         if n == 0:

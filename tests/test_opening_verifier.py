@@ -146,7 +146,7 @@ def test_device_front_end_equals_host_front_end(gold):
         assert got_d == got_h and vd.last_status == vh.last_status
     assert vd.verify_many(items)[: len(want)] == want
     for seed in (bytes(32), bytes(range(32))):                 # seed-derived weights: the two front-ends draw the same ones
-        assert vd.verify_many(items * 5, seed=seed) == vh.verify_many(items * 5, seed=seed) and vd.last_status == vh.last_status
+        assert vd.verify_many(items * 5, _seed=seed) == vh.verify_many(items * 5, _seed=seed) and vd.last_status == vh.last_status
     # byte level
     n, trk, kcs, pfs, pre = vd._pack(items * 3)
     weights = vd._weights(n, random.Random(11))

@@ -70,8 +70,8 @@ while time.time() - t0 < budget:
         trk += a; kcs += k; pfs += p
     trk, kcs, pfs = bytes(trk), bytes(kcs), bytes(pfs)
     seed = rng.getrandbits(256).to_bytes(32, "little")
-    vd = dev.verify_packed(trk, kcs, pfs, seed=seed); sd = list(dev.last_status)
-    vh = host.verify_packed(trk, kcs, pfs, seed=seed); sh = list(host.last_status)
+    vd = dev.verify_packed(trk, kcs, pfs, _seed=seed); sd = list(dev.last_status)
+    vh = host.verify_packed(trk, kcs, pfs, _seed=seed); sh = list(host.last_status)
     if sd != sh:
         print("FRONT-ENDS DIFFER", seed0, it, [(i, x, y) for i, (x, y) in enumerate(zip(sd, sh)) if x != y][:8]); sys.exit(1)
     for i in range(B):
