@@ -498,7 +498,171 @@ static PyObject* pf_decode_lazy(PyObject* self, PyObject* data) {
   return o;
 }
 
+/* ---- deferred values: the coefficient bookkeeping of py_arkworks_bls12381.py in C (integers stay Python ints: one multiply + one
+ * remainder per coefficient through the number protocol, without a bytecode per element) */
+
+/* scale(coefs, v, R) -> [c * v % R for c in coefs] */
+static PyObject* pf_scale(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 3 || !PyList_CheckExact(args[0])) { PyErr_SetString(PyExc_TypeError, "scale(list, v, R)"); return NULL; }
+  PyObject *src = args[0], *v = args[1], *R = args[2];
+  const Py_ssize_t n = PyList_GET_SIZE(src);
+  PyObject* out = PyList_New(n);
+  if (!out) return NULL;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject* m = PyNumber_Multiply(PyList_GET_ITEM(src, i), v);
+    PyObject* r = m ? PyNumber_Remainder(m, R) : NULL;
+    Py_XDECREF(m);
+    if (!r) { Py_DECREF(out); return NULL; }
+    PyList_SET_ITEM(out, i, r);
+  }
+  return out;
+}
+
+/* msm_terms(bases, scalars, n, R) -> (coefs, leaves, all_leaves_in_g1): sum_i scalars[i] * bases[i] as one coefficient list over
+ * leaves; a deferred base (its `_t` = (coefs, leaves, from_msm); the caller made sure its leaves are in G1) contributes its terms with
+ * the scalar folded in mod R.  TypeError for anything that is not a G1Point / Scalar (or an int in [0, R)). */
+static PyObject* pf_msm_terms(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 4) { PyErr_SetString(PyExc_TypeError, "msm_terms(bases, scalars, n, R)"); return NULL; }
+  if (!g_point_type || !g_scalar_type || g_t_off < 0 || g_sg_off < 0) { PyErr_SetString(PyExc_RuntimeError, "_pyface.bind() has not run"); return NULL; }
+  PyObject* fb = PySequence_Fast(args[0], "msm_terms expects sequences");
+  if (!fb) return NULL;
+  PyObject* fs = PySequence_Fast(args[1], "msm_terms expects sequences");
+  if (!fs) { Py_DECREF(fb); return NULL; }
+  const Py_ssize_t n = PyLong_AsSsize_t(args[2]);
+  PyObject* R = args[3];
+  PyObject *coefs = NULL, *leaves = NULL, *zero = NULL;
+  int all_g1 = 1;
+  if (n < 0 || n > PySequence_Fast_GET_SIZE(fb) || n > PySequence_Fast_GET_SIZE(fs)) { PyErr_SetString(PyExc_ValueError, "msm_terms: n outside the sequences"); goto fail; }
+  coefs = PyList_New(0); leaves = PyList_New(0); zero = PyLong_FromLong(0);
+  if (!coefs || !leaves || !zero) goto fail;
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    PyObject* b = PySequence_Fast_GET_ITEM(fb, i);
+    PyObject* sc = PySequence_Fast_GET_ITEM(fs, i);
+    PyObject* v;
+    if (Py_TYPE(b) != g_point_type) { PyErr_Format(PyExc_TypeError, "compute_MSM: bases must be G1Point, not %s", Py_TYPE(b)->tp_name); goto fail; }
+    if (Py_TYPE(sc) == g_scalar_type) v = slot_get(sc, g_scalar_off);
+    else if (PyLong_CheckExact(sc)) {
+      v = sc;
+      const int neg = PyObject_RichCompareBool(v, zero, Py_LT), big = PyObject_RichCompareBool(v, R, Py_GE);
+      if (neg < 0 || big < 0) goto fail;
+      if (neg || big) { PyErr_SetString(PyExc_TypeError, "compute_MSM: scalars must be Scalar"); goto fail; }
+    } else { PyErr_Format(PyExc_TypeError, "compute_MSM: scalars must be Scalar, not %s", Py_TYPE(sc)->tp_name); goto fail; }
+    if (!v || !PyLong_Check(v)) { PyErr_SetString(PyExc_TypeError, "compute_MSM: a Scalar holds no integer"); goto fail; }
+    PyObject* t = slot_get(b, g_t_off);
+    if (!t || t == Py_None) {
+      if (PyList_Append(coefs, v) < 0 || PyList_Append(leaves, b) < 0) goto fail;
+      if (slot_get(b, g_sg_off) != Py_True) all_g1 = 0;
+    } else {
+      if (!PyTuple_CheckExact(t) || PyTuple_GET_SIZE(t) != 3) { PyErr_SetString(PyExc_TypeError, "malformed deferred value"); goto fail; }
+      PyObject *cs = PyTuple_GET_ITEM(t, 0), *ls = PyTuple_GET_ITEM(t, 1);
+      if (!PyList_CheckExact(cs) || !PyList_CheckExact(ls) || PyList_GET_SIZE(cs) != PyList_GET_SIZE(ls)) { PyErr_SetString(PyExc_TypeError, "malformed deferred value"); goto fail; }
+      const Py_ssize_t k = PyList_GET_SIZE(cs);
+      for (Py_ssize_t j = 0; j < k; ++j) {
+        PyObject* m = PyNumber_Multiply(PyList_GET_ITEM(cs, j), v);
+        PyObject* r = m ? PyNumber_Remainder(m, R) : NULL;
+        Py_XDECREF(m);
+        if (!r) goto fail;
+        const int rc = PyList_Append(coefs, r);
+        Py_DECREF(r);
+        if (rc < 0 || PyList_Append(leaves, PyList_GET_ITEM(ls, j)) < 0) goto fail;
+      }
+    }
+  }
+  Py_DECREF(fb); Py_DECREF(fs); Py_DECREF(zero);
+  return Py_BuildValue("NNO", coefs, leaves, all_g1 ? Py_True : Py_False);
+fail:
+  Py_DECREF(fb); Py_DECREF(fs); Py_XDECREF(coefs); Py_XDECREF(leaves); Py_XDECREF(zero);
+  return NULL;
+}
+
+/* assemble(nodes, R) -> (leaf_list, offsets, term_base, scalars32, from_msm): the arrays cg1_lincomb_batch takes for a flush of the
+ * deferred values `nodes` (each `_t` = (coefs, leaves, from_msm), `_sg` True = every leaf in G1).  Over G1 leaves a coefficient goes
+ * in as c mod R; otherwise it stays the integer it is (|c| < R), the sign moving to the base (bit 31 of term_base).  Zero coefficients
+ * are dropped; equal leaves share one base index. */
+static PyObject* pf_assemble(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
+  if (nargs != 2) { PyErr_SetString(PyExc_TypeError, "assemble(nodes, R)"); return NULL; }
+  if (!g_point_type || g_t_off < 0 || g_sg_off < 0) { PyErr_SetString(PyExc_RuntimeError, "_pyface.bind() has not run"); return NULL; }
+  PyObject* fn = PySequence_Fast(args[0], "assemble expects a sequence of deferred values");
+  if (!fn) return NULL;
+  PyObject* R = args[1];
+  const Py_ssize_t n_out = PySequence_Fast_GET_SIZE(fn);
+  Py_ssize_t total = 0;
+  for (Py_ssize_t j = 0; j < n_out; ++j) {
+    PyObject* nd = PySequence_Fast_GET_ITEM(fn, j);
+    PyObject* t = Py_TYPE(nd) == g_point_type ? slot_get(nd, g_t_off) : NULL;
+    if (!t || !PyTuple_CheckExact(t) || PyTuple_GET_SIZE(t) != 3 || !PyList_CheckExact(PyTuple_GET_ITEM(t, 0)) || !PyList_CheckExact(PyTuple_GET_ITEM(t, 1)) ||
+        PyList_GET_SIZE(PyTuple_GET_ITEM(t, 0)) != PyList_GET_SIZE(PyTuple_GET_ITEM(t, 1))) {
+      Py_DECREF(fn); PyErr_Format(PyExc_TypeError, "element %zd is not a deferred value", j); return NULL;
+    }
+    total += PyList_GET_SIZE(PyTuple_GET_ITEM(t, 0));
+  }
+  size_t cap = 16;
+  while (cap < (size_t)total * 2 + 2) cap <<= 1;
+  PyObject** keys = (PyObject**)calloc(cap, sizeof(PyObject*));
+  uint32_t* vals = (uint32_t*)malloc(cap * sizeof(uint32_t));
+  PyObject* offs = PyBytes_FromStringAndSize(NULL, (n_out + 1) * 4);
+  PyObject* tb = PyBytes_FromStringAndSize(NULL, (total ? total : 1) * 4);
+  PyObject* sc = PyBytes_FromStringAndSize(NULL, (total ? total : 1) * 32);
+  PyObject* leaf_list = PyList_New(0);
+  PyObject* zero = PyLong_FromLong(0);
+  int from_msm = 0;
+  Py_ssize_t T = 0;
+  if (!keys || !vals || !offs || !tb || !sc || !leaf_list || !zero) { PyErr_NoMemory(); goto fail; }
+  {
+    uint32_t* po = (uint32_t*)PyBytes_AS_STRING(offs);
+    uint32_t* pt = (uint32_t*)PyBytes_AS_STRING(tb);
+    uint8_t* ps = (uint8_t*)PyBytes_AS_STRING(sc);
+    po[0] = 0;
+    for (Py_ssize_t j = 0; j < n_out; ++j) {
+      PyObject* nd = PySequence_Fast_GET_ITEM(fn, j);
+      PyObject* t = slot_get(nd, g_t_off);
+      PyObject *cs = PyTuple_GET_ITEM(t, 0), *ls = PyTuple_GET_ITEM(t, 1);
+      if (PyObject_IsTrue(PyTuple_GET_ITEM(t, 2))) from_msm = 1;
+      const int in_g1 = slot_get(nd, g_sg_off) == Py_True;
+      const Py_ssize_t k = PyList_GET_SIZE(cs);
+      for (Py_ssize_t i = 0; i < k; ++i) {
+        PyObject* c = PyList_GET_ITEM(cs, i);
+        PyObject* leaf = PyList_GET_ITEM(ls, i);
+        PyObject* mag = NULL;
+        uint32_t negbit = 0;
+        if (in_g1) {
+          mag = PyNumber_Remainder(c, R);                      /* non-negative for a positive R */
+        } else {
+          const int neg = PyObject_RichCompareBool(c, zero, Py_LT);
+          if (neg < 0) goto fail;
+          if (neg) { mag = PyNumber_Negative(c); negbit = 0x80000000u; } else { mag = c; Py_INCREF(mag); }
+        }
+        if (!mag) goto fail;
+        const int is_zero = PyObject_RichCompareBool(mag, zero, Py_EQ);
+        if (is_zero < 0) { Py_DECREF(mag); goto fail; }
+        if (is_zero) { Py_DECREF(mag); continue; }
+        if (!PyLong_Check(mag) || (!long_to_le32(mag, ps + 32 * T) && pf_long_as_le32(mag, ps + 32 * T) < 0)) { Py_DECREF(mag); if (!PyErr_Occurred()) PyErr_SetString(PyExc_TypeError, "coefficient is not an int"); goto fail; }
+        Py_DECREF(mag);
+        size_t h = ((size_t)(uintptr_t)leaf >> 4) * 0x9E3779B97F4A7C15ull;
+        h = (h >> 17) & (cap - 1);
+        while (keys[h] && keys[h] != leaf) h = (h + 1) & (cap - 1);
+        if (!keys[h]) {
+          keys[h] = leaf;
+          vals[h] = (uint32_t)PyList_GET_SIZE(leaf_list);
+          if (PyList_Append(leaf_list, leaf) < 0) goto fail;
+        }
+        pt[T] = vals[h] | negbit;
+        ++T;
+      }
+      po[j + 1] = (uint32_t)T;
+    }
+  }
+  free(keys); free(vals); Py_DECREF(fn); Py_DECREF(zero);
+  return Py_BuildValue("NNNNnO", leaf_list, offs, tb, sc, T, from_msm ? Py_True : Py_False);
+fail:
+  free(keys); free(vals); Py_DECREF(fn); Py_XDECREF(offs); Py_XDECREF(tb); Py_XDECREF(sc); Py_XDECREF(leaf_list); Py_XDECREF(zero);
+  return NULL;
+}
+
 static PyMethodDef methods[] = {
+    {"scale", (PyCFunction)(void (*)(void))pf_scale, METH_FASTCALL, "scale(coefs, v, R) -> [c * v % R]"},
+    {"msm_terms", (PyCFunction)(void (*)(void))pf_msm_terms, METH_FASTCALL, "msm_terms(bases, scalars, n, R) -> (coefs, leaves, all_in_g1)"},
+    {"assemble", (PyCFunction)(void (*)(void))pf_assemble, METH_FASTCALL, "assemble(nodes, R) -> (leaves, offsets, term_base, scalars32, T, from_msm)"},
     {"mk", (PyCFunction)(void (*)(void))pf_mk, METH_FASTCALL, "mk(blob, a, k, t, sg, seq) -> G1Point"},
     {"decode_lazy", pf_decode_lazy, METH_O, "decode_lazy(data48) -> G1Point (validated, y deferred)"},
     {"set_native", pf_set_native, METH_VARARGS, "set_native(address of cg1_validate_compressed)"},

@@ -279,8 +279,7 @@ class G1Point(metaclass=_PinnedDir):
             # a base outside the prime-order subgroup (or one that cannot be tested): no folding -- the inner value first, as the wheel computes it
             _force(self)
             return _mk(None, None, None, ([s._v], [self], False), self._sg, _next_seq())
-        v = s._v
-        return _mk(None, None, None, ([c * v % CURVE_ORDER for c in t[0]], t[1], t[2]), True, _next_seq())
+        return _mk(None, None, None, (_scale(t[0], s._v, CURVE_ORDER), t[1], t[2]), True, _next_seq())
 
     __rmul__ = __mul__
 
@@ -380,13 +379,19 @@ _IDENTITY_BLOB = _ib.raw
 del _ib
 
 # ---------------------------------------------------------------- marshalling: lists of objects <-> contiguous buffers
+def _scale_py(coefs, v, R):
+    return [c * v % R for c in coefs]
+
+
 if _pyface is not None:
     _pyface.bind(G1Point, Scalar, _pending, _IDENTITY_BLOB)
     _pyface.set_native(ctypes.cast(N.lib.cg1_validate_compressed, ctypes.c_void_p).value)
     _mk = _pyface.mk
+    _scale = _pyface.scale
     Unforced = _pyface.Unforced
 else:
     _mk = _mk_py
+    _scale = _scale_py
 
     class Unforced(LookupError):
         pass
@@ -541,6 +546,9 @@ def _flush(nodes) -> None:
     """Evaluate deferred values in one native call (cg1_lincomb_batch): the host's worker pool for a handful of operator results, the GPU's
     batched MSM for anything larger and for everything that came out of compute_MSM.  Every value leaves with its blob (Z = 1), its
     affine96 record and its 48-byte compression."""
+    if _pyface is not None:
+        leaf_list, offs, tba, scb, T, from_msm = _pyface.assemble(nodes, CURVE_ORDER)
+        return _flush_run(nodes, leaf_list, offs, tba, scb, T, from_msm)
     index = {}
     leaf_list = []
     offsets = [0]
@@ -579,13 +587,19 @@ def _flush(nodes) -> None:
                     tb.append(i)
                     sc.append(c)
         offsets.append(len(tb))
-    ensure_normalised(leaf_list)
     n_out, T = len(nodes), len(tb)
-    bases = b"".join([l._a for l in leaf_list])
     offs = (ctypes.c_uint32 * (n_out + 1))(*offsets)
     tba = (ctypes.c_uint32 * max(T, 1))(*tb)
     scb = ctypes.create_string_buffer(32 * max(T, 1))
     pack_scalars(sc, ctypes.addressof(scb), T)
+    return _flush_run(nodes, leaf_list, offs, tba, scb, T, from_msm)
+
+
+def _flush_run(nodes, leaf_list, offs, tba, scb, T: int, from_msm: bool) -> None:
+    """The native half of a flush: bases normalised (undecoded leaves decoded in one pooled call), one cg1_lincomb_batch, results stored."""
+    ensure_normalised(leaf_list)
+    n_out = len(nodes)
+    bases = b"".join([l._a for l in leaf_list])
     out_b = ctypes.create_string_buffer(N.POINT_BYTES * n_out)
     out_a = ctypes.create_string_buffer(96 * n_out)
     out_k = ctypes.create_string_buffer(48 * n_out)
@@ -629,6 +643,9 @@ def msm_node(bases, scalars, n: int) -> G1Point:
         still = [b for b in unsure if b._sg is not True]
         if still:
             materialise(still)
+    if _pyface is not None:
+        coefs, leaves, sg = _pyface.msm_terms(bases, scalars, n, R)
+        return _mk(None, None, None, (coefs, leaves, True), True if sg else None, _next_seq())
     coefs, leaves = [], []
     sg = True
     for b, s in zip(bases, scalars):
