@@ -530,7 +530,7 @@ static PyObject* pf_msm_terms(PyObject* self, PyObject* const* args, Py_ssize_t 
   if (!fs) { Py_DECREF(fb); return NULL; }
   const Py_ssize_t n = PyLong_AsSsize_t(args[2]);
   PyObject* R = args[3];
-  PyObject *coefs = NULL, *leaves = NULL, *zero = NULL;
+  PyObject *coefs = NULL, *leaves = NULL, *zero = NULL, *unsure = NULL;
   int all_g1 = 1;
   if (n < 0 || n > PySequence_Fast_GET_SIZE(fb) || n > PySequence_Fast_GET_SIZE(fs)) { PyErr_SetString(PyExc_ValueError, "msm_terms: n outside the sequences"); goto fail; }
   coefs = PyList_New(0); leaves = PyList_New(0); zero = PyLong_FromLong(0);
@@ -554,6 +554,13 @@ static PyObject* pf_msm_terms(PyObject* self, PyObject* const* args, Py_ssize_t 
       if (slot_get(b, g_sg_off) != Py_True) all_g1 = 0;
     } else {
       if (!PyTuple_CheckExact(t) || PyTuple_GET_SIZE(t) != 3) { PyErr_SetString(PyExc_TypeError, "malformed deferred value"); goto fail; }
+      if (slot_get(b, g_sg_off) != Py_True) {
+        /* a deferred base over leaves not known to be in G1: the caller has them tested (or evaluates the base) and calls again */
+        if (!unsure) { unsure = PyList_New(0); if (!unsure) goto fail; }
+        if (PyList_Append(unsure, b) < 0) goto fail;
+        continue;
+      }
+      if (unsure) continue;
       PyObject *cs = PyTuple_GET_ITEM(t, 0), *ls = PyTuple_GET_ITEM(t, 1);
       if (!PyList_CheckExact(cs) || !PyList_CheckExact(ls) || PyList_GET_SIZE(cs) != PyList_GET_SIZE(ls)) { PyErr_SetString(PyExc_TypeError, "malformed deferred value"); goto fail; }
       const Py_ssize_t k = PyList_GET_SIZE(cs);
@@ -569,9 +576,10 @@ static PyObject* pf_msm_terms(PyObject* self, PyObject* const* args, Py_ssize_t 
     }
   }
   Py_DECREF(fb); Py_DECREF(fs); Py_DECREF(zero);
-  return Py_BuildValue("NNO", coefs, leaves, all_g1 ? Py_True : Py_False);
+  if (unsure) { Py_DECREF(coefs); Py_DECREF(leaves); return Py_BuildValue("OOON", Py_None, Py_None, Py_None, unsure); }
+  return Py_BuildValue("NNOO", coefs, leaves, all_g1 ? Py_True : Py_False, Py_None);
 fail:
-  Py_DECREF(fb); Py_DECREF(fs); Py_XDECREF(coefs); Py_XDECREF(leaves); Py_XDECREF(zero);
+  Py_DECREF(fb); Py_DECREF(fs); Py_XDECREF(coefs); Py_XDECREF(leaves); Py_XDECREF(zero); Py_XDECREF(unsure);
   return NULL;
 }
 
@@ -661,7 +669,7 @@ fail:
 
 static PyMethodDef methods[] = {
     {"scale", (PyCFunction)(void (*)(void))pf_scale, METH_FASTCALL, "scale(coefs, v, R) -> [c * v % R]"},
-    {"msm_terms", (PyCFunction)(void (*)(void))pf_msm_terms, METH_FASTCALL, "msm_terms(bases, scalars, n, R) -> (coefs, leaves, all_in_g1)"},
+    {"msm_terms", (PyCFunction)(void (*)(void))pf_msm_terms, METH_FASTCALL, "msm_terms(bases, scalars, n, R) -> (coefs, leaves, all_in_g1, None) | (None, None, None, [deferred bases whose leaves must be tested first])"},
     {"assemble", (PyCFunction)(void (*)(void))pf_assemble, METH_FASTCALL, "assemble(nodes, R) -> (leaves, offsets, term_base, scalars32, T, from_msm)"},
     {"mk", (PyCFunction)(void (*)(void))pf_mk, METH_FASTCALL, "mk(blob, a, k, t, sg, seq) -> G1Point"},
     {"decode_lazy", pf_decode_lazy, METH_O, "decode_lazy(data48) -> G1Point (validated, y deferred)"},

@@ -637,15 +637,22 @@ def msm_node(bases, scalars, n: int) -> G1Point:
     (msm_accumulator.compute_MSM, for the protocol's own sizes).  Deferred bases over points not known to be in G1 are tested (one
     pooled call) and, if a base really lies outside, evaluated first."""
     R = CURVE_ORDER
+    if _pyface is not None:
+        coefs, leaves, sg, unsure = _pyface.msm_terms(bases, scalars, n, R)
+        if unsure is not None:
+            certify_all(unsure)
+            still = [b for b in unsure if b._sg is not True]
+            if still:
+                materialise(still)
+            coefs, leaves, sg, unsure = _pyface.msm_terms(bases, scalars, n, R)
+            assert unsure is None
+        return _mk(None, None, None, (coefs, leaves, True), True if sg else None, _next_seq())
     unsure = [b for b in bases if type(b) is G1Point and b._t is not None and b._sg is not True]
     if unsure:
         certify_all(unsure)
         still = [b for b in unsure if b._sg is not True]
         if still:
             materialise(still)
-    if _pyface is not None:
-        coefs, leaves, sg = _pyface.msm_terms(bases, scalars, n, R)
-        return _mk(None, None, None, (coefs, leaves, True), True if sg else None, _next_seq())
     coefs, leaves = [], []
     sg = True
     for b, s in zip(bases, scalars):

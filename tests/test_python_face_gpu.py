@@ -424,3 +424,35 @@ def test_drop_in_from_four_threads(api):
         th.join()
     assert errors == []
     M.clear_vec_cache()
+
+
+def test_compute_msm_over_deferred_bases_outside_g1(api):
+    """compute_MSM whose bases are themselves deferred values (a prover's folded `G_L[i] + G_R[i] * gamma`, ipa.py:142-146) over points
+    decoded unchecked: over bases of G1 the coefficients fold into the scalars; a base carrying the order-3 point (0, 2) must be evaluated
+    first (`(P * a) * b != P * (a b mod r)` there) -- either way the oracle's point comes back."""
+    A, U = api
+    rng = random.Random(51)
+    T3 = (0, 2)
+    raw = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(12)]
+    raw[3] = O.g1_add(raw[3], T3)
+    raw[8] = O.g1_add(raw[8], O.g1_neg(T3))
+    pts = [A.G1Point.from_compressed_bytes_unchecked(O.g1_compress(p)) for p in raw]
+    gamma = rng.randrange(2, O.R)
+    half = 6
+    folded = [pts[i] + pts[half + i] * A.Scalar(gamma) for i in range(half)]                  # deferred (or computed at once: the other parameter)
+    want_folded = [O.g1_add(raw[i], O.g1_mul(raw[half + i], gamma)) for i in range(half)]
+    sc = [rng.randrange(O.R) for _ in range(half)]
+    got = A.compute_MSM(folded, [A.Scalar(s) for s in sc])
+    want = None
+    for p, s in zip(want_folded, sc):
+        want = O.g1_add(want, O.g1_mul(p, s))
+    assert bytes(got.to_compressed_bytes()) == O.g1_compress(want)
+    # a second round of folding over the first (depth 2), then an MSM over it
+    g2 = rng.randrange(2, O.R)
+    folded2 = [folded[i] + folded[3 + i] * A.Scalar(g2) for i in range(3)]
+    want2 = None
+    sc2 = [rng.randrange(O.R) for _ in range(3)]
+    for i in range(3):
+        f = O.g1_add(want_folded[i], O.g1_mul(want_folded[3 + i], g2))
+        want2 = O.g1_add(want2, O.g1_mul(f, sc2[i]))
+    assert bytes(A.compute_MSM(folded2, [A.Scalar(s) for s in sc2]).to_compressed_bytes()) == O.g1_compress(want2)
