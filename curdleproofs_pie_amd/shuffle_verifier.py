@@ -125,12 +125,13 @@ class ShuffleBatchVerifier:
 
     def __init__(self, crs, ctx: Optional["N.Context"] = None, threads: int = 0, chunk: int = 256, device_rows: bool = True,
                  blocking_sync: Optional[bool] = None, device_front_end: Optional[bool] = None, fe_lanes: Optional[int] = None, fe_cus: int = 0, fe_prio: int = 0,
-                 pipelines: Optional[int] = None, max_pinned_bytes: Optional[int] = None):
+                 pipelines: Optional[int] = None, max_pinned_bytes: Optional[int] = None, coalesce: Optional[int] = None):
         # max_pinned_bytes: budget for the page-locked staging of the batch slots of ONE pipeline (None = no limit).  A stream keeps
         # 3 + fe_lanes + 1 slots rotating so that packing, decoding, front-end launches and the MSM of different batches overlap; under a
         # budget the rotation shrinks towards the minimum of 3 (fewer batches in flight: throughput cost in profiles/r05_verify_footprint.txt).
         # The other knob is `pipelines` (each is a complete set of contexts, threads and slots).  footprint() reports what is held.
         self.max_pinned_bytes = max_pinned_bytes
+        self._coalesce_arg = coalesce
         self.crs = crs if isinstance(crs, ShuffleCrs) else ShuffleCrs(crs)
         self._ctx = ctx
         self.threads = threads
@@ -176,6 +177,12 @@ class ShuffleBatchVerifier:
             fe_lanes = 2 if (self.pipelines > 1 or N.hw_queues() < 8) else 3
         self._kids = None
         self.fe_lanes = max(1, int(fe_lanes)) if self.device_front_end else 0
+        # coalesce: with fewer than 12 hardware queues (nobody raised GPU_MAX_HW_QUEUES) a STREAM of batches is verified in internal batches
+        # of up to 4 096 proofs (_verify_stream_coalesced); 0 = never, N = that many proofs.  With 12 queues and more the pipelines do the job.
+        if self._coalesce_arg is None:
+            self.coalesce = 4096 if (self.device_front_end and N.hw_queues() < 12) else 0
+        else:
+            self.coalesce = max(0, int(self._coalesce_arg))
         # fe_cus > 0 (A/B switch, off): the front-end launches get that many compute units of their own (the last ones) and the
         # throughput kernels are confined to the others (hipExtStreamCreateWithCUMask).  Measured a loss: the masked decompression
         # stream took 30 ms instead of 6 per batch (profiles/r03_verify_fe_ab.txt)
@@ -884,6 +891,9 @@ class ShuffleBatchVerifier:
             if self._host_twin is not None:            # (its lanes would keep hardware queues the pipelines need)
                 self._host_twin.close()
                 self._host_twin = None
+            if self.coalesce and not (isinstance(batches, (list, tuple)) and len(batches) <= 1):
+                yield from self._verify_stream_coalesced(batches, mode, rng)
+                return
             yield from self._verify_stream_device(batches, mode, rng)
             return
         it = iter(batches)
@@ -911,6 +921,48 @@ class ShuffleBatchVerifier:
             left = [t for t in (pending, tk, tk_next) if t is not None and not t["done"].is_set()]
             if left:
                 self._gpu_submit(lambda: self._gpu_submit(lambda: [t["done"].set() for t in left], lane=1))
+
+    def _verify_stream_coalesced(self, batches, mode: str, rng):
+        """verify_stream for a process with few hardware queues (the runtime's default is 4): a front-end launch takes ~12 ms whatever it
+        carries and only one or two run side by side there, so consecutive batches of the stream travel together -- up to `coalesce` proofs
+        per internal batch (one front-end launch, one decoding pass, one merged MSM for all of them) -- and every caller's batch still gets
+        its own status list, in order.  Batches that bring their own pre_status / weights, and batches already that large, go through
+        as they are.  (profiles/r05_verify_queues_ab.txt: 4 queues, 1 024 proofs per batch: 7.8e4 proofs/s alone, ~1.5e5 in fours.)"""
+        from collections import deque
+
+        limit = int(self.coalesce)
+        groups = deque()                                        # per internal batch: the sizes of the callers' batches inside it
+
+        def merged():
+            pend, size = [], 0
+            for b in batches:
+                n = b[2]
+                plain = len(b) == 3
+                if not plain or n >= limit or (pend and size + n > limit):
+                    if pend:
+                        groups.append([x[2] for x in pend])
+                        yield (b"".join(x[0] for x in pend), b"".join(x[1] for x in pend), size) if len(pend) > 1 else pend[0]
+                        pend, size = [], 0
+                    if not plain or n >= limit:
+                        groups.append([n])
+                        yield b
+                        continue
+                pend.append(b)
+                size += n
+                if size >= limit:
+                    groups.append([x[2] for x in pend])
+                    yield (b"".join(x[0] for x in pend), b"".join(x[1] for x in pend), size) if len(pend) > 1 else pend[0]
+                    pend, size = [], 0
+            if pend:
+                groups.append([x[2] for x in pend])
+                yield (b"".join(x[0] for x in pend), b"".join(x[1] for x in pend), size) if len(pend) > 1 else pend[0]
+
+        for st in self._verify_stream_device(merged(), mode, rng):
+            sizes = groups.popleft()
+            lo = 0
+            for n in sizes:
+                yield st[lo: lo + n]
+                lo += n
 
     def verify_packed(self, instances: bytes, proofs: bytes, n: int, mode: str = "merged", rng=None, weights=None,
                       pre_status: Optional[Sequence[int]] = None) -> List[int]:

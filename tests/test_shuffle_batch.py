@@ -183,3 +183,29 @@ def test_large_call_is_streamed_in_pieces(native_lib, fx, device_front_end):
     want2[100] = want2[3000] = False
     assert [s == 0 for s in got] == want2 and got[100] == 1 and got[3000] == 1
     v.close()
+
+
+@pytest.mark.gpu
+def test_stream_travels_in_coalesced_batches_when_queues_are_scarce(native_lib, fx):
+    """With few hardware queues (the runtime's default 4) consecutive batches of a stream share one internal batch -- one front-end launch,
+    one decoding pass, one merged MSM -- and every caller's batch still gets its own verdicts, in order: seven batches of 300 / 512
+    proofs, tampered proofs at known slots of three of them, coalesced up to 1 100 proofs; an oversized batch and one with its own
+    weights pass through on their own."""
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    v = ShuffleBatchVerifier(fx.crs, native_lib.Context(0), device_front_end=True, pipelines=1, fe_lanes=1, coalesce=1100)
+    plain = ShuffleBatchVerifier(fx.crs, native_lib.Context(0), device_front_end=True, pipelines=1, fe_lanes=1, coalesce=0)
+    sizes = [300, 512, 300, 300, 1200, 512, 300]
+    slots = [{}, {5: 1, 511: 3}, {0: 2}, {}, {7: 4, 1100: 5}, {}, {299: 6}]
+    batches, want = [], []
+    for n, sl in zip(sizes, slots):
+        inst, proofs, w = fx.tiled(n, sl)
+        batches.append((inst, proofs, n))
+        want.append(w)
+    w5 = plain.draw_weights(512, random.Random(3))
+    batches[5] = (batches[5][0], batches[5][1], 512, None, w5)       # brings its own weights: not merged with its neighbours
+    got = list(v.verify_stream(iter(batches)))
+    assert [len(st) for st in got] == sizes
+    assert [[s == 0 for s in st] for st in got] == want
+    assert [[s == 0 for s in st] for st in plain.verify_stream(iter(batches))] == want
+    v.close(); plain.close()
