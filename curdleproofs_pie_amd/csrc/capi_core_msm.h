@@ -286,6 +286,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "horner_row")) { ctx->horner_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "batch_mul_row")) { ctx->batch_mul_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "small_msm")) { ctx->small_msm = value ? 1 : 0; return CG1_OK; }
+  if (!strcmp(name, "small_row_tail")) { ctx->small_row_tail = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "split")) { ctx->split = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "split_min_log2n")) { if (value < 10 || value > 31) return CG1_ERR_ARG; ctx->split_min_n = (size_t)1 << value; return CG1_OK; }
   if (!strcmp(name, "reduce_2d")) { ctx->reduce_2d = value ? 1 : 0; return CG1_OK; }

@@ -154,6 +154,12 @@ __device__ __forceinline__ xyzz row_to_xyzz(const xyzz_row& a, uint32_t lane16) 
   return r;
 }
 
+// the exceptional additions (P + P, P - P): decided and computed by the one-lane formulas.  Out of line on purpose: it is ~40 KB of code
+// that a kernel with a row_add in its hot path should not carry at every call site (arguments and result travel in registers).
+__device__ __attribute__((noinline)) xyzz_row row_add_exceptional(xyzz_row a, xyzz_row b, uint32_t lane16) {
+  return row_from_xyzz(xyzz_add(row_to_xyzz(a, lane16), row_to_xyzz(b, lane16)), lane16);
+}
+
 // a + b (both XYZZ, any points): the stages of quad_add, one product per row
 __device__ __forceinline__ xyzz_row row_add(const xyzz_row& a, const xyzz_row& b, const RowK& k) {
   if (a.inf) return b;
@@ -164,7 +170,7 @@ __device__ __forceinline__ xyzz_row row_add(const xyzz_row& a, const xyzz_row& b
   const uint32_t U1 = from_row<0>(m1, l), U2 = from_row<1>(m1, l), S1 = from_row<2>(m1, l), S2 = from_row<3>(m1, l);
   const uint32_t P = U2 + (k.kp3 - U1), R = S2 + (k.kp3 - S1);            // fp_sub<3>: limbs < 2^28 + 2^29, value < 4.1p
   if (row_is_zero_mod_p(P, 6)) {                                           // P + P or P - P: the one-lane formulas decide (rare)
-    return row_from_xyzz(xyzz_add(row_to_xyzz(a, l), row_to_xyzz(b, l)), l);
+    return row_add_exceptional(a, b, l);
   }
   // stage 2: PP = P P;  RR = R R;  ZZ12 = ZZ1 ZZ2;  ZZZ12 = ZZZ1 ZZZ2
   const uint32_t m2 = row_mul(row_sel(P, R, a.ZZ, a.ZZZ, q), row_sel(P, R, b.ZZ, b.ZZZ, q), k);
@@ -216,6 +222,13 @@ __device__ __forceinline__ xyzz_row row_load_sum(const PointSum* src, uint32_t l
   r.X = row_load14(src->c[0], lane16); r.Y = row_load14(src->c[1], lane16); r.ZZ = row_load14(src->c[2], lane16); r.ZZZ = row_load14(src->c[3], lane16);
   r.inf = src->inf;
   return r;
+}
+
+// the inverse of row_load_sum: row 0 of the wave writes the record (limbs nearly normal: only row code reads it back)
+__device__ __forceinline__ void row_store_sum(PointSum* dst, const xyzz_row& a, uint32_t lane16) {
+  const uint32_t lane = (uint32_t)__lane_id();
+  if (lane < (uint32_t)NL) { dst->c[0][lane16] = a.X; dst->c[1][lane16] = a.Y; dst->c[2][lane16] = a.ZZ; dst->c[3][lane16] = a.ZZZ; }
+  if (lane == 0) dst->inf = a.inf;
 }
 
 __device__ __forceinline__ void row_export(const xyzz_row& acc, uint32_t lane16, PointWords* dst) {

@@ -459,6 +459,7 @@ static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32
   a.n = (uint32_t)n; a.M = M; a.S = S; a.c = (uint32_t)c; a.nwin = nwin; a.hb = hb2; a.lb = lb2; a.nitems = nitems;
   a.partial = ctx->d_small_partial; a.counters = ctx->d_small_ctr;
   a.out_host = ctx->h_small_out_dev; a.flag_host = ctx->h_flag_dev; a.seq = ++ctx->seq;
+  a.row_tail = ctx->small_row_tail ? 1u : 0u;
   int kind = (int)src.kind;
   if (src.kind == PtSrc::BLOBS && !src.normalised) {           // invert first (one lane per point), then run on the prepared records
     if (n > ctx->cap_small_pts) {

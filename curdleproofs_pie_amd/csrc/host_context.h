@@ -157,6 +157,7 @@ struct Ctx {
   hipEvent_t ev_prep = nullptr, ev_acc = nullptr;
   bool pend_split = false;
   int last_acc_launches = 0;            // k_accumulate launches of the last MSM call: 2 (split), 1, or 0 (k_msm_small)
+  int small_row_tail = 1;               // "small_row_tail": k_msm_small's items / combine / export one limb per lane, one wave per item (A/B switch)
   int small_msm = 1;                    // "small_msm": MSMs of <= SM_MAX_N = 2048 terms as ONE launch (k_msm_small); 0 = the regime-A chain (A/B switch)
   PointSum* d_small_partial = nullptr; size_t cap_small_partial = 0;
   uint32_t* d_small_ctr = nullptr;

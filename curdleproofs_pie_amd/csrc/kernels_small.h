@@ -39,6 +39,7 @@ struct SmallArgs {
   PointWords* out_host;                   // mapped host memory: M x nwin x nitems records, then one record of status words
   uint32_t* flag_host;
   uint32_t seq;
+  uint32_t row_tail;                      // 1: the items, the combine and the export run one limb per lane, one wave per item (fp_row.h)
 };
 
 template <int SRC>
@@ -263,6 +264,7 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
         if (sg < nsum && (Q & 3u) == 0u && q == 0u) store_sum(&s_rc[sg < R ? sg : 16u + (sg - R)], acc);
         i1 = 0; phase = PH_TREE;
         __syncthreads();
+        if (a.row_tail && nitems <= 8u) break;                 // the rest runs below, one wave per item
       }
     } else if (phase == PH_TREE) {
       if (++i1 == ST + 3u) {
@@ -282,6 +284,40 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
     } else {  // PH_COMBINE
       if (++i1 == 1u + comb_levels) { exp_live = (Q >> 3) < nitems && (Q & 7u) == 0u; exp_item = Q >> 3; phase = PH_EXPORT; break; }
     }
+  }
+
+  // ---- row tail (a.row_tail): the 1 + hb + lb items of the window, the combine over the slices and the export with ONE WAVE PER ITEM and
+  // one limb per lane.  At this point at most nitems * 8 additions are left and they form chains: a quad addition costs ~10 us at this
+  // kernel's two waves per SIMD, a wave of rows ~2.4 us -- 7 dependent row additions (item 0) against 4 quad steps, S - 1 against
+  // 1 + log2(S) for the combine (profiles/r05_rowlane_ab.txt).
+  if (phase == PH_TREE) {
+    const RowK k = row_constants();
+    const uint32_t wv = tid >> 6;
+    const bool live = wv < nitems;
+    xyzz_row racc; racc.X = racc.Y = racc.ZZ = racc.ZZZ = 0; racc.inf = 1;
+    if (live) {
+      const bool on_rows = wv <= a.hb;
+      const uint32_t J = on_rows ? R : Cn, bit = on_rows ? wv - 1u : wv - 1u - a.hb;
+      for (uint32_t e = 0; e < J; ++e)
+        if (wv == 0u || ((e >> bit) & 1u)) racc = row_add(racc, row_load_sum(&s_rc[(on_rows ? 0u : 16u) + e], k.lane16), k);
+    }
+    if (S > 1u) {
+      if (live) row_store_sum(a.partial + ((size_t)wslot * S + sl) * nitems + wv, racc, k.lane16);
+      if (tid == 0) atomicAdd(&a.counters[gctr + 2], s_off[256]);
+      __threadfence();
+      __syncthreads();
+      if (tid == 0) s_misc[2] = atomicAdd(&a.counters[wslot], 1u);
+      __syncthreads();
+      if (s_misc[2] != S - 1u) return;                           // not the last slice of this window
+      __threadfence();
+      if (live) {
+        racc.X = racc.Y = racc.ZZ = racc.ZZZ = 0; racc.inf = 1;
+        for (uint32_t s2 = 0; s2 < S; ++s2) racc = row_add(racc, row_load_sum(a.partial + ((size_t)wslot * S + s2) * nitems + wv, k.lane16), k);
+      }
+    }
+    acc = row_to_xyzz(racc, k.lane16);
+    exp_live = live && (tid & 63u) < 4u;                         // lanes 0..3 of the item's wave write its four coordinates
+    exp_item = wv;
   }
 
   // ---- export: lane q of the item's quad converts and writes coordinate q (canonical, the host's Montgomery form)

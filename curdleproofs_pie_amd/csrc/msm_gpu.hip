@@ -54,13 +54,13 @@ namespace cg1 {
 int pick_window(size_t n);
 
 #include "kernels_records.h"
+#include "fp_row.h"
 #include "kernels_prepare_digits.h"
 #include "kernels_sort.h"
 #include "kernels_accumulate.h"
 #include "kernels_reduce.h"
 #include "kernels_small.h"
 #include "kernels_batch.h"
-#include "fp_row.h"
 }  // namespace cg1
 #include "kernels_rows.h"
 #include "kernels_merlin.h"

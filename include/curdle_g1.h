@@ -93,7 +93,7 @@ void* cg1_ctx_stream(cg1_ctx* ctx);                                  /* the cont
 /* Tuning and A/B switches of a context (defaults are the measured best; DESIGN.md section 9 has the measurements):
  *   MSM plan / phases   "chunk_len" "seg_m" "auto_plan" "stage_sort" "partition_sort" "big_bins" "wave_agg" "quad" "reduce_2d" "rowcol_quad"
  *                       "rowcol_quad_max" "fold_pass" "tree_half" "scan_one" "host_split" "horner_threads" "zero_copy" "batched_host_horner_max"
- *                       "batch_mul_quad_max" "batch_mul_host_max" "batch_mul_row" "horner_row" "sort_sub_bits" "rowcol_lgq" "tree_shift" "arm_helpers" "small_msm" (1: calls of <= 2048 terms run as ONE launch, k_msm_small; 0: the regime-A chain)
+ *                       "batch_mul_quad_max" "batch_mul_host_max" "batch_mul_row" "horner_row" "small_row_tail" "sort_sub_bits" "rowcol_lgq" "tree_shift" "arm_helpers" "small_msm" (1: calls of <= 2048 terms run as ONE launch, k_msm_small; 0: the regime-A chain)
  *                       "split" (A/B switch, default 0: a call of >= 2^"split_min_log2n" terms as two launch chains -- high and low half of its windows -- on
  *                       two streams; measured slower than the single chain, profiles/r04_split_ab.txt)
  *   waiting             "blocking_sync" (sleep instead of spinning on the stream), "profile" (0: no events, 1: around k_accumulate, 2: every phase)

@@ -132,6 +132,30 @@ def applications(N, ctx):
         assert ob.raw == ref
     out["map_of_248_results_ms"] = {k2: round(v, 3) for k2, v in mm.items()}
     out["host_pool_threads"] = int(N.cg1_shuffle_default_threads())
+    # one small MSM (k_msm_small) with its items / combine / export on quads against one wave per item with one limb per lane
+    sm = {}
+    for n in (4, 124, 256, 627, 1024, 2048):
+        pts = b"".join(recs[i % n_base] for i in range(n))
+        scs = b"".join(rng.randrange(1, 2 ** 254).to_bytes(32, "little") for _ in range(n))
+        d_p, d_s = ctx.alloc(len(pts)), ctx.alloc(len(scs))
+        d_p.upload(pts); d_s.upload(scs)
+        row = {}
+        ref = None
+        for flag in (0, 1, 0, 1):
+            ctx.set_param("small_row_tail", flag)
+            best = 1e9
+            for _ in range(30):
+                t0 = time.perf_counter()
+                blob = ctx.msm_device(d_p, d_s, n)
+                best = min(best, (time.perf_counter() - t0) * 1e3)
+            row[flag] = min(row.get(flag, 1e9), best)
+            if ref is None:
+                ref = blob
+            assert N.cg1_eq(ref, blob) == 1
+        sm[str(n)] = {"quads_ms": round(row[0], 4), "rows_ms": round(row[1], 4)}
+        d_p.free(); d_s.free()
+    ctx.set_param("small_row_tail", 1)
+    out["one_small_msm_device_resident_ms"] = sm
     return out
 
 
