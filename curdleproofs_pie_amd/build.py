@@ -39,7 +39,7 @@ def _source_hash() -> str:
 
 
 HASH_FILE = LIB + ".srchash"
-HOST_ONLY = ("host_g1.cpp", "merlin.cpp", "shuffle_verify.cpp", "comm.cpp", "lazy_host.cpp", "merlin_group.h", "fe_mul_x86.h", "pool.h", "lazy_host.h")
+HOST_ONLY = ("host_g1.cpp", "merlin.cpp", "shuffle_verify.cpp", "comm.cpp", "lazy_host.cpp", "merlin_group.h", "fe_mul_x86.h")      # (pool.h and lazy_host.h are included by the .hip unit too)
 
 
 def _hip_unit_hash(extra_flags=()) -> str:

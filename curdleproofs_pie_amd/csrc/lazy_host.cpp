@@ -268,6 +268,22 @@ int lincomb_pool_jac(const uint8_t* bases_affine96, size_t n_bases, const uint32
       if (!loaded[b]) { if (!load_affine96(bases_affine96 + 96 * (size_t)b, pts[b])) return 3; loaded[b] = 1; }
     }
   }
+  // threads by the work at hand: a thread is worth waking for ~0.1 ms of arithmetic (~400 group operations), not for three additions
+  if (n_threads <= 0) {
+    double ops = 0;
+    for (size_t q = 0; q < n_sel; ++q) {
+      const size_t j = sel ? sel[q] : q;
+      size_t heavy = 0, unit = 0;
+      for (size_t t = offsets[j]; t < offsets[j + 1]; ++t) {
+        const uint8_t* sc = term_scalars32 + 32 * t;
+        bool small = sc[0] <= 1;
+        for (int b = 1; b < 32 && small; ++b) small = sc[b] == 0;
+        if (small) ++unit; else ++heavy;
+      }
+      ops += (heavy ? 255.0 : 0.0) + 52.0 * (double)heavy + (double)unit;
+    }
+    n_threads = (int)std::max<double>(1.0, std::min<double>(256.0, ops / 400.0));
+  }
   std::atomic<size_t> next{0};
   std::function<void()> work = [&]() {
     std::vector<uint32_t> idx(max_k);
@@ -320,6 +336,7 @@ int cg1_batch_decompress_pool(const uint8_t* in48, size_t n, uint8_t* out_blobs1
   std::atomic<size_t> bad{(size_t)-1};
   std::atomic<int> bad_rc{0};
   const size_t slice = 8, items = (n + slice - 1) / slice;
+  if (n_threads <= 0) n_threads = (int)std::max<size_t>(1, std::min<size_t>(256, n / 8));        // ~0.1 ms of square roots per thread
   std::function<void()> work = [&]() {
     for (;;) {
       const size_t it = next.fetch_add(1);
@@ -353,6 +370,7 @@ int cg1_batch_subgroup_pool(const uint8_t* affine96, size_t n, uint8_t* out_flag
   std::atomic<size_t> next{0};
   std::atomic<int> bad{0};
   const size_t slice = 4, items = (n + slice - 1) / slice;
+  if (n_threads <= 0) n_threads = (int)std::max<size_t>(1, std::min<size_t>(256, n / 3));        // ~0.1 ms of subgroup tests per thread
   std::function<void()> work = [&]() {
     for (;;) {
       const size_t it = next.fetch_add(1);

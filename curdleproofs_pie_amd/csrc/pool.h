@@ -1,7 +1,9 @@
 // The host's persistent worker pool: the verifier front-end (shuffle_verify.cpp), the pooled batch operators and the deferred G1Point
 // evaluation (lazy_host.cpp) share ONE set of threads per process.
 #pragma once
+#include <pthread.h>
 #include <sched.h>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
@@ -17,8 +19,17 @@ namespace cg1 {
 // purpose: its threads sleep on a condition variable until the process exits.
 class Pool {
  public:
+  // The pool of THIS process: threads do not survive fork(), so a forked child (multiprocessing workers that inherited a parent which had
+  // already used the pool) starts a pool of its own at its first use -- the parent's object is abandoned there, never touched (its mutexes
+  // may have been held by threads that no longer exist).
   static Pool& get() {
-    static Pool* p = new Pool;
+    static std::once_flag reg;
+    std::call_once(reg, [] { pthread_atfork(nullptr, nullptr, [] { slot().store(nullptr, std::memory_order_release); }); });
+    Pool* p = slot().load(std::memory_order_acquire);
+    if (!p) {
+      Pool* fresh = new Pool;
+      if (slot().compare_exchange_strong(p, fresh, std::memory_order_acq_rel)) p = fresh;      // (a loser's pool idles on, unreferenced: rare and harmless)
+    }
     return *p;
   }
   size_t size() const { return threads_.size(); }
@@ -41,6 +52,7 @@ class Pool {
   }
 
  private:
+  static std::atomic<Pool*>& slot() { static std::atomic<Pool*> s{nullptr}; return s; }
   // CPUs this process may really use: the affinity mask, cut down to the cgroup CPU quota when there is one (a
   // container that sees 256 cores but owns 16 cores' worth of quota gets throttled, not faster, with 256 threads)
   static size_t usable_cpus() {

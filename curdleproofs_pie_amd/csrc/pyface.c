@@ -201,6 +201,14 @@ static void* pf_crew_main(void* arg) {
 
 static int g_walk_threads = -1;            /* -1: not decided yet; set_threads(n) overrides (1 = never use helpers) */
 
+/* threads do not survive fork(): a forked child starts a crew of its own at its first long walk */
+static void pf_crew_after_fork(void) {
+  pthread_mutex_init(&g_crew.m, NULL);
+  pthread_cond_init(&g_crew.work, NULL);
+  pthread_cond_init(&g_crew.done, NULL);
+  g_crew.started = 0; g_crew.parts = 0; g_crew.pending = 0; g_crew.job = NULL;
+}
+
 static int pf_crew_size(void) {
   if (g_walk_threads < 0) {
     long c = sysconf(_SC_NPROCESSORS_ONLN);
@@ -689,6 +697,7 @@ static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_pyface", "marshalli
 PyMODINIT_FUNC PyInit__pyface(void) {
   PyObject* m = PyModule_Create(&moddef);
   if (!m) return NULL;
+  pthread_atfork(NULL, NULL, pf_crew_after_fork);
   g_unforced = PyErr_NewException("_pyface.Unforced", PyExc_LookupError, NULL);
   if (!g_unforced) { Py_DECREF(m); return NULL; }
   Py_INCREF(g_unforced);

@@ -349,3 +349,29 @@ def test_lincomb_batch_on_the_gpu_and_split_between_both(native_lib):
                 acc = O.g1_add(acc, _imul(O.g1_neg(b) if tb[t] >> 31 else b, sc[t]))
             assert outs[0][2][48 * j: 48 * j + 48] == O.g1_compress(acc)
     assert seen == {1, 2, 3}
+
+
+def _forked_child(q):
+    import curdleproofs_pie_amd.py_arkworks_bls12381 as B
+
+    G = B.G1Point()
+    vals = [G * B.Scalar(1000 + k) + G for k in range(40)]          # enough work for the pool to be asked for several threads
+    q.put([bytes(v.to_compressed_bytes()) for v in vals])
+
+
+def test_deferred_values_in_a_forked_child(B):
+    """multiprocessing workers forked from a parent that already used the native worker pool (the fixture generators work like this):
+    the pool's threads do not exist in the child, which starts its own at first use instead of waiting for them forever."""
+    import multiprocessing as mp
+
+    G = B.G1Point()
+    warm = [G * B.Scalar(7 + k) + G for k in range(40)]
+    assert len({bytes(v.to_compressed_bytes()) for v in warm}) == 40    # the parent's pool has run
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forked_child, args=(q,))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(timeout=30)
+    assert p.exitcode == 0
+    assert got == [_enc(O.g1_mul(O.G1_GEN, 1001 + k)) for k in range(40)]
