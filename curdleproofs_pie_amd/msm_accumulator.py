@@ -34,6 +34,14 @@ def _locked(fn):
 LAZY_MSM_MAX = 2048                      # compute_MSM of up to this many terms returns a deferred value when deferred evaluation is on (= k_msm_small's reach)
 
 _ZERO96 = bytes(96)
+_FP = 0x1A0111EA397FE69A4B1BA7B6434BACD764774B84F38512BF6730D2A0F6B0F6241EABFFFEB153FFFFB9FEFFFFFFFFAAAB
+
+
+def _neg_affine96(rec: bytes) -> bytes:
+    """(x, y) -> (x, p - y) on an affine96 record (the identity record stays all-zero; y != 0 on this curve)."""
+    if rec == _ZERO96:
+        return rec
+    return rec[:48] + (_FP - int.from_bytes(rec[48:], "little")).to_bytes(48, "little")
 
 
 # ---------------------------------------------------------------- staging and the resident-vector cache
@@ -476,8 +484,10 @@ class MSMAccumulator:
             for C, rho in self._lhs_pts:
                 t = C._t
                 if t is None:
-                    pts.append(C._a)
-                    sc.append((-rho) % R)
+                    # - (rho * C) as rho * (-C): exact for EVERY curve point ((r - rho) * C is -(rho * C) only for C of order r, and the
+                    # reference's callers pass points decoded unchecked)
+                    pts.append(_neg_affine96(C._a))
+                    sc.append(rho)
                 else:
                     for c, l in zip(t[0], t[1]):
                         pts.append(l._a)

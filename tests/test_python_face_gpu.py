@@ -456,3 +456,61 @@ def test_compute_msm_over_deferred_bases_outside_g1(api):
         f = O.g1_add(want_folded[i], O.g1_mul(want_folded[3 + i], g2))
         want2 = O.g1_add(want2, O.g1_mul(f, sc2[i]))
     assert bytes(A.compute_MSM(folded2, [A.Scalar(s) for s in sc2]).to_compressed_bytes()) == O.g1_compress(want2)
+
+
+def test_accumulator_with_points_outside_g1(api):
+    """accumulate_check over bases decoded unchecked that carry the order-3 point (0, 2): the reference computes A_c += C * rho and
+    compares it with the MSM over the merged (mod r) scalars (msm_accumulator.py:45,56-68) as curve points, whatever their order -- so
+    `-(rho * C)` must enter the final MSM as rho * (-C), not as (r - rho) * C.  Honest and dishonest checks, leaf and deferred left-hand
+    sides, against the oracle's restatement of the class (found by tools/gpu_lazy_fuzz.py)."""
+    A, U = api
+    import curdleproofs_pie_amd.msm_accumulator as M
+    from oracle import py_arkworks_shim as S
+
+    rng = random.Random(61)
+    T3 = (0, 2)
+    raw = [O.g1_mul(O.G1_GEN, rng.randrange(1, O.R)) for _ in range(6)]
+    raw[1] = O.g1_add(raw[1], T3)
+    raw[4] = O.g1_add(raw[4], O.g1_neg(T3))
+    enc = [O.g1_compress(p) for p in raw]
+
+    def omsm(bs, ss):
+        cur = S.G1Point.identity()
+        for b, s in zip(bs, ss):
+            cur = cur + b * s
+        return cur
+
+    for case in range(12):
+        mine = [A.G1Point.from_compressed_bytes_unchecked(e) for e in enc]
+        ref = [S.G1Point.from_compressed_bytes_unchecked(e) for e in enc]
+        acc = A.MSMAccumulator()
+        o_A, o_map = S.G1Point.identity(), {}
+        honest = case % 3 != 2
+        for call in range(2):
+            idx = [rng.randrange(6) for _ in range(rng.choice([1, 3, 5]))]
+            sc = [rng.randrange(O.R) for _ in idx]
+            C_o = omsm([ref[t] for t in idx], [S.Scalar(s) for s in sc])
+            if case % 2:                                       # a deferred left-hand side (compute_MSM of the same terms) ...
+                C_m = A.compute_MSM([mine[t] for t in idx], [A.Scalar(s) for s in sc])
+            else:                                              # ... or a decoded leaf
+                C_m = A.G1Point.from_compressed_bytes_unchecked(bytes(C_o.to_compressed_bytes()))
+            if not honest and call == 1:
+                C_o = C_o + ref[0]; C_m = C_m + mine[0]
+            rho = rng.randrange(1, O.R)
+            orig = M.random_scalar
+            M.random_scalar = lambda rho=rho: A.Scalar(rho)
+            try:
+                acc.accumulate_check(C_m, [mine[t] for t in idx], [A.Scalar(s) for s in sc])
+            finally:
+                M.random_scalar = orig
+            o_A = o_A + C_o * S.Scalar(rho)
+            for t, s in zip(idx, sc):
+                k = bytes(ref[t].to_compressed_bytes())
+                o_map[k] = o_map.get(k, S.Scalar(0)) + S.Scalar(rho) * S.Scalar(s)
+        keys, vals = zip(*o_map.items())
+        want = omsm([S.G1Point.from_compressed_bytes_unchecked(k) for k in keys], vals) == o_A
+        try:
+            acc.verify(); got = True
+        except AssertionError:
+            got = False
+        assert got == want, (case, got, want)
