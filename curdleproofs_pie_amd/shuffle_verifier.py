@@ -45,6 +45,45 @@ def _addr(b) -> int:
     return ctypes.addressof(b)
 
 
+class _Segments:
+    """Several callers' batches travelling as ONE internal batch without being copied together: item i of the internal batch is item
+    i - first of the segment that holds it.  `runs(lo, hi)` cuts [lo, hi) at the segment boundaries."""
+
+    def __init__(self, parts, item_bytes: int):
+        self.parts = list(parts)                              # [(bytes-like, n_items)]
+        self.item_bytes = item_bytes
+        self.first = [0]
+        for _, n in self.parts:
+            self.first.append(self.first[-1] + n)
+
+    def __len__(self) -> int:
+        return self.first[-1] * self.item_bytes
+
+    def runs(self, lo: int, hi: int):
+        """(address of item `a`, a, count) for every maximal run [a, a + count) of [lo, hi) inside one segment"""
+        for k, (buf, n) in enumerate(self.parts):
+            f = self.first[k]
+            a, b = max(lo, f), min(hi, f + n)
+            if a < b:
+                yield _addr(buf) + (a - f) * self.item_bytes, a, b - a
+
+    def item_addr(self, i: int) -> int:
+        for addr, a, cnt in self.runs(i, i + 1):
+            return addr
+        raise IndexError(i)
+
+    def joined(self) -> bytes:
+        return b"".join(bytes(buf) for buf, _ in self.parts)
+
+
+def _runs(buf, item_bytes: int, lo: int, hi: int):
+    """The same for a plain contiguous buffer: one run."""
+    if isinstance(buf, _Segments):
+        yield from buf.runs(lo, hi)
+    else:
+        yield _addr(buf) + lo * item_bytes, lo, hi - lo
+
+
 def _tracker_bytes(trackers) -> Tuple[bytes, bytes]:
     """Sequence of WhiskTracker-likes (r_G, k_r_G attributes; whisk_interface.py:24-30) or (r_G, k_r_G) pairs.
     Every encoding must be exactly 48 bytes (the reference decodes them one by one, whisk_interface.py:96-100, and raises on
@@ -443,8 +482,8 @@ class ShuffleBatchVerifier:
         crs, ctx = self.crs, self.ctx
         L = crs.points_per_proof
         wire = b["host"]["wire"].ptr + lo * L * 48
-        ctx.check(N.cg1_shuffle_gather_points(crs.handle, hi - lo, _addr(instances) + lo * 4 * crs.ell * 48,
-                                              _addr(proofs) + lo * crs.proof_bytes, wire))
+        for (ia, a, cnt), (pa, _, _) in zip(_runs(instances, 4 * crs.ell * 48, lo, hi), _runs(proofs, crs.proof_bytes, lo, hi)):
+            ctx.check(N.cg1_shuffle_gather_points(crs.handle, cnt, ia, pa, b["host"]["wire"].ptr + a * L * 48))
         ctx.check(N.cg1_h2d_async(ctx.handle, b["wire"].ptr + lo * L * 48, wire, (hi - lo) * L * 48))
 
     def _decompress_launch(self, b: dict, lo: int, hi: int) -> None:
@@ -524,6 +563,11 @@ class ShuffleBatchVerifier:
         return tk
 
     def _front_end(self, tk: dict) -> None:
+        if isinstance(tk["instances"], _Segments):            # (the host front-end takes contiguous bytes; coalescing is the device front-end's)
+            tk["instances"], tk["proofs"] = tk["instances"].joined(), tk["proofs"].joined()
+        return self._front_end_contiguous(tk)
+
+    def _front_end_contiguous(self, tk: dict) -> None:
         """Stage 2 (caller's thread, all cores through the native pool): the front-end of each sub-batch as soon as the
         GPU has decoded it.  device_rows: it emits the row builder's input blocks (challenges + derived scalars), which go
         to the device with the host's reject codes; else the rows themselves, then point verdicts, early rejects and the
@@ -603,7 +647,8 @@ class ShuffleBatchVerifier:
         L, C = crs.points_per_proof, crs.ncrs
         b, n = tk["slot"], tk["n"]
         ib, pb = 4 * crs.ell * 48, crs.proof_bytes
-        inst, proof = _addr(tk["instances"]) + i * ib, _addr(tk["proofs"]) + i * pb
+        inst = next(_runs(tk["instances"], ib, i, i + 1))[0]
+        proof = next(_runs(tk["proofs"], pb, i, i + 1))[0]
         ok = ctypes.c_int(0)
         ctx.check(N.cg1_shuffle_exact_same_scalar(crs.handle, inst, proof, ctypes.byref(ok)))
         if not ok.value:
@@ -666,7 +711,9 @@ class ShuffleBatchVerifier:
                         raise r
                 t0 = time.perf_counter()
                 cx, fe, aux_h, aux_d = self._fe_lane(k, n)
-                cx.check(N.cg1_shuffle_gather_aux(self.crs.handle, n, _addr(tk["proofs"]), _addr(tk["weights"]), aux_h.ptr))
+                aux_rec = N.cg1_shuffle_fe_aux_bytes()
+                for pa, a, cnt in _runs(tk["proofs"], self.crs.proof_bytes, 0, n):
+                    cx.check(N.cg1_shuffle_gather_aux(self.crs.handle, cnt, pa, _addr(tk["weights"]) + a * N_WEIGHTS * 32, aux_h.ptr + a * aux_rec))
                 cx.check(N.cg1_h2d(cx.handle, aux_d.ptr, aux_h.ptr, n * 19 * 32))
                 cx.check(N.cg1_shuffle_fe_enqueue(fe, cx.handle, n, b["wire"].ptr, b["pts"].ptr, aux_d.ptr, b["rowin"].ptr, b["hstat"].ptr, 0))
                 cx.check(N.cg1_stream_sync(cx.handle))
@@ -933,6 +980,16 @@ class ShuffleBatchVerifier:
         limit = int(self.coalesce)
         groups = deque()                                        # per internal batch: the sizes of the callers' batches inside it
 
+        ib, pb = 4 * self.crs.ell * 48, self.crs.proof_bytes
+
+        def together(pend, size):
+            """the callers' batches as one internal batch, NOT copied together: the stages gather from the segments where they lie"""
+            if len(pend) == 1:
+                return pend[0]
+            for x in pend:
+                assert len(x[0]) == x[2] * ib and len(x[1]) == x[2] * pb
+            return (_Segments([(x[0], x[2]) for x in pend], ib), _Segments([(x[1], x[2]) for x in pend], pb), size)
+
         def merged():
             pend, size = [], 0
             for b in batches:
@@ -941,7 +998,7 @@ class ShuffleBatchVerifier:
                 if not plain or n >= limit or (pend and size + n > limit):
                     if pend:
                         groups.append([x[2] for x in pend])
-                        yield (b"".join(x[0] for x in pend), b"".join(x[1] for x in pend), size) if len(pend) > 1 else pend[0]
+                        yield together(pend, size)
                         pend, size = [], 0
                     if not plain or n >= limit:
                         groups.append([n])
@@ -951,11 +1008,11 @@ class ShuffleBatchVerifier:
                 size += n
                 if size >= limit:
                     groups.append([x[2] for x in pend])
-                    yield (b"".join(x[0] for x in pend), b"".join(x[1] for x in pend), size) if len(pend) > 1 else pend[0]
+                    yield together(pend, size)
                     pend, size = [], 0
             if pend:
                 groups.append([x[2] for x in pend])
-                yield (b"".join(x[0] for x in pend), b"".join(x[1] for x in pend), size) if len(pend) > 1 else pend[0]
+                yield together(pend, size)
 
         for st in self._verify_stream_device(merged(), mode, rng):
             sizes = groups.popleft()
