@@ -196,9 +196,10 @@ class ShuffleBatchVerifier:
         self._fe_by_default = device_front_end is None      # nobody asked for one of the two: an ISOLATED batch may take the other (verify_packed)
         self._host_twin = None
         if device_front_end is None:
-            # ... with the runtime's default of 4 hardware queues (N.hw_queues(); the application did not call N.tune_runtime()) the device
-            # front-end is one pipeline at 13.5 ms per batch (76 K proofs/s): the host front-end is the better default from 8 threads up
-            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < (24 if N.hw_queues() >= 12 else 8)
+            # (round 5: also with the runtime's default of 4 hardware queues -- a stream then travels in coalesced internal batches of up to
+            # 4 096 proofs, _verify_stream_coalesced: 1.55e5 proofs/s whatever the host's cores, against 7.6e4 for 1 024-proof batches alone;
+            # profiles/r05_verify_queues_ab.txt, r05_bench_verify_4_queues.json)
+            device_front_end = (threads or int(N.cg1_shuffle_default_threads())) < 24
         self.device_front_end = bool(device_front_end)
         # pipelines (device front-end only): that many complete pipelines -- decoding lane, front-end launches, MSM lane, each on contexts
         # of its own -- take the batches of a stream in turn.  One pipeline leaves the GPU idle between its dependent kernels (the
