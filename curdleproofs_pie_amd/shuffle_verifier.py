@@ -217,10 +217,12 @@ class ShuffleBatchVerifier:
             fe_lanes = 2 if (self.pipelines > 1 or N.hw_queues() < 8) else 3
         self._kids = None
         self.fe_lanes = max(1, int(fe_lanes)) if self.device_front_end else 0
-        # coalesce: with fewer than 12 hardware queues (nobody raised GPU_MAX_HW_QUEUES) a STREAM of batches is verified in internal batches
-        # of up to 4 096 proofs (_verify_stream_coalesced); 0 = never, N = that many proofs.  With 12 queues and more the pipelines do the job.
+        # coalesce: a STREAM of batches is verified in internal batches of up to this many proofs (_verify_stream_coalesced; 0 = never): a
+        # front-end launch takes ~12 ms whatever it carries, so larger internal batches amortise it.  Measured with 1 024-proof batches
+        # (profiles/r05_verify_queues_ab.txt): 4 hardware queues (the runtime's default; one pipeline) 8.2e4 -> 1.55e5 proofs/s at 4 096;
+        # 24 queues (three pipelines) 1.72e5 -> 1.86e5 at 2 048 (4 096 starves the pipelines: 1.51e5).
         if self._coalesce_arg is None:
-            self.coalesce = 4096 if (self.device_front_end and N.hw_queues() < 12) else 0
+            self.coalesce = (4096 if N.hw_queues() < 12 else 2048) if self.device_front_end else 0
         else:
             self.coalesce = max(0, int(self._coalesce_arg))
         # fe_cus > 0 (A/B switch, off): the front-end launches get that many compute units of their own (the last ones) and the

@@ -18,10 +18,10 @@ sys.path.insert(0, ROOT)
 import bench
 from curdleproofs_pie_amd import _native as N
 from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
-batch, fe_lanes, pipelines, steps = (int(x) for x in sys.argv[1:5])
+batch, fe_lanes, pipelines, steps, coalesce = (int(x) for x in sys.argv[1:6])
 ctx = N.Context(0)
 fx = bench.load_batch_fixture()
-v = ShuffleBatchVerifier(fx.crs, ctx, threads=4, device_front_end=True, fe_lanes=(fe_lanes or None), pipelines=(pipelines or None))
+v = ShuffleBatchVerifier(fx.crs, ctx, threads=4, device_front_end=True, fe_lanes=(fe_lanes or None), pipelines=(pipelines or None), coalesce=(None if coalesce < 0 else coalesce))
 inst, proofs, want = fx.tiled(batch)
 for st in v.verify_stream(((inst, proofs, batch) for _ in range(v.pipelines * (v.fe_lanes + 2) + 2))):
     assert not any(st)
@@ -31,7 +31,7 @@ for st in v.verify_stream(((inst, proofs, batch) for _ in range(steps))):
     assert not any(st)
 ctx.sync()
 el = time.perf_counter() - t0
-print(json.dumps({"hw_queues": N.hw_queues(), "batch": batch, "fe_lanes": v.fe_lanes, "pipelines": v.pipelines, "ms_per_batch": round(el / steps * 1e3, 3),
+print(json.dumps({"hw_queues": N.hw_queues(), "batch": batch, "coalesce": v.coalesce, "fe_lanes": v.fe_lanes, "pipelines": v.pipelines, "ms_per_batch": round(el / steps * 1e3, 3),
                   "proofs_per_s": round(batch * steps / el)}))
 v.close()
 '''
@@ -39,11 +39,12 @@ v.close()
 
 def main():
     rows = []
-    for queues, batch, fe, pipes in ((4, 1024, 0, 0), (4, 2048, 1, 1), (4, 2048, 2, 1), (4, 4096, 1, 1), (4, 4096, 2, 1), (4, 2048, 2, 2), (8, 2048, 2, 1), (24, 1024, 0, 0), (24, 2048, 0, 0)):
+    for queues, batch, fe, pipes, co in ((4, 1024, 0, 0, 0), (4, 1024, 0, 0, -1), (4, 2048, 2, 1, 0), (4, 4096, 2, 1, 0), (8, 1024, 0, 0, -1),
+                                         (24, 1024, 0, 0, 0), (24, 1024, 0, 0, 2048), (24, 1024, 0, 0, 4096), (24, 2048, 0, 0, 0)):
         env = dict(os.environ)
         env["GPU_MAX_HW_QUEUES"] = str(queues)             # said explicitly, 4 included (= the runtime's default): bench.py's import would otherwise raise it
-        steps = max(12, 24576 // batch)
-        r = subprocess.run([sys.executable, "-c", CHILD % ROOT, str(batch), str(fe), str(pipes), str(steps)], capture_output=True, text=True, timeout=600, env=env)
+        steps = max(12, 49152 // batch)
+        r = subprocess.run([sys.executable, "-c", CHILD % ROOT, str(batch), str(fe), str(pipes), str(steps), str(co)], capture_output=True, text=True, timeout=600, env=env)
         if r.returncode != 0:
             rows.append({"hw_queues": queues, "batch": batch, "error": (r.stdout + r.stderr)[-400:]})
         else:
