@@ -747,7 +747,8 @@ class ShuffleBatchVerifier:
             dev = self.ctx.device
             self._kids = [ShuffleBatchVerifier(self.crs, N.Context(dev), threads=self.threads, chunk=self.chunk, device_rows=self.device_rows,
                                                blocking_sync=self.blocking_sync, device_front_end=True, fe_lanes=self.fe_lanes, fe_prio=self.fe_prio, pipelines=1,
-                                               max_pinned_bytes=self.max_pinned_bytes)
+                                               max_pinned_bytes=self.max_pinned_bytes, coalesce=0)      # (the stream is coalesced once, by this verifier: a child
+                                                                                                       # waiting for a second batch to merge would starve its siblings' order)
                           for _ in range(self.pipelines)]
             for k in self._kids:
                 k._own_ctx = True

@@ -209,3 +209,24 @@ def test_stream_travels_in_coalesced_batches_when_queues_are_scarce(native_lib, 
     assert [[s == 0 for s in st] for st in got] == want
     assert [[s == 0 for s in st] for st in plain.verify_stream(iter(batches))] == want
     v.close(); plain.close()
+
+
+@pytest.mark.gpu
+def test_coalesced_stream_over_pipelines(native_lib, fx):
+    """The same with several pipelines behind the coalescing verifier (24 hardware queues: the default shape), for limits that merge
+    two caller batches, none at all (every internal batch = one caller batch: the children must not wait for a second one), and
+    uneven sizes; the stream ends cleanly each time."""
+    from curdleproofs_pie_amd.shuffle_verifier import ShuffleBatchVerifier
+
+    sizes = [512, 512, 300, 700, 512, 512, 512, 100, 512]
+    slots = [{}, {3: 1}, {}, {650: 2}, {}, {}, {511: 3}, {}, {0: 4}]
+    batches, want = [], []
+    for n, sl in zip(sizes, slots):
+        inst, proofs, w = fx.tiled(n, sl)
+        batches.append((inst, proofs, n))
+        want.append(w)
+    for limit in (1024, 600, 4096):
+        v = ShuffleBatchVerifier(fx.crs, native_lib.Context(0), device_front_end=True, pipelines=2, fe_lanes=1, coalesce=limit)
+        got = list(v.verify_stream(iter(batches)))
+        assert [[s == 0 for s in st] for st in got] == want, limit
+        v.close()

@@ -39,8 +39,12 @@ v.close()
 
 def main():
     rows = []
-    for queues, batch, fe, pipes, co in ((4, 1024, 0, 0, 0), (4, 1024, 0, 0, -1), (4, 2048, 2, 1, 0), (4, 4096, 2, 1, 0), (8, 1024, 0, 0, -1),
-                                         (24, 1024, 0, 0, 0), (24, 1024, 0, 0, 2048), (24, 1024, 0, 0, 4096), (24, 2048, 0, 0, 0)):
+    import sys as _s
+    rows_spec = ((4, 1024, 0, 0, 0), (4, 1024, 0, 0, -1), (4, 2048, 2, 1, 0), (4, 4096, 2, 1, 0), (8, 1024, 0, 0, -1),
+                 (24, 1024, 0, 0, 0), (24, 1024, 0, 0, 2048), (24, 1024, 0, 0, 4096), (24, 2048, 0, 0, 0))
+    if len(_s.argv) > 1 and _s.argv[1] == "shapes":          # the 24-queue shapes around the default (pipelines x front-end launches x coalescing)
+        rows_spec = tuple((24, 1024, fe, pp, co) for pp in (2, 3, 4) for fe in (1, 2, 3) for co in (2048,)) + ((24, 1024, 2, 3, 3072), (24, 1024, 2, 3, 1536), (32, 1024, 2, 4, 2048))
+    for queues, batch, fe, pipes, co in rows_spec:
         env = dict(os.environ)
         env["GPU_MAX_HW_QUEUES"] = str(queues)             # said explicitly, 4 included (= the runtime's default): bench.py's import would otherwise raise it
         steps = max(12, 49152 // batch)
