@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcurdle_g1.so")
 SOURCES = [os.path.join(CSRC, "msm_gpu.hip"), os.path.join(CSRC, "host_g1.cpp"), os.path.join(CSRC, "merlin.cpp"), os.path.join(CSRC, "shuffle_verify.cpp"), os.path.join(CSRC, "comm.cpp"), os.path.join(CSRC, "lazy_host.cpp")]
 DEPS = SOURCES + [os.path.join(CSRC, f) for f in ("kernels_opening.h", "fp28.h", "g1_xyzz.h", "g1_quad.h", "host_g1.h", "fe_mul_x86.h", "fr.h", "merlin_group.h", "bls_consts.h", "kernels_records.h", "kernels_prepare_digits.h",
-                                                    "kernels_sort.h", "kernels_accumulate.h", "kernels_reduce.h", "kernels_small.h", "kernels_batch.h", "kernels_rows.h", "kernels_merlin.h", "kernels_frontend.h", "pool.h", "lazy_host.h", "fp_row.h", "host_context.h", "host_chains.h", "capi_core_msm.h", "capi_vec_batched.h", "capi_lincomb.h",
+                                                    "kernels_sort.h", "kernels_accumulate.h", "kernels_reduce.h", "kernels_small.h", "kernels_batch.h", "kernels_rows.h", "kernels_merlin.h", "kernels_frontend.h", "pool.h", "lazy_host.h", "fp_row.h", "glv.h", "host_context.h", "host_chains.h", "capi_core_msm.h", "capi_vec_batched.h", "capi_lincomb.h",
                                                     "capi_timing_batchmul.h", "capi_codec_transcripts.h", "capi_frontend.h", "capi_rows_probes.h")] + [
     os.path.join(HERE, "..", "include", "curdle_g1.h")
 ]

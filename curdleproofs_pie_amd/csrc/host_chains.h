@@ -7,10 +7,17 @@ namespace cg1 {
 // c > 0: uniform windows of width c (nwin = 255 / c + 1).  c < 0: a BALANCED plan with cmax = -c: the 256 bit positions
 // are cut into nwin = ceil(256 / cmax) windows of width cmax (the low ones) or cmax - 1, so the top window keeps
 // >= cmax - 2 scalar bits and the recoding carry never leaves it (scalars are < 2^255).
-static WinPlan make_plan(int c) {
+// glv: the same over the 128 bit positions of the halves of the endomorphism split (glv.h: magnitudes < 0.68 * 2^127).
+static WinPlan make_plan(int c, bool glv = false) {
   WinPlan pl;
-  if (c > 0) { pl.cmax = c; pl.nwin = 255 / c + 1; pl.n_hi = pl.nwin; }
-  else { const int cm = -c, nw = (256 + cm - 1) / cm; pl.cmax = cm; pl.nwin = nw; pl.n_hi = 256 - nw * (cm - 1); }
+  const int bits = glv ? 127 : 255;
+  pl.glv = glv ? 1 : 0;
+  if (c > 0) { pl.cmax = c; pl.nwin = bits / c + 1; pl.n_hi = pl.nwin; }
+  else {
+    const int cm = -c, nw = (bits + 1 + cm - 1) / cm;
+    pl.cmax = cm; pl.nwin = nw; pl.n_hi = bits + 1 - nw * (cm - 1);
+    if (pl.n_hi < 0) pl.n_hi = 0;        // nw windows of width cm - 1 already cover every position (128 positions at cm = 14: 10 x 13): all narrow
+  }
   return pl;
 }
 
@@ -92,6 +99,10 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   ctx->pend.active = false;
   HIPCHK(hipSetDevice(ctx->device));
   const int c = plan.cmax, nwin = plan.nwin;
+  // an endomorphism-split call (plan.glv) runs over 2n records -- P_i, then phi(P_i) -- and 2n rows of digits; everything behind the digit
+  // kernel sees an MSM of `n` = 2 n_real points
+  const size_t n_real = n;
+  if (plan.glv) n *= 2;
   const int nlw = win_count(nwin, rank, world);                // `world` is a window selector (kernels_prepare_digits.h win_sel): the share w = rank (mod world), or a run of it
   if (nlw <= 0) return CG1_OK;
   const uint32_t NB = 1u << (c - 1);
@@ -136,8 +147,12 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_out + nout_words);       // [0] set by the digit kernels: a scalar >= 2^255; [1], [2]: counts
   if (hooks.before_start) HIPCHK(hipStreamWaitEvent(st, hooks.before_start, 0));
   if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[0], st));
-  if (resident) HIPCHK(hipMemsetAsync(bad_flag, 0, 16, st));
-  else launch_prepare(st, src, ctx->d_pts, ctx->d_flags, n32, bad_flag);
+  const uint32_t n_real32 = (uint32_t)n_real;
+  if (resident) HIPCHK(hipMemsetAsync(bad_flag, 0, 16, st));                       // (an endomorphism-split call: the source already holds both halves)
+  else {
+    launch_prepare(st, src, ctx->d_pts, ctx->d_flags, n_real32, bad_flag);
+    if (plan.glv) hipLaunchKernelGGL(k_phi_records, dim3((n_real32 + 255) / 256), dim3(256), 0, st, ctx->d_pts, ctx->d_flags, n_real32);
+  }
   if (hooks.after_prepare) HIPCHK(hipEventRecord(hooks.after_prepare, st));
   if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[1], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
@@ -151,7 +166,7 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
     const uint32_t nbins = 1u << (bb - sub_bits);
     const uint32_t nslices = (n32 + PART_TILE - 1) / PART_TILE;
     const uint32_t nbc = (uint32_t)nlw * nbins * nslices;
-    hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_digits, n32, plan, rank, world, bad_flag);
+    hipLaunchKernelGGL(k_digits, dim3((n_real32 + 255) / 256), dim3(256), 0, st, (const uint32_t*)d_scalars32, flags, ctx->d_digits, n_real32, plan, rank, world, bad_flag);
     hipLaunchKernelGGL(k_part_count, dim3(nslices, nlw), dim3(256), 0, st, ctx->d_digits, ctx->d_blockcnt, n32, nslices, nbins, sub_bits);
     const uint32_t ublk = (nbc + SCAN_ITEMS - 1) / SCAN_ITEMS;
     if (ctx->scan_one && nbc <= USCAN1_MAX) {
@@ -332,7 +347,7 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
   for (int lw = 0; lw < nlw; ++lw) {
     const int w = win_global(lw, rank, world), base = plan.off(w);
     const PointWords* row = pd.hout + (size_t)lw * nitems;
-    auto put = [&](int e, const PointWords* p) { if (!p->inf) { items.emplace_back(e, p); if (e > e_top) e_top = e; } };
+    auto put = [&](int e, const PointWords* p) { if (!p->inf && e >= 0 && e < EMAX) { items.emplace_back(e, p); if (e > e_top) e_top = e; } };      // (a plan never leaves [0, EMAX): the guard keeps a planner bug off the stack)
     put(base, &row[0]);
     if (use2d) {
       for (uint32_t k = 0; k < hb2; ++k) put(base + (int)lb2 + (int)k, &row[1 + k]);
@@ -591,10 +606,13 @@ int msm_begin(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int
     ctx->pend_c = c;
     return msm_enqueue_small(ctx, src, d_scalars32, n, c);
   }
-  if (c == 0) c = pick_plan_c(n, ctx->auto_plan);
+  // the endomorphism split ("glv": the caller vouches that the points lie in G1): 2n records, half the windows.  Not for resident
+  // vectors (their tables hold n records) nor beyond the partition sort's 2^23 entries per window.
+  const bool glv = ctx->glv && src.kind != PtSrc::PREPARED && ctx->use_partition_sort && 2 * n <= PART_MAX_N && n >= (size_t)ctx->glv_min_n;
+  if (c == 0) c = pick_plan_c(glv ? 2 * n : n, ctx->auto_plan);
   const int cabs = c < 0 ? -c : c;
   if (cabs < 4 || cabs > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
-  const WinPlan plan = make_plan(c);
+  const WinPlan plan = make_plan(c, glv);
   ctx->pend_c = c;
   ctx->pend_split = false;
   if (ctx->split && n >= ctx->split_min_n && win_count(plan.nwin, rank, world) >= 2) return msm_begin_split(ctx, src, d_scalars32, n, plan, rank, world);

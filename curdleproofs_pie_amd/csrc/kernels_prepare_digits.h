@@ -147,6 +147,8 @@ __global__ void __launch_bounds__(128) k_prepare_blobs(const uint32_t* __restric
 // a thin top window would pile all n terms into a handful of buckets).  Digit w: value in [-(2^(width-1)-1), 2^(width-1)].
 struct WinPlan {
   int nwin, cmax, n_hi;                  // windows 0 .. n_hi-1 have width cmax, the others cmax - 1 (uniform: n_hi = nwin)
+  int glv;                               // 1: the windows cut the 127-bit halves of the endomorphism split (glv.h); the digit kernel then
+                                         // writes TWO rows of digits per scalar, for the points i and n + i (= phi(P_i)) of a 2n-record table
   CG1_HD int width(int w) const { return w < n_hi ? cmax : cmax - 1; }
   CG1_HD int off(int w) const { return w < n_hi ? w * cmax : n_hi * cmax + (w - n_hi) * (cmax - 1); }
 };
@@ -184,6 +186,8 @@ struct WinWalk {
 struct DigitIter {
   uint32_t s[8];
   uint32_t carry;
+  uint32_t flip;                         // 1: the digits of the NEGATED value: the tie d = 2^(c-1) goes the other way, so that the negated
+                                         // digit stays in the u16 range (-2^15 has no encoding; 0x8000 means +2^15)
   // must be called for w = 0, 1, 2, ... in order: the window's bits are the low c bits of s, which is then shifted down by c as a
   // whole (eight v_alignbit with a wave-uniform count).  Picking the words by the window's bit offset instead indexes a register array
   // with a run-time index: k_digits took 31 us for 2^16 scalars of a 20-window plan that way, 3x what the shifts need.
@@ -194,9 +198,10 @@ struct DigitIter {
     for (int k = 0; k < 7; ++k) s[k] = __builtin_amdgcn_alignbit(s[k + 1], s[k], (uint32_t)c);
     s[7] >>= c;
     uint32_t d = raw + carry;
-    if (d > (1u << (c - 1))) { carry = 1; return (int)d - (1 << c); }
-    carry = 0;
-    return (int)d;
+    int r;
+    if (d > (1u << (c - 1)) - flip) { carry = 1; r = (int)d - (1 << c); }
+    else { carry = 0; r = (int)d; }
+    return flip ? -r : r;
   }
 };
 __device__ __forceinline__ void load_scalar(const uint32_t* scalars, uint32_t i, DigitIter& it) {
@@ -204,7 +209,33 @@ __device__ __forceinline__ void load_scalar(const uint32_t* scalars, uint32_t i,
   uint4 a = q[0], b = q[1];
   it.s[0] = a.x; it.s[1] = a.y; it.s[2] = a.z; it.s[3] = a.w;
   it.s[4] = b.x; it.s[5] = b.y; it.s[6] = b.z; it.s[7] = b.w;
-  it.carry = 0;
+  it.carry = 0; it.flip = 0;
+}
+// one 127-bit half of the endomorphism split as a digit source
+__device__ __forceinline__ void load_half(const uint32_t (&mag)[4], uint32_t neg, DigitIter& it) {
+  it.s[0] = mag[0]; it.s[1] = mag[1]; it.s[2] = mag[2]; it.s[3] = mag[3];
+  it.s[4] = it.s[5] = it.s[6] = it.s[7] = 0;
+  it.carry = 0; it.flip = neg;
+}
+
+// ------------------------------------------------------------------ k_phi_records
+// record n + i = phi(record i) = (beta x, y): the second half of the 2n-record table of an endomorphism-split MSM (glv.h).
+__global__ void __launch_bounds__(256) k_phi_records(PreparedPoint* __restrict__ pts, uint8_t* __restrict__ inf_flag, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
+  fp beta; for (int k = 0; k < NL; ++k) beta.l[k] = bt[k];
+  const uint4* src = reinterpret_cast<const uint4*>(pts + i);
+  uint32_t w[32];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const uint4 v = src[k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+  fp x; for (int k = 0; k < NL; ++k) x.l[k] = w[k];
+  const fp bx = fp_norm(fp_mul(x, beta));
+  for (int k = 0; k < NL; ++k) w[k] = bx.l[k];
+  uint4* dst = reinterpret_cast<uint4*>(pts + n + i);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) dst[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
+  inf_flag[n + i] = inf_flag[i];
 }
 
 // counts per (local window, bucket); skips zero digits and identity points

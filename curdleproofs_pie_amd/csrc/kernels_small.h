@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
     load_scalar(a.scalars, i, it);
     if (it.s[7] >> 31) atomicOr(&a.counters[gctr + 1], 1u);        // a scalar >= 2^255: the host rejects the call
     WinPlan pl;
-    pl.nwin = (int)nwin; pl.cmax = (int)c; pl.n_hi = (int)nwin;
+    pl.nwin = (int)nwin; pl.cmax = (int)c; pl.n_hi = (int)nwin; pl.glv = 0;
     int d = 0;
     for (uint32_t ww = 0; ww <= w; ++ww) d = it.next(pl, (int)ww);
     if (!inf && d != 0) {

@@ -50,6 +50,25 @@ __global__ void __launch_bounds__(256) k_digits(const uint32_t* __restrict__ sca
   DigitIter it;
   load_scalar(scalars, i, it);
   if (it.s[7] >> 31) *bad_flag = 1u;              // >= 2^255: the signed-digit recoding would carry out of the top window
+  if (pl.glv) {
+    // two digit rows per scalar: the halves k1 (on P_i, row entry i) and k2 (on phi(P_i), entry n + i) of k = k1 + k2 lambda; both
+    // magnitudes are <= (lambda + 1) / 2 < 0.68 * 2^127, so the recoding carry never leaves the top window of a 128-position plan
+    GlvParts g;
+    glv_split(it.s, g);
+    DigitIter a, b;
+    load_half(g.k1, g.neg1, a);
+    load_half(g.k2, g.neg2, b);
+    const size_t nv = 2 * (size_t)n;
+    WinWalk ww(rank, world);
+    for (int w = 0; w < pl.nwin; ++w) {
+      const int d1 = a.next(pl, w), d2 = b.next(pl, w);
+      const int lw = ww.step(w);
+      if (lw < 0) continue;
+      digits[(size_t)lw * nv + i] = inf ? (uint16_t)0 : (uint16_t)(d1 & 0xFFFF);
+      digits[(size_t)lw * nv + n + i] = inf ? (uint16_t)0 : (uint16_t)(d2 & 0xFFFF);
+    }
+    return;
+  }
   WinWalk ww(rank, world);
   for (int w = 0; w < pl.nwin; ++w) {
     int d = it.next(pl, w);

@@ -9,6 +9,13 @@
 #include <cstring>
 #include <vector>
 
+#ifndef CG1_HD
+#define CG1_HD inline
+#endif
+namespace cg1 {
+#include "glv.h"
+}
+
 namespace cg1h {
 
 typedef unsigned __int128 u128;
@@ -419,6 +426,17 @@ void cg1_lincomb_write_outputs(const void* jac_results, size_t n_out, uint8_t* o
     }
     if (out_comp48) cg1h::g1_compress_affine(xs[j], ys[j], inf[j] != 0, out_comp48 + 48 * j);
   }
+}
+
+// The endomorphism split the device digit kernels use (csrc/glv.h), one scalar: for the CPU tests.
+void cg1_glv_split(const uint8_t* scalar32, uint8_t* k1_16, uint8_t* k2_16, int* neg1, int* neg2) {
+  uint32_t k[8];
+  memcpy(k, scalar32, 32);
+  cg1::GlvParts o;
+  cg1::glv_split(k, o);
+  memcpy(k1_16, o.k1, 16);
+  memcpy(k2_16, o.k2, 16);
+  *neg1 = (int)o.neg1; *neg2 = (int)o.neg2;
 }
 
 }  // extern "C"

@@ -55,6 +55,7 @@ int pick_window(size_t n);
 
 #include "kernels_records.h"
 #include "fp_row.h"
+#include "glv.h"
 #include "kernels_prepare_digits.h"
 #include "kernels_sort.h"
 #include "kernels_accumulate.h"

@@ -1,0 +1,84 @@
+"""The endomorphism split k = k1 + k2 * lambda (csrc/glv.h) as the device digit kernels compute it, against Python integers; on the
+GPU: an MSM with the split against the same MSM without it, and the refusal outside the subgroup being the CALLER's to make."""
+import ctypes
+import os
+import random
+
+import numpy as np
+import pytest
+
+from curdleproofs_pie_amd import _native as N
+from oracle import bls12_381 as O
+
+Z = 0xD201000000010000
+LAM = Z * Z - 1
+R = O.R
+
+
+def _split(k: int):
+    k1 = ctypes.create_string_buffer(16)
+    k2 = ctypes.create_string_buffer(16)
+    n1, n2 = ctypes.c_int(), ctypes.c_int()
+    N.cg1_glv_split(k.to_bytes(32, "little"), k1, k2, ctypes.byref(n1), ctypes.byref(n2))
+    a, b = int.from_bytes(k1.raw, "little"), int.from_bytes(k2.raw, "little")
+    return (-a if n1.value else a), (-b if n2.value else b)
+
+
+def test_lambda_is_the_eigenvalue_of_phi():
+    assert (LAM * LAM + LAM + 1) % R == 0
+    beta = 0x1A0111EA397FE699EC02408663D4DE85AA0D857D89759AD4897D29650FB85F9B409427EB4F49FFFD8BFD00000000AAAC
+    g = O.G1_GEN
+    p = O.g1_mul(g, 0x1234567)
+    assert O.g1_mul(p, LAM) == (p[0] * beta % O.P, p[1])
+
+
+def test_split_identity_and_bounds():
+    rng = random.Random(5)
+    edge = [0, 1, 2, R - 1, R, R + 1, (R + 1) // 2, (R + 1) // 2 - 1, (R + 1) // 2 + 1, (1 << 255) - 1, LAM, LAM - 1, LAM + 1, LAM >> 1, (LAM >> 1) + 1,
+            LAM * LAM, LAM * (LAM >> 1), R - LAM, R // 2, 1 << 254, (1 << 254) - 1, 1 << 127, (1 << 128) - 1]
+    cases = edge + [rng.getrandbits(255) for _ in range(20000)] + [rng.getrandbits(rng.randrange(1, 255)) for _ in range(2000)]
+    bound = (LAM + 1) // 2 + 1
+    for k in cases:
+        k1, k2 = _split(k)
+        assert (k1 + k2 * LAM - k) % R == 0, hex(k)
+        assert abs(k1) <= bound and abs(k2) <= bound, hex(k)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c", [(3000, 0), (1 << 14, 0), (1 << 14, 16), (1 << 14, -13), (1 << 14, -14), (1 << 14, 14), (1 << 14, 11), ((1 << 16) + 77, 0), (1 << 18, 0)])
+def test_msm_with_the_split_equals_the_msm_without(n, c):
+    ctx = N.Context(0)
+    rng = np.random.default_rng(n + 100 * abs(c))
+    # points of G1: multiples of the generator made on the device, with a few identities and repeats
+    m = min(n, 4096)
+    gen = O.G1_GEN
+    gen96 = gen[0].to_bytes(48, "little") + gen[1].to_bytes(48, "little")
+    ks = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x3F
+    base = ctx.batch_mul_add_host(gen96, 1, ks.tobytes(), m, None, m)
+    pts = np.frombuffer(base, dtype=np.uint8).reshape(m, 96)
+    pts = pts[rng.integers(0, m, n)].copy()
+    pts[5] = 0
+    pts[n // 2] = 0
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x3F
+    sc[0] = 0
+    sc[1] = np.frombuffer((R - 1).to_bytes(32, "little"), dtype=np.uint8)
+    sc[2] = np.frombuffer(((R + 1) // 2).to_bytes(32, "little"), dtype=np.uint8)
+    sc[3] = np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint8)
+    sc[4, 16:] = 0                                        # a 128-bit scalar
+    d_p = ctx.alloc(n * 96); d_p.upload(pts.tobytes())
+    d_s = ctx.alloc(n * 32); d_s.upload(sc.tobytes())
+    ctx.set_param("glv", 0)
+    want = ctx.msm_device(d_p, d_s, n, window_c=c)
+    ctx.set_param("glv", 1)
+    got = ctx.msm_device(d_p, d_s, n, window_c=c)
+    assert N.cg1_eq(got, want) == 1
+    if n <= 3000:
+        aff = [(int.from_bytes(p[:48].tobytes(), "little"), int.from_bytes(p[48:].tobytes(), "little")) for p in pts]
+        aff = [None if a == (0, 0) else a for a in aff]
+        ref = O.compute_MSM_fast(aff, [int.from_bytes(s.tobytes(), "little") for s in sc])
+        out = ctypes.create_string_buffer(96)
+        N.cg1_to_affine96(out, got)
+        assert out.raw == (bytes(96) if ref is None else ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little"))
+    ctx.close()
