@@ -283,8 +283,8 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "chunk_len")) { if (value < 1 || value > 65536) return CG1_ERR_ARG; ctx->L0 = (uint32_t)value; cg1::free_bufs(ctx); return CG1_OK; }
   if (!strcmp(name, "stage_sort")) { ctx->stage_sort = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "quad")) { ctx->quad = value ? 1 : 0; return CG1_OK; }
-  if (!strcmp(name, "glv")) { ctx->glv = value ? 1 : 0; return CG1_OK; }
-  if (!strcmp(name, "glv_min_n")) { if (value < 0) return CG1_ERR_ARG; ctx->glv_min_n = value; return CG1_OK; }
+  if (!strcmp(name, "glv")) { if (value < 0 || value > 2) return CG1_ERR_ARG; ctx->glv = value; return CG1_OK; }
+  if (!strcmp(name, "glv_max_n")) { if (value < 0) return CG1_ERR_ARG; ctx->glv_max_n = value; return CG1_OK; }
   if (!strcmp(name, "horner_row")) { ctx->horner_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "batch_mul_row")) { ctx->batch_mul_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "small_msm")) { ctx->small_msm = value ? 1 : 0; return CG1_OK; }

@@ -376,7 +376,7 @@ static int msm_finish(Ctx* ctx, cg1h::jac& result) {
     return a;
   };
   cg1h::jac acc;
-  const int nth = (!ctx->host_split || e_top < 96) ? 1 : (ctx->horner_threads >= 4 && e_top >= 192 ? 4 : 2);
+  const int nth = (!ctx->host_split || e_top < 96) ? 1 : (ctx->horner_threads >= 4 && e_top >= 112 ? 4 : 2);      // (112: the 128-position plans of the endomorphism split)
   if (nth > 1) {
     // the exponent range cut into nth parts: part j (on its own thread) forms horner(lo_j, hi_j) and then doubles it lo_j times, so
     // every part ends with its full weight and the parts are simply added.  The critical path is the top part: e_top doublings,
@@ -445,13 +445,14 @@ static int pick_small_c(size_t n) {
 // One launch (two when un-normalised blobs have to be inverted first) for an MSM of n <= SM_MAX_N terms -- or for M <= SM_MAX_MSMS
 // independent ones of at most max_n terms each (d_offs: their M + 1 term offsets on the device); fills ctx->pend like msm_enqueue, so
 // msm_finish polls the same flag and runs the same host Horner (M = 1), or msm_small_batched_finish does (M > 1).
-static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int c, uint32_t M = 1, const uint32_t* d_offs = nullptr, size_t max_n = 0) {
+static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int c, uint32_t M = 1, const uint32_t* d_offs = nullptr, size_t max_n = 0,
+                             bool glv = false) {
   ctx->pend.active = false;
   HIPCHK(hipSetDevice(ctx->device));
-  const WinPlan plan = make_plan(c);
+  const WinPlan plan = make_plan(c, glv);
   const uint32_t nwin = (uint32_t)plan.nwin, bb = (uint32_t)c - 1u, lb2 = (bb + 1u) / 2u, hb2 = bb - lb2, nitems = 1u + hb2 + lb2;
   if (M == 1) max_n = n;
-  const uint32_t S = (uint32_t)((max_n + SM_SLICE - 1) / SM_SLICE);
+  const uint32_t S = (uint32_t)(((glv ? 2 * max_n : max_n) + SM_SLICE - 1) / SM_SLICE);      // (split: slices of the 2n entries)
   auto h0 = std::chrono::steady_clock::now();
   if (!ctx->h_small_out) {
     HIPCHK(hipHostMalloc((void**)&ctx->h_small_out, ((size_t)SM_MAX_MSMS * 64 * 9 + 1) * sizeof(PointWords), hipHostMallocMapped | hipHostMallocCoherent));
@@ -475,6 +476,7 @@ static int msm_enqueue_small(Ctx* ctx, const PtSrc& src, const void* d_scalars32
   a.partial = ctx->d_small_partial; a.counters = ctx->d_small_ctr;
   a.out_host = ctx->h_small_out_dev; a.flag_host = ctx->h_flag_dev; a.seq = ++ctx->seq;
   a.row_tail = ctx->small_row_tail ? 1u : 0u;
+  a.glv = glv ? 1u : 0u;
   int kind = (int)src.kind;
   if (src.kind == PtSrc::BLOBS && !src.normalised) {           // invert first (one lane per point), then run on the prepared records
     if (n > ctx->cap_small_pts) {
@@ -600,15 +602,22 @@ int msm_begin(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, int
   if (n == 0) return CG1_OK;
   if (n >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "n too large"); return CG1_ERR_ARG; }
   if (world < 1 || world > 255 || rank < 0 || rank >= world) { snprintf(ctx->err, sizeof ctx->err, "bad window shard %d/%d", rank, world); return CG1_ERR_ARG; }
-  if (ctx->small_msm && n <= SM_MAX_N && world == 1 && (c == 0 || (c >= 4 && c <= 9 && c != 5)) &&
-      (size_t)(255 / (c ? c : pick_small_c(n)) + 1) * ((n + SM_SLICE - 1) / SM_SLICE) <= SM_ONE_ROUND) {
-    if (c == 0) c = pick_small_c(n);
-    ctx->pend_c = c;
-    return msm_enqueue_small(ctx, src, d_scalars32, n, c);
+  // the single-launch kernel; with "glv" (the caller vouches for G1) over the 2n entries of the endomorphism split when they fit
+  for (int pass = (ctx->glv && 2 * n <= SM_MAX_N) ? 1 : 0; pass >= 0; --pass) {
+    const bool sglv = pass == 1;
+    const size_t nn = sglv ? 2 * n : n;
+    const int bits = sglv ? 127 : 255;
+    if (ctx->small_msm && nn <= SM_MAX_N && world == 1 && (c == 0 || (c >= 4 && c <= 9 && c != 5)) &&
+        (size_t)(bits / (c ? c : pick_small_c(nn)) + 1) * ((nn + SM_SLICE - 1) / SM_SLICE) <= SM_ONE_ROUND) {
+      if (c == 0) c = pick_small_c(nn);
+      ctx->pend_c = c;
+      return msm_enqueue_small(ctx, src, d_scalars32, n, c, 1, nullptr, 0, sglv);
+    }
   }
   // the endomorphism split ("glv": the caller vouches that the points lie in G1): 2n records, half the windows.  Not for resident
   // vectors (their tables hold n records) nor beyond the partition sort's 2^23 entries per window.
-  const bool glv = ctx->glv && src.kind != PtSrc::PREPARED && ctx->use_partition_sort && 2 * n <= PART_MAX_N && n >= (size_t)ctx->glv_min_n;
+  const bool glv = src.kind != PtSrc::PREPARED && ctx->use_partition_sort && 2 * n <= PART_MAX_N &&
+                   (ctx->glv == 2 || (ctx->glv == 1 && n <= (size_t)ctx->glv_max_n));
   if (c == 0) c = pick_plan_c(glv ? 2 * n : n, ctx->auto_plan);
   const int cabs = c < 0 ? -c : c;
   if (cabs < 4 || cabs > 16) { snprintf(ctx->err, sizeof ctx->err, "window width %d out of range [4,16]", c); return CG1_ERR_ARG; }
@@ -684,9 +693,11 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
     // (grid.z = MSM) and their Horners run side by side on the host -- the regime-B launch chain costs ~0.5 ms whatever it sums.
     size_t max_n = 0;
     for (size_t j = 0; j < M; ++j) max_n = std::max<size_t>(max_n, h_offsets[j + 1] - h_offsets[j]);
-    const int cs = c > 0 ? c : pick_small_c(max_n);
-    const size_t groups = (size_t)M * (size_t)(255 / cs + 1) * ((max_n + SM_SLICE - 1) / SM_SLICE);
-    if (ctx->small_msm && M <= SM_MAX_MSMS && max_n <= SM_MAX_N && groups <= SM_MAX_GROUPS && cs >= 4 && cs <= 9 && cs != 5) {
+    const bool sglv = ctx->glv && 2 * max_n <= SM_MAX_N;
+    const size_t max_nn = sglv ? 2 * max_n : max_n;
+    const int cs = c > 0 ? c : pick_small_c(max_nn);
+    const size_t groups = (size_t)M * (size_t)((sglv ? 127 : 255) / cs + 1) * ((max_nn + SM_SLICE - 1) / SM_SLICE);
+    if (ctx->small_msm && M <= SM_MAX_MSMS && max_nn <= SM_MAX_N && groups <= SM_MAX_GROUPS && cs >= 4 && cs <= 9 && cs != 5) {
       HIPCHK(hipSetDevice(ctx->device));
       if ((M + 1) > ctx->cap_boffs) {
         if (ctx->d_boffs) (void)hipFree(ctx->d_boffs);
@@ -695,7 +706,7 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
         ctx->cap_boffs = M + 1;
       }
       HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-      int rc = msm_enqueue_small(ctx, PtSrc(d_points96), d_scalars32, N, cs, (uint32_t)M, ctx->d_boffs, max_n);
+      int rc = msm_enqueue_small(ctx, PtSrc(d_points96), d_scalars32, N, cs, (uint32_t)M, ctx->d_boffs, max_n, sglv);
       if (rc) return rc;
       if (async_small) { *async_small = true; return CG1_OK; }
       return msm_batched_small_end(ctx, M, results);

@@ -171,9 +171,10 @@ struct Ctx {
   PointSum* d_gsum = nullptr; size_t cap_gsum = 0;
   PointWords* d_bout = nullptr; PointWords* h_bout = nullptr; size_t cap_bout = 0;
   PointWords* d_gout = nullptr; PointWords* h_gout = nullptr; size_t cap_gout = 0;       // regime B, few MSMs: window sums exported for the host Horner
-  int glv = 0;                          // "glv": 1 = the caller vouches that every point of its MSM calls lies in the prime-order subgroup; regime A then
-                                        // runs the endomorphism split (csrc/glv.h): 2n records, half the windows.  WRONG results outside G1: default 0.
-  int glv_min_n = 0;                    // "glv_min_n": smallest regime-A call the split is applied to
+  int glv = 0;                          // "glv": the caller vouches that every point of its MSM calls lies in the prime-order subgroup, and the engine may run
+                                        // the endomorphism split (csrc/glv.h): 1 = where it pays (the single-launch kernel up to 1 024 terms, regime A up to
+                                        // glv_max_n terms), 2 = wherever it can (A/B runs).  WRONG results outside G1: default 0.
+  int glv_max_n = 1 << 14;              // "glv_max_n": largest regime-A call glv = 1 splits (profiles/r05_glv_ab.txt: slower from 2^15 terms up)
   int horner_row = 1;                   // "horner_row": regime B's device Horner with one wave per MSM, one limb per lane (A/B switch; 0: one quad per MSM)
   int batch_mul_row = 1;                // "batch_mul_row": deferred map / fold batches of 96 .. 4096 results on k_batch_mul_row (A/B switch; 0: pool / k_batch_mul)
   int batched_host_horner_max = 24;     // regime B calls with at most this many MSMs run their Horner on the host ("batched_host_horner_max")

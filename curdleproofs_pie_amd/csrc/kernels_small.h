@@ -40,6 +40,8 @@ struct SmallArgs {
   uint32_t* flag_host;
   uint32_t seq;
   uint32_t row_tail;                      // 1: the items, the combine and the export run one limb per lane, one wave per item (fp_row.h)
+  uint32_t glv;                           // 1: the endomorphism split (glv.h; the caller vouches for G1): an MSM of n terms runs as 2n entries -- entry v < n is
+                                          // (k1 of scalar v, P_v), entry n + v is (k2, phi(P_v)) -- over the windows of a 128-position plan; S counts slices of 2n
 };
 
 template <int SRC>
@@ -55,7 +57,8 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
   const uint32_t c = a.c, NB = 1u << (c - 1), nwin = a.nwin, S = a.S, nitems = a.nitems;
   const uint32_t first = a.offs ? a.offs[msm] : 0u, n_msm = a.offs ? a.offs[msm + 1] - first : a.n;
   const uint32_t base = sl * SM_SLICE;                          // (an MSM shorter than the launch's longest leaves its last slices empty)
-  const uint32_t ns = base >= n_msm ? 0u : ((n_msm - base < SM_SLICE) ? n_msm - base : SM_SLICE);
+  const uint32_t n_ent = a.glv ? 2u * n_msm : n_msm;           // entries of this MSM: terms, or both halves of every term
+  const uint32_t ns = base >= n_ent ? 0u : ((n_ent - base < SM_SLICE) ? n_ent - base : SM_SLICE);
   const uint32_t wslot = msm * nwin + w, gctr = a.M * nwin;     // this (MSM, window)'s slot; the launch-wide counters behind the tickets
   if (tid < 256) s_hist[tid] = 0;
   if (tid < 8) s_misc[tid] = 0;
@@ -65,7 +68,9 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
   uint32_t my_b = 0, my_pos = 0, my_neg = 0;
   bool my_valid = false;
   if (tid < ns) {
-    const uint32_t i = first + base + tid;
+    const uint32_t ve = base + tid;
+    const bool second = a.glv && ve >= n_msm;                    // the phi(P) half of a split term
+    const uint32_t i = first + (second ? ve - n_msm : ve);
     uint32_t inf;
     fp x, y;
     if (SRC == 0) {
@@ -94,6 +99,11 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
       load_affine(static_cast<const PreparedPoint*>(a.src) + i, x, y, fl);
       inf = a.flags[i];
     }
+    if (second) {
+      constexpr uint32_t bt[NL] = {D_BETA[0], D_BETA[1], D_BETA[2], D_BETA[3], D_BETA[4], D_BETA[5], D_BETA[6], D_BETA[7], D_BETA[8], D_BETA[9], D_BETA[10], D_BETA[11], D_BETA[12], D_BETA[13]};
+      fp beta; for (int k = 0; k < NL; ++k) beta.l[k] = bt[k];
+      x = fp_norm(fp_mul(x, beta));
+    }
     uint32_t* o = reinterpret_cast<uint32_t*>(&s_pts[tid]);
 #pragma unroll
     for (int k = 0; k < NL; ++k) { o[k] = x.l[k]; o[NL + k] = y.l[k]; }
@@ -101,6 +111,11 @@ __global__ void __launch_bounds__(512) k_msm_small(SmallArgs a) {
     DigitIter it;
     load_scalar(a.scalars, i, it);
     if (it.s[7] >> 31) atomicOr(&a.counters[gctr + 1], 1u);        // a scalar >= 2^255: the host rejects the call
+    if (a.glv) {
+      GlvParts g;
+      glv_split(it.s, g);
+      if (second) load_half(g.k2, g.neg2, it); else load_half(g.k1, g.neg1, it);
+    }
     WinPlan pl;
     pl.nwin = (int)nwin; pl.cmax = (int)c; pl.n_hi = (int)nwin; pl.glv = 0;
     int d = 0;

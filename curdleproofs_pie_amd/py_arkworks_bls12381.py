@@ -161,11 +161,12 @@ def _div_by_zero():
 # A/B switch: CURDLE_G1_LAZY=0 or set_lazy(False) -- every operator then computes at once on the host library (round-4 behaviour).
 _LOCK = threading.RLock()        # one lock for everything that evaluates or touches the default context's staging (msm_accumulator.py too)
 _LAZY = os.environ.get("CURDLE_G1_LAZY", "1") != "0"
+_GLV = os.environ.get("CURDLE_G1_GLV", "1") != "0"      # flushes whose bases are all certified in G1 may use the endomorphism split (A/B switch)
 _SIBLING_LOOKBEHIND = 0          # a flush takes the asked-for value and every live deferred value created after it (+ this many before)
 _pending: list = []              # weak references to deferred values, in creation order
 _next_seq = itertools.count(1).__next__
 _ref = weakref.ref
-stats = {"flushes": 0, "flushed_values": 0, "flush_terms": 0, "flush_host": 0, "flush_device": 0, "flush_hybrid": 0, "decoded": 0, "decode_batches": 0, "subgroup_tests": 0, "subgroup_device": 0, "subgroup_host": 0}
+stats = {"flushes": 0, "flushed_values": 0, "flush_terms": 0, "flush_host": 0, "flush_device": 0, "flush_hybrid": 0, "flush_split": 0, "decoded": 0, "decode_batches": 0, "subgroup_tests": 0, "subgroup_device": 0, "subgroup_host": 0}
 
 
 def set_lazy(on: bool) -> bool:
@@ -609,7 +610,18 @@ def _flush_run(nodes, leaf_list, offs, tba, scb, T: int, from_msm: bool) -> None
     # the one- to three-term operator results on the host's worker pool meanwhile)
     ctx = N.default_context() if from_msm else _have_gpu()
     handle = ctx.handle if ctx is not None else None
-    rc = N.cg1_lincomb_batch(handle, bases, len(leaf_list), offs, n_out, tba, scb, 0, out_b, out_a, out_k, ctypes.byref(used))
+    # every base certified in G1 (generator multiples, results of earlier MSMs, points that passed the subgroup test): the engine may use
+    # the endomorphism split for this one call (context parameter "glv", csrc/glv.h); never on a guess -- outside G1 it would be wrong
+    split = ctx is not None and _GLV and all([l._sg is True for l in leaf_list])
+    if split:
+        ctx.set_param("glv", 1)
+    try:
+        rc = N.cg1_lincomb_batch(handle, bases, len(leaf_list), offs, n_out, tba, scb, 0, out_b, out_a, out_k, ctypes.byref(used))
+    finally:
+        if split:
+            ctx.set_param("glv", 0)
+    if split:
+        stats["flush_split"] += 1
     if rc != N.OK:
         if ctx is not None:
             ctx.check(rc)

@@ -291,11 +291,14 @@ int cg1_lincomb_batch_pool(const uint8_t* bases_affine96, size_t n_bases, const 
                            const uint8_t* term_scalars32, uint8_t* out_blobs144, uint8_t* out_affine96, uint8_t* out_comp48, int n_threads);
 
 /* ---------------- the endomorphism split (csrc/glv.h) -----------------------------------------------------------------------
- * For P in the prime-order subgroup phi(x, y) = (beta x, y) equals lambda P, lambda = z^2 - 1.  With the context parameter "glv" = 1 the
+ * For P in the prime-order subgroup phi(x, y) = (beta x, y) equals lambda P, lambda = z^2 - 1.  With the context parameter "glv" != 0 the
  * CALLER VOUCHES that every point of its MSM calls lies in G1 (CRS points, outputs of earlier MSMs, points that passed the subgroup
- * test); the engine then runs the MSM over the 2n points P_i, phi(P_i) with the 127-bit halves k = k1 + k2 lambda: the same bucket
- * additions, half the windows (half the buckets to reduce, half the doublings of the Horner tail).  Outside G1 phi(P) != lambda P and
- * the result would be wrong: the default is 0, and the Python face switches it on per call only for bases it has certified.
+ * test); the engine may then run an MSM over the 2n entries (k1, P_i), (k2, phi(P_i)) of the 127-bit halves k = k1 + k2 lambda: the same
+ * bucket additions, half the windows (half the doublings of the Horner tail).  1 = where it pays: the single-launch kernel (n <= 1 024,
+ * also the <= 64 MSMs of one cg1_msm_batched* / cg1_lincomb_batch launch) and regime A up to "glv_max_n" terms (2^14: above, the second
+ * half of the table costs more than the tail gains, profiles/r05_glv_ab.txt); 2 = wherever it can (A/B runs).  Outside G1
+ * phi(P) != lambda P and the result would be wrong: the default is 0, and the Python face switches it on for single calls whose bases it
+ * has certified.
  * cg1_glv_split: the split of one scalar (< 2^255, little-endian) as the digit kernels compute it -- magnitudes < 2^127 and signs --
  * for tests: (-1)^neg1 k1 + (-1)^neg2 k2 lambda == k (mod r). */
 void cg1_glv_split(const uint8_t scalar32[32], uint8_t k1_16[16], uint8_t k2_16[16], int* neg1, int* neg2);

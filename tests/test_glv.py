@@ -71,7 +71,7 @@ def test_msm_with_the_split_equals_the_msm_without(n, c):
     d_s = ctx.alloc(n * 32); d_s.upload(sc.tobytes())
     ctx.set_param("glv", 0)
     want = ctx.msm_device(d_p, d_s, n, window_c=c)
-    ctx.set_param("glv", 1)
+    ctx.set_param("glv", 2)                               # 2: wherever the engine can (1 stops at glv_max_n terms in regime A)
     got = ctx.msm_device(d_p, d_s, n, window_c=c)
     assert N.cg1_eq(got, want) == 1
     if n <= 3000:
@@ -81,4 +81,49 @@ def test_msm_with_the_split_equals_the_msm_without(n, c):
         out = ctypes.create_string_buffer(96)
         N.cg1_to_affine96(out, got)
         assert out.raw == (bytes(96) if ref is None else ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little"))
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 17, 96, 97, 124, 128, 255, 256, 257, 400, 512, 627, 1000, 1024])
+def test_small_kernel_with_the_split(n):
+    """k_msm_small over the 2n entries of the split (n <= 1 024) against the same call without it and against the oracle."""
+    ctx = N.Context(0)
+    rng = np.random.default_rng(1000 + n)
+    gen96 = O.G1_GEN[0].to_bytes(48, "little") + O.G1_GEN[1].to_bytes(48, "little")
+    ks = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x3F
+    pts = np.frombuffer(ctx.batch_mul_add_host(gen96, 1, ks.tobytes(), n, None, n), dtype=np.uint8).reshape(n, 96).copy()
+    if n > 4:
+        pts[3] = 0
+        pts[4] = pts[2]
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x3F
+    sc[0] = np.frombuffer((R - 1).to_bytes(32, "little"), dtype=np.uint8)
+    if n > 2:
+        sc[1] = 0
+        sc[2] = sc[4 % n] if n > 4 else sc[2]
+    d_p = ctx.alloc(n * 96); d_p.upload(pts.tobytes())
+    d_s = ctx.alloc(n * 32); d_s.upload(sc.tobytes())
+    ctx.set_param("glv", 0)
+    want = ctx.msm_device(d_p, d_s, n)
+    assert ctx.last_counts()["accumulate_launches"] == 0          # the single-launch kernel
+    ctx.set_param("glv", 1)
+    got = ctx.msm_device(d_p, d_s, n)
+    assert ctx.last_counts()["accumulate_launches"] == 0
+    assert N.cg1_eq(got, want) == 1
+    aff = [(int.from_bytes(p[:48].tobytes(), "little"), int.from_bytes(p[48:].tobytes(), "little")) for p in pts]
+    aff = [None if a == (0, 0) else a for a in aff]
+    ref = O.compute_MSM_fast(aff, [int.from_bytes(s.tobytes(), "little") for s in sc]) if n > 8 else O.compute_MSM(aff, [int.from_bytes(s.tobytes(), "little") for s in sc])
+    out = ctypes.create_string_buffer(96)
+    N.cg1_to_affine96(out, got)
+    assert out.raw == (bytes(96) if ref is None else ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little"))
+    # several MSMs in one launch (the deferred flush's shape): 5 MSMs over slices of the same input
+    if n >= 20:
+        offs = [0, n // 5, 2 * n // 5, 3 * n // 5, 4 * n // 5, n]
+        ctx.set_param("glv", 0)
+        a = ctx.msm_batched_device(d_p, d_s, offs)
+        ctx.set_param("glv", 1)
+        b = ctx.msm_batched_device(d_p, d_s, offs)
+        assert all(N.cg1_eq(x, y) == 1 for x, y in zip(a, b))
     ctx.close()

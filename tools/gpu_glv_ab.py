@@ -40,7 +40,7 @@ def main():
         row = []
         res = []
         for glv in ab_glv:
-            ctx.set_param("glv", glv)
+            ctx.set_param("glv", 2 if glv else 0)
             ctx.set_param("profile", 1)
             w = med(lambda: ctx.msm_device(dp, ds, n, window_c=0))
             ctx.set_param("profile", 2)
@@ -52,7 +52,7 @@ def main():
             print(f"n=2^{logn} glv={glv} c={tm['window_c']}: {w:.3f} ms | " + " ".join(f"{k}={v:.3f}" for k, v in tm.items() if k not in ('window_c', 'host_events')) + ("" if glv == 0 else f" | same result: {same}"), flush=True)
     if sweep:
         print(f"## window plan (glv = {sweep_glv})", flush=True)
-        ctx.set_param("glv", sweep_glv)
+        ctx.set_param("glv", 2 if sweep_glv else 0)
         ctx.set_param("profile", 1)
         for logn in tuple(int(x) for x in os.environ.get('SWEEP_N', '13,14,15,16,17,18,19,20').split(',')):
             n = 1 << logn

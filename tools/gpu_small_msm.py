@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--reps", type=int, default=200)
     ap.add_argument("--sizes", default="4,7,32,64,124,128,256,307,512,627,1024,1391,1536,1792,2048")
     ap.add_argument("--sweep-c", default="", help="also time k_msm_small at these window widths (device-resident inputs), e.g. 4,6,7,8,9")
+    ap.add_argument("--glv", action="store_true", help="only the A/B of the endomorphism split on the single-launch kernel (device-resident inputs; points are generator multiples)")
     a = ap.parse_args()
     from curdleproofs_pie_amd import _native as N
 
@@ -37,6 +38,28 @@ def main():
     dg.upload(g96.raw)
     ctx.batch_mul_device(dg, 1, dk, dp, nmax)
     p96 = dp.download()
+    if a.glv:
+        print("n      glv  c   wall_us   (min)    wait   horner  (k_msm_small, device-resident inputs; same result checked)")
+        for n in [int(x) for x in a.sizes.split(",") if int(x) <= 1024]:
+            ds = ctx.alloc(32 * n); ds.upload(b"".join(rng.randint(0, R - 1).to_bytes(32, "little") for _ in range(n)))
+            ref = None
+            for glv in (0, 1, 0, 1):
+                ctx.set_param("glv", glv)
+                for _ in range(10):
+                    out = ctx.msm_device(dp, ds, n)
+                ref = ref or out
+                assert N.cg1_eq(out, ref) == 1
+                wd, wt, hh = [], 0.0, 0.0
+                for _ in range(a.reps):
+                    t0 = time.perf_counter()
+                    ctx.msm_device(dp, ds, n)
+                    wd.append((time.perf_counter() - t0) * 1e6)
+                    t = ctx.timings()
+                    wt += t["host_wait"]; hh += t["host_horner"]
+                wd.sort()
+                print("%-6d %-4d %-3d %8.1f %7.1f  %6.1f %7.1f" % (n, glv, ctx.timings()["window_c"], wd[len(wd) // 2], wd[0], wt / a.reps * 1e3, hh / a.reps * 1e3), flush=True)
+            ds.free()
+        return
     print("n      path        c   wall_us   (min)   enqueue  wait   horner   | device-resident inputs: wall_us")
     for n in [int(x) for x in a.sizes.split(",")]:
         s32 = b"".join(rng.randint(0, R - 1).to_bytes(32, "little") for _ in range(n))
