@@ -659,17 +659,20 @@ int msm_device(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, in
 }
 
 
-int pick_window_batched(size_t n_avg) {
+int pick_window_batched(size_t n_avg, bool glv) {
+  const int bits = glv ? 127 : 255;
+  if (glv) n_avg *= 2;                                 // entries per MSM: both halves of every term
   int best = 4; double best_cost = 1e300;
   for (int c = 4; c <= 9; ++c) {                       // NB <= 256: a group's counting sort fits one block's LDS
-    if (255 % c == 0) continue;                        // top window would hold only the recoding carry: one hot bucket
-    int nwin = 255 / c + 1;
+    if (bits % c == 0) continue;                       // top window would hold only the recoding carry: one hot bucket
+    int nwin = bits / c + 1;
     double NB = (double)(1u << (c - 1));
-    double cost = (double)nwin * ((double)n_avg + 1.4 * (2.0 * NB + 3.0 * NB / 8.0)) + 1.4 * 255.0;
+    double cost = (double)nwin * ((double)n_avg + 1.4 * (2.0 * NB + 3.0 * NB / 8.0)) + 1.4 * (double)bits;
     if (cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
 }
+int pick_window_batched(size_t n_avg) { return pick_window_batched(n_avg, false); }
 
 // M independent MSMs over one concatenated (points, scalars) input resident on the device.
 // async_small (may be NULL): when the call fits ONE k_msm_small launch it is only ENQUEUED and *async_small set; the caller does other
@@ -712,18 +715,24 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
       return msm_batched_small_end(ctx, M, results);
     }
   }
-  if (c <= 0) c = pick_window_batched((N + M - 1) / M);
+  // regime B with the endomorphism split ("glv" != 0: the caller vouches for G1): 2N records and entries, half the windows -- half the
+  // (MSM, window) groups whose buckets k_seg_reduce / k_group_reduce sum at the lane rate, half the doublings of every MSM's Horner
+  const bool glv = ctx->glv != 0 && 2 * N < (1ull << 31);
+  const size_t N_real = N;
+  if (c <= 0) c = pick_window_batched((N + M - 1) / M, glv);
   if (c < 4 || c > 9) { snprintf(ctx->err, sizeof ctx->err, "batched window width %d out of range [4,9]", c); return CG1_ERR_ARG; }
   HIPCHK(hipSetDevice(ctx->device));
-  const uint32_t nwin = 255 / c + 1, NB = 1u << (c - 1);
+  const WinPlan bplan = make_plan(c, glv);
+  const uint32_t nwin = (uint32_t)bplan.nwin, NB = 1u << (c - 1);
   const size_t G = M * nwin, nb_total = G * NB;
-  if (nb_total >= (1ull << 31) || N * nwin >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "batch too large"); return CG1_ERR_ARG; }
+  const size_t Nv = glv ? 2 * N : N;                    // entries per digit row = prepared records
+  if (nb_total >= (1ull << 31) || Nv * nwin >= (1ull << 31)) { snprintf(ctx->err, sizeof ctx->err, "batch too large"); return CG1_ERR_ARG; }
   const uint32_t m = 8 < NB ? 8 : NB;                 // segment length of k_seg_reduce
   uint32_t log2m = 0; while ((1u << log2m) < m) ++log2m;
   const uint32_t J = NB / m;
   uint32_t L0 = ctx->L0;
-  while (L0 < 65536u && ((uint64_t)N * (uint64_t)nwin >> 18) > (uint64_t)L0) L0 <<= 1;
-  int rc = ensure(ctx, N, nb_total, nwin, 1, L0);
+  while (L0 < 65536u && ((uint64_t)Nv * (uint64_t)nwin >> 18) > (uint64_t)L0) L0 <<= 1;
+  int rc = ensure(ctx, Nv, nb_total, nwin, 1, L0);
   if (rc) return rc;
   // batch-only buffers
   if ((M + 1) > ctx->cap_boffs) {
@@ -743,31 +752,32 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
     HIPCHK(hipHostMalloc(&ctx->h_bout, (M + 1) * sizeof(PointWords)));
     ctx->cap_bout = M;
   }
-  if (N * nwin > ctx->cap_digits) {
+  if (Nv * nwin > ctx->cap_digits) {
     if (ctx->d_digits) (void)hipFree(ctx->d_digits);
-    HIPCHK(hipMalloc(&ctx->d_digits, N * nwin * 2 + 16));
-    ctx->cap_digits = N * nwin;
+    HIPCHK(hipMalloc(&ctx->d_digits, Nv * nwin * 2 + 16));
+    ctx->cap_digits = Nv * nwin;
   }
   hipStream_t st = ctx->stream;
-  const uint32_t N32 = (uint32_t)N, gn = (N32 + 255) / 256;
+  const uint32_t N32 = (uint32_t)N_real, gn = (N32 + 255) / 256, Nv32 = (uint32_t)Nv, split = glv ? N32 : 0u;
   auto h0 = std::chrono::steady_clock::now();
   HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, st));
   if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[0], st));
   uint32_t* bad_flag = reinterpret_cast<uint32_t*>(ctx->d_bout + M);
   hipLaunchKernelGGL(k_prepare_points, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_points96, ctx->d_pts, ctx->d_flags, N32, bad_flag);
+  if (glv) hipLaunchKernelGGL(k_phi_records, dim3(gn), dim3(256), 0, st, ctx->d_pts, ctx->d_flags, N32);
   if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[1], st));
-  hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, N32, make_plan(c), 0, 1, bad_flag);
-  hipLaunchKernelGGL(k_group_count, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_hist, N32, NB, nwin);
+  hipLaunchKernelGGL(k_digits, dim3(gn), dim3(256), 0, st, (const uint32_t*)d_scalars32, ctx->d_flags, ctx->d_digits, N32, bplan, 0, 1, bad_flag);
+  hipLaunchKernelGGL(k_group_count, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_hist, Nv32, NB, nwin, split);
   if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[2], st));
   const uint32_t nblk = (uint32_t)((nb_total + SCAN_ITEMS - 1) / SCAN_ITEMS);
   hipLaunchKernelGGL(k_scan1, dim3(nblk), dim3(256), 0, st, ctx->d_hist, ctx->d_off, ctx->d_choff, ctx->d_blocktot, (uint32_t)nb_total, L0);
   hipLaunchKernelGGL(k_scan2, dim3(1), dim3(256), 0, st, ctx->d_blocktot, nblk, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
   hipLaunchKernelGGL(k_scan3, dim3(nblk), dim3(256), 0, st, ctx->d_blocktot, ctx->d_off, ctx->d_choff, (uint32_t)nb_total);
-  hipLaunchKernelGGL(k_group_scatter, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_off, ctx->d_sorted, N32, NB, nwin);
+  hipLaunchKernelGGL(k_group_scatter, dim3((uint32_t)M, nwin), dim3(256), 0, st, ctx->d_digits, ctx->d_boffs, ctx->d_off, ctx->d_sorted, Nv32, NB, nwin, split);
   if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[3], st));
   HIPCHK(hipMemsetAsync(ctx->d_zblock, 0, zblock_clear_bytes(ctx), st));
   hipLaunchKernelGGL(k_chunk_desc, dim3((uint32_t)std::min<size_t>(CHUNK_DESC_BLOCKS, (nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_off, ctx->d_choff, ctx->d_desc, ctx->d_lenhist, ctx->d_heavy, (uint32_t)ctx->cap_heavy, (uint32_t)nb_total, L0, ctx->d_any_multi);
-  const size_t max_chunks = nb_total + (N * (size_t)nwin) / L0 + 1;
+  const size_t max_chunks = nb_total + (Nv * (size_t)nwin) / L0 + 1;
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
   hipLaunchKernelGGL(k_order, dim3((gchunks + ORDER_PER - 1) / ORDER_PER), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);

@@ -418,19 +418,23 @@ __global__ void __launch_bounds__(1024) k_uscan_one(uint32_t* __restrict__ a, ui
 // group g = j*nwin + w; with NB <= 256 buckets per group the counting sort of a group lives in one block's
 // LDS.  Everything between the sort and the bucket sums (chunking, length ordering, k_accumulate, k_seg_reduce)
 // is the same code as regime A, so lanes of one wave work on chunks of equal length from ANY msm/window.
+// split != 0 (the endomorphism split, glv.h): a row of digits holds 2 * split entries -- the k1 halves of all terms, then the k2
+// halves -- so MSM j owns the two runs [o0, o1) and [split + o0, split + o1); N is the row stride.
 __global__ void __launch_bounds__(256) k_group_count(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ offs,
-                                                     uint32_t* __restrict__ hist, uint32_t N, uint32_t NB, uint32_t nwin) {
+                                                     uint32_t* __restrict__ hist, uint32_t N, uint32_t NB, uint32_t nwin, uint32_t split) {
   __shared__ uint32_t cnt[256];
   cnt[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t j = blockIdx.x, w = blockIdx.y;
   const uint32_t o0 = offs[j], o1 = offs[j + 1];
-  const uint16_t* dg = digits + (size_t)w * N;
   const uint32_t span = ((o1 - o0 + 255u) / 256u) * 256u;
-  for (uint32_t o = threadIdx.x; o < span; o += 256) {
-    const uint32_t e = (o0 + o < o1) ? (uint32_t)dg[o0 + o] : 0u;
-    uint32_t neg;
-    lds_ranked_inc(cnt, e ? digit_mag(e, neg) - 1u : 0u, e != 0u);
+  for (uint32_t half = 0; half < (split ? 2u : 1u); ++half) {
+    const uint16_t* dg = digits + (size_t)w * N + (size_t)half * split;
+    for (uint32_t o = threadIdx.x; o < span; o += 256) {
+      const uint32_t e = (o0 + o < o1) ? (uint32_t)dg[o0 + o] : 0u;
+      uint32_t neg;
+      lds_ranked_inc(cnt, e ? digit_mag(e, neg) - 1u : 0u, e != 0u);
+    }
   }
   __syncthreads();
   if (threadIdx.x < NB) hist[((size_t)j * nwin + w) * NB + threadIdx.x] = cnt[threadIdx.x];
@@ -438,7 +442,7 @@ __global__ void __launch_bounds__(256) k_group_count(const uint16_t* __restrict_
 
 __global__ void __launch_bounds__(256) k_group_scatter(const uint16_t* __restrict__ digits, const uint32_t* __restrict__ offs,
                                                        const uint32_t* __restrict__ off, uint32_t* __restrict__ sorted,
-                                                       uint32_t N, uint32_t NB, uint32_t nwin) {
+                                                       uint32_t N, uint32_t NB, uint32_t nwin, uint32_t split) {
   __shared__ uint32_t cur[256];
   const uint32_t j = blockIdx.x, w = blockIdx.y;
   if (threadIdx.x < NB) cur[threadIdx.x] = off[((size_t)j * nwin + w) * NB + threadIdx.x];
@@ -446,13 +450,15 @@ __global__ void __launch_bounds__(256) k_group_scatter(const uint16_t* __restric
   const uint32_t o0 = offs[j], o1 = offs[j + 1];
   const uint16_t* dg = digits + (size_t)w * N;
   const uint32_t span = ((o1 - o0 + 255u) / 256u) * 256u;
-  for (uint32_t o = threadIdx.x; o < span; o += 256) {
-    const uint32_t i = o0 + o;
-    const uint32_t e = (i < o1) ? (uint32_t)dg[i] : 0u;
-    uint32_t neg = 0;
-    const uint32_t b = e ? digit_mag(e, neg) - 1u : 0u;
-    const uint32_t pos = lds_ranked_inc(cur, b, e != 0u);
-    if (e) sorted[pos] = i | (neg << 31);
+  for (uint32_t half = 0; half < (split ? 2u : 1u); ++half) {
+    for (uint32_t o = threadIdx.x; o < span; o += 256) {
+      const uint32_t i = half * split + o0 + o;                 // entry = record index: phi(P_t) is record split + t
+      const uint32_t e = (o0 + o < o1) ? (uint32_t)dg[i] : 0u;
+      uint32_t neg = 0;
+      const uint32_t b = e ? digit_mag(e, neg) - 1u : 0u;
+      const uint32_t pos = lds_ranked_inc(cur, b, e != 0u);
+      if (e) sorted[pos] = i | (neg << 31);
+    }
   }
 }
 

@@ -295,7 +295,7 @@ int cg1_lincomb_batch_pool(const uint8_t* bases_affine96, size_t n_bases, const 
  * CALLER VOUCHES that every point of its MSM calls lies in G1 (CRS points, outputs of earlier MSMs, points that passed the subgroup
  * test); the engine may then run an MSM over the 2n entries (k1, P_i), (k2, phi(P_i)) of the 127-bit halves k = k1 + k2 lambda: the same
  * bucket additions, half the windows (half the doublings of the Horner tail).  1 = where it pays: the single-launch kernel (n <= 1 024,
- * also the <= 64 MSMs of one cg1_msm_batched* / cg1_lincomb_batch launch) and regime A up to "glv_max_n" terms (2^14: above, the second
+ * also the <= 64 MSMs of one cg1_msm_batched* / cg1_lincomb_batch launch), the regime-B chain, and regime A up to "glv_max_n" terms (2^14: above, the second
  * half of the table costs more than the tail gains, profiles/r05_glv_ab.txt); 2 = wherever it can (A/B runs).  Outside G1
  * phi(P) != lambda P and the result would be wrong: the default is 0, and the Python face switches it on for single calls whose bases it
  * has certified.

@@ -127,3 +127,45 @@ def test_small_kernel_with_the_split(n):
         b = ctx.msm_batched_device(d_p, d_s, offs)
         assert all(N.cg1_eq(x, y) == 1 for x, y in zip(a, b))
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,n,c", [(200, 70, 0), (100, 627, 0), (100, 627, 6), (100, 627, 8), (300, 33, 0)])
+def test_regime_b_with_the_split(M, n, c):
+    """M independent MSMs in the regime-B chain (more than one single-launch batch): split against no split, ragged offsets with
+    empty MSMs, and a few of them against the oracle."""
+    ctx = N.Context(0)
+    rng = np.random.default_rng(M * 1000 + n + c)
+    tot = M * n
+    gen96 = O.G1_GEN[0].to_bytes(48, "little") + O.G1_GEN[1].to_bytes(48, "little")
+    m = 512
+    ks = rng.integers(0, 256, (m, 32), dtype=np.uint8)
+    ks[:, 31] &= 0x3F
+    base = np.frombuffer(ctx.batch_mul_add_host(gen96, 1, ks.tobytes(), m, None, m), dtype=np.uint8).reshape(m, 96)
+    pts = base[rng.integers(0, m, tot)].copy()
+    pts[7] = 0
+    sc = rng.integers(0, 256, (tot, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x3F
+    sc[3] = 0
+    cuts = sorted(int(x) for x in rng.integers(0, tot + 1, M - 1))
+    offs = [0] + cuts + [tot]
+    offs[5] = offs[4]                                       # an empty MSM
+    offs = sorted(offs)
+    d_p = ctx.alloc(tot * 96); d_p.upload(pts.tobytes())
+    d_s = ctx.alloc(tot * 32); d_s.upload(sc.tobytes())
+    ctx.set_param("glv", 0)
+    a = ctx.msm_batched_device(d_p, d_s, offs, window_c=c)
+    ctx.set_param("glv", 1)
+    b = ctx.msm_batched_device(d_p, d_s, offs, window_c=c)
+    assert len(a) == len(b) == M
+    assert all(N.cg1_eq(x, y) == 1 for x, y in zip(a, b))
+    for j in (0, 4, M - 1):
+        lo, hi = offs[j], offs[j + 1]
+        aff = [(int.from_bytes(p[:48].tobytes(), "little"), int.from_bytes(p[48:].tobytes(), "little")) for p in pts[lo:hi]]
+        aff = [None if q == (0, 0) else q for q in aff]
+        ss = [int.from_bytes(s.tobytes(), "little") for s in sc[lo:hi]]
+        ref = O.compute_MSM_fast(aff, ss) if hi - lo > 8 else O.compute_MSM(aff, ss)
+        out = ctypes.create_string_buffer(96)
+        N.cg1_to_affine96(out, b[j])
+        assert out.raw == (bytes(96) if ref is None else ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little"))
+    ctx.close()

@@ -23,7 +23,9 @@ def main():
     ctx.batch_mul_device(dg, 1, dk, dp, tot)
     ctx.gen_scalars_device(ds, tot, 2)
     offs = [n * j for j in range(M + 1)]
-    for c in cs:
+    glvs = [int(x) for x in os.environ.get("GLV", "0").split(",")]
+    for glv, c in [(g, c) for g in glvs for c in cs]:
+        ctx.set_param("glv", glv)
         walls = []
         for r in range(5):
             t = time.perf_counter()
@@ -31,9 +33,10 @@ def main():
             walls.append((time.perf_counter() - t) * 1e3)
         tm = ctx.timings()
         w = sorted(walls[1:])[len(walls[1:]) // 2]
-        print(f"batched {M} x {n} c={tm['window_c']}: wall {w:.2f} ms -> {M/w*1e3:.0f} MSM/s, {tot/w/1e3:.1f} M scalar-mul/s | " +
+        print(f"batched {M} x {n} glv={glv} c={tm['window_c']}: wall {w:.2f} ms -> {M/w*1e3:.0f} MSM/s, {tot/w/1e3:.1f} M scalar-mul/s | " +
               " ".join(f"{k}={v:.3f}" for k, v in tm.items() if k != "window_c"), flush=True)
     # serial single-MSM calls for comparison
+    ctx.set_param("glv", 0)
     t = time.perf_counter()
     for j in range(32):
         ctx.msm_device(dp.ptr + 96 * n * j, ds.ptr + 32 * n * j, n)
