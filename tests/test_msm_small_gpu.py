@@ -154,14 +154,17 @@ def test_scalar_out_of_range_is_rejected(native_lib, ctx, pool):
     assert compress_blob(N, ctx.msm_host(p96, s32, n)) == O.g1_compress(O.g1_mul(O.G1_GEN, tot))
 
 
-def test_point_sources_and_ab_switch(native_lib, ctx, pool):
+@pytest.mark.parametrize("glv", [0, 1])
+def test_point_sources_and_ab_switch(native_lib, ctx, pool, glv):
     """affine96, blobs (Z = 1 and projective), resident prepared records: the same result; `small_msm` = 0 sends the call through
-    the regime-A launch chain, which must agree too."""
+    the regime-A launch chain, which must agree too.  glv = 1: the same with the endomorphism split (the pool's points are multiples
+    of the generator, so the promise the parameter makes holds)."""
     N = native_lib
     ks, pts = pool
     rng = random.Random(408)
     g = ctypes.create_string_buffer(144)
     N.cg1_generator(g)
+    ctx.set_param("glv", glv)
     for n in (3, 200, 627, 1000):
         idx = [rng.randrange(len(pts)) for _ in range(n)]
         sc = [rng.randint(0, O.R - 1) for _ in range(n)]
@@ -192,6 +195,7 @@ def test_point_sources_and_ab_switch(native_lib, ctx, pool):
             assert ctx.timings()["window_c"] in (4, 8)                          # the regime-A plan for these sizes
         finally:
             ctx.set_param("small_msm", 1)
+    ctx.set_param("glv", 0)
 
 
 def test_golden_vectors_through_the_small_kernel(native_lib, ctx, golden):
@@ -211,13 +215,15 @@ def test_golden_vectors_through_the_small_kernel(native_lib, ctx, golden):
         dp.free(); ds.free()
 
 
-def test_several_msms_in_one_launch(native_lib, ctx, pool):
+@pytest.mark.parametrize("glv", [0, 1])
+def test_several_msms_in_one_launch(native_lib, ctx, pool, glv):
     """cg1_msm_batched with a handful of small MSMs (the 4 - 6 of a prover's halving round; compute_MSM_batch): they ride ONE
     k_msm_small launch (grid.z = MSM).  Ragged sizes, an empty MSM in the middle, sizes across the slice edge; M = 17 falls back to
     the regime-B launch chain -- every result against the oracle."""
     N = native_lib
     ks, pts = pool
     rng = random.Random(409)
+    ctx.set_param("glv", glv)
     for sizes in ([5], [3, 0, 7], [64, 65, 64, 64], [128, 129, 1, 128, 0, 127], [257, 300, 2], [1024, 1], [1500, 700], [2048], [33] * 16, [20] * 17, [0, 0, 9]):
         idx = [[rng.randrange(len(pts)) for _ in range(n)] for n in sizes]
         sc = [[rng.randint(0, O.R - 1) for _ in range(n)] for n in sizes]
@@ -238,3 +244,4 @@ def test_several_msms_in_one_launch(native_lib, ctx, pool):
     with pytest.raises(N.NativeError):
         ctx.msm_batched_host(p96, bytes(bad), offs)
     assert compress_blob(N, ctx.msm_batched_host(p96, s32, offs)[2]) == O.g1_compress(O.g1_mul(O.G1_GEN, sum(ks[i] * s for i, s in zip(idx[2], sc[2])) % O.R))
+    ctx.set_param("glv", 0)
