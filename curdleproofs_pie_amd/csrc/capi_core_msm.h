@@ -12,16 +12,22 @@ static Ctx* child_of(Ctx* ctx) { return static_cast<Ctx*>(ctx->child); }
 // One call as two launch chains: this context takes the HIGH half of the plan's windows (and prepares the points), its child the
 // LOW half on its own stream.  The child starts once the prepared records exist, and its k_accumulate waits for this context's to
 // finish: the two dominant launches run back to back, everything around them overlaps with one of them.
-static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan, int rank, int world) {
-  HIPCHK(hipSetDevice(ctx->device));
+static int ensure_child(Ctx* ctx) {
   if (!ctx->child) {
     cg1_ctx* made = ctx->cu_mask.empty() ? cg1_ctx_create(ctx->device) : cg1_ctx_create_cu_mask(ctx->device, ctx->cu_mask.data(), ctx->cu_mask.size());
     if (!made) { snprintf(ctx->err, sizeof ctx->err, "could not create the second launch chain's context"); return CG1_ERR_HIP; }
     made->split = 0;
+    made->batched_split = 0;
     ctx->child = made;
-    HIPCHK(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming));
   }
+  if (!ctx->ev_prep) HIPCHK(hipEventCreateWithFlags(&ctx->ev_prep, hipEventDisableTiming));
+  if (!ctx->ev_acc) HIPCHK(hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming));
+  return CG1_OK;
+}
+
+static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size_t n, const WinPlan& plan, int rank, int world) {
+  HIPCHK(hipSetDevice(ctx->device));
+  { int crc = ensure_child(ctx); if (crc) return crc; }
   Ctx* ch = child_of(ctx);
   ch->profile = ctx->profile; ch->L0 = ctx->L0; ch->seg_m = ctx->seg_m; ch->quad = ctx->quad; ch->reduce_2d = ctx->reduce_2d;
   ch->rowcol_quad = ctx->rowcol_quad; ch->rowcol_quad_max = ctx->rowcol_quad_max; ch->fold_pass = ctx->fold_pass; ch->tree_half = ctx->tree_half; ch->tree_shift = ctx->tree_shift; ch->rowcol_lgq = ctx->rowcol_lgq; ch->sort_sub_bits = ctx->sort_sub_bits;
@@ -285,6 +291,8 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "quad")) { ctx->quad = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "glv")) { if (value < 0 || value > 2) return CG1_ERR_ARG; ctx->glv = value; return CG1_OK; }
   if (!strcmp(name, "glv_max_n")) { if (value < 0) return CG1_ERR_ARG; ctx->glv_max_n = value; return CG1_OK; }
+  if (!strcmp(name, "batched_split")) { ctx->batched_split = value ? 1 : 0; return CG1_OK; }
+  if (!strcmp(name, "batched_split_min_m")) { if (value < 2) return CG1_ERR_ARG; ctx->batched_split_min_m = value; return CG1_OK; }
   if (!strcmp(name, "horner_row")) { ctx->horner_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "batch_mul_row")) { ctx->batch_mul_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "small_msm")) { ctx->small_msm = value ? 1 : 0; return CG1_OK; }

@@ -674,53 +674,19 @@ int pick_window_batched(size_t n_avg, bool glv) {
 }
 int pick_window_batched(size_t n_avg) { return pick_window_batched(n_avg, false); }
 
-// M independent MSMs over one concatenated (points, scalars) input resident on the device.
-// async_small (may be NULL): when the call fits ONE k_msm_small launch it is only ENQUEUED and *async_small set; the caller does other
-// work and collects the results with msm_batched_small_end.  Calls that take the regime-B chain complete before returning.
-static int msm_batched_small_end(Ctx* ctx, size_t M, std::vector<cg1h::jac>& results) {
-  if (M == 1) { cg1h::jac r; int rc = msm_finish(ctx, r); ctx->last_acc_launches = 0; if (rc == CG1_OK) results[0] = r; return rc; }
-  return msm_small_batched_finish(ctx, (uint32_t)M, results);
-}
-int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, const uint32_t* h_offsets, size_t M,
-                       int c, std::vector<cg1h::jac>& results, bool* async_small = nullptr) {
-  if (async_small) *async_small = false;
-  results.assign(M, cg1h::jac_identity());
-  if (M == 0) return CG1_OK;
-  const size_t N = h_offsets[M];
-  for (size_t j = 0; j < M; ++j) if (h_offsets[j] > h_offsets[j + 1]) { snprintf(ctx->err, sizeof ctx->err, "offsets not monotone"); return CG1_ERR_ARG; }
-  if (h_offsets[0] != 0) { snprintf(ctx->err, sizeof ctx->err, "offsets[0] must be 0"); return CG1_ERR_ARG; }
-  if (N == 0) return CG1_OK;
-  if (N >= (1ull << 31) || M > 65535) { snprintf(ctx->err, sizeof ctx->err, "batch too large"); return CG1_ERR_ARG; }
-  {
-    // A handful of small MSMs (the 4 - 6 of a prover's halving round, prover_kernels.py): ONE k_msm_small launch carries them all
-    // (grid.z = MSM) and their Horners run side by side on the host -- the regime-B launch chain costs ~0.5 ms whatever it sums.
-    size_t max_n = 0;
-    for (size_t j = 0; j < M; ++j) max_n = std::max<size_t>(max_n, h_offsets[j + 1] - h_offsets[j]);
-    const bool sglv = ctx->glv && 2 * max_n <= SM_MAX_N;
-    const size_t max_nn = sglv ? 2 * max_n : max_n;
-    const int cs = c > 0 ? c : pick_small_c(max_nn);
-    const size_t groups = (size_t)M * (size_t)((sglv ? 127 : 255) / cs + 1) * ((max_nn + SM_SLICE - 1) / SM_SLICE);
-    if (ctx->small_msm && M <= SM_MAX_MSMS && max_nn <= SM_MAX_N && groups <= SM_MAX_GROUPS && cs >= 4 && cs <= 9 && cs != 5) {
-      HIPCHK(hipSetDevice(ctx->device));
-      if ((M + 1) > ctx->cap_boffs) {
-        if (ctx->d_boffs) (void)hipFree(ctx->d_boffs);
-        ctx->d_boffs = nullptr; ctx->cap_boffs = 0;
-        HIPCHK(hipMalloc(&ctx->d_boffs, (M + 1) * 4));
-        ctx->cap_boffs = M + 1;
-      }
-      HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-      int rc = msm_enqueue_small(ctx, PtSrc(d_points96), d_scalars32, N, cs, (uint32_t)M, ctx->d_boffs, max_n, sglv);
-      if (rc) return rc;
-      if (async_small) { *async_small = true; return CG1_OK; }
-      return msm_batched_small_end(ctx, M, results);
-    }
-  }
+static int ensure_child(Ctx* ctx);      // the second launch chain's context and the two events between the chains (capi_core_msm.h)
+
+// The regime-B launch chain of one (sub-)batch, in two steps so that two of them can be in flight (msm_batched_device below):
+// batched_chain_enqueue queues everything up to the D2H of the results and returns; batched_chain_finish waits and reads them back.
+struct BatchedChain {
+  size_t M = 0; int c = 0; uint32_t nwin = 0; bool host_horner = false;
+  std::chrono::steady_clock::time_point h0, h1;
+};
+static int batched_chain_enqueue(Ctx* ctx, const void* d_points96, const void* d_scalars32, const uint32_t* h_offsets, size_t M, int c, bool glv,
+                                 hipEvent_t wait_before_accumulate, hipEvent_t record_after_accumulate, BatchedChain& bc) {
   // regime B with the endomorphism split ("glv" != 0: the caller vouches for G1): 2N records and entries, half the windows -- half the
   // (MSM, window) groups whose buckets k_seg_reduce / k_group_reduce sum at the lane rate, half the doublings of every MSM's Horner
-  const bool glv = ctx->glv != 0 && 2 * N < (1ull << 31);
-  const size_t N_real = N;
-  if (c <= 0) c = pick_window_batched((N + M - 1) / M, glv);
-  if (c < 4 || c > 9) { snprintf(ctx->err, sizeof ctx->err, "batched window width %d out of range [4,9]", c); return CG1_ERR_ARG; }
+  const size_t N = h_offsets[M], N_real = N;
   HIPCHK(hipSetDevice(ctx->device));
   const WinPlan bplan = make_plan(c, glv);
   const uint32_t nwin = (uint32_t)bplan.nwin, NB = 1u << (c - 1);
@@ -781,9 +747,11 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   const uint32_t gchunks = (uint32_t)((max_chunks + 255) / 256);
   hipLaunchKernelGGL(k_len_scan, dim3(1), dim3(256), 0, st, ctx->d_lenhist, ctx->d_lenhist + LEN_BINS, ctx->d_off + nb_total, ctx->d_choff + nb_total, bad_flag);
   hipLaunchKernelGGL(k_order, dim3((gchunks + ORDER_PER - 1) / ORDER_PER), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_lenhist + LEN_BINS, ctx->d_order);
+  if (wait_before_accumulate) HIPCHK(hipStreamWaitEvent(st, wait_before_accumulate, 0));
   if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[4], st));
   hipLaunchKernelGGL(k_accumulate, dim3(gchunks), dim3(256), 0, st, ctx->d_desc, ctx->d_choff + nb_total, ctx->d_order, ctx->d_sorted, ctx->d_pts, ctx->d_sums);
   if (ctx->profile >= 1) HIPCHK(hipEventRecord(ctx->ev[5], st));
+  if (record_after_accumulate) HIPCHK(hipEventRecord(record_after_accumulate, st));
   const uint32_t nseg_total = (uint32_t)(nb_total / m);
   hipLaunchKernelGGL(k_heavy_combine, dim3(512), dim3(256), 0, st, ctx->d_heavy, (uint32_t)ctx->cap_heavy, ctx->d_choff, ctx->d_sums, ctx->d_combined);
   hipLaunchKernelGGL(k_seg_reduce, dim3((nseg_total + 255) / 256), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, ctx->d_segrun, ctx->d_segtot, nseg_total, m);
@@ -814,7 +782,14 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
     HIPCHK(hipMemcpyAsync(ctx->h_bout, ctx->d_bout, (M + 1) * sizeof(PointWords), hipMemcpyDeviceToHost, st));
   }
   if (ctx->profile >= 2) HIPCHK(hipEventRecord(ctx->ev[7], st));
-  auto h1 = std::chrono::steady_clock::now();
+  bc.M = M; bc.c = c; bc.nwin = nwin; bc.host_horner = host_horner; bc.h0 = h0; bc.h1 = std::chrono::steady_clock::now();
+  return CG1_OK;
+}
+
+static int batched_chain_finish(Ctx* ctx, const BatchedChain& bc, cg1h::jac* results) {
+  const size_t M = bc.M; const int c = bc.c; const uint32_t nwin = bc.nwin; const bool host_horner = bc.host_horner;
+  const auto h0 = bc.h0, h1 = bc.h1;
+  HIPCHK(hipSetDevice(ctx->device));
   { int wrc = wait_stream(ctx); if (wrc) return wrc; }
   HIPCHK(hipGetLastError());
   {
@@ -850,6 +825,87 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
   ctx->host_ms[2] = 0;
   ctx->host_ms[3] = ctx->host_tail_ms = std::chrono::duration<float, std::milli>(h3 - h2).count();
   return CG1_OK;
+}
+
+// M independent MSMs over one concatenated (points, scalars) input resident on the device.
+// async_small (may be NULL): when the call fits ONE k_msm_small launch it is only ENQUEUED and *async_small set; the caller does other
+// work and collects the results with msm_batched_small_end.  Calls that take the regime-B chain complete before returning.
+static int msm_batched_small_end(Ctx* ctx, size_t M, std::vector<cg1h::jac>& results) {
+  if (M == 1) { cg1h::jac r; int rc = msm_finish(ctx, r); ctx->last_acc_launches = 0; if (rc == CG1_OK) results[0] = r; return rc; }
+  return msm_small_batched_finish(ctx, (uint32_t)M, results);
+}
+int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, const uint32_t* h_offsets, size_t M,
+                       int c, std::vector<cg1h::jac>& results, bool* async_small = nullptr) {
+  if (async_small) *async_small = false;
+  results.assign(M, cg1h::jac_identity());
+  if (M == 0) return CG1_OK;
+  const size_t N = h_offsets[M];
+  for (size_t j = 0; j < M; ++j) if (h_offsets[j] > h_offsets[j + 1]) { snprintf(ctx->err, sizeof ctx->err, "offsets not monotone"); return CG1_ERR_ARG; }
+  if (h_offsets[0] != 0) { snprintf(ctx->err, sizeof ctx->err, "offsets[0] must be 0"); return CG1_ERR_ARG; }
+  if (N == 0) return CG1_OK;
+  if (N >= (1ull << 31) || M > 65535) { snprintf(ctx->err, sizeof ctx->err, "batch too large"); return CG1_ERR_ARG; }
+  {
+    // A handful of small MSMs (the 4 - 6 of a prover's halving round, prover_kernels.py): ONE k_msm_small launch carries them all
+    // (grid.z = MSM) and their Horners run side by side on the host -- the regime-B launch chain costs ~0.5 ms whatever it sums.
+    size_t max_n = 0;
+    for (size_t j = 0; j < M; ++j) max_n = std::max<size_t>(max_n, h_offsets[j + 1] - h_offsets[j]);
+    const bool sglv = ctx->glv && 2 * max_n <= SM_MAX_N;
+    const size_t max_nn = sglv ? 2 * max_n : max_n;
+    const int cs = c > 0 ? c : pick_small_c(max_nn);
+    const size_t groups = (size_t)M * (size_t)((sglv ? 127 : 255) / cs + 1) * ((max_nn + SM_SLICE - 1) / SM_SLICE);
+    if (ctx->small_msm && M <= SM_MAX_MSMS && max_nn <= SM_MAX_N && groups <= SM_MAX_GROUPS && cs >= 4 && cs <= 9 && cs != 5) {
+      HIPCHK(hipSetDevice(ctx->device));
+      if ((M + 1) > ctx->cap_boffs) {
+        if (ctx->d_boffs) (void)hipFree(ctx->d_boffs);
+        ctx->d_boffs = nullptr; ctx->cap_boffs = 0;
+        HIPCHK(hipMalloc(&ctx->d_boffs, (M + 1) * 4));
+        ctx->cap_boffs = M + 1;
+      }
+      HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+      int rc = msm_enqueue_small(ctx, PtSrc(d_points96), d_scalars32, N, cs, (uint32_t)M, ctx->d_boffs, max_n, sglv);
+      if (rc) return rc;
+      if (async_small) { *async_small = true; return CG1_OK; }
+      return msm_batched_small_end(ctx, M, results);
+    }
+  }
+  // regime B with the endomorphism split ("glv" != 0: the caller vouches for G1): 2N records and entries, half the windows -- half the
+  // (MSM, window) groups whose buckets k_seg_reduce / k_group_reduce sum at the lane rate, half the doublings of every MSM's Horner
+  const bool glv = ctx->glv != 0 && 2 * N < (1ull << 31);
+  if (c <= 0) c = pick_window_batched((N + M - 1) / M, glv);
+  if (c < 4 || c > 9) { snprintf(ctx->err, sizeof ctx->err, "batched window width %d out of range [4,9]", c); return CG1_ERR_ARG; }
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!ctx->batched_split || M < (size_t)ctx->batched_split_min_m || h_offsets[M / 2] == 0 || h_offsets[M / 2] == N) {      // (an empty half: one chain)
+    BatchedChain bc;
+    int rc = batched_chain_enqueue(ctx, d_points96, d_scalars32, h_offsets, M, c, glv, nullptr, nullptr, bc);
+    if (rc) return rc;
+    return batched_chain_finish(ctx, bc, results.data());
+  }
+  // Two chains, half the MSMs each, on two streams: the second half's k_accumulate starts when the first half's has finished, so the
+  // first half's latency-bound tail (group sums, one wave per MSM for 255 doublings, D2H) runs UNDER the second half's additions
+  // instead of after them.  ("batched_split", default off: measured slower, profiles/r05_regime_b_split.txt.)
+  { int crc = ensure_child(ctx); if (crc) return crc; }
+  Ctx* ch = child_of(ctx);
+  ch->profile = ctx->profile; ch->L0 = ctx->L0; ch->quad = ctx->quad; ch->horner_row = ctx->horner_row; ch->blocking_sync = ctx->blocking_sync;
+  ch->batched_host_horner_max = ctx->batched_host_horner_max; ch->use_partition_sort = ctx->use_partition_sort;
+  const size_t Mlo = M / 2, Mhi = M - Mlo;
+  std::vector<uint32_t> offs_hi(Mhi + 1);
+  for (size_t j = 0; j <= Mhi; ++j) offs_hi[j] = h_offsets[Mlo + j] - h_offsets[Mlo];
+  BatchedChain lo, hi;
+  int rc = batched_chain_enqueue(ctx, d_points96, d_scalars32, h_offsets, Mlo, c, glv, nullptr, ctx->ev_acc, lo);
+  if (rc) return rc;
+  rc = batched_chain_enqueue(ch, static_cast<const uint8_t*>(d_points96) + 96ull * h_offsets[Mlo], static_cast<const uint8_t*>(d_scalars32) + 32ull * h_offsets[Mlo],
+                             offs_hi.data(), Mhi, c, glv, ctx->ev_acc, nullptr, hi);
+  if (rc) { snprintf(ctx->err, sizeof ctx->err, "%s", ch->err); (void)batched_chain_finish(ctx, lo, results.data()); return rc; }
+  rc = batched_chain_finish(ctx, lo, results.data());
+  const float acc_lo = ctx->phase_ms[4], enq_lo = ctx->host_ms[0], wait_lo = ctx->host_ms[1];
+  const uint32_t e_lo = ctx->last_entries, c_lo = ctx->last_chunks;
+  int rc2 = batched_chain_finish(ch, hi, results.data() + Mlo);
+  if (rc2 != CG1_OK) snprintf(ctx->err, sizeof ctx->err, "%s", ch->err);
+  if (rc == CG1_OK) rc = rc2;
+  ctx->phase_ms[4] = acc_lo + ch->phase_ms[4];
+  ctx->last_entries = e_lo + ch->last_entries; ctx->last_chunks = c_lo + ch->last_chunks;
+  ctx->host_ms[0] = enq_lo + ch->host_ms[0]; ctx->host_ms[1] = wait_lo + ch->host_ms[1];
+  return rc;
 }
 
 }  // namespace cg1

@@ -177,6 +177,10 @@ struct Ctx {
   int glv_max_n = 1 << 14;              // "glv_max_n": largest regime-A call glv = 1 splits (profiles/r05_glv_ab.txt: slower from 2^15 terms up)
   int horner_row = 1;                   // "horner_row": regime B's device Horner with one wave per MSM, one limb per lane (A/B switch; 0: one quad per MSM)
   int batch_mul_row = 1;                // "batch_mul_row": deferred map / fold batches of 96 .. 4096 results on k_batch_mul_row (A/B switch; 0: pool / k_batch_mul)
+  int batched_split = 0;                // "batched_split": regime B as two launch chains of half the MSMs each, the second half's k_accumulate behind the first's
+                                        // (so that the first half's tail runs under it).  Measured SLOWER (1 024 x 627: 5.2-5.3 -> 5.6-5.8 ms, with the
+                                        // endomorphism split 4.72 -> 4.76-4.85, profiles/r05_regime_b_split.txt): the tails are not idle time.  A/B switch, off.
+  int batched_split_min_m = 256;        // "batched_split_min_m": ... from this many MSMs on
   int batched_host_horner_max = 24;     // regime B calls with at most this many MSMs run their Horner on the host ("batched_host_horner_max")
   PointSum *d_sums = nullptr, *d_segrun = nullptr, *d_segtot = nullptr;
   PointWords* d_out = nullptr;

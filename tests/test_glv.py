@@ -130,7 +130,7 @@ def test_small_kernel_with_the_split(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,n,c", [(200, 70, 0), (100, 627, 0), (100, 627, 6), (100, 627, 8), (300, 33, 0)])
+@pytest.mark.parametrize("M,n,c", [(200, 70, 0), (100, 627, 0), (100, 627, 6), (100, 627, 8), (300, 33, 0), (513, 40, 0)])
 def test_regime_b_with_the_split(M, n, c):
     """M independent MSMs in the regime-B chain (more than one single-launch batch): split against no split, ragged offsets with
     empty MSMs, and a few of them against the oracle."""
@@ -158,6 +158,11 @@ def test_regime_b_with_the_split(M, n, c):
     ctx.set_param("glv", 1)
     b = ctx.msm_batched_device(d_p, d_s, offs, window_c=c)
     assert len(a) == len(b) == M
+    if M >= 256:                                            # the two-chain form (A/B switch, off by default) must agree
+        ctx.set_param("batched_split", 1)
+        b1 = ctx.msm_batched_device(d_p, d_s, offs, window_c=c)
+        ctx.set_param("batched_split", 0)
+        assert all(N.cg1_eq(x, y) == 1 for x, y in zip(b, b1))
     assert all(N.cg1_eq(x, y) == 1 for x, y in zip(a, b))
     for j in (0, 4, M - 1):
         lo, hi = offs[j], offs[j + 1]

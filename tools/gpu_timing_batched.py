@@ -24,8 +24,10 @@ def main():
     ctx.gen_scalars_device(ds, tot, 2)
     offs = [n * j for j in range(M + 1)]
     glvs = [int(x) for x in os.environ.get("GLV", "0").split(",")]
-    for glv, c in [(g, c) for g in glvs for c in cs]:
+    splits = [int(x) for x in os.environ.get("BSPLIT", "1").split(",")]
+    for split, glv, c in [(sp, g, c) for sp in splits for g in glvs for c in cs]:
         ctx.set_param("glv", glv)
+        ctx.set_param("batched_split", split)
         walls = []
         for r in range(5):
             t = time.perf_counter()
@@ -33,7 +35,7 @@ def main():
             walls.append((time.perf_counter() - t) * 1e3)
         tm = ctx.timings()
         w = sorted(walls[1:])[len(walls[1:]) // 2]
-        print(f"batched {M} x {n} glv={glv} c={tm['window_c']}: wall {w:.2f} ms -> {M/w*1e3:.0f} MSM/s, {tot/w/1e3:.1f} M scalar-mul/s | " +
+        print(f"batched {M} x {n} two_chains={split} glv={glv} c={tm['window_c']}: wall {w:.2f} ms -> {M/w*1e3:.0f} MSM/s, {tot/w/1e3:.1f} M scalar-mul/s | " +
               " ".join(f"{k}={v:.3f}" for k, v in tm.items() if k != "window_c"), flush=True)
     # serial single-MSM calls for comparison
     ctx.set_param("glv", 0)
