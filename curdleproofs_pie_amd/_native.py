@@ -156,6 +156,7 @@ cg1_get_timings = _proto("cg1_get_timings", c_int, c_void_p, POINTER(c_float), P
 cg1_get_host_timings = _proto("cg1_get_host_timings", c_int, c_void_p, POINTER(c_float))
 cg1_get_last_counts = _proto("cg1_get_last_counts", c_int, c_void_p, POINTER(ctypes.c_uint32), POINTER(ctypes.c_uint32))
 cg1_get_last_launches = _proto("cg1_get_last_launches", c_int, c_void_p)
+cg1_plan_describe = _proto("cg1_plan_describe", c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int)
 cg1_timer_begin = _proto("cg1_timer_begin", c_int, c_void_p)
 cg1_timer_end = _proto("cg1_timer_end", c_int, c_void_p, POINTER(c_float))
 cg1_batch_mul_device = _proto("cg1_batch_mul_device", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t)
@@ -262,7 +263,7 @@ EXPORTED_SYMBOLS = [
     "cg1_comm_create", "cg1_comm_port", "cg1_comm_rank", "cg1_comm_connect", "cg1_comm_set_timeout", "cg1_comm_attach_rccl", "cg1_comm_transport",
     "cg1_comm_world_seen", "cg1_comm_error", "cg1_comm_allgather", "cg1_comm_allgather_host", "cg1_comm_barrier", "cg1_comm_allreduce_g1", "cg1_comm_destroy",
     "cg1_validate_compressed", "cg1_fp_jacobi", "cg1_batch_decompress_pool", "cg1_batch_subgroup_pool", "cg1_batch_subgroup", "cg1_lincomb_batch", "cg1_lincomb_batch_pool", "cg1_glv_split",
-    "cg1_probe_add_chain", "cg1_msm_blobs", "cg1_stage_reserve", "cg1_msm_blobs_device", "cg1_vec_create", "cg1_vec_destroy", "cg1_vec_len", "cg1_msm_vec", "cg1_batch_normalize", "cg1_batch_from_affine96", "cg1_get_last_launches",
+    "cg1_probe_add_chain", "cg1_msm_blobs", "cg1_stage_reserve", "cg1_msm_blobs_device", "cg1_vec_create", "cg1_vec_destroy", "cg1_vec_len", "cg1_msm_vec", "cg1_batch_normalize", "cg1_batch_from_affine96", "cg1_get_last_launches", "cg1_plan_describe",
 ]
 
 

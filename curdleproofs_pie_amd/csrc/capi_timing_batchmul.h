@@ -13,6 +13,16 @@ int cg1_get_timings(const cg1_ctx* ctx, float* phase_ms, float* host_tail_ms, in
 
 int cg1_get_last_launches(const cg1_ctx* ctx) { return ctx ? ctx->last_acc_launches : -1; }
 
+// The window plan the engine would use (no GPU needed): (offset, width) of every window; returns the window count, or -1.
+int cg1_plan_describe(int window_c, int glv, int* out_offsets, int* out_widths, int capacity) {
+  const int cabs = window_c < 0 ? -window_c : window_c;
+  if (cabs < 4 || cabs > 16) return -1;
+  const cg1::WinPlan pl = cg1::make_plan(window_c, glv != 0);
+  if (pl.nwin > capacity) return -1;
+  for (int w = 0; w < pl.nwin; ++w) { out_offsets[w] = pl.off(w); out_widths[w] = pl.width(w); }
+  return pl.nwin;
+}
+
 int cg1_get_last_counts(const cg1_ctx* ctx, uint32_t* entries, uint32_t* chunks) {
   if (!ctx) return CG1_ERR_ARG;
   if (entries) *entries = ctx->last_entries;

@@ -162,6 +162,10 @@ int cg1_get_timings(const cg1_ctx* ctx, float phase_ms[CG1_NPHASE], float* host_
 int cg1_get_last_counts(const cg1_ctx* ctx, uint32_t* entries, uint32_t* chunks);
 /* k_accumulate launches of the last MSM call: 2 when it ran as two launch chains ("split"), 1, or 0 when k_msm_small served it */
 int cg1_get_last_launches(const cg1_ctx* ctx);
+/* The window plan of a width (window_c > 0: uniform; < 0: balanced with widths |c| and |c| - 1; glv: over the 128 positions of the halves of
+ * the endomorphism split instead of 256): offset and width of every window, low to high.  Returns the number of windows (<= capacity) or -1.
+ * No GPU involved: the CPU tests check that every plan tiles the bit positions from 0 without a gap. */
+int cg1_plan_describe(int window_c, int glv, int* out_offsets, int* out_widths, int capacity);
 /* hipEvent stopwatch on the context's compute stream: device time of everything enqueued between begin and end */
 int cg1_timer_begin(cg1_ctx* ctx);
 int cg1_timer_end(cg1_ctx* ctx, float* ms);

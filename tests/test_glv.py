@@ -44,6 +44,27 @@ def test_split_identity_and_bounds():
         assert abs(k1) <= bound and abs(k2) <= bound, hex(k)
 
 
+@pytest.mark.parametrize("glv", [0, 1])
+def test_every_window_plan_tiles_the_bit_positions(glv):
+    """Uniform and balanced plans, every width: windows start at bit 0, follow each other without gap or overlap, are cmax or cmax - 1
+    wide, and cover all 256 (128 with the split) positions -- a balanced plan whose narrow windows alone cover the range (128 positions
+    at width 14) once produced a negative first offset."""
+    positions = 128 if glv else 256
+    for c in list(range(4, 17)) + [-x for x in range(4, 17)]:
+        offs = (ctypes.c_int * 80)()
+        wid = (ctypes.c_int * 80)()
+        nw = N.cg1_plan_describe(c, glv, offs, wid, 80)
+        assert nw > 0, c
+        assert offs[0] == 0, (c, list(offs[:nw]))
+        for w in range(nw):
+            assert wid[w] in (abs(c), abs(c) - 1) and wid[w] >= 1
+            if w:
+                assert offs[w] == offs[w - 1] + wid[w - 1], (c, w)
+        assert offs[nw - 1] + wid[nw - 1] >= positions, c
+        assert offs[nw - 1] <= positions - 1, c                     # (255 / c integral: the top window holds the recoding carry only)
+    assert N.cg1_plan_describe(3, glv, offs, wid, 80) == -1 and N.cg1_plan_describe(17, glv, offs, wid, 80) == -1
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n,c", [(3000, 0), (1 << 14, 0), (1 << 14, 16), (1 << 14, -13), (1 << 14, -14), (1 << 14, 14), (1 << 14, 11), ((1 << 16) + 77, 0), (1 << 18, 0)])
 def test_msm_with_the_split_equals_the_msm_without(n, c):
