@@ -255,6 +255,78 @@ __global__ void __launch_bounds__(64) k_msm_horner_row(const PointSum* __restric
   row_export(acc, k.lane16, out + j);
 }
 
+// One item of regime A's 2-D bucket reduction (k_small_tree_quad's job: T0 = sum of all row sums, then one masked sum per row / column bit)
+// by a block of W <= 16 waves with one limb per lane: wave v adds the selected elements of rank v, v + W, ... one after the other (a
+// lone wave's addition is ~1.7 us against a quad's 5-10), an LDS tree joins the waves, wave 0 exports.  256 elements: 8 + 4 dependent
+// additions instead of 4 + 4 + 2 quad levels at three to five times the latency each.
+// canonical words of a row-form point with FOUR lanes, one coordinate each (row_export: one lane, four conversions in a row)
+__device__ __forceinline__ void row_export4(const xyzz_row& racc, uint32_t lane16, PointWords* dst) {
+  const xyzz acc = row_to_xyzz(racc, lane16);
+  const uint32_t q = threadIdx.x & 63u;
+  if (q < 4u) {
+    fp coord;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const uint32_t lo = (q & 1u) ? acc.Y.l[j] : acc.X.l[j], hi = (q & 1u) ? acc.ZZZ.l[j] : acc.ZZ.l[j];
+      coord.l[j] = (q & 2u) ? hi : lo;
+    }
+    uint32_t ow[12];
+    fp_to_host_words(coord, ow);
+    if (acc.inf) {
+#pragma unroll
+      for (int j = 0; j < 12; ++j) ow[j] = 0;
+    }
+    uint4* d4 = reinterpret_cast<uint4*>(&dst->w[q][0]);
+    d4[0] = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    d4[1] = make_uint4(ow[4], ow[5], ow[6], ow[7]);
+    d4[2] = make_uint4(ow[8], ow[9], ow[10], ow[11]);
+    if (q == 0u) dst->inf = acc.inf;
+  }
+}
+
+// out_host != NULL (zero-copy calls): the items go straight into the mapped host records; the LAST block to finish (ticket = status word
+// 3, zero at the start of every launch chain) copies the call's status words behind them and publishes the sequence number the host
+// polls -- k_export_host's job without its launch.
+__global__ void __launch_bounds__(1024) k_small_tree_row(const PointSum* __restrict__ rowsum, const PointSum* __restrict__ colsum,
+                                                         PointWords* __restrict__ out, uint32_t hb, uint32_t lb,
+                                                         PointWords* __restrict__ out_host, uint32_t* __restrict__ status_words,
+                                                         uint32_t* __restrict__ flag_host, uint32_t seq) {
+  __shared__ PointSum sh[8];
+  const uint32_t item = blockIdx.x, lw = blockIdx.y, wv = threadIdx.x >> 6, W = blockDim.x >> 6;
+  const RowK k = row_constants();
+  const bool on_rows = item <= hb;
+  const uint32_t J = on_rows ? (1u << hb) : (1u << lb);
+  const PointSum* src = (on_rows ? rowsum : colsum) + (size_t)lw * J;
+  const uint32_t bit = on_rows ? item - 1u : item - 1u - hb;
+  xyzz_row acc; acc.X = acc.Y = acc.ZZ = acc.ZZZ = 0; acc.inf = 1;
+  const uint32_t cnt = item == 0u ? J : J >> 1;                 // item 0: every element; a bit's item: the elements with that bit set
+  for (uint32_t r = wv; r < cnt; r += W) {                      // (wave-uniform trip count)
+    const uint32_t e = item == 0u ? r : (((((r >> bit) << 1) | 1u) << bit) | (r & ((1u << bit) - 1u)));
+    acc = row_add(acc, row_load_sum(src + e, k.lane16), k);
+  }
+  for (uint32_t d = W >> 1; d >= 1u; d >>= 1) {
+    if (wv >= d && wv < 2u * d) row_store_sum(&sh[wv - d], acc, k.lane16);
+    __syncthreads();
+    if (wv < d) acc = row_add(acc, row_load_sum(&sh[wv], k.lane16), k);
+    __syncthreads();
+  }
+  PointWords* dst = (out_host ? out_host : out) + (size_t)lw * gridDim.x + item;
+  if (wv != 0u) return;                                         // (past the last barrier)
+  row_export4(acc, k.lane16, dst);
+  if (out_host) {
+    __threadfence_system();                                     // the four exporting lanes' stores are visible to the host before the ticket is drawn
+    if (threadIdx.x == 0) {
+      const uint32_t total = gridDim.x * gridDim.y;
+      if (atomicAdd(&status_words[3], 1u) == total - 1u) {
+        uint32_t* st = reinterpret_cast<uint32_t*>(out_host + total);
+        st[0] = atomicAdd(&status_words[0], 0u); st[1] = atomicAdd(&status_words[1], 0u); st[2] = atomicAdd(&status_words[2], 0u); st[3] = 0;
+        __threadfence_system();
+        __hip_atomic_store(flag_host, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
 // out[i] = addend[i] + scalars[i % nscalars] * bases[i % nbase] with one WAVE per output (k_batch_mul_quad's job for a few hundred to a few
 // thousand outputs: the map / fold loops of the callers, curdleproofs.py:310-311, ipa.py:142-146, as a deferred batch): 4-bit windows over
 // a table of 15 multiples kept in registers (a point is four VGPRs here), 255 doublings + <= 64 additions.  Inputs affine96 (standard

@@ -228,6 +228,7 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
     hipLaunchKernelGGL(k_bucket_fold_quad, dim3((uint32_t)((nb_total * 4 + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);
   else if (ctx->fold_pass)
     hipLaunchKernelGGL(k_bucket_fold, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);
+  bool tree_exports = false;
   if (use2d) {
     const uint32_t R = 1u << hb2, Cn = 1u << lb2;
     const uint32_t lpr = Cn < 32u ? Cn : 32u, lpc = R < 16u ? R : 16u;
@@ -252,7 +253,16 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
     if (profile >= 2) HIPCHK(hipEventRecord(ctx->ev[6], st));
     // 4 lanes per element of the longer of the two sums (2^hb rows, 2^lb columns), at most 512 threads: no idle quads in the block
     const uint32_t tree_threads = std::min<uint32_t>(512u, std::max<uint32_t>(64u, 4u << std::max(hb2, lb2)) >> (ctx->tree_shift >= 0 ? ctx->tree_shift : (ctx->tree_half ? 1 : 0)));
-    if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(std::max<uint32_t>(64u, tree_threads)), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
+    if (ctx->tree_row) {
+      uint32_t W = (1u << std::max(hb2, lb2)) >> 3;              // ~8 selected elements per wave at most, 16 waves at most
+      W = W < 1u ? 1u : (W > 16u ? 16u : W);
+      // zero-copy calls: the items, the status words and the flag word go to the mapped host records from this kernel (no k_export_host)
+      tree_exports = ctx->zero_copy != 0;
+      if (tree_exports) ++ctx->seq;
+      hipLaunchKernelGGL(k_small_tree_row, dim3(nitems, nlw), dim3(64u * W), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2,
+                         tree_exports ? ctx->h_out_dev : (PointWords*)nullptr, bad_flag, ctx->h_flag_dev, ctx->seq);
+    }
+    else if (ctx->quad) hipLaunchKernelGGL(k_small_tree_quad, dim3(nitems, nlw), dim3(std::max<uint32_t>(64u, tree_threads)), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
     else hipLaunchKernelGGL(k_small_tree, dim3(nitems, nlw), dim3(256), 0, st, rowsum, colsum, ctx->d_out, hb2, lb2);
   } else {
     const uint32_t nseg_total = (uint32_t)(nb_total / m);
@@ -263,7 +273,9 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
     hipLaunchKernelGGL(k_bit_tree_final, dim3((uint32_t)(nitems * nlw)), dim3(64), 0, st, ctx->d_partial, ctx->d_out, S);
   }
   const bool zc = ctx->zero_copy != 0;
-  if (zc) {
+  if (zc && tree_exports) {
+    // (k_small_tree_row has written the records, the status words and the flag)
+  } else if (zc) {
     // the window sums + status words go straight into mapped host memory, then the call's sequence number into the flag word the
     // host polls: no DMA copy to set up, no stream wait to wake from (~25 us per call, all of it on the critical path of a small MSM)
     ++ctx->seq;

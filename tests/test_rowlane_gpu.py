@@ -128,3 +128,37 @@ def test_map_and_fold_batches_on_one_wave_per_result(native_lib):
             ctx.set_param("batch_mul_row", 1)
     assert outs["row_kernel"][3] == 2 and outs["pool"][3] == 1
     assert outs["pool"][:3] == outs["row_kernel"][:3] == outs["without_row_kernel"][:3]
+
+
+@pytest.mark.parametrize("n,c", [(3000, 0), (1 << 13, 8), (1 << 14, -12), (1 << 14, 5), (1 << 15, -13), (1 << 16, 16), (70000, -15), (1 << 17, 11)])
+def test_item_sums_on_rows_equal_the_quads(n, c):
+    """Regime A's 1 + hb + lb item sums per window: k_small_tree_row ("tree_row" = 1, the default) against k_small_tree_quad, and both
+    against the closed form (sum k_i s_i) G for points k_i G."""
+    import numpy as np
+    from curdleproofs_pie_amd import _native as N
+    from oracle import bls12_381 as O
+
+    ctx = N.Context(0)
+    rng = np.random.default_rng(n + 7 * abs(c))
+    gen96 = O.G1_GEN[0].to_bytes(48, "little") + O.G1_GEN[1].to_bytes(48, "little")
+    m = 256
+    ks = [int(x) for x in rng.integers(1, 1 << 62, m)]
+    base = ctx.batch_mul_add_host(gen96, 1, b"".join(k.to_bytes(32, "little") for k in ks), m, None, m)
+    idx = rng.integers(0, m, n)
+    pts = np.frombuffer(base, dtype=np.uint8).reshape(m, 96)[idx].copy()
+    sc = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    sc[:, 31] &= 0x3F
+    d_p = ctx.alloc(n * 96); d_p.upload(pts.tobytes())
+    d_s = ctx.alloc(n * 32); d_s.upload(sc.tobytes())
+    ctx.set_param("small_msm", 0)
+    ctx.set_param("tree_row", 0)
+    want = ctx.msm_device(d_p, d_s, n, window_c=c)
+    ctx.set_param("tree_row", 1)
+    got = ctx.msm_device(d_p, d_s, n, window_c=c)
+    assert N.cg1_eq(got, want) == 1
+    tot = sum(ks[i] * int.from_bytes(s.tobytes(), "little") for i, s in zip(idx, sc)) % O.R
+    ref = O.g1_mul(O.G1_GEN, tot)
+    out = ctypes.create_string_buffer(96)
+    N.cg1_to_affine96(out, got)
+    assert out.raw == ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little")
+    ctx.close()
