@@ -30,7 +30,7 @@ static int msm_begin_split(Ctx* ctx, const PtSrc& src, const void* d_scalars32, 
   { int crc = ensure_child(ctx); if (crc) return crc; }
   Ctx* ch = child_of(ctx);
   ch->profile = ctx->profile; ch->L0 = ctx->L0; ch->seg_m = ctx->seg_m; ch->quad = ctx->quad; ch->reduce_2d = ctx->reduce_2d;
-  ch->rowcol_quad = ctx->rowcol_quad; ch->rowcol_quad_max = ctx->rowcol_quad_max; ch->fold_pass = ctx->fold_pass; ch->tree_half = ctx->tree_half; ch->tree_shift = ctx->tree_shift; ch->rowcol_lgq = ctx->rowcol_lgq; ch->tree_row = ctx->tree_row; ch->sort_sub_bits = ctx->sort_sub_bits;
+  ch->rowcol_quad = ctx->rowcol_quad; ch->rowcol_quad_max = ctx->rowcol_quad_max; ch->fold_pass = ctx->fold_pass; ch->tree_half = ctx->tree_half; ch->tree_shift = ctx->tree_shift; ch->rowcol_lgq = ctx->rowcol_lgq; ch->tree_row = ctx->tree_row; ch->rowcol_row = ctx->rowcol_row; ch->sort_sub_bits = ctx->sort_sub_bits;
   ch->scan_one = ctx->scan_one; ch->zero_copy = ctx->zero_copy; ch->horner_threads = ctx->horner_threads; ch->host_split = ctx->host_split;
   ch->blocking_sync = ctx->blocking_sync; ch->stage_sort = ctx->stage_sort; ch->use_partition_sort = ctx->use_partition_sort; ch->big_bins = ctx->big_bins;
   const int n_own = win_count(plan.nwin, rank, world), n_lo = n_own / 2, n_hi = n_own - n_lo;      // this rank's windows: the upper ones here, the lower ones on the child
@@ -293,6 +293,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "glv_max_n")) { if (value < 0) return CG1_ERR_ARG; ctx->glv_max_n = value; return CG1_OK; }
   if (!strcmp(name, "batched_split")) { ctx->batched_split = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "batched_split_min_m")) { if (value < 2) return CG1_ERR_ARG; ctx->batched_split_min_m = value; return CG1_OK; }
+  if (!strcmp(name, "rowcol_row")) { ctx->rowcol_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "tree_row")) { ctx->tree_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "horner_row")) { ctx->horner_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "batch_mul_row")) { ctx->batch_mul_row = value ? 1 : 0; return CG1_OK; }

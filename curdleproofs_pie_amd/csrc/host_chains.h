@@ -224,7 +224,11 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   // Buckets cut into 2..16 chunks are folded into their first slot before the row / column sums (k_rowcol_quad requires it;
   // k_rowcol / k_seg_reduce could add the chunk sums themselves -- bucket_sum -- but the divergent trip counts inside their lanes
   // cost more than the separate pass: profiles/r03_rowcol_ab.txt).
-  if (small_quad)
+  // k_rowcol_quad_row can add a bucket's chunk sums itself: worth it only for a few thousand buckets (2^12 terms 0.354 -> 0.336 ms; at 2^15 -
+  // 2^16 the uneven trip counts of a wave's quads cost more than the separate pass: 0.605 -> 0.657, profiles/r05_tree_row_ab.txt)
+  const bool rows_fold = small_quad && use2d && ctx->rowcol_row && ctx->tree_row && nb_total <= 8192;
+  if (rows_fold) {}
+  else if (small_quad)
     hipLaunchKernelGGL(k_bucket_fold_quad, dim3((uint32_t)((nb_total * 4 + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);
   else if (ctx->fold_pass)
     hipLaunchKernelGGL(k_bucket_fold, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);
@@ -244,6 +248,10 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
       uint32_t lgq = (R == Cn) ? 2u : 3u;
       if (ctx->rowcol_lgq >= 2 && ctx->rowcol_lgq <= 4) lgq = (uint32_t)ctx->rowcol_lgq;
       const uint32_t rc_waves = ((uint32_t)nlw * (R + Cn) + (16u >> lgq) - 1u) / (16u >> lgq);
+      if (ctx->rowcol_row && ctx->tree_row)              // one wave per row / column, the cross-quad levels on rows (its sums are in row form: k_small_tree_row reads them)
+        hipLaunchKernelGGL(k_rowcol_quad_row, dim3(((uint32_t)nlw * (R + Cn) + 3u) / 4u), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined,
+                           rowsum, colsum, (uint32_t)nlw, hb2, lb2);
+      else
       hipLaunchKernelGGL(k_rowcol_quad, dim3((rc_waves + 3u) / 4u), dim3(256), 0, st, ctx->d_choff, ctx->d_sums,
                          rowsum, colsum, (uint32_t)nlw, hb2, lb2, lgq);
     }

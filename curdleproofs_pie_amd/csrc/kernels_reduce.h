@@ -216,6 +216,54 @@ __global__ void __launch_bounds__(256, 2) k_rowcol_quad(const uint32_t* __restri
   if (live_row && p == 0u && q == 0u) store_sum(is_row ? rowsum + gw : colsum + (gw - nrows), acc);
 }
 
+// k_rowcol_quad with the cross-quad levels on rows: ONE WAVE per row / column, its 16 quads take the elements p, p + 16, ... (len / 16
+// serial quad additions), park their partial sums in LDS, and the wave then adds the 16 partials one after the other with one limb per
+// lane (fp_row.h: ~2.4 us per addition where a quad-shuffle level costs ~23: 56 words through ds_bpermute plus a quad addition).
+// 64-element rows: 4 + 15 short steps instead of 16 + 2 long ones.  The sums are written in row form (nearly normal limbs): only
+// k_small_tree_row reads them.
+__global__ void __launch_bounds__(256, 2) k_rowcol_quad_row(const uint32_t* __restrict__ choff, const PointSum* __restrict__ sums,
+                                                            const uint8_t* __restrict__ combined,
+                                                            PointSum* __restrict__ rowsum, PointSum* __restrict__ colsum,
+                                                            uint32_t nlw, uint32_t hb, uint32_t lb) {
+  __shared__ PointSum part[4 * 16];
+  const uint32_t R = 1u << hb, Cn = 1u << lb;
+  const uint32_t wib = threadIdx.x >> 6, gw = blockIdx.x * 4u + wib, lane = threadIdx.x & 63u, q = lane & 3u, p = lane >> 2;
+  const uint32_t nrows = nlw * R, ncols = nlw * Cn;
+  if (gw >= nrows + ncols) return;                                              // whole waves leave together (no block-wide barrier below)
+  const bool is_row = gw < nrows;
+  uint32_t first, stride;
+  const uint32_t len = is_row ? Cn : R;
+  if (is_row) { first = gw * Cn; stride = 1u; }
+  else { const uint32_t gc = gw - nrows, lw = gc / Cn, l = gc % Cn; first = lw * R * Cn + l; stride = Cn; }
+  // The quad walks its elements p, p + 16, ... and, inside an element (a bucket), the bucket's chunk sums: a bucket cut into a few chunks
+  // needs no k_bucket_fold_quad pass in front (75 us at 2^16 terms for one addition per bucket); buckets k_heavy_combine joined have
+  // their total in the first slot.  ONE quad_add call site.
+  xyzz acc = xyzz_identity();
+  uint32_t i = p, c0 = 0, nch = 0, kk = 0;
+  bool fresh = true;
+#pragma unroll 1
+  for (;;) {
+    if (fresh) {
+      if (i >= len) break;
+      const uint32_t b = first + i * stride;
+      c0 = choff[b];
+      nch = choff[b + 1] - c0;
+      if (nch > 1u && combined[b]) nch = 1u;
+      kk = 0; i += 16u; fresh = false;
+    }
+    if (kk < nch) { acc = quad_add(acc, load_sum(sums + c0 + kk), q); ++kk; }
+    if (kk >= nch) fresh = true;
+  }
+  if (q == 0u) store_sum(&part[wib * 16u + p], acc);
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xc07f);                                           // lgkmcnt(0): the wave's own LDS stores have landed
+  const RowK k = row_constants();
+  xyzz_row racc = row_load_sum(&part[wib * 16u], k.lane16);
+#pragma unroll 1
+  for (uint32_t j = 1; j < 16u; ++j) racc = row_add(racc, row_load_sum(&part[wib * 16u + j], k.lane16), k);
+  row_store_sum(is_row ? rowsum + gw : colsum + (gw - nrows), racc, k.lane16);
+}
+
 // grid = (1 + hb + lb, nlw), 256 threads.  item 0: T0 = sum_h A_h; item 1+k (k < hb): sum of A_h with bit k of h set;
 // item 1+hb+k (k < lb): sum of C_l with bit k of l set.  Requires 2^hb, 2^lb <= 256.  Emits canonical words.
 __global__ void __launch_bounds__(256) k_small_tree(const PointSum* __restrict__ rowsum, const PointSum* __restrict__ colsum,

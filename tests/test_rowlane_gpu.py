@@ -154,8 +154,11 @@ def test_item_sums_on_rows_equal_the_quads(n, c):
     ctx.set_param("tree_row", 0)
     want = ctx.msm_device(d_p, d_s, n, window_c=c)
     ctx.set_param("tree_row", 1)
+    ctx.set_param("rowcol_row", 0)
+    mid = ctx.msm_device(d_p, d_s, n, window_c=c)
+    ctx.set_param("rowcol_row", 1)                          # (small bucket counts: the row / column sums' cross-quad levels on rows too)
     got = ctx.msm_device(d_p, d_s, n, window_c=c)
-    assert N.cg1_eq(got, want) == 1
+    assert N.cg1_eq(got, want) == 1 and N.cg1_eq(mid, want) == 1
     tot = sum(ks[i] * int.from_bytes(s.tobytes(), "little") for i, s in zip(idx, sc)) % O.R
     ref = O.g1_mul(O.G1_GEN, tot)
     out = ctypes.create_string_buffer(96)

@@ -1,6 +1,5 @@
 #!/usr/bin/env python3
-"""A/B of regime A's item sums (1 + hb + lb masked sums per window behind the row / column sums): k_small_tree_quad against
-k_small_tree_row (context parameter "tree_row"), wall time and phases of one MSM call, results compared."""
+"""Minimum chunk length ("chunk_len") against the size of a regime-A call: wall time of one MSM, inputs resident."""
 import os
 import sys
 import time
@@ -21,24 +20,22 @@ def med(f, reps=11):
 
 def main():
     ctx = N.Context(0)
-    nmax = 1 << 20
+    nmax = 1 << 18
     dk, dp, ds, dg = ctx.alloc(32 * nmax), ctx.alloc(96 * nmax), ctx.alloc(32 * nmax), ctx.alloc(96)
     dg.upload(GX.to_bytes(48, "little") + GY.to_bytes(48, "little"))
     ctx.gen_scalars_device(dk, nmax, 1)
     ctx.batch_mul_device(dg, 1, dk, dp, nmax)
     ctx.gen_scalars_device(ds, nmax, 2)
-    for logn in (12, 13, 14, 15, 16, 17, 18, 19, 20):
+    ctx.set_param("chunk_rule", int(os.environ.get("CHUNK_RULE", "1")))
+    for logn in (13, 14, 15, 16, 17, 18):
         n = 1 << logn
-        res = []
-        for tr, rr in ((0, 0), (1, 0), (1, 1), (0, 0), (1, 0), (1, 1)):
-            ctx.set_param("tree_row", tr)
-            ctx.set_param("rowcol_row", rr)
+        out = []
+        for L in (4, 6, 8, 10, 12, 16, 20, 24, 32, 48):
+            ctx.set_param("chunk_len", L)
             ctx.set_param("profile", 1)
             w = med(lambda: ctx.msm_device(dp, ds, n, window_c=0))
-            ctx.set_param("profile", 2)
-            res.append(ctx.msm_device(dp, ds, n, window_c=0))
-            tm = ctx.timings()
-            print(f"n=2^{logn} tree_row={tr} rowcol_row={rr} c={tm['window_c']}: {w:.3f} ms | seg_reduce={tm['seg_reduce']:.3f} bit_tree={tm['bit_tree']:.3f} host_tail={tm['host_tail']:.3f}" + (f" | same result: {N.cg1_eq(res[0], res[-1]) == 1}" if tr else ""), flush=True)
+            out.append((w, L))
+        print(f"n=2^{logn}: " + "  ".join(f"L={L}: {w:.3f}" for w, L in out) + f"   best L={min(out)[1]}", flush=True)
     for b in (dk, dp, ds, dg):
         b.free()
     ctx.close()
