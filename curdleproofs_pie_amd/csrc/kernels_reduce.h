@@ -259,8 +259,9 @@ __global__ void __launch_bounds__(256, 2) k_rowcol_quad_row(const uint32_t* __re
   __builtin_amdgcn_s_waitcnt(0xc07f);                                           // lgkmcnt(0): the wave's own LDS stores have landed
   const RowK k = row_constants();
   xyzz_row racc = row_load_sum(&part[wib * 16u], k.lane16);
+  const uint32_t np = len < 16u ? len : 16u;                                    // quads beyond the row's length hold the identity
 #pragma unroll 1
-  for (uint32_t j = 1; j < 16u; ++j) racc = row_add(racc, row_load_sum(&part[wib * 16u + j], k.lane16), k);
+  for (uint32_t j = 1; j < np; ++j) racc = row_add(racc, row_load_sum(&part[wib * 16u + j], k.lane16), k);
   row_store_sum(is_row ? rowsum + gw : colsum + (gw - nrows), racc, k.lane16);
 }
 
