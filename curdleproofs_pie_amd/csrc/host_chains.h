@@ -228,7 +228,7 @@ static int msm_enqueue(Ctx* ctx, const PtSrc& src, const void* d_scalars32, size
   // 2^16 the uneven trip counts of a wave's quads cost more than the separate pass: 0.605 -> 0.657, profiles/r05_tree_row_ab.txt)
   const bool rows_fold = small_quad && use2d && ctx->rowcol_row && ctx->tree_row && nb_total <= 8192;
   if (rows_fold) {}
-  else if (small_quad)
+  else if (small_quad && ctx->fold_quad)
     hipLaunchKernelGGL(k_bucket_fold_quad, dim3((uint32_t)((nb_total * 4 + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);
   else if (ctx->fold_pass)
     hipLaunchKernelGGL(k_bucket_fold, dim3((uint32_t)((nb_total + 255) / 256)), dim3(256), 0, st, ctx->d_choff, ctx->d_sums, ctx->d_combined, (uint32_t)nb_total, ctx->d_any_multi);

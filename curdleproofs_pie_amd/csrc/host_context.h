@@ -175,6 +175,7 @@ struct Ctx {
                                         // the endomorphism split (csrc/glv.h): 1 = where it pays (the single-launch kernel up to 1 024 terms, regime A up to
                                         // glv_max_n terms), 2 = wherever it can (A/B runs).  WRONG results outside G1: default 0.
   int glv_max_n = 1 << 14;              // "glv_max_n": largest regime-A call glv = 1 splits (profiles/r05_glv_ab.txt: slower from 2^15 terms up)
+  int fold_quad = 1;                    // "fold_quad": small bucket counts: k_bucket_fold_quad (1) or the one-lane-per-bucket k_bucket_fold (0); A/B switch
   int rowcol_row = 1;                   // "rowcol_row": with tree_row, small bucket counts: k_rowcol_quad_row (one wave per row / column, the cross-quad levels on rows)
   int tree_row = 1;                     // "tree_row": regime A's 1 + hb + lb items per window by blocks of waves with one limb per lane (k_small_tree_row); 0: k_small_tree_quad
   int horner_row = 1;                   // "horner_row": regime B's device Horner with one wave per MSM, one limb per lane (A/B switch; 0: one quad per MSM)

@@ -30,15 +30,16 @@ def main():
     for logn in (12, 13, 14, 15, 16, 17, 18, 19, 20):
         n = 1 << logn
         res = []
-        for tr, rr in ((0, 0), (1, 0), (1, 1), (0, 0), (1, 0), (1, 1)):
+        for tr, rr, fq in ((0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (1, 1, 0)):
             ctx.set_param("tree_row", tr)
             ctx.set_param("rowcol_row", rr)
+            ctx.set_param("fold_quad", fq)
             ctx.set_param("profile", 1)
             w = med(lambda: ctx.msm_device(dp, ds, n, window_c=0))
             ctx.set_param("profile", 2)
             res.append(ctx.msm_device(dp, ds, n, window_c=0))
             tm = ctx.timings()
-            print(f"n=2^{logn} tree_row={tr} rowcol_row={rr} c={tm['window_c']}: {w:.3f} ms | seg_reduce={tm['seg_reduce']:.3f} bit_tree={tm['bit_tree']:.3f} host_tail={tm['host_tail']:.3f}" + (f" | same result: {N.cg1_eq(res[0], res[-1]) == 1}" if tr else ""), flush=True)
+            print(f"n=2^{logn} tree_row={tr} rowcol_row={rr} fold_quad={fq} c={tm['window_c']}: {w:.3f} ms | seg_reduce={tm['seg_reduce']:.3f} bit_tree={tm['bit_tree']:.3f} host_tail={tm['host_tail']:.3f}" + (f" | same result: {N.cg1_eq(res[0], res[-1]) == 1}" if tr else ""), flush=True)
     for b in (dk, dp, ds, dg):
         b.free()
     ctx.close()
