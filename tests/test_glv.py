@@ -195,3 +195,50 @@ def test_regime_b_with_the_split(M, n, c):
         N.cg1_to_affine96(out, b[j])
         assert out.raw == (bytes(96) if ref is None else ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little"))
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [6, 60, 600, 3000, 20000])
+def test_split_with_bases_that_are_each_others_images(n):
+    """P, phi(P), phi^2(P) and their negatives side by side, equal scalars among them: the split's second halves phi(P_i) then COINCIDE with
+    other inputs (and with their negatives) inside the same buckets -- the doubling and cancellation cases of the bucket additions --
+    and sums like P + phi(P) + phi^2(P) = 0 appear.  Split against no split against the oracle."""
+    beta = 0x1A0111EA397FE699EC02408663D4DE85AA0D857D89759AD4897D29650FB85F9B409427EB4F49FFFD8BFD00000000AAAC
+    ctx = N.Context(0)
+    rng = random.Random(900 + n)
+    seeds = [O.g1_mul(O.G1_GEN, rng.randrange(1, R)) for _ in range(3)]
+    fam = []
+    for p in seeds:
+        p1 = (p[0] * beta % O.P, p[1])
+        p2 = (p1[0] * beta % O.P, p[1])
+        fam += [p, p1, p2, O.g1_neg(p), O.g1_neg(p1), O.g1_neg(p2)]
+    few = [rng.randrange(R) for _ in range(3)] + [1, R - 1, LAM, LAM + 1, R - LAM, (R + 1) // 2]
+    pts, sc = [], []
+    for i in range(n):
+        pts.append(fam[i % len(fam)] if i % 7 else rng.choice(fam))
+        sc.append(rng.choice(few) if i % 3 else rng.randrange(R))
+    raw = b"".join(p[0].to_bytes(48, "little") + p[1].to_bytes(48, "little") for p in pts)
+    s32 = b"".join(s.to_bytes(32, "little") for s in sc)
+    d_p = ctx.alloc(n * 96); d_p.upload(raw)
+    d_s = ctx.alloc(n * 32); d_s.upload(s32)
+    ctx.set_param("glv", 0)
+    want = ctx.msm_device(d_p, d_s, n)
+    ctx.set_param("glv", 2)
+    got = ctx.msm_device(d_p, d_s, n)
+    assert N.cg1_eq(got, want) == 1
+    if n <= 3000:
+        ref = O.compute_MSM_fast(pts, sc) if n > 8 else O.compute_MSM(pts, sc)
+        out = ctypes.create_string_buffer(96)
+        N.cg1_to_affine96(out, got)
+        assert out.raw == (bytes(96) if ref is None else ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little"))
+    if n >= 60:                                             # the same inputs as 12 MSMs of one launch, and as regime B (M = 90)
+        for M in (12, 90):
+            if M * 2 > n:
+                continue
+            offs = [n * j // M for j in range(M + 1)]
+            ctx.set_param("glv", 0)
+            a = ctx.msm_batched_device(d_p, d_s, offs)
+            ctx.set_param("glv", 1)
+            b = ctx.msm_batched_device(d_p, d_s, offs)
+            assert all(N.cg1_eq(x, y) == 1 for x, y in zip(a, b))
+    ctx.close()
