@@ -165,3 +165,40 @@ def test_item_sums_on_rows_equal_the_quads(n, c):
     N.cg1_to_affine96(out, got)
     assert out.raw == ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little")
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [2500, 5000, 40000, 1 << 17])
+def test_row_form_tails_meet_doublings_and_cancellations(n):
+    """A handful of distinct points and their negatives under a handful of distinct scalars: whole buckets, rows and columns hold EQUAL or
+    OPPOSITE sums, so the row-form additions of k_rowcol_quad_row / k_small_tree_row run into P + P and P - P all the time (their
+    out-of-line exceptional path).  Rows against quads against the closed form."""
+    import numpy as np
+    from curdleproofs_pie_amd import _native as N
+    from oracle import bls12_381 as O
+
+    ctx = N.Context(0)
+    rng = np.random.default_rng(n)
+    ks = [5, 7, O.R - 5, O.R - 7, 5, 11, O.R - 11, 5]
+    gen96 = O.G1_GEN[0].to_bytes(48, "little") + O.G1_GEN[1].to_bytes(48, "little")
+    base = ctx.batch_mul_add_host(gen96, 1, b"".join(k.to_bytes(32, "little") for k in ks), len(ks), None, len(ks))
+    idx = np.arange(n) % len(ks)
+    pts = np.frombuffer(base, dtype=np.uint8).reshape(len(ks), 96)[idx].copy()
+    few = [0x0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF0123456789ABCDEF % O.R, 3, O.R - 3, (1 << 200) + 12345]
+    pick = rng.integers(0, len(few), n)
+    pick[: n // 2] = 0                                      # half the terms share ONE scalar
+    sc = b"".join(few[j].to_bytes(32, "little") for j in pick)
+    d_p = ctx.alloc(n * 96); d_p.upload(pts.tobytes())
+    d_s = ctx.alloc(n * 32); d_s.upload(sc)
+    ctx.set_param("small_msm", 0)
+    outs = []
+    for tr, rr in ((0, 0), (1, 0), (1, 1)):
+        ctx.set_param("tree_row", tr)
+        ctx.set_param("rowcol_row", rr)
+        outs.append(ctx.msm_device(d_p, d_s, n))
+    assert N.cg1_eq(outs[0], outs[1]) == 1 and N.cg1_eq(outs[0], outs[2]) == 1
+    tot = sum(ks[i] * few[j] for i, j in zip(idx, pick)) % O.R
+    out = ctypes.create_string_buffer(96)
+    N.cg1_to_affine96(out, outs[2])
+    ref = O.g1_mul(O.G1_GEN, tot) if tot else None
+    assert out.raw == (bytes(96) if ref is None else ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little"))
+    ctx.close()
