@@ -293,6 +293,7 @@ int cg1_ctx_set_param(cg1_ctx* ctx, const char* name, int value) {
   if (!strcmp(name, "glv_max_n")) { if (value < 0) return CG1_ERR_ARG; ctx->glv_max_n = value; return CG1_OK; }
   if (!strcmp(name, "batched_split")) { ctx->batched_split = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "batched_split_min_m")) { if (value < 2) return CG1_ERR_ARG; ctx->batched_split_min_m = value; return CG1_OK; }
+  if (!strcmp(name, "lincomb_zero_copy")) { ctx->lincomb_zero_copy = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "fold_quad")) { ctx->fold_quad = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "rowcol_row")) { ctx->rowcol_row = value ? 1 : 0; return CG1_OK; }
   if (!strcmp(name, "tree_row")) { ctx->tree_row = value ? 1 : 0; return CG1_OK; }

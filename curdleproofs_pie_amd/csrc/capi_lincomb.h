@@ -19,6 +19,7 @@ extern "C" void cg1_lincomb_write_outputs(const void* jac_results, size_t n_out,
 
 constexpr size_t LINCOMB_ROW_MAX = 4096;         // map / fold results k_batch_mul_row takes (one wave each); beyond: k_batch_mul, one lane each
 constexpr size_t LINCOMB_ROW_MIN = 96;           // fewer are quicker on the host's pool (~77 us each over its threads) than a ~0.7 ms launch
+constexpr size_t LINCOMB_ZERO_COPY_MAX = 4096;   // terms of a GPU share the kernels read from mapped host memory instead of a staged copy
 constexpr size_t LINCOMB_MAX_REGIME_B = 2048;    // independent MSMs cg1_lincomb_batch hands the regime-B chain in one call (r04: 1 024 - 2 048 x 627 terms)
 
 // results[sel[q]] = s * B (+ A) for the selected outputs, each one weighted term and at most one unit term: one k_batch_mul launch
@@ -223,11 +224,13 @@ int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_base
   bool pending = false;
   if (TG) {
     HIPCHK(hipSetDevice(ctx->device));
-    if (TG * 128 > ctx->cap_h_lin) {
+    const size_t need_lin = TG * 128 + (G + 1) * 4 + 64;
+    if (need_lin > ctx->cap_h_lin) {
       if (ctx->h_lin) (void)hipHostFree(ctx->h_lin);
-      ctx->h_lin = nullptr; ctx->cap_h_lin = 0;
-      const size_t want = TG * 128 + TG * 32 + 4096;
-      HIPCHK(hipHostMalloc((void**)&ctx->h_lin, want, hipHostMallocDefault));
+      ctx->h_lin = nullptr; ctx->h_lin_dev = nullptr; ctx->cap_h_lin = 0;
+      const size_t want = need_lin + TG * 32 + 4096;
+      HIPCHK(hipHostMalloc((void**)&ctx->h_lin, want, hipHostMallocMapped));
+      HIPCHK(hipHostGetDevicePointer((void**)&ctx->h_lin_dev, ctx->h_lin, 0));
       ctx->cap_h_lin = want;
     }
     uint8_t* hp = ctx->h_lin;
@@ -251,10 +254,21 @@ int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_base
         memcpy(hs + 32 * o, term_scalars32 + 32 * t, 32);
       }
     }
-    { int src = ensure_stage(ctx, TG * 96, TG * 32); if (src) return src; }
-    HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, hp, TG * 96, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, hs, TG * 32, hipMemcpyHostToDevice, ctx->stream));
-    int rc = cg1::msm_batched_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, goffs.data(), G, 0, gres, &pending);
+    int rc;
+    if (TG <= LINCOMB_ZERO_COPY_MAX && ctx->lincomb_zero_copy) {
+      // a handful of small combinations (a halving round's 6 MSMs: ~100 KB): the single-launch kernel reads the gathered terms and the
+      // offsets straight from the mapped staging buffer -- three copies (~8 us each, one after the other) less in front of a 0.2 ms launch
+      uint32_t* ho = reinterpret_cast<uint32_t*>(ctx->h_lin + ((TG * 128 + 63) & ~(size_t)63));
+      memcpy(ho, goffs.data(), (G + 1) * 4);
+      const uint8_t* dv = ctx->h_lin_dev;
+      rc = cg1::msm_batched_device(ctx, dv, dv + TG * 96, goffs.data(), G, 0, gres, &pending,
+                                   reinterpret_cast<const uint32_t*>(dv + ((TG * 128 + 63) & ~(size_t)63)));
+    } else {
+      { int src = ensure_stage(ctx, TG * 96, TG * 32); if (src) return src; }
+      HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, hp, TG * 96, hipMemcpyHostToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, hs, TG * 32, hipMemcpyHostToDevice, ctx->stream));
+      rc = cg1::msm_batched_device(ctx, ctx->d_stage_pts, ctx->d_stage_sc, goffs.data(), G, 0, gres, &pending);
+    }
     if (rc != CG1_OK) return rc;
   } else {
     gres.assign(G, cg1h::jac_identity());

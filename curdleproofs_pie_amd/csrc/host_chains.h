@@ -857,8 +857,10 @@ static int msm_batched_small_end(Ctx* ctx, size_t M, std::vector<cg1h::jac>& res
   if (M == 1) { cg1h::jac r; int rc = msm_finish(ctx, r); ctx->last_acc_launches = 0; if (rc == CG1_OK) results[0] = r; return rc; }
   return msm_small_batched_finish(ctx, (uint32_t)M, results);
 }
+// d_offsets_ready (may be NULL): the same M + 1 offsets at an address the DEVICE can read (mapped host memory); the single-launch path
+// then reads them there instead of waiting for a copy.
 int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32, const uint32_t* h_offsets, size_t M,
-                       int c, std::vector<cg1h::jac>& results, bool* async_small = nullptr) {
+                       int c, std::vector<cg1h::jac>& results, bool* async_small = nullptr, const uint32_t* d_offsets_ready = nullptr) {
   if (async_small) *async_small = false;
   results.assign(M, cg1h::jac_identity());
   if (M == 0) return CG1_OK;
@@ -878,14 +880,18 @@ int msm_batched_device(Ctx* ctx, const void* d_points96, const void* d_scalars32
     const size_t groups = (size_t)M * (size_t)((sglv ? 127 : 255) / cs + 1) * ((max_nn + SM_SLICE - 1) / SM_SLICE);
     if (ctx->small_msm && M <= SM_MAX_MSMS && max_nn <= SM_MAX_N && groups <= SM_MAX_GROUPS && cs >= 4 && cs <= 9 && cs != 5) {
       HIPCHK(hipSetDevice(ctx->device));
-      if ((M + 1) > ctx->cap_boffs) {
-        if (ctx->d_boffs) (void)hipFree(ctx->d_boffs);
-        ctx->d_boffs = nullptr; ctx->cap_boffs = 0;
-        HIPCHK(hipMalloc(&ctx->d_boffs, (M + 1) * 4));
-        ctx->cap_boffs = M + 1;
+      const uint32_t* d_offs = d_offsets_ready;
+      if (!d_offs) {
+        if ((M + 1) > ctx->cap_boffs) {
+          if (ctx->d_boffs) (void)hipFree(ctx->d_boffs);
+          ctx->d_boffs = nullptr; ctx->cap_boffs = 0;
+          HIPCHK(hipMalloc(&ctx->d_boffs, (M + 1) * 4));
+          ctx->cap_boffs = M + 1;
+        }
+        HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+        d_offs = ctx->d_boffs;
       }
-      HIPCHK(hipMemcpyAsync(ctx->d_boffs, h_offsets, (M + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-      int rc = msm_enqueue_small(ctx, PtSrc(d_points96), d_scalars32, N, cs, (uint32_t)M, ctx->d_boffs, max_n, sglv);
+      int rc = msm_enqueue_small(ctx, PtSrc(d_points96), d_scalars32, N, cs, (uint32_t)M, d_offs, max_n, sglv);
       if (rc) return rc;
       if (async_small) { *async_small = true; return CG1_OK; }
       return msm_batched_small_end(ctx, M, results);

@@ -175,6 +175,7 @@ struct Ctx {
                                         // the endomorphism split (csrc/glv.h): 1 = where it pays (the single-launch kernel up to 1 024 terms, regime A up to
                                         // glv_max_n terms), 2 = wherever it can (A/B runs).  WRONG results outside G1: default 0.
   int glv_max_n = 1 << 14;              // "glv_max_n": largest regime-A call glv = 1 splits (profiles/r05_glv_ab.txt: slower from 2^15 terms up)
+  int lincomb_zero_copy = 1;            // "lincomb_zero_copy": small GPU shares of cg1_lincomb_batch are read from mapped host memory (no staged copy); A/B switch
   int fold_quad = 1;                    // "fold_quad": small bucket counts: k_bucket_fold_quad (1) or the one-lane-per-bucket k_bucket_fold (0); A/B switch
   int rowcol_row = 1;                   // "rowcol_row": with tree_row, small bucket counts: k_rowcol_quad_row (one wave per row / column, the cross-quad levels on rows)
   int tree_row = 1;                     // "tree_row": regime A's 1 + hb + lb items per window by blocks of waves with one limb per lane (k_small_tree_row); 0: k_small_tree_quad
@@ -197,7 +198,7 @@ struct Ctx {
   int horner_threads = 4;               // host threads of the Horner tail: 1, 2 or 4 (A/B switch; host_split = 0 forces 1)
   // staging for host-pointer entry points
   void* d_stage_pts = nullptr; void* d_stage_sc = nullptr; size_t cap_stage_pts = 0, cap_stage_sc = 0;      // bytes
-  uint8_t* h_lin = nullptr; size_t cap_h_lin = 0;   // page-locked gather buffer of cg1_lincomb_batch (terms' points | scalars)
+  uint8_t* h_lin = nullptr; uint8_t* h_lin_dev = nullptr; size_t cap_h_lin = 0;   // page-locked gather buffer of cg1_lincomb_batch (terms' points | scalars)
   // timing
   hipEvent_t ev[CG1_NPHASE + 1];
   float phase_ms[CG1_NPHASE] = {0};
@@ -221,7 +222,7 @@ static void free_bufs(Ctx* c) {
   F(c->d_digits); F(c->d_part); F(c->d_blockcnt); F(c->d_ublocktot); F(c->d_boffs); F(c->d_gsum); F(c->d_bout);
   F(c->d_slice_base); F(c->d_slicehist); F(c->d_subbase); F(c->d_bigflag); c->cap_bigflag = 0; c->cap_slices = 0;
   if (c->h_bout) { (void)hipHostFree(c->h_bout); c->h_bout = nullptr; }
-  if (c->h_lin) { (void)hipHostFree(c->h_lin); c->h_lin = nullptr; c->cap_h_lin = 0; }
+  if (c->h_lin) { (void)hipHostFree(c->h_lin); c->h_lin = nullptr; c->h_lin_dev = nullptr; c->cap_h_lin = 0; }
   if (c->d_gout) { (void)hipFree(c->d_gout); c->d_gout = nullptr; }
   if (c->h_gout) { (void)hipHostFree(c->h_gout); c->h_gout = nullptr; }
   c->cap_gout = 0;

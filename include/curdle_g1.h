@@ -94,6 +94,7 @@ void* cg1_ctx_stream(cg1_ctx* ctx);                                  /* the cont
  *   MSM plan / phases   "chunk_len" "seg_m" "auto_plan" "stage_sort" "partition_sort" "big_bins" "wave_agg" "quad" "reduce_2d" "rowcol_quad"
  *                       "rowcol_quad_max" "fold_pass" "tree_half" "scan_one" "host_split" "horner_threads" "zero_copy" "batched_host_horner_max"
  *                       "batch_mul_quad_max" "batch_mul_host_max" "batch_mul_row" "horner_row" "small_row_tail" "sort_sub_bits" "rowcol_lgq" "tree_shift" "arm_helpers" "small_msm" (1: calls of <= 2048 terms run as ONE launch, k_msm_small; 0: the regime-A chain)
+ *                       "lincomb_zero_copy" (1: GPU shares of cg1_lincomb_batch up to 4 096 terms are read by the kernel from mapped host memory, no staged copy),
  *                       "fold_quad" (1: quads fold a bucket's chunk sums at small bucket counts; 0: one lane per bucket, measured slower),
  *                       "tree_row" / "rowcol_row" (1: regime A's item sums, and for <= 2^18 buckets the cross-quad levels of the row / column sums, with one
  *                       limb per lane; 0: the quad kernels), "glv" / "glv_max_n" (the endomorphism split, see below: a PROMISE about the points, not a tuning
