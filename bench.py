@@ -626,11 +626,15 @@ def main():
                 break
         ex["t"], ex["n"] = 0.0, 0
         phase_acc.clear()
+        import gc
+        gc.collect()
+        gc.disable()                                        # (the interpreter's cyclic collector must not land inside the 20 timed steps: it does none of the step's work)
         barrier_sync()
         t0 = time.perf_counter()
         results += stream(steps)                            # every step is begun AND collected inside the timed region
         barrier_sync()
         elapsed = mine = time.perf_counter() - t0
+        gc.enable()
         counts = ctx.last_counts()
         if not all(N.cg1_eq(r, results[0]) for r in results[1:]):
             sys.exit("bench.py: MSM results differ between steps")

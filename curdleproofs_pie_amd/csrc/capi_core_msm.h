@@ -407,10 +407,30 @@ static int ensure_stage(cg1_ctx* ctx, size_t pts_bytes, size_t sc_bytes) {
   return CG1_OK;
 }
 
+// the context's mapped page-locked scratch (cg1_lincomb_batch's gather buffer, cg1_msm's small inputs): at least `bytes`
+static int ensure_lin(cg1_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->cap_h_lin) return CG1_OK;
+  if (ctx->h_lin) (void)hipHostFree(ctx->h_lin);
+  ctx->h_lin = nullptr; ctx->h_lin_dev = nullptr; ctx->cap_h_lin = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  HIPCHK(hipHostMalloc((void**)&ctx->h_lin, want, hipHostMallocMapped));
+  HIPCHK(hipHostGetDevicePointer((void**)&ctx->h_lin_dev, ctx->h_lin, 0));
+  ctx->cap_h_lin = want;
+  return CG1_OK;
+}
+
 int cg1_msm(cg1_ctx* ctx, const uint8_t* points, const uint8_t* scalars, size_t n, uint8_t* out) {
   if (!ctx) return CG1_ERR_HIP;
   if (n == 0) { blob_out(out, cg1h::jac_identity()); return CG1_OK; }
   HIPCHK(hipSetDevice(ctx->device));
+  if (n <= 4096 && ctx->lincomb_zero_copy) {
+    // the protocol's own sizes (the accumulator's final 5 ell + 7 terms): two copies from pageable memory cost more than the kernels'
+    // reading ~100 KB from mapped host memory
+    { int lrc = ensure_lin(ctx, n * 128); if (lrc) return lrc; }
+    memcpy(ctx->h_lin, points, n * 96);
+    memcpy(ctx->h_lin + n * 96, scalars, n * 32);
+    return cg1_msm_device(ctx, ctx->h_lin_dev, ctx->h_lin_dev + n * 96, n, 0, 0, 1, out);
+  }
   { int src = ensure_stage(ctx, n * 96, n * 32); if (src) return src; }
   HIPCHK(hipMemcpyAsync(ctx->d_stage_pts, points, n * 96, hipMemcpyHostToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(ctx->d_stage_sc, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));

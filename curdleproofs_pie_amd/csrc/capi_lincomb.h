@@ -224,15 +224,7 @@ int cg1_lincomb_batch(cg1_ctx* ctx, const uint8_t* bases_affine96, size_t n_base
   bool pending = false;
   if (TG) {
     HIPCHK(hipSetDevice(ctx->device));
-    const size_t need_lin = TG * 128 + (G + 1) * 4 + 64;
-    if (need_lin > ctx->cap_h_lin) {
-      if (ctx->h_lin) (void)hipHostFree(ctx->h_lin);
-      ctx->h_lin = nullptr; ctx->h_lin_dev = nullptr; ctx->cap_h_lin = 0;
-      const size_t want = need_lin + TG * 32 + 4096;
-      HIPCHK(hipHostMalloc((void**)&ctx->h_lin, want, hipHostMallocMapped));
-      HIPCHK(hipHostGetDevicePointer((void**)&ctx->h_lin_dev, ctx->h_lin, 0));
-      ctx->cap_h_lin = want;
-    }
+    { int lrc = ensure_lin(ctx, TG * 128 + (G + 1) * 4 + 64); if (lrc) return lrc; }
     uint8_t* hp = ctx->h_lin;
     uint8_t* hs = ctx->h_lin + TG * 96;
     size_t o = 0;
