@@ -179,6 +179,7 @@ cg1_batch_sum = _proto("cg1_batch_sum", c_int, c_void_p, _u8p, POINTER(ctypes.c_
 cg1_validate_compressed = _proto("cg1_validate_compressed", c_int, _u8p, POINTER(c_int))
 cg1_fp_jacobi = _proto("cg1_fp_jacobi", c_int, _u8p)
 cg1_batch_decompress_pool = _proto("cg1_batch_decompress_pool", c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_int, POINTER(c_size_t))
+cg1_batch_decompress_rows = _proto("cg1_batch_decompress_rows", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, POINTER(c_size_t))
 cg1_batch_subgroup_pool = _proto("cg1_batch_subgroup_pool", c_int, c_void_p, c_size_t, c_void_p, c_int)
 cg1_batch_subgroup = _proto("cg1_batch_subgroup", c_int, c_void_p, c_void_p, c_size_t, c_void_p, POINTER(c_int))
 cg1_lincomb_batch = _proto("cg1_lincomb_batch", c_int, c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, POINTER(c_int))
@@ -262,7 +263,7 @@ EXPORTED_SYMBOLS = [
     "cg1_merlin_last_passes", "cg1_merlin_last_kernel", "cg1_merlin_block_program_emulate", "cg1_probe_mad_rate", "cg1_batch_sum_device", "cg1_batch_sum", "cg1_ctx_device", "cg1_ctx_stream", "cg1_msm_multi_device",
     "cg1_comm_create", "cg1_comm_port", "cg1_comm_rank", "cg1_comm_connect", "cg1_comm_set_timeout", "cg1_comm_attach_rccl", "cg1_comm_transport",
     "cg1_comm_world_seen", "cg1_comm_error", "cg1_comm_allgather", "cg1_comm_allgather_host", "cg1_comm_barrier", "cg1_comm_allreduce_g1", "cg1_comm_destroy",
-    "cg1_validate_compressed", "cg1_fp_jacobi", "cg1_batch_decompress_pool", "cg1_batch_subgroup_pool", "cg1_batch_subgroup", "cg1_lincomb_batch", "cg1_lincomb_batch_pool", "cg1_glv_split",
+    "cg1_validate_compressed", "cg1_fp_jacobi", "cg1_batch_decompress_pool", "cg1_batch_subgroup_pool", "cg1_batch_subgroup", "cg1_lincomb_batch", "cg1_lincomb_batch_pool", "cg1_glv_split", "cg1_batch_decompress_rows",
     "cg1_probe_add_chain", "cg1_msm_blobs", "cg1_stage_reserve", "cg1_msm_blobs_device", "cg1_vec_create", "cg1_vec_destroy", "cg1_vec_len", "cg1_msm_vec", "cg1_batch_normalize", "cg1_batch_from_affine96", "cg1_get_last_launches", "cg1_plan_describe",
 ]
 

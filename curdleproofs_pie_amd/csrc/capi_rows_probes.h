@@ -48,6 +48,27 @@ int cg1_batch_decompress_gpu(cg1_ctx* ctx, const uint8_t* in48, uint8_t* out_aff
   return CG1_OK;
 }
 
+// n validated (or not) encodings -> blobs and / or affine96 through k_batch_decompress_row, everything in the context's mapped scratch:
+// no allocation, no staged copy.  The GPU twin of cg1_batch_decompress_pool (same outputs, same error reporting); n <= 8 192.
+int cg1_batch_decompress_rows(cg1_ctx* ctx, const uint8_t* in48, size_t n, uint8_t* out_blobs144, uint8_t* out_affine96, size_t* bad_index) {
+  if (!ctx) return CG1_ERR_HIP;
+  if (n == 0) return CG1_OK;
+  if (n > 8192 || !in48) return CG1_ERR_ARG;
+  HIPCHK(hipSetDevice(ctx->device));
+  const size_t o_out = (n * 48 + 63) & ~(size_t)63, o_st = o_out + n * 96;
+  { int lrc = ensure_lin(ctx, o_st + n + 64); if (lrc) return lrc; }
+  memcpy(ctx->h_lin, in48, n * 48);
+  hipLaunchKernelGGL(cg1::k_batch_decompress_row, dim3((unsigned)((n + 3) / 4)), dim3(64), 0, ctx->stream, (const uint8_t*)ctx->h_lin_dev,
+                     reinterpret_cast<uint32_t*>(ctx->h_lin_dev + o_out), ctx->h_lin_dev + o_st, (uint32_t)n);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  HIPCHK(hipGetLastError());
+  const uint8_t* st = ctx->h_lin + o_st;
+  for (size_t i = 0; i < n; ++i) if (st[i]) { if (bad_index) *bad_index = i; return st[i]; }
+  if (out_affine96) memcpy(out_affine96, ctx->h_lin + o_out, n * 96);
+  if (out_blobs144) return cg1_batch_from_affine96(out_blobs144, ctx->h_lin + o_out, n);
+  return CG1_OK;
+}
+
 int cg1_gen_scalars_device(cg1_ctx* ctx, void* d_out, size_t n, uint64_t seed) {
   if (!ctx) return CG1_ERR_HIP;
   if (n == 0) return CG1_OK;

@@ -309,6 +309,94 @@ __global__ void __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(WAVES,
   status[i] = CG1_OK;
 }
 
+// The same decoding for a few hundred points at a time (the 585 single from_compressed_bytes_unchecked of one verification, decoded in
+// one batch by the deferred G1Point layer): ONE DPP ROW per point, four points per wave, the square-root chain with one limb per lane
+// (fp_row.h: a product in ~0.2 us where the one-lane form needs ~0.9, so the chain of 461 takes ~0.1 ms instead of ~0.4; the host's
+// worker pool needs 0.58 ms for 585 points).  Parsing, x^3 + 4, the check y^2 = x^3 + 4 and the sign choice run in the one-lane form,
+// redundantly in the 16 lanes of the row; lane 0 of the row writes.  No subgroup test (the unchecked decoding).
+__global__ void __launch_bounds__(64) k_batch_decompress_row(const uint8_t* __restrict__ in48, uint32_t* __restrict__ out_raw,
+                                                             uint8_t* __restrict__ status, uint32_t n) {
+  const uint32_t lane = threadIdx.x & 63u, row = lane >> 4;
+  const uint32_t i = blockIdx.x * 4u + row;
+  const RowK k = row_constants();
+  const bool have = i < n;
+  uint32_t w[12];
+  uint32_t st = CG1_OK;
+  bool live = false, largest = false;
+  fp rhs = fp_one();                                     // rows without a point to decode run the chain on 1
+  if (have) {
+    const uint8_t* b = in48 + 48ull * i;
+    const uint8_t flags = b[0];
+    const bool compressed = flags & 0x80, infinity = flags & 0x40;
+    largest = flags & 0x20;
+    for (int j = 0; j < 12; ++j) {                // big-endian bytes -> little-endian words
+      const uint8_t* q = b + 44 - 4 * j;
+      const uint32_t b0 = (j == 11) ? (uint32_t)(q[0] & 0x1F) : (uint32_t)q[0];
+      w[j] = (b0 << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | (uint32_t)q[3];
+    }
+    if (!compressed) st = CG1_ERR_ENCODING;
+    else if (!infinity) {
+      bool lt = false, decided = false;             // x < p ?
+      for (int j = 11; j >= 0 && !decided; --j) if (w[j] != W_P[j]) { lt = w[j] < W_P[j]; decided = true; }
+      if (!lt) st = CG1_ERR_ENCODING;
+      else {
+        live = true;
+        const fp x = fp_to_mont(fp_from_words(w));
+        fp four = fp_one(); four = fp_dbl(fp_dbl(four));
+        rhs = fp_norm(fp_add(fp_mul(fp_sqr(x), x), four));
+      }
+    }
+  }
+  // ---- y = rhs^((p+1)/4): the chain of fp_sqrt_chain, on rows (every lane of the wave takes part)
+  const uint32_t a = row_from_fp(rhs, k.lane16);
+  const uint32_t a2 = row_mul(a, a, k);
+  uint32_t T0 = a, T1, T2, T3, T4, T5, T6, T7;
+  T1 = row_mul(T0, a2, k); T2 = row_mul(T1, a2, k); T3 = row_mul(T2, a2, k); T4 = row_mul(T3, a2, k);
+  T5 = row_mul(T4, a2, k); T6 = row_mul(T5, a2, k); T7 = row_mul(T6, a2, k);
+  static_assert(D_SQRT_CHAIN_FIRST == 6, "the chain starts from a^13");
+  uint32_t r = T6;
+#pragma unroll 1
+  for (int s = 0; s < D_SQRT_CHAIN_LEN; ++s) {
+    const uint32_t op = g_sqrt_chain[s];
+#pragma unroll 1
+    for (uint32_t m = op >> 8; m; --m) r = row_mul(r, r, k);
+    const uint32_t idx = op & 0xffu;                     // wave-uniform
+    if (idx != 0xffu) {
+      uint32_t t;
+      switch (idx) {
+        case 0: t = T0; break; case 1: t = T1; break; case 2: t = T2; break; case 3: t = T3; break;
+        case 4: t = T4; break; case 5: t = T5; break; case 6: t = T6; break; default: t = T7; break;
+      }
+      r = row_mul(r, t, k);
+    }
+  }
+  fp y = fp_norm(row_to_fp(r));
+  // ---- the one-lane tail
+  if (!have) return;
+  uint32_t* dst = out_raw + 24ull * i;
+  uint32_t yw[12];
+  for (int j = 0; j < 12; ++j) yw[j] = 0;
+  if (live) {
+    if (!fp_is_zero_mod_p(fp_sub<3>(fp_sqr(y), fp_mul(rhs, fp_one())), 8)) { st = CG1_ERR_NOT_ON_CURVE; live = false; }
+    else {
+      fp_to_words(y, yw);
+      bool is_large = false, decided = false;       // y > (p-1)/2 ?
+      for (int j = 11; j >= 0 && !decided; --j) if (yw[j] != W_P_MINUS_1_HALF[j]) { is_large = yw[j] > W_P_MINUS_1_HALF[j]; decided = true; }
+      if (is_large != largest) {                     // y := p - y
+        uint64_t borrow = 0;
+        for (int j = 0; j < 12; ++j) {
+          const uint64_t d = (uint64_t)W_P[j] - yw[j] - borrow;
+          yw[j] = (uint32_t)d; borrow = (d >> 32) & 1;
+        }
+      }
+    }
+  }
+  if (k.lane16 == 0u) {
+    for (int j = 0; j < 12; ++j) { dst[j] = live ? w[j] : 0u; dst[12 + j] = live ? yw[j] : 0u; }
+    status[i] = (uint8_t)st;
+  }
+}
+
 // splitmix64-derived scalars, uniform in [1, r-1] (the reference's random_scalar distribution,
 // util.py:21-24) by rejection from 255-bit draws; deterministic in (seed, i)
 __global__ void __launch_bounds__(256) k_gen_scalars(uint32_t* __restrict__ out, uint32_t n, uint64_t seed) {

@@ -161,12 +161,13 @@ def _div_by_zero():
 # A/B switch: CURDLE_G1_LAZY=0 or set_lazy(False) -- every operator then computes at once on the host library (round-4 behaviour).
 _LOCK = threading.RLock()        # one lock for everything that evaluates or touches the default context's staging (msm_accumulator.py too)
 _LAZY = os.environ.get("CURDLE_G1_LAZY", "1") != "0"
+_DECODE_GPU_MIN = int(os.environ.get("CURDLE_G1_DECODE_GPU_MIN", "192"))      # smallest batch of encodings decoded on the GPU (A/B switch: a huge value = never)
 _GLV = os.environ.get("CURDLE_G1_GLV", "1") != "0"      # flushes whose bases are all certified in G1 may use the endomorphism split (A/B switch)
 _SIBLING_LOOKBEHIND = 0          # a flush takes the asked-for value and every live deferred value created after it (+ this many before)
 _pending: list = []              # weak references to deferred values, in creation order
 _next_seq = itertools.count(1).__next__
 _ref = weakref.ref
-stats = {"flushes": 0, "flushed_values": 0, "flush_terms": 0, "flush_host": 0, "flush_device": 0, "flush_hybrid": 0, "flush_split": 0, "decoded": 0, "decode_batches": 0, "subgroup_tests": 0, "subgroup_device": 0, "subgroup_host": 0}
+stats = {"flushes": 0, "flushed_values": 0, "flush_terms": 0, "flush_host": 0, "flush_device": 0, "flush_hybrid": 0, "flush_split": 0, "decoded": 0, "decode_batches": 0, "decode_device": 0, "subgroup_tests": 0, "subgroup_device": 0, "subgroup_host": 0}
 
 
 def set_lazy(on: bool) -> bool:
@@ -480,7 +481,14 @@ def _decode_leaves(leaves) -> None:
     blobs = ctypes.create_string_buffer(N.POINT_BYTES * n)
     aff = ctypes.create_string_buffer(96 * n)
     bad = ctypes.c_size_t(0)
-    rc = N.cg1_batch_decompress_pool(enc, n, blobs, aff, 0, ctypes.byref(bad))
+    # 192 .. 8 192 encodings and a GPU: one DPP row per point, the square-root chain with one limb per lane (~0.2 ms whatever n is;
+    # the pool needs 0.54 ms for the 585 of one verification); otherwise the host's worker pool
+    ctx = _have_gpu() if _DECODE_GPU_MIN <= n <= 8192 else None
+    if ctx is not None:
+        rc = N.cg1_batch_decompress_rows(ctx.handle, enc, n, blobs, aff, ctypes.byref(bad))
+        stats["decode_device"] += 1
+    else:
+        rc = N.cg1_batch_decompress_pool(enc, n, blobs, aff, 0, ctypes.byref(bad))
     if rc != N.OK:      # cannot happen for encodings that passed the validation
         raise ValueError(f"Err From Rust: serialised data seems to be invalid (point {bad.value}, code {rc})")
     blobs, aff = blobs.raw, aff.raw

@@ -282,6 +282,9 @@ int cg1_validate_compressed(const uint8_t in48[48], int* is_identity);
 int cg1_fp_jacobi(const uint8_t le48[48]);               /* Jacobi symbol (a / p) of a 48-byte little-endian a < p: 1, -1, 0; 2 = a >= p */
 /* n encodings (already validated, or not: the first failing index / status come back) -> blobs and / or affine96, on the worker pool */
 int cg1_batch_decompress_pool(const uint8_t* in48, size_t n, uint8_t* out_blobs144, uint8_t* out_affine96, int n_threads, size_t* bad_index);
+/* the same on the GPU for up to 8 192 encodings (k_batch_decompress_row: one DPP row per point, the square-root chain with one limb per
+ * lane; ~0.15 ms whatever n is, through the context's mapped scratch): what the deferred layer uses for batches of >= 192 encodings */
+int cg1_batch_decompress_rows(cg1_ctx* ctx, const uint8_t* in48, size_t n, uint8_t* out_blobs144, uint8_t* out_affine96, size_t* bad_index);
 /* out_flags[i] = 1 iff affine96 point i (on the curve; zeros = identity) lies in the prime-order subgroup G1: [z^2]P == phi(P) + P.
  * Only for such bases may the coefficient of a deferred product be reduced mod r (`(P * a) * b` == P * (a b mod r)). */
 int cg1_batch_subgroup_pool(const uint8_t* affine96, size_t n, uint8_t* out_flags, int n_threads);

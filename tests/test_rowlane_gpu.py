@@ -202,3 +202,55 @@ def test_row_form_tails_meet_doublings_and_cancellations(n):
     ref = O.g1_mul(O.G1_GEN, tot) if tot else None
     assert out.raw == (bytes(96) if ref is None else ref[0].to_bytes(48, "little") + ref[1].to_bytes(48, "little"))
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 64, 255, 585, 2000])
+def test_decompress_on_rows_equals_the_pool(n):
+    """cg1_batch_decompress_rows (one DPP row per point, the square-root chain with one limb per lane) against cg1_batch_decompress_pool:
+    blobs and affine96 byte for byte -- both y signs, the identity's encodings -- and the same first failing index / status for an
+    encoding that is off the curve, has x >= p, or lacks the compression flag."""
+    import random
+    from curdleproofs_pie_amd import _native as N
+    from oracle import bls12_381 as O
+
+    ctx = N.Context(0)
+    rng = random.Random(700 + n)
+    encs = []
+    for i in range(n):
+        p = O.g1_mul(O.G1_GEN, rng.randrange(1, O.R))
+        if rng.random() < 0.5:
+            p = O.g1_neg(p)
+        encs.append(O.g1_compress(p))
+    if n > 4:
+        encs[2] = O.g1_compress(None)
+        encs[4] = bytes([0xC0 | 0x1F]) + bytes([0xAB]) * 47          # infinity flag with junk below it: still the identity (the wheel's leniency)
+    enc = b"".join(encs)
+
+    def both(data, count):
+        outs = []
+        for gpu in (False, True):
+            blobs, aff, bad = ctypes.create_string_buffer(144 * count), ctypes.create_string_buffer(96 * count), ctypes.c_size_t(0)
+            if gpu:
+                rc = N.cg1_batch_decompress_rows(ctx.handle, data, count, blobs, aff, ctypes.byref(bad))
+            else:
+                rc = N.cg1_batch_decompress_pool(data, count, blobs, aff, 0, ctypes.byref(bad))
+            outs.append((rc, bad.value if rc else 0, blobs.raw if rc == 0 else b"", aff.raw if rc == 0 else b""))
+        return outs
+
+    a, b = both(enc, n)
+    assert a[0] == N.OK and a == b
+    for j in range(min(n, 6)):                                       # and the oracle on a few
+        pt = O.g1_decompress(encs[j])
+        assert a[3][96 * j: 96 * j + 96] == (bytes(96) if pt is None else pt[0].to_bytes(48, "little") + pt[1].to_bytes(48, "little"))
+    if n >= 5:
+        x = 5
+        while O.fp_sqrt((x ** 3 + 4) % O.P) is not None:
+            x += 1
+        for pos, bad_enc in ((n - 2, bytes([0x80 | (x >> 376)]) + (x & ((1 << 376) - 1)).to_bytes(47, "big")),      # no y for this x
+                             (1, bytes([0x9F]) + bytes([0xFF]) * 47),                                               # x >= p
+                             (n // 2, bytes([0x00]) + encs[0][1:])):                                                # compression flag missing
+            data = bytearray(enc)
+            data[48 * pos: 48 * pos + 48] = bad_enc
+            a, b = both(bytes(data), n)
+            assert a[0] != N.OK and a[:2] == b[:2], (pos, a[:2], b[:2])
+    ctx.close()
