@@ -459,6 +459,51 @@ static inline void slot_put(PyObject* o, Py_ssize_t off, PyObject* v) {
   *(PyObject**)((char*)o + off) = v;
 }
 
+/* store(points, blobs144 | None, affine96 | None, comp48 | None, clear_terms): the results of one batched evaluation back into the
+ * objects -- record i of each buffer becomes a bytes object in the matching slot of points[i] (_blob, _a, _k); clear_terms: _t = None.
+ * (The Python loop this replaces cost ~0.5 us per object and slot: 0.3 ms for the 585 points of one verification.) */
+static void slot_replace(PyObject* o, Py_ssize_t off, PyObject* v /* reference stolen */) {
+  PyObject** p = (PyObject**)((char*)o + off);
+  PyObject* old = *p;
+  *p = v;
+  Py_XDECREF(old);
+}
+static PyObject* pf_store(PyObject* self, PyObject* args) {
+  PyObject *seq, *src[3];
+  int clear_t = 0;
+  if (!PyArg_ParseTuple(args, "OOOOp", &seq, &src[0], &src[1], &src[2], &clear_t)) return NULL;
+  if (!g_point_type || g_t_off < 0) { PyErr_SetString(PyExc_RuntimeError, "_pyface.bind() has not run"); return NULL; }
+  const Py_ssize_t rec[3] = {144, 96, 48};
+  const Py_ssize_t off[3] = {g_point_off, g_cache_off[0], g_cache_off[1]};
+  PyObject* fast = PySequence_Fast(seq, "store: points must be a sequence");
+  if (!fast) return NULL;
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+  PyObject** items = PySequence_Fast_ITEMS(fast);
+  Py_buffer view[3];
+  int have[3] = {0, 0, 0}, ok = 1;
+  for (int k = 0; k < 3 && ok; ++k) {
+    if (src[k] == Py_None) continue;
+    if (off[k] < 0 || PyObject_GetBuffer(src[k], &view[k], PyBUF_SIMPLE) < 0) { if (off[k] < 0) PyErr_SetString(PyExc_RuntimeError, "slot not bound"); ok = 0; break; }
+    have[k] = 1;
+    if (view[k].len < n * rec[k]) { PyErr_SetString(PyExc_ValueError, "store: buffer shorter than the point list"); ok = 0; }
+  }
+  for (Py_ssize_t i = 0; i < n && ok; ++i) {
+    PyObject* o = items[i];
+    if (Py_TYPE(o) != g_point_type) { PyErr_SetString(PyExc_TypeError, "store: not a G1Point"); ok = 0; break; }
+    for (int k = 0; k < 3; ++k) {
+      if (!have[k]) continue;
+      PyObject* v = PyBytes_FromStringAndSize((const char*)view[k].buf + i * rec[k], rec[k]);
+      if (!v) { ok = 0; break; }
+      slot_replace(o, off[k], v);
+    }
+    if (ok && clear_t) { Py_INCREF(Py_None); slot_replace(o, g_t_off, Py_None); }
+  }
+  for (int k = 0; k < 3; ++k) if (have[k]) PyBuffer_Release(&view[k]);
+  Py_DECREF(fast);
+  if (!ok) return NULL;
+  Py_RETURN_NONE;
+}
+
 /* mk(blob, a, k, t, sg, seq) -> G1Point with exactly these slot values; a value with terms (t is not None) is entered in the pending list */
 static PyObject* pf_mk(PyObject* self, PyObject* const* args, Py_ssize_t nargs) {
   if (nargs != 6) { PyErr_SetString(PyExc_TypeError, "mk(blob, a, k, t, sg, seq)"); return NULL; }
@@ -679,6 +724,7 @@ static PyMethodDef methods[] = {
     {"scale", (PyCFunction)(void (*)(void))pf_scale, METH_FASTCALL, "scale(coefs, v, R) -> [c * v % R]"},
     {"msm_terms", (PyCFunction)(void (*)(void))pf_msm_terms, METH_FASTCALL, "msm_terms(bases, scalars, n, R) -> (coefs, leaves, all_in_g1, None) | (None, None, None, [deferred bases whose leaves must be tested first])"},
     {"assemble", (PyCFunction)(void (*)(void))pf_assemble, METH_FASTCALL, "assemble(nodes, R) -> (leaves, offsets, term_base, scalars32, T, from_msm)"},
+    {"store", pf_store, METH_VARARGS, "store(points, blobs144 | None, affine96 | None, comp48 | None, clear_terms)"},
     {"mk", (PyCFunction)(void (*)(void))pf_mk, METH_FASTCALL, "mk(blob, a, k, t, sg, seq) -> G1Point"},
     {"decode_lazy", pf_decode_lazy, METH_O, "decode_lazy(data48) -> G1Point (validated, y deferred)"},
     {"set_native", pf_set_native, METH_VARARGS, "set_native(address of cg1_validate_compressed)"},

@@ -161,6 +161,7 @@ def _div_by_zero():
 # A/B switch: CURDLE_G1_LAZY=0 or set_lazy(False) -- every operator then computes at once on the host library (round-4 behaviour).
 _LOCK = threading.RLock()        # one lock for everything that evaluates or touches the default context's staging (msm_accumulator.py too)
 _LAZY = os.environ.get("CURDLE_G1_LAZY", "1") != "0"
+_STORE = getattr(_pyface, "store", None) if _pyface is not None else None      # C helper: results of a batched evaluation back into the objects
 _DECODE_GPU_MIN = int(os.environ.get("CURDLE_G1_DECODE_GPU_MIN", "192"))      # smallest batch of encodings decoded on the GPU (A/B switch: a huge value = never)
 _GLV = os.environ.get("CURDLE_G1_GLV", "1") != "0"      # flushes whose bases are all certified in G1 may use the endomorphism split (A/B switch)
 _SIBLING_LOOKBEHIND = 0          # a flush takes the asked-for value and every live deferred value created after it (+ this many before)
@@ -491,10 +492,13 @@ def _decode_leaves(leaves) -> None:
         rc = N.cg1_batch_decompress_pool(enc, n, blobs, aff, 0, ctypes.byref(bad))
     if rc != N.OK:      # cannot happen for encodings that passed the validation
         raise ValueError(f"Err From Rust: serialised data seems to be invalid (point {bad.value}, code {rc})")
-    blobs, aff = blobs.raw, aff.raw
-    for i, l in enumerate(leaves):
-        _set(l, "_a", aff[96 * i: 96 * i + 96])
-        _set(l, "_blob", blobs[144 * i: 144 * i + 144])
+    if _STORE is not None:
+        _STORE(leaves, blobs, aff, None, False)
+    else:
+        blobs, aff = blobs.raw, aff.raw
+        for i, l in enumerate(leaves):
+            _set(l, "_a", aff[96 * i: 96 * i + 96])
+            _set(l, "_blob", blobs[144 * i: 144 * i + 144])
     stats["decoded"] += n
     stats["decode_batches"] += 1
 
@@ -634,12 +638,15 @@ def _flush_run(nodes, leaf_list, offs, tba, scb, T: int, from_msm: bool) -> None
         if ctx is not None:
             ctx.check(rc)
         raise N.NativeError(f"cg1_lincomb_batch failed ({rc})")
-    rb, ra, rk = out_b.raw, out_a.raw, out_k.raw
-    for j, nd in enumerate(nodes):
-        _set(nd, "_a", ra[96 * j: 96 * j + 96])
-        _set(nd, "_k", rk[48 * j: 48 * j + 48])
-        _set(nd, "_blob", rb[144 * j: 144 * j + 144])
-        _set(nd, "_t", None)
+    if _STORE is not None:
+        _STORE(nodes, out_b, out_a, out_k, True)
+    else:
+        rb, ra, rk = out_b.raw, out_a.raw, out_k.raw
+        for j, nd in enumerate(nodes):
+            _set(nd, "_a", ra[96 * j: 96 * j + 96])
+            _set(nd, "_k", rk[48 * j: 48 * j + 48])
+            _set(nd, "_blob", rb[144 * j: 144 * j + 144])
+            _set(nd, "_t", None)
     pend = _pending                  # drop what the tail of the pending list no longer needs: evaluated values, values that died unevaluated
     while pend:
         o = pend[-1]()
